@@ -1,0 +1,210 @@
+"""Independent NumPy/SciPy transcription of the reference's Gibbs-sweep path (TEST INFRASTRUCTURE).
+
+Second restatement, written separately from oracle/rc_oracle.c, used (a) by tests/golden/make_golden.py
+to produce the committed golden vectors and (b) by tests to cross-check the C oracle.  It follows the
+reference's formulas literally (scipy.special.gammaln for loggamma, f64 sums):
+
+  sample_labels_Gibbs!   /root/reference/src/mcmc.jl:158-256
+  loglik                 /root/reference/src/mcmc.jl:1-56
+  logprior               /root/reference/src/mcmc.jl:58-78
+  sample_logweights      /root/reference/src/utils.jl:2-6
+  sortlabels             /root/reference/src/utils.jl:69-74
+  adjacencymatrix        /root/reference/src/utils.jl:59-63
+  MCMCData / MCMCState   /root/reference/src/types.jl:131-157
+  likelihood hyperparameters from a labelling   /root/reference/src/prior.jl:73-75,96-110
+
+The uniform stream is the counter-based Philox4x32-10 stream defined in DESIGN.md (Julia's RNG stream
+cannot be reproduced outside Julia).
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.special import gammaln
+
+M32 = 0xFFFFFFFF
+
+
+def philox4x32_10(ctr, key):
+    c0, c1, c2, c3 = [int(x) & M32 for x in ctr]
+    k0, k1 = [int(x) & M32 for x in key]
+    for _ in range(10):
+        p0 = 0xD2511F53 * c0
+        p1 = 0xCD9E8D57 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & M32, p1 & M32, ((p0 >> 32) ^ c3 ^ k1) & M32, p0 & M32
+        k0 = (k0 + 0x9E3779B9) & M32
+        k1 = (k1 + 0xBB67AE85) & M32
+    return c0, c1, c2, c3
+
+
+def uniform(seed: int, sweep: int, i: int, pos: int) -> float:
+    """u(seed, sweep, i, pos) in (0,1): 52 random bits + 0.5, scaled by 2^-52."""
+    c = philox4x32_10((pos, i, sweep & M32, (sweep >> 32) & M32), (seed & M32, (seed >> 32) & M32))
+    bits = ((c[0] << 32) | c[1]) >> 12
+    return (bits + 0.5) * 2.0 ** -52
+
+
+def make_logD(D: np.ndarray) -> np.ndarray:
+    """types.jl:155 — log.(D - Diagonal(D) + I)."""
+    if np.any(D != D.T):
+        raise ValueError("D must be symmetric.")
+    M = D - np.diag(np.diag(D)) + np.eye(D.shape[0])
+    with np.errstate(divide="ignore"):
+        return np.log(M)
+
+
+def state_from_labels(clusts: np.ndarray):
+    n = len(clusts)
+    sizes = np.bincount(clusts, minlength=n + 1)[1:].astype(np.int64)  # counts(clusts, 1:n)
+    return sizes, int(np.sum(sizes > 0))
+
+
+def likelihood_hyperparams(D: np.ndarray, labels: np.ndarray) -> dict:
+    """prior.jl:73-75,96-110 with the notional clustering replaced by the given labels: A/B = within/
+    between-cluster upper-triangle distances, δ = Gamma-MLE shape, α=|A|δ1, β=ΣA, ζ=|B|δ2, γ=ΣB."""
+    n = D.shape[0]
+    iu = np.triu_indices(n, 1)
+    same = labels[iu[0]] == labels[iu[1]]
+    A = D[iu][same]
+    B = D[iu][~same]
+
+    def gamma_shape_mle(x):
+        # Newton iteration on log(k) - digamma(k) = log(mean) - mean(log), Distributions.fit_mle(Gamma)
+        from scipy.special import digamma, polygamma
+        s = np.log(x.mean()) - np.log(x).mean()
+        k = (3 - s + np.sqrt((s - 3) ** 2 + 24 * s)) / (12 * s)
+        for _ in range(100):
+            k_new = k - (np.log(k) - digamma(k) - s) / (1 / k - polygamma(1, k))
+            if abs(k_new - k) < 1e-14 * k:
+                k = k_new
+                break
+            k = k_new
+        return float(k)
+
+    d1 = gamma_shape_mle(A)
+    d2 = gamma_shape_mle(B)
+    return dict(delta1=d1, delta2=d2, alpha=len(A) * d1, beta=float(A.sum()), zeta=len(B) * d2,
+                gamma=float(B.sum()), eta=1.0, sigma=1.0, u=1.0, v=1.0, repulsion=True, maxK=0)
+
+
+def point_scores(D, logD, clusts, sizes, P, r, p, i):
+    """Candidate labels and logprobs (mcmc.jl:247) for 0-based point i, which is removed first
+    (mcmc.jl:193-194).  Returns (cands (1-based labels), logprobs)."""
+    n = len(clusts)
+    clusts = clusts.copy()
+    sizes = sizes.copy()
+    sizes[clusts[i] - 1] -= 1
+    clusts[i] = -1
+    d1, d2, al, be, ze, ga = (P[k] for k in ("delta1", "delta2", "alpha", "beta", "zeta", "gamma"))
+    abratio = al * np.log(be) - gammaln(al)
+    zgratio = ze * np.log(ga) - gammaln(ze)
+    C_i = np.flatnonzero(sizes > 0) + 1
+    K_i = len(C_i)
+    if (P["maxK"] == 0 or K_i < P["maxK"]) and K_i < n:
+        cands = np.concatenate([C_i, [np.flatnonzero(sizes == 0)[0] + 1]])
+    else:
+        cands = C_i
+    m = len(cands)
+    sumD = np.zeros(n)
+    sumL = np.zeros(n)
+    for k in C_i:
+        mem = np.flatnonzero(clusts == k)
+        # sequential ascending-member sums (np.sum would pairwise-reassociate)
+        s = 0.0
+        t = 0.0
+        for j in mem:
+            s += D[i, j]
+            t += logD[i, j]
+        sumD[k - 1] = s
+        sumL[k - 1] = t
+    L1 = np.zeros(m)
+    lpr = np.zeros(m)
+    for k in range(m):
+        c = cands[k] - 1
+        sz = sizes[c]
+        if sz == 0:
+            lpr[k] = np.log(K_i + 1) + r * np.log(1 - p)
+            L1[k] = 0.0
+        else:
+            a_i = al + d1 * sz
+            b_i = be + sumD[c]
+            L1[k] = gammaln(a_i) + abratio - a_i * np.log(b_i) + (d1 - 1) * sumL[c] - sz * gammaln(d1)
+            lpr[k] = np.log(sz + 1) + np.log(p) + np.log(sz - 1 + r) - np.log(sz)
+    L2p = {}
+    L2_i = 0.0
+    for k in C_i:
+        c = k - 1
+        z_i = ze + d2 * sizes[c]
+        g_i = ga + sumD[c]
+        L2p[k] = gammaln(z_i) - z_i * np.log(g_i) + zgratio + (d2 - 1) * sumL[c] - sizes[c] * gammaln(d2)
+    for k in C_i:
+        L2_i += L2p[k]
+    L2 = np.array([L2_i - L2p[c] if sizes[c - 1] != 0 else L2_i for c in cands])
+    rep = 1.0 if P["repulsion"] else 0.0
+    logprobs = lpr + (L1 + (L2 * rep if rep else 0.0))
+    return cands, logprobs
+
+
+def sample_logweights(logprobs, seed, sweep, i):
+    lp = logprobs - logprobs.min()
+    g = np.array([-np.log(-np.log(uniform(seed, sweep, i, k))) for k in range(len(lp))])
+    return int(np.argmax(g + lp))  # first maximum
+
+
+def sweep(D, logD, clusts, sizes, P, r, p, seed, sweep_index):
+    """One sample_labels_Gibbs! pass; clusts/sizes are modified in place; returns K."""
+    n = len(clusts)
+    for i in range(n):
+        cands, lp = point_scores(D, logD, clusts, sizes, P, r, p, i)
+        k = sample_logweights(lp, seed, sweep_index, i)
+        sizes[clusts[i] - 1] -= 1
+        clusts[i] = cands[k]
+        sizes[cands[k] - 1] += 1
+    return int(np.sum(sizes > 0))
+
+
+def loglik(D, logD, clusts, sizes, P):
+    d1, d2, al, be, ze, ga = (P[k] for k in ("delta1", "delta2", "alpha", "beta", "zeta", "gamma"))
+    abratio = al * np.log(be) - gammaln(al)
+    zgratio = ze * np.log(ga) - gammaln(ze)
+    C = np.flatnonzero(sizes > 0) + 1
+    members = [np.flatnonzero(clusts == k) for k in C]
+    L1 = 0.0
+    for k, mem in zip(C, members):
+        sz = int(sizes[k - 1])
+        pairs = sz * (sz - 1) // 2
+        a = al + d1 * pairs
+        b = be + D[np.ix_(mem, mem)].sum() / 2
+        L1 += (d1 - 1) * logD[np.ix_(mem, mem)].sum() / 2 - pairs * gammaln(d1) + abratio + gammaln(a) - a * np.log(b)
+    L2 = 0.0
+    for x in range(len(C)):
+        for y in range(x + 1, len(C)):
+            pairs = int(sizes[C[x] - 1]) * int(sizes[C[y] - 1])
+            z = ze + d2 * pairs
+            g = ga + D[np.ix_(members[x], members[y])].sum()
+            L2 += (d2 - 1) * logD[np.ix_(members[x], members[y])].sum() - pairs * gammaln(d2) + zgratio + gammaln(z) - z * np.log(g)
+    return float(L1 + (L2 if P["repulsion"] else 0.0))
+
+
+def logprior(sizes, r, p, P):
+    from scipy.stats import beta as beta_dist, gamma as gamma_dist
+    nz = sizes[sizes > 0].astype(float)
+    K = len(nz)
+    n = int(sizes.sum())
+    L = (gammaln(K + 1) + (n - K) * np.log(p) + (r * K) * np.log(1 - p) - K * gammaln(r)
+         + gamma_dist.logpdf(r, a=P["eta"], scale=1 / P["sigma"]) + beta_dist.logpdf(p, P["u"], P["v"]))
+    L += np.sum(np.log(nz) + gammaln(nz + r - 1))
+    return float(L)
+
+
+def sortlabels(x):
+    seen = {}
+    out = np.empty_like(x)
+    for t, v in enumerate(x):
+        if v not in seen:
+            seen[v] = len(seen) + 1
+        out[t] = seen[v]
+    return out
+
+
+def adjacencymatrix(x):
+    return x[:, None] == x[None, :]

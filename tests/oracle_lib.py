@@ -1,0 +1,164 @@
+"""ctypes binding of oracle/librc_oracle.so (TEST INFRASTRUCTURE — see oracle/rc_oracle.c header).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+SO = os.path.join(ORACLE_DIR, "librc_oracle.so")
+
+
+class OrcParams(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("delta1", "delta2", "alpha", "beta", "zeta", "gamma", "eta",
+                                          "sigma", "u", "v")] + [("repulsion", C.c_int32), ("maxK", C.c_int64)]
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(ORACLE_DIR, "rc_oracle.c")
+    if force or not os.path.exists(SO) or os.path.getmtime(SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    return SO
+
+
+_lib = None
+_dp = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_ip = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+_up = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    L = C.CDLL(build())
+    PP = C.POINTER(OrcParams)
+    i64, f64, u64, i32 = C.c_int64, C.c_double, C.c_uint64, C.c_int
+    L.orc_uniform.restype = f64
+    L.orc_uniform.argtypes = [u64, u64, u64, u64]
+    L.orc_philox.argtypes = [_up, _up, _up]
+    L.orc_make_logD.argtypes = [i64, _dp, _dp]
+    L.orc_state_from_labels.argtypes = [i64, _ip, _ip, C.POINTER(i64)]
+    L.orc_quant_exponent.argtypes = [i64, _dp, i64]
+    L.orc_quantize.argtypes = [_dp, i64, i32, _ip]
+    L.orc_sweep_literal.argtypes = [i64, _dp, _dp, _ip, _ip, C.POINTER(i64), PP, f64, f64, u64, u64, i32]
+    L.orc_point_scores_literal.restype = i64
+    L.orc_point_scores_literal.argtypes = [i64, _dp, _dp, _ip, _ip, PP, f64, f64, i64, _ip, _dp]
+    L.orc_size_table.argtypes = [i64, PP, _dp]
+    L.orc_sweep_stable.argtypes = [i64, _ip, _ip, i32, i32, _dp, _ip, _ip, C.POINTER(i64), PP, f64, f64,
+                                   u64, u64, C.POINTER(i64)]
+    L.orc_point_scores_stable.restype = i64
+    L.orc_point_scores_stable.argtypes = [i64, _ip, _ip, i32, i32, _dp, _ip, _ip, PP, f64, f64, i64, _ip, _dp]
+    L.orc_loglik_literal.restype = f64
+    L.orc_loglik_literal.argtypes = [i64, _dp, _dp, _ip, _ip, PP]
+    L.orc_loglik_stable.restype = f64
+    L.orc_loglik_stable.argtypes = [i64, _ip, _ip, i32, i32, _ip, _ip, PP]
+    L.orc_logprior.restype = f64
+    L.orc_logprior.argtypes = [i64, _ip, f64, f64, PP]
+    L.orc_sortlabels.argtypes = [i64, _ip, _ip]
+    L.orc_cocluster_add.argtypes = [i64, _ip, _up]
+    L.orc_matsum_idx.restype = f64
+    L.orc_matsum_idx.argtypes = [i64, _dp, _ip, i64, _ip, i64]
+    L.orc_vecsum_idx.restype = f64
+    L.orc_vecsum_idx.argtypes = [_dp, _ip, i64]
+    _lib = L
+    return L
+
+
+def params(P: dict) -> OrcParams:
+    return OrcParams(P["delta1"], P["delta2"], P["alpha"], P["beta"], P["zeta"], P["gamma"],
+                     P.get("eta", 1.0), P.get("sigma", 1.0), P.get("u", 1.0), P.get("v", 1.0),
+                     int(bool(P.get("repulsion", True))), int(P.get("maxK", 0)))
+
+
+class Oracle:
+    """Convenience wrapper holding one dataset (D, logD, fixed-point copies) and one label state."""
+
+    def __init__(self, D: np.ndarray, P: dict, logD: np.ndarray | None = None):
+        self.L = lib()
+        self.n = int(D.shape[0])
+        self.D = np.ascontiguousarray(D, dtype=np.float64)
+        if logD is None:
+            logD = np.empty_like(self.D)
+            if self.L.orc_make_logD(self.n, self.D, logD) != 0:
+                raise ValueError("D must be symmetric.")
+        self.logD = np.ascontiguousarray(logD, dtype=np.float64)
+        self.set_params(P)
+        nn = self.n * self.n
+        self.eD = self.L.orc_quant_exponent(self.n, self.D.ravel(), nn)
+        self.eL = self.L.orc_quant_exponent(self.n, self.logD.ravel(), nn)
+        self.Dq = np.empty((self.n, self.n), np.int64)
+        self.Lq = np.empty((self.n, self.n), np.int64)
+        self.L.orc_quantize(self.D.ravel(), nn, self.eD, self.Dq.reshape(-1))
+        self.L.orc_quantize(self.logD.ravel(), nn, self.eL, self.Lq.reshape(-1))
+        self.clusts = None
+        self.sizes = None
+        self.K = 0
+
+    def set_params(self, P: dict):
+        self.Pd = dict(P)
+        self.P = params(P)
+        self.A = np.zeros(self.n + 1)
+        self.L.orc_size_table(self.n, C.byref(self.P), self.A)
+
+    def set_state(self, clusts):
+        self.clusts = np.ascontiguousarray(clusts, dtype=np.int64).copy()
+        self.sizes = np.zeros(self.n, np.int64)
+        K = C.c_int64()
+        if self.L.orc_state_from_labels(self.n, self.clusts, self.sizes, C.byref(K)) != 0:
+            raise ValueError("labels must lie in 1..n")
+        self.K = K.value
+
+    def sweep_literal(self, r, p, seed, sweep, cost_mode=0):
+        K = C.c_int64()
+        rc = self.L.orc_sweep_literal(self.n, self.D.reshape(-1), self.logD.reshape(-1), self.clusts, self.sizes,
+                                      C.byref(K), C.byref(self.P), r, p, seed, sweep, cost_mode)
+        assert rc == 0
+        self.K = K.value
+        return self.K
+
+    def sweep_stable(self, r, p, seed, sweep):
+        K = C.c_int64()
+        ch = C.c_int64()
+        rc = self.L.orc_sweep_stable(self.n, self.Dq.reshape(-1), self.Lq.reshape(-1), self.eD, self.eL, self.A,
+                                     self.clusts, self.sizes, C.byref(K), C.byref(self.P), r, p, seed, sweep,
+                                     C.byref(ch))
+        assert rc == 0
+        self.K = K.value
+        self.last_changes = ch.value
+        return self.K
+
+    def point_scores_literal(self, r, p, i):
+        cands = np.zeros(self.n + 1, np.int64)
+        lp = np.zeros(self.n + 1)
+        m = self.L.orc_point_scores_literal(self.n, self.D.reshape(-1), self.logD.reshape(-1), self.clusts,
+                                            self.sizes, C.byref(self.P), r, p, i, cands, lp)
+        return cands[:m].copy(), lp[:m].copy()
+
+    def point_scores_stable(self, r, p, i):
+        cands = np.zeros(self.n + 1, np.int64)
+        sc = np.zeros(self.n + 1)
+        m = self.L.orc_point_scores_stable(self.n, self.Dq.reshape(-1), self.Lq.reshape(-1), self.eD, self.eL,
+                                           self.A, self.clusts, self.sizes, C.byref(self.P), r, p, i, cands, sc)
+        return cands[:m].copy(), sc[:m].copy()
+
+    def loglik_literal(self):
+        return self.L.orc_loglik_literal(self.n, self.D.reshape(-1), self.logD.reshape(-1), self.clusts,
+                                         self.sizes, C.byref(self.P))
+
+    def loglik_stable(self):
+        return self.L.orc_loglik_stable(self.n, self.Dq.reshape(-1), self.Lq.reshape(-1), self.eD, self.eL,
+                                        self.clusts, self.sizes, C.byref(self.P))
+
+    def logprior(self, r, p):
+        return self.L.orc_logprior(self.n, self.sizes, r, p, C.byref(self.P))
+
+    def sortlabels(self):
+        y = np.zeros(self.n, np.int64)
+        self.L.orc_sortlabels(self.n, self.clusts, y)
+        return y
