@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py — Gibbs sweeps/sec of the MI355X sweep on BASELINE.json's roofline configuration.
+
+  python bench.py --gpus N --steps K --warmup W          (N=1: plain python; N>1: one rank per GPU under
+  python -m torch.distributed.run --nproc-per-node N …    torch.distributed, backend nccl = RCCL)
+
+A "step" is one Gibbs sweep (sample_labels_Gibbs!, /root/reference/src/mcmc.jl:158-256) of one chain over the
+synthetic N=8192, K=50 dense Float64 dissimilarity matrix (BASELINE.json configs[2], the configuration the
+north_star's roofline target is quoted on); D and logD are already resident in HBM when the timed region
+starts.  Chains are independent: with N GPUs every rank runs its own chain (weak scaling) and the only
+collective is the final sum all-reduce of the n×n co-clustering counts (outside the timed region, reported).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (k_bulk, HBM-bound, timed
+with HIP events on the library's own stream) and `cpu_baseline` (the C restatement of the reference's loop,
+faithful-cost mode, one host core, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_POINTS = int(os.environ.get("RC_BENCH_N", 8192))
+N_CLUST = int(os.environ.get("RC_BENCH_K", 50))
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ≈6300 GB/s is the measured copy ceiling
+
+
+def cpu_baseline(D, P, labels, r, p, max_seconds=20.0):
+    """Reference loop restated in C (oracle/, literal arithmetic, faithful-cost: per-(point,cluster) member
+    scans and the three strided gathers of mcmc.jl:195-214), single thread, on a bounded sample of one sweep."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    n = D.shape[0]
+    orc = O.Oracle.__new__(O.Oracle)  # skip the fixed-point copies (1 GiB) — literal mode does not use them
+    orc.L = O.lib()
+    orc.n = n
+    orc.D = np.ascontiguousarray(D)
+    logD = np.log(np.where(np.eye(n, dtype=bool), 1.0, D))
+    orc.logD = np.ascontiguousarray(logD)
+    orc.P = O.params(P)
+    orc.set_state(labels)
+    pts = 16
+    t0 = time.perf_counter()
+    orc.sweep_literal_range(r, p, 1, 0, 1, 0, pts)
+    dt = time.perf_counter() - t0
+    # grow the sample to ≈ max_seconds of CPU work (capped at one full sweep)
+    want = int(min(n, max(pts, pts * max_seconds / max(dt, 1e-9) * 0.8)))
+    orc.set_state(labels)
+    t0 = time.perf_counter()
+    orc.sweep_literal_range(r, p, 1, 0, 1, 0, want)
+    dt = time.perf_counter() - t0
+    sweeps_per_s = 1.0 / (dt * n / want)
+    return {"value": sweeps_per_s, "unit": "sweeps/s", "cores": 1, "kind": "port",
+            "sample": f"first {want} of {n} points of one sweep (faithful-cost literal C restatement of "
+                      f"mcmc.jl:158-256, single thread, {dt:.1f} s), scaled to a full sweep; host has {os.cpu_count()} cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import redclust_amd as rc
+    n, K = N_POINTS, N_CLUST
+    data = rc.generatemixture(n, K, seed=1)          # same data on every rank; chains differ by seed
+    D, truth = data["distancematrix"], data["clusts"]
+    P = rc.likelihood_hyperparams(D, truth)
+    r, p = 1.0, 0.5
+    chain_seed = 1 + rank                             # chain seeds 1..N
+
+    ctx = rc.Context(D, device=local_rank, kcap=max(128, 2 * K))
+    ctx.set_params(**P)
+    ctx.set_state(truth)                              # stationary regime: generating labels
+    ctx.cocluster_reset()
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sweep = 0
+    for _ in range(args.warmup):
+        ctx.gibbs_sweep(r, p, chain_seed, sweep, blocking=False)
+        sweep += 1
+    ctx.synchronize()
+    ctx.kernel_timing(enable=1)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.gibbs_sweep(r, p, chain_seed, sweep, blocking=False)
+        sweep += 1
+    ctx.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    bulk_ms, bulk_launches = ctx.kernel_timing(enable=0)
+    stats = ctx.sweep_stats()
+
+    # recorded sample + the one collective of the path: sum all-reduce of the integer co-clustering counts
+    ctx.record_sample(False)
+    ptr, ldc = ctx.cocluster_device_buffer()
+    allreduce_ms = None
+    if distributed:
+        class _Buf:
+            __cuda_array_interface__ = {"shape": (n, ldc), "typestr": "<i4", "data": (ptr, False), "version": 3}
+        counts = torch.as_tensor(_Buf(), device=torch.device("cuda", local_rank))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        allreduce_ms = (time.perf_counter() - t1) * 1e3
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        diag_ok = bool((counts.diagonal() == world).all().item())
+    else:
+        diag_ok = True
+
+    if rank == 0:
+        alg_bytes = 2.0 * n * n * 8.0                 # every row of D and of logD read once per sweep
+        value = world * args.steps / dt
+        bulk_avg_ms = bulk_ms / max(bulk_launches, 1)
+        achieved = alg_bytes / (bulk_avg_ms * 1e-3) / 1e9 if bulk_launches else None
+        out = {
+            "metric": "Gibbs sweeps/sec (n×n distM)", "value": value, "unit": "sweeps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i64 fixed-point sums, f64 scores",
+            "data": "synthetic",
+            "config": {"workload": f"generatemixture N={n} K={K} dim={K} sigma=0.1 dense Float64 distM, 1 chain per GPU, "
+                                   "numMH=0 Gibbs sweep, init = generating labels (stationary), r=1 p=0.5",
+                       "chains": world, "n": n, "K": K, "parallelism": f"chains x{world}"},
+            "sweep_GBps_algorithmic": value / world * alg_bytes / 1e9,
+            "sweep_frac_of_hbm_peak": value / world * alg_bytes / 1e9 / HBM_PEAK_GBPS,
+            "label_changes_last_sweep": stats["n_changes"], "K_final": stats["K"],
+            "coclustering_allreduce_ms": allreduce_ms, "coclustering_diag_ok": diag_ok,
+            "roofline": {"kernel": "k_bulk", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": None,
+                         "avg_launch_ms": bulk_avg_ms, "launches": bulk_launches, "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(D, P, truth, r, p)
+        print(json.dumps(out))
+    ctx.close()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

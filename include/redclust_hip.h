@@ -1,0 +1,119 @@
+/*
+ * redclust_hip.h — C ABI of libredclust_hip.so: the MI355X (gfx950) implementation of RedClust.jl's
+ * per-iteration Gibbs label sweep and the observables computed from the same device-resident data.
+ *
+ * The reference (RedClust.jl v1.2.2, pure Julia) has no FFI seam on this path: sample_labels_Gibbs! is an
+ * ordinary Julia function.  This header DEFINES the seam; each entry point cites the reference code it
+ * replaces (path:line under the reference checkout).  The Julia-side binding (ccall stubs keeping
+ * runsampler / MCMCData / MCMCOptionsList / MCMCResult unchanged) is shown in INTEGRATION.md and
+ * julia/RedClustHIP.jl; the Python host (redclust.jl_amd/) binds the same symbols through ctypes.
+ *
+ * Conventions
+ *   - every function returns int32_t: 0 = RC_OK, negative = error class; rc_last_error() gives the text.
+ *     Nothing aborts and nothing throws across the boundary.
+ *   - labels are Julia Int = int64_t, 1-based, in 1..n (src/types.jl:1,135); matrices are n×n Float64,
+ *     column-major == row-major because MCMCData enforces exact symmetry (src/types.jl:149-151).
+ *   - the caller owns every host buffer and keeps it alive for the duration of the call; the library owns
+ *     all device memory behind rc_ctx.  One rc_ctx is not thread-safe; distinct contexts are independent.
+ *   - uniforms: the m uniforms sample_logweights (src/utils.jl:4) draws for point i (0-based) of sweep t
+ *     are Philox4x32-10(key = seed)(counter = (pos, i, t_lo, t_hi)), pos = 0..m-1 in candidate order,
+ *     u = (top 52 bits + 0.5) * 2^-52  (DESIGN.md "Uniform stream").
+ */
+#ifndef REDCLUST_HIP_H
+#define REDCLUST_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RC_OK 0
+#define RC_ERR_ARG (-1)      /* bad argument (null pointer, n < 1, label outside 1..n, r <= 0, p outside (0,1)) */
+#define RC_ERR_HIP (-2)      /* HIP runtime error, including "no device" */
+#define RC_ERR_OOM (-3)      /* host or device allocation failed */
+#define RC_ERR_DOMAIN (-4)   /* D not symmetric / not finite / non-positive off-diagonal entry (log D = -Inf) */
+#define RC_ERR_STATE (-5)    /* call sequence error (params or state not set) */
+#define RC_ERR_CAPACITY (-6) /* number of clusters exceeded the slot capacity given to rc_create */
+
+typedef struct rc_ctx rc_ctx;
+
+/* Fields read by the sweep at src/mcmc.jl:171-178 (δ1 δ2 α β ζ γ repulsion maxK) and by logprior at
+ * src/mcmc.jl:65-68 (η σ u v); struct PriorHyperparamsList, src/types.jl:93-108. */
+typedef struct rc_params {
+    double delta1, delta2, alpha, beta, zeta, gamma;
+    double eta, sigma, u, v;
+    int64_t maxK;      /* 0 = unbounded */
+    uint8_t repulsion; /* Julia Bool */
+    uint8_t pad_[7];
+} rc_params;
+
+/* Counters of the last rc_gibbs_sweep (diagnostics; no reference counterpart). */
+typedef struct rc_sweep_stats {
+    int64_t n_changes; /* points whose label changed in the sweep */
+    int64_t n_rounds;  /* scoring passes launched (1 + n_changes in the exact speculative scheme) */
+    int64_t K;         /* clusters after the sweep (state.K, src/mcmc.jl:254) */
+} rc_sweep_stats;
+
+/* MCMCData constructor, src/types.jl:145-157.  Copies the n×n matrix D to HBM once, checks symmetry
+ * (types.jl:149-151) and derives logD = log.(D - Diagonal(D) + I) on the device (types.jl:155; diagonal 0,
+ * D's own diagonal kept as stored) unless the caller passes its own logD (e.g. MCMCData.logD).
+ * storage_bits: 64 (int64 fixed point, the Float64 path) or 32 (int32 fixed point, half the HBM traffic).
+ * kcap: slot capacity = most clusters the state may hold at once (0 = default min(n, 1024)).
+ * device_id: HIP device ordinal. */
+int32_t rc_create(int64_t n, const double *D, const double *logD_or_null, int32_t storage_bits,
+                  int32_t device_id, int64_t kcap, rc_ctx **out);
+int32_t rc_destroy(rc_ctx *ctx);
+
+/* Last error text of ctx (or of the calling thread's last failed rc_create when ctx == NULL). */
+const char *rc_last_error(const rc_ctx *ctx);
+
+int32_t rc_set_params(rc_ctx *ctx, const rc_params *params);
+
+/* MCMCState, src/types.jl:131-137: clustsizes and K are derived from the labels (types.jl:135-136). */
+int32_t rc_set_state(rc_ctx *ctx, const int64_t *clusts /* n, 1-based */);
+int32_t rc_get_state(rc_ctx *ctx, int64_t *clusts /* n */, int64_t *clustsizes /* n, by label */, int64_t *K);
+
+/* sample_labels_Gibbs!(data, state, params), src/mcmc.jl:158-256 — one full sequential sweep with the
+ * r, p of the current iteration (mcmc.jl:169-170); mutates the device state exactly as the sequential loop
+ * would under the uniform stream (seed, sweep_index).  Blocking. */
+int32_t rc_gibbs_sweep(rc_ctx *ctx, double r, double p, uint64_t seed, uint64_t sweep_index);
+int32_t rc_last_sweep_stats(rc_ctx *ctx, rc_sweep_stats *out);
+
+/* Non-blocking sweep for the stationary fast path and for benchmarking: enqueues one sweep on the
+ * context's stream and returns; label changes are resolved on the device.  rc_synchronize() (or any
+ * blocking call) waits for completion. */
+int32_t rc_gibbs_sweep_async(rc_ctx *ctx, double r, double p, uint64_t seed, uint64_t sweep_index);
+int32_t rc_synchronize(rc_ctx *ctx);
+
+/* loglik(data, state, params), src/mcmc.jl:1-56. */
+int32_t rc_loglik(rc_ctx *ctx, double *out);
+/* logprior(state, params), src/mcmc.jl:58-78, with the given r, p. */
+int32_t rc_logprior(rc_ctx *ctx, double r, double p, double *out);
+
+/* Recording step of runsampler, src/mcmc.jl:546-553: canonical labels = sortlabels(state.clusts)
+ * (src/utils.jl:69-74) written to canonical_out (nullable), and counts += adjacencymatrix(clusts)
+ * (src/utils.jl:59-63), the running sum behind src/mcmc.jl:560. */
+int32_t rc_record_sample(rc_ctx *ctx, int64_t *canonical_out /* n or NULL */);
+/* posterior_coclustering = sum(adjacencymatrix.(result.clusts)) ./ numsamples, src/mcmc.jl:560. */
+int32_t rc_cocluster(rc_ctx *ctx, double *out_n_by_n, int64_t numsamples);
+/* Raw integer counts (exact), e.g. for cross-chain reduction on the host. */
+int32_t rc_cocluster_counts(rc_ctx *ctx, uint32_t *out_n_by_n);
+/* Device address and leading dimension (elements) of the uint32 count matrix, for a device-side
+ * all-reduce across chains (RCCL through torch.distributed); valid until rc_destroy. */
+int32_t rc_cocluster_device_buffer(rc_ctx *ctx, void **dev_ptr, int64_t *ld);
+int32_t rc_cocluster_reset(rc_ctx *ctx);
+
+/* Introspection used by the parity tests: exact fixed-point row sums Σ_j D[i,j]·[c_j = label] of the
+ * current state (the matsum(D,[i],clust_k) of src/mcmc.jl:210-213 before β is added), value = q·2^-e. */
+int32_t rc_debug_rowsums(rc_ctx *ctx, int64_t label, int64_t *sumD_q /* n */, int64_t *sumL_q /* n */,
+                         int32_t *eD, int32_t *eL);
+
+/* Timing of the dominant kernel (row-bucket reduction) measured with HIP events on the context's own
+ * stream: accumulated milliseconds and launch count since the last reset. */
+int32_t rc_kernel_timing(rc_ctx *ctx, int32_t enable, double *bulk_ms_total, int64_t *bulk_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REDCLUST_HIP_H */

@@ -280,14 +280,15 @@ static int64_t lit_point_scores(int64_t n, const double *D, const double *logD, 
 }
 
 /* sample_labels_Gibbs! (src/mcmc.jl:158-256), literal.  clusts 1-based, clustsizes length n.
- * cost_mode: 0 single-pass, 1 faithful-cost.  Returns 0 or <0 on allocation failure. */
-int orc_sweep_literal(int64_t n, const double *D, const double *logD, int64_t *clusts,
-                      int64_t *clustsizes, int64_t *K, const orc_params *P, double r, double p,
-                      uint64_t seed, uint64_t sweep, int cost_mode)
+ * cost_mode: 0 single-pass, 1 faithful-cost.  Returns 0 or <0 on allocation failure.
+ * The _range form visits points i_begin..i_end-1 only (bounded CPU-baseline sample in bench.py). */
+int orc_sweep_literal_range(int64_t n, const double *D, const double *logD, int64_t *clusts,
+                            int64_t *clustsizes, int64_t *K, const orc_params *P, double r, double p,
+                            uint64_t seed, uint64_t sweep, int cost_mode, int64_t i_begin, int64_t i_end)
 {
     lit_ws w;
     if (lit_ws_alloc(&w, n)) { lit_ws_free(&w); return -2; }
-    for (int64_t i = 0; i < n; ++i) {
+    for (int64_t i = i_begin; i < i_end; ++i) {
         clustsizes[clusts[i] - 1] -= 1;                         /* mcmc.jl:193 */
         clusts[i] = -1;                                         /* mcmc.jl:194 */
         int64_t m = lit_point_scores(n, D, logD, clusts, clustsizes, P, r, p, i, cost_mode, &w);
@@ -301,6 +302,13 @@ int orc_sweep_literal(int64_t n, const double *D, const double *logD, int64_t *c
     *K = k;
     lit_ws_free(&w);
     return 0;
+}
+
+int orc_sweep_literal(int64_t n, const double *D, const double *logD, int64_t *clusts,
+                      int64_t *clustsizes, int64_t *K, const orc_params *P, double r, double p,
+                      uint64_t seed, uint64_t sweep, int cost_mode)
+{
+    return orc_sweep_literal_range(n, D, logD, clusts, clustsizes, K, P, r, p, seed, sweep, cost_mode, 0, n);
 }
 
 /* Candidate labels and log-weights (mcmc.jl:247, before sample_logweights) for ONE point of the

@@ -1,0 +1,11 @@
+"""redclust.jl_amd — MI355X-native Gibbs-sweep hot path of RedClust.jl behind the reference's
+runsampler / MCMCData / MCMCOptionsList / MCMCResult surface.
+
+The directory name is not a valid Python identifier; import it through the repo-root shim:
+
+    import redclust_amd as rc
+"""
+from ._lib import Context, RedClustHIPError, build, lib, SIGNATURES  # noqa: F401
+from .types import MCMCData, MCMCOptionsList, MCMCResult, MCMCState, PriorHyperparamsList  # noqa: F401
+from .sampler import runsampler, sample_r, sample_p, iac_ess_acf  # noqa: F401
+from .datagen import generatemixture, likelihood_hyperparams  # noqa: F401

@@ -1,0 +1,210 @@
+"""ctypes binding of libredclust_hip.so (include/redclust_hip.h).  No CPU fallback: if the HIP library is
+missing or no GPU is present, every compute entry point raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG_DIR)
+CSRC = os.path.join(PKG_DIR, "csrc")
+SO = os.path.join(CSRC, "libredclust_hip.so")
+HEADER = os.path.join(ROOT, "include", "redclust_hip.h")
+
+RC_OK = 0
+ERRORS = {-1: "RC_ERR_ARG", -2: "RC_ERR_HIP", -3: "RC_ERR_OOM", -4: "RC_ERR_DOMAIN", -5: "RC_ERR_STATE",
+          -6: "RC_ERR_CAPACITY"}
+
+
+class RedClustHIPError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{ERRORS.get(code, code)}: {msg}")
+        self.code = code
+
+
+class RcParams(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("delta1", "delta2", "alpha", "beta", "zeta", "gamma", "eta", "sigma",
+                                          "u", "v")] + [("maxK", C.c_int64), ("repulsion", C.c_uint8),
+                                                        ("pad_", C.c_uint8 * 7)]
+
+
+class RcSweepStats(C.Structure):
+    _fields_ = [("n_changes", C.c_int64), ("n_rounds", C.c_int64), ("K", C.c_int64)]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, "redclust_hip.hip"), HEADER]
+    if not force and os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(s) for s in srcs):
+        return SO
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", SO, srcs[0]]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return SO
+
+
+_dp = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_ip = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+_up = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+
+# every symbol include/redclust_hip.h declares, with its ctypes signature
+SIGNATURES = {
+    "rc_create": (C.c_int32, [C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_void_p)]),
+    "rc_destroy": (C.c_int32, [C.c_void_p]),
+    "rc_last_error": (C.c_char_p, [C.c_void_p]),
+    "rc_set_params": (C.c_int32, [C.c_void_p, C.POINTER(RcParams)]),
+    "rc_set_state": (C.c_int32, [C.c_void_p, _ip]),
+    "rc_get_state": (C.c_int32, [C.c_void_p, _ip, _ip, C.POINTER(C.c_int64)]),
+    "rc_gibbs_sweep": (C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_uint64, C.c_uint64]),
+    "rc_gibbs_sweep_async": (C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_uint64, C.c_uint64]),
+    "rc_last_sweep_stats": (C.c_int32, [C.c_void_p, C.POINTER(RcSweepStats)]),
+    "rc_synchronize": (C.c_int32, [C.c_void_p]),
+    "rc_loglik": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double)]),
+    "rc_logprior": (C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.POINTER(C.c_double)]),
+    "rc_record_sample": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "rc_cocluster": (C.c_int32, [C.c_void_p, _dp, C.c_int64]),
+    "rc_cocluster_counts": (C.c_int32, [C.c_void_p, _up]),
+    "rc_cocluster_device_buffer": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "rc_cocluster_reset": (C.c_int32, [C.c_void_p]),
+    "rc_debug_rowsums": (C.c_int32, [C.c_void_p, C.c_int64, _ip, _ip, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "rc_kernel_timing": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the in-tree HIP library; fails loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO):
+            raise RedClustHIPError(-2, f"{SO} not built — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                       "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(SO)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class Context:
+    """Owns one rc_ctx: device-resident D/logD (fixed point), the label state and the sweep kernels."""
+
+    def __init__(self, D: np.ndarray, logD: np.ndarray | None = None, device: int = 0, kcap: int = 0,
+                 storage_bits: int = 64):
+        self.L = lib()
+        D = np.ascontiguousarray(D, dtype=np.float64)
+        if D.ndim != 2 or D.shape[0] != D.shape[1]:
+            raise ValueError("D must be a square matrix.")  # types.jl:152-154
+        self.n = int(D.shape[0])
+        lp = None
+        if logD is not None:
+            logD = np.ascontiguousarray(logD, dtype=np.float64)
+            assert logD.shape == D.shape
+            lp = logD.ctypes.data_as(C.c_void_p)
+        h = C.c_void_p()
+        rc = self.L.rc_create(self.n, D.ctypes.data_as(C.c_void_p), lp, storage_bits, device, kcap, C.byref(h))
+        if rc != RC_OK:
+            raise RedClustHIPError(rc, self.L.rc_last_error(None).decode())
+        self.h = h
+
+    def _chk(self, rc):
+        if rc != RC_OK:
+            raise RedClustHIPError(rc, self.L.rc_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_params(self, delta1, delta2, alpha, beta, zeta, gamma, eta=1.0, sigma=1.0, u=1.0, v=1.0,
+                   repulsion=True, maxK=0, **_ignored):
+        P = RcParams(delta1, delta2, alpha, beta, zeta, gamma, eta, sigma, u, v, int(maxK), int(bool(repulsion)))
+        self._chk(self.L.rc_set_params(self.h, C.byref(P)))
+
+    def set_state(self, clusts):
+        c = np.ascontiguousarray(clusts, dtype=np.int64)
+        if c.shape != (self.n,):
+            raise ValueError("clusts must have length n")
+        self._chk(self.L.rc_set_state(self.h, c))
+
+    def get_state(self):
+        clusts = np.zeros(self.n, np.int64)
+        sizes = np.zeros(self.n, np.int64)
+        K = C.c_int64()
+        self._chk(self.L.rc_get_state(self.h, clusts, sizes, C.byref(K)))
+        return clusts, sizes, K.value
+
+    def gibbs_sweep(self, r, p, seed, sweep_index, blocking=True):
+        fn = self.L.rc_gibbs_sweep if blocking else self.L.rc_gibbs_sweep_async
+        self._chk(fn(self.h, float(r), float(p), int(seed), int(sweep_index)))
+
+    def synchronize(self):
+        self._chk(self.L.rc_synchronize(self.h))
+
+    def sweep_stats(self):
+        s = RcSweepStats()
+        self._chk(self.L.rc_last_sweep_stats(self.h, C.byref(s)))
+        return dict(n_changes=s.n_changes, n_rounds=s.n_rounds, K=s.K)
+
+    def loglik(self):
+        out = C.c_double()
+        self._chk(self.L.rc_loglik(self.h, C.byref(out)))
+        return out.value
+
+    def logprior(self, r, p):
+        out = C.c_double()
+        self._chk(self.L.rc_logprior(self.h, float(r), float(p), C.byref(out)))
+        return out.value
+
+    def record_sample(self, want_labels=True):
+        if want_labels:
+            out = np.zeros(self.n, np.int64)
+            self._chk(self.L.rc_record_sample(self.h, out.ctypes.data_as(C.c_void_p)))
+            return out
+        self._chk(self.L.rc_record_sample(self.h, None))
+        return None
+
+    def cocluster(self, numsamples):
+        out = np.zeros((self.n, self.n))
+        self._chk(self.L.rc_cocluster(self.h, out.reshape(-1), int(numsamples)))
+        return out
+
+    def cocluster_counts(self):
+        out = np.zeros((self.n, self.n), np.uint32)
+        self._chk(self.L.rc_cocluster_counts(self.h, out.reshape(-1)))
+        return out
+
+    def cocluster_device_buffer(self):
+        p = C.c_void_p()
+        ld = C.c_int64()
+        self._chk(self.L.rc_cocluster_device_buffer(self.h, C.byref(p), C.byref(ld)))
+        return p.value, ld.value
+
+    def cocluster_reset(self):
+        self._chk(self.L.rc_cocluster_reset(self.h))
+
+    def debug_rowsums(self, label):
+        sd = np.zeros(self.n, np.int64)
+        sl = np.zeros(self.n, np.int64)
+        eD, eL = C.c_int32(), C.c_int32()
+        self._chk(self.L.rc_debug_rowsums(self.h, int(label), sd, sl, C.byref(eD), C.byref(eL)))
+        return sd, sl, eD.value, eL.value
+
+    def kernel_timing(self, enable=-1):
+        ms = C.c_double()
+        cnt = C.c_int64()
+        self._chk(self.L.rc_kernel_timing(self.h, int(enable), C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value

@@ -1,0 +1,1363 @@
+// redclust_hip.hip — MI355X (gfx950 / CDNA4) implementation of RedClust.jl's Gibbs label sweep and its
+// observables behind the C ABI of include/redclust_hip.h.  Written for gfx950 only.
+//
+// Reference path (RedClust.jl v1.2.2, paths under the reference checkout):
+//   sample_labels_Gibbs!  src/mcmc.jl:158-256     loglik  src/mcmc.jl:1-56     logprior  src/mcmc.jl:58-78
+//   sample_logweights     src/utils.jl:2-6        matsum/vecsum  src/utils.jl:9-38
+//   adjacencymatrix / sortlabels  src/utils.jl:59-74      MCMCData / MCMCState  src/types.jl:131-157
+//
+// Design (DESIGN.md has the long form):
+//   * D and logD live in HBM as 64-bit FIXED-POINT integers (q = rint(x·2^e), e chosen so that any sum
+//     of n entries fits in int64).  Every row/block sum is therefore exact and independent of the order of
+//     summation: launch geometry, atomics and incremental updates cannot change a single bit of a result.
+//   * S[k][i] = Σ_j D[i,j]·[c_j in slot k]  (and the same for logD) is the n×K sufficient-statistic
+//     table of the sweep (the matsum(D,[i],clust_k) of mcmc.jl:210-213 for every i and k at once).
+//     k_bulk recomputes it from the matrices once per sweep: this is the HBM-bound kernel (2·n²·8 B).
+//     It uses D's symmetry: lanes own columns i, the wave walks rows j grouped by cluster, so the
+//     per-cluster accumulator is a register and every load is a coalesced 16 B/lane row segment.
+//   * The sequential dependence of the sweep is resolved exactly by speculation: every point is scored
+//     and drawn in parallel under "no earlier point of this sweep has changed"; the first point whose
+//     draw differs from its label is the true first change of the sequential sweep; it is committed,
+//     S is corrected for the two clusters involved (exactly — integers), and the points after it are
+//     re-drawn.  Draws are deterministic functions of (state, counter-based uniforms), so the result
+//     is identical to the sequential loop.  k_resolve runs this loop inside ONE persistent launch (one
+//     grid barrier per change); at stationarity it is a single scoring pass.
+//   * Scores use the regrouped arithmetic of SURVEY.md §7 H2 (size-only lgamma terms tabulated on the
+//     host in long double; log(β+S) = log β + log1p(S/β)); terms common to all candidates (L2_i, the
+//     subtracted minimum) are dropped — they cannot change the Gumbel-max argmax.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/redclust_hip.h"
+
+typedef long long ll2 __attribute__((ext_vector_type(2)));
+typedef unsigned long long u64;
+
+#define RC_KEY_NONE 0xFFFFFFFFFFFFFFFFull
+#define RC_SCORE_THREADS 1024
+#define RC_PTS 32          // points per chunk (lanes of a half wave)
+#define RC_MAX_KCAP 4096
+#define RC_SPIN_LIMIT (1u << 22)
+
+// error bits in DevScalars.err
+#define RC_DERR_CAPACITY 1
+#define RC_DERR_BARRIER 2
+
+struct DevScalars {
+    int K;              // number of non-empty clusters
+    int n_changes;      // label changes committed in the last sweep
+    int n_rounds;       // scoring passes of the last sweep
+    int err;            // RC_DERR_* bits
+    int perm_valid;     // perm/pslot describe the current slot_of
+    int pad[3];
+};
+
+// Everything a kernel needs, passed by value.
+struct View {
+    int n, ld, kcap;
+    const long long *Dq, *Lq;  // [n][ld] fixed point
+    const long long *diagq;    // [n] Dq[i][i]
+    long long *SD, *SL;        // [kcap][ld]
+    int *slot_of;              // [n]
+    int *slot_size;            // [kcap]
+    int *slot_label;           // [kcap] 1-based label, 0 = free slot
+    int *perm, *pslot;         // [n] rows grouped by slot, and the slot of each sorted position
+    const double *A;           // [n+1] size table
+    u64 *keys;                 // [n+2] one first-change word per round
+    unsigned *arrive;          // grid-barrier arrival counter
+    DevScalars *sc;
+    double scD, scL;           // 2^-eD, 2^-eL
+    double alpha, beta, zeta, gamma, delta1, delta2, cL;
+    int repulsion;
+    long long maxK;
+};
+
+struct SweepArgs {
+    double r, logp, log1mp;
+    unsigned k0, k1, sw_lo, sw_hi;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Uniform stream: Philox4x32-10, counter (pos, i, sweep_lo, sweep_hi), key = seed.  (include/redclust_hip.h)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rc_uniform(const SweepArgs &a, unsigned i, unsigned pos)
+{
+    unsigned c0 = pos, c1 = i, c2 = a.sw_lo, c3 = a.sw_hi, k0 = a.k0, k1 = a.k1;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const u64 bits = (((u64)c0 << 32) | c1) >> 12;
+    return ((double)bits + 0.5) * 0x1p-52;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Staging (MCMCData, src/types.jl:145-157)
+// ---------------------------------------------------------------------------------------------------
+// flags: bit0 asymmetric, bit1 non-finite, bit2 non-positive off-diagonal entry
+__global__ void k_check(const double *__restrict__ D, int n, unsigned *flags, u64 *maxabs_bits)
+{
+    const size_t total = (size_t)n * n;
+    unsigned f = 0;
+    u64 m = 0;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(t / n), j = (int)(t % n);
+        const double x = D[t];
+        if (x != D[(size_t)j * n + i]) f |= 1u;
+        if (!(fabs(x) <= 1.79769313486231570e308)) f |= 2u;
+        if (i != j && !(x > 0.0)) f |= 4u;
+        const u64 b = (u64)__double_as_longlong(fabs(x));
+        m = b > m ? b : m;
+    }
+    if (f) atomicOr(flags, f);
+    atomicMax(maxabs_bits, m);
+}
+
+__global__ void k_make_log(const double *__restrict__ D, double *__restrict__ L, int n)
+{
+    const size_t total = (size_t)n * n;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(t / n), j = (int)(t % n);
+        L[t] = (i == j) ? 0.0 : log(D[t]);  // types.jl:155: log.(D - Diagonal(D) + I)
+    }
+}
+
+__global__ void k_maxabs(const double *__restrict__ X, size_t total, unsigned *flags, u64 *maxabs_bits)
+{
+    u64 m = 0;
+    unsigned f = 0;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const double x = fabs(X[t]);
+        if (!(x <= 1.79769313486231570e308)) f |= 2u;
+        const u64 b = (u64)__double_as_longlong(x);
+        m = b > m ? b : m;
+    }
+    if (f) atomicOr(flags, f);
+    atomicMax(maxabs_bits, m);
+}
+
+__global__ void k_quantize(const double *__restrict__ X, int n, int ld, int e, long long *__restrict__ Q,
+                           long long *__restrict__ diag_or_null)
+{
+    const size_t total = (size_t)n * n;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(t / n), j = (int)(t % n);
+        const long long q = __double2ll_rn(scalbn(X[t], e));
+        Q[(size_t)i * ld + j] = q;
+        if (diag_or_null && i == j) diag_or_null[i] = q;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// perm / pslot: rows grouped by slot (order inside a group is irrelevant — sums are exact integers).
+// One block.  LDS: 2*kcap ints.
+// ---------------------------------------------------------------------------------------------------
+__device__ void build_perm_block(const View &V, int *lds_off /*kcap*/, int *lds_cur /*kcap*/)
+{
+    for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) lds_cur[k] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < V.n; i += blockDim.x) atomicAdd(&lds_cur[V.slot_of[i]], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int o = 0;
+        for (int k = 0; k < V.kcap; ++k) { lds_off[k] = o; o += lds_cur[k]; }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) lds_cur[k] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < V.n; i += blockDim.x) {
+        const int s = V.slot_of[i];
+        const int p = lds_off[s] + atomicAdd(&lds_cur[s], 1);
+        V.perm[p] = i;
+        V.pslot[p] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) V.sc->perm_valid = 1;
+}
+
+__global__ __launch_bounds__(1024) void k_build_perm(View V)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *off = (int *)smem, *cur = off + V.kcap;
+    build_perm_block(V, off, cur);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_zero: clears the S rows of the active slots (free slots are all-zero by invariant: a cluster that
+// dies has had every contribution subtracted exactly), the per-round key words and the barrier counter.
+// grid (ld/512, kcap), 256 threads.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_zero(View V)
+{
+    const int k = blockIdx.y;
+    if (k == 0) {
+        const int t = blockIdx.x * 256 + threadIdx.x;
+        for (int q = t; q < V.n + 2; q += gridDim.x * 256) V.keys[q] = RC_KEY_NONE;
+        if (t == 0) *V.arrive = 0u;
+    }
+    if (V.slot_size[k] == 0) return;
+    const size_t o = (size_t)k * V.ld + (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
+    const ll2 z = {0, 0};
+    *(ll2 *)(V.SD + o) = z;
+    *(ll2 *)(V.SL + o) = z;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_bulk — THE HBM-BOUND KERNEL.  Row-bucket reduction of D and logD into S (matsum(D,[i],clust_k) and
+// matsum(logD,[i],clust_k), src/mcmc.jl:210-213, for all i and k).  Algorithmic traffic 2·n²·8 bytes.
+//   block = 256 threads = 512 consecutive columns i (2 per lane, 16-byte loads, 4 KiB contiguous per row);
+//   blockIdx.y = split of the cluster-sorted row list; rows of one cluster accumulate in registers and are
+//   flushed with exact 64-bit integer atomics when the cluster changes.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bulk_flush(const View &V, int slot, int i, long long d0, long long d1,
+                                           long long l0, long long l1)
+{
+    u64 *pd = (u64 *)(V.SD + (size_t)slot * V.ld + i);
+    u64 *pl = (u64 *)(V.SL + (size_t)slot * V.ld + i);
+    __hip_atomic_fetch_add(pd, (u64)d0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(pd + 1, (u64)d1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(pl, (u64)l0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(pl + 1, (u64)l1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#define RC_BULK_U 8
+__global__ __launch_bounds__(256) void k_bulk(View V, int rows_per_split)
+{
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 2;
+    const int p0 = blockIdx.y * rows_per_split;
+    const int p1 = min(V.n, p0 + rows_per_split);
+    if (p0 >= p1) return;
+    const int *__restrict__ perm = V.perm;
+    const int *__restrict__ pslot = V.pslot;
+    const long long *__restrict__ Dq = V.Dq + i;
+    const long long *__restrict__ Lq = V.Lq + i;
+    const size_t ld = (size_t)V.ld;
+    long long aD0 = 0, aD1 = 0, aL0 = 0, aL1 = 0;
+    int cur = pslot[p0];
+    int p = p0;
+    for (; p + RC_BULK_U <= p1; p += RC_BULK_U) {
+        int j[RC_BULK_U], s[RC_BULK_U];
+        ll2 d[RC_BULK_U], l[RC_BULK_U];
+#pragma unroll
+        for (int u = 0; u < RC_BULK_U; ++u) { j[u] = perm[p + u]; s[u] = pslot[p + u]; }
+#pragma unroll
+        for (int u = 0; u < RC_BULK_U; ++u) {
+            d[u] = *(const ll2 *)(Dq + (size_t)j[u] * ld);
+            l[u] = *(const ll2 *)(Lq + (size_t)j[u] * ld);
+        }
+#pragma unroll
+        for (int u = 0; u < RC_BULK_U; ++u) {
+            if (s[u] != cur) {
+                bulk_flush(V, cur, i, aD0, aD1, aL0, aL1);
+                aD0 = aD1 = aL0 = aL1 = 0;
+                cur = s[u];
+            }
+            aD0 += d[u].x; aD1 += d[u].y; aL0 += l[u].x; aL1 += l[u].y;
+        }
+    }
+    for (; p < p1; ++p) {
+        const int j = perm[p], s = pslot[p];
+        const ll2 d = *(const ll2 *)(Dq + (size_t)j * ld);
+        const ll2 l = *(const ll2 *)(Lq + (size_t)j * ld);
+        if (s != cur) {
+            bulk_flush(V, cur, i, aD0, aD1, aL0, aL1);
+            aD0 = aD1 = aL0 = aL1 = 0;
+            cur = s;
+        }
+        aD0 += d.x; aD1 += d.y; aL0 += l.x; aL1 += l.y;
+    }
+    bulk_flush(V, cur, i, aD0, aD1, aL0, aL1);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Slot tables replicated in LDS by every block of k_resolve.
+// ---------------------------------------------------------------------------------------------------
+struct Tab {
+    int *size;       // [kcap]
+    int *label;      // [kcap] 0 = free
+    short *pos;      // [kcap] rank of the slot's label among active labels (candidate order, mcmc.jl:195)
+    short *act;      // [kcap] act[pos] = slot
+    double *base_o;  // [kcap] A[s] + log p + log(s-1+r), s = size          (candidate cluster of another point)
+    double *base_s;  // [kcap] same with s = size-1                          (the point's own cluster, itself removed)
+    unsigned *used;  // [(n+31)/32] label occupancy bitset, bit (label-1)
+    double *red_v;   // [NS][32] reduction scratch
+    int *red_pos, *red_slot;
+    int *misc;       // [0]=K [1]=smallest_empty(1-based, n+1 if none) [2]=scratch min [3]=b [4]=structural [5]=fail [6]=barrier ok
+    u64 *blk_key;    // block-local first-change key
+};
+
+__device__ __forceinline__ size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+__device__ Tab tab_carve(char *smem, int kcap, int n, int ns)
+{
+    Tab T;
+    size_t o = 0;
+    T.base_o = (double *)(smem + o); o = align16(o + sizeof(double) * kcap);
+    T.base_s = (double *)(smem + o); o = align16(o + sizeof(double) * kcap);
+    T.red_v = (double *)(smem + o); o = align16(o + sizeof(double) * ns * RC_PTS);
+    T.blk_key = (u64 *)(smem + o); o = align16(o + sizeof(u64));
+    T.size = (int *)(smem + o); o = align16(o + sizeof(int) * kcap);
+    T.label = (int *)(smem + o); o = align16(o + sizeof(int) * kcap);
+    T.red_pos = (int *)(smem + o); o = align16(o + sizeof(int) * ns * RC_PTS);
+    T.red_slot = (int *)(smem + o); o = align16(o + sizeof(int) * ns * RC_PTS);
+    T.used = (unsigned *)(smem + o); o = align16(o + sizeof(unsigned) * ((n + 31) / 32));
+    T.misc = (int *)(smem + o); o = align16(o + sizeof(int) * 8);
+    T.pos = (short *)(smem + o); o = align16(o + sizeof(short) * kcap);
+    T.act = (short *)(smem + o); o = align16(o + sizeof(short) * kcap);
+    return T;
+}
+
+static size_t tab_bytes(int kcap, int n, int ns)
+{
+    auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    size_t o = 0;
+    o = a16(o + sizeof(double) * kcap);
+    o = a16(o + sizeof(double) * kcap);
+    o = a16(o + sizeof(double) * ns * RC_PTS);
+    o = a16(o + sizeof(u64));
+    o = a16(o + sizeof(int) * kcap);
+    o = a16(o + sizeof(int) * kcap);
+    o = a16(o + sizeof(int) * ns * RC_PTS);
+    o = a16(o + sizeof(int) * ns * RC_PTS);
+    o = a16(o + sizeof(unsigned) * ((n + 31) / 32));
+    o = a16(o + sizeof(int) * 8);
+    o = a16(o + sizeof(short) * kcap);
+    o = a16(o + sizeof(short) * kcap);
+    return o;
+}
+
+__device__ __forceinline__ double tab_base(const View &V, const SweepArgs &a, int s)
+{
+    // A[s] + (log p + log(s - 1 + r)): size-only terms of mcmc.jl:223-226,240-241 (see orc_size_table)
+    return V.A[s] + (a.logp + log((double)s - 1.0 + a.r));
+}
+
+// ranks (candidate order = ascending label), act list, base constants.  All threads; ends synchronised.
+__device__ void tab_derive(const View &V, const SweepArgs &a, Tab &T)
+{
+    const int kcap = V.kcap;
+    for (int k = threadIdx.x; k < kcap; k += blockDim.x) {
+        const int lab = T.label[k];
+        if (lab > 0) {
+            int c = 0;
+            for (int q = 0; q < kcap; ++q) {
+                const int lq = T.label[q];
+                c += (lq > 0 && lq < lab);
+            }
+            T.pos[k] = (short)c;
+            T.act[c] = (short)k;
+            const int s = T.size[k];
+            T.base_o[k] = tab_base(V, a, s);
+            T.base_s[k] = (s >= 2) ? tab_base(V, a, s - 1) : 0.0;
+        }
+    }
+    __syncthreads();
+}
+
+// smallest empty label from the bitset (findfirst(clustsizes .== 0), mcmc.jl:199).  Ends synchronised.
+__device__ void tab_smallest_empty(const View &V, Tab &T)
+{
+    if (threadIdx.x == 0) T.misc[2] = V.n + 1;
+    __syncthreads();
+    const int nw = (V.n + 31) / 32;
+    for (int w = threadIdx.x; w < nw; w += blockDim.x) {
+        const unsigned inv = ~T.used[w];
+        if (inv) {
+            const int lab = w * 32 + __ffs((int)inv);  // 1-based label
+            if (lab <= V.n) atomicMin(&T.misc[2], lab);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) T.misc[1] = T.misc[2];
+    __syncthreads();
+}
+
+__device__ void tab_load(const View &V, const SweepArgs &a, Tab &T)
+{
+    const int nw = (V.n + 31) / 32;
+    for (int w = threadIdx.x; w < nw; w += blockDim.x) T.used[w] = 0u;
+    for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) {
+        T.size[k] = V.slot_size[k];
+        T.label[k] = V.slot_label[k];
+    }
+    if (threadIdx.x == 0) { T.misc[0] = V.sc->K; *T.blk_key = RC_KEY_NONE; }
+    __syncthreads();
+    for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) {
+        const int lab = T.label[k];
+        if (lab > 0) atomicOr(&T.used[(lab - 1) >> 5], 1u << ((lab - 1) & 31));
+    }
+    __syncthreads();
+    tab_smallest_empty(V, T);
+    tab_derive(V, a, T);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Scoring + Gumbel-max draw of one chunk of 32 points (src/mcmc.jl:192-252 for each point of the chunk,
+// src/utils.jl:2-6 for the draw), under the state held in T.  Thread (pt, st): point pt of the chunk,
+// candidate positions st, st+NS, ...  Points with index <= after_i are skipped (already final).
+// ---------------------------------------------------------------------------------------------------
+__device__ void score_chunk(const View &V, const SweepArgs &a, Tab &T, int chunk, int after_i)
+{
+    const int pt = threadIdx.x & (RC_PTS - 1), st = threadIdx.x >> 5, NS = blockDim.x >> 5;
+    const int i = chunk * RC_PTS + pt;
+    const bool valid = (i < V.n) && (i > after_i);
+    const int K = T.misc[0];
+    double bestv = -INFINITY;
+    int bestpos = 0x7fffffff, bestslot = -2;
+    int own = 0, Ki = K, single = 0;
+    if (valid) {
+        own = V.slot_of[i];
+        single = (T.size[own] == 1);
+        const int pown = T.pos[own];
+        Ki = K - single;
+        const long long dg = V.diagq[i];
+        const size_t ld = (size_t)V.ld;
+        for (int pos = st; pos < K; pos += NS) {
+            const int k = T.act[pos];
+            const int isown = (k == own);
+            const int s = T.size[k] - isown;
+            if (s == 0) continue;  // own singleton cluster: not a candidate once i is removed (mcmc.jl:193-196)
+            const int pe = pos - (single && pos > pown);
+            const long long sd = V.SD[(size_t)k * ld + i] - (isown ? dg : 0);  // i itself excluded (clusts[i] = -1)
+            const long long sl = V.SL[(size_t)k * ld + i];                      // logD diagonal is 0 (types.jl:155)
+            const double SDr = (double)sd * V.scD, SLr = (double)sl * V.scL;
+            const double base = isown ? T.base_s[k] : T.base_o[k];
+            double lik = V.cL * SLr - (V.alpha + V.delta1 * (double)s) * log1p(SDr / V.beta);
+            if (V.repulsion) lik += (V.zeta + V.delta2 * (double)s) * log1p(SDr / V.gamma);
+            const double u = rc_uniform(a, (unsigned)i, (unsigned)pe);
+            const double v = (base + lik) + (-log(-log(u)));
+            if (v > bestv) { bestv = v; bestpos = pe; bestslot = k; }
+        }
+        // new-cluster candidate, last position (mcmc.jl:198-203, 228-230); one stream handles it
+        if (st == (K % NS) && (V.maxK == 0 || (long long)Ki < V.maxK) && Ki < V.n) {
+            const double u = rc_uniform(a, (unsigned)i, (unsigned)Ki);
+            const double v = (log((double)(Ki + 1)) + a.r * a.log1mp) + (-log(-log(u)));
+            if (v > bestv || bestslot == -2) { bestv = v; bestpos = Ki; bestslot = -1; }
+        }
+    }
+    T.red_v[st * RC_PTS + pt] = bestv;
+    T.red_pos[st * RC_PTS + pt] = bestpos;
+    T.red_slot[st * RC_PTS + pt] = bestslot;
+    __syncthreads();
+    if (st == 0 && valid) {
+        for (int q = 1; q < NS; ++q) {
+            const int sl = T.red_slot[q * RC_PTS + pt];
+            if (sl == -2) continue;
+            const double v = T.red_v[q * RC_PTS + pt];
+            const int ps = T.red_pos[q * RC_PTS + pt];
+            if (bestslot == -2 || v > bestv || (v == bestv && ps < bestpos)) { bestv = v; bestpos = ps; bestslot = sl; }
+        }
+        bool changed;
+        if (bestslot >= 0) {
+            changed = (bestslot != own);
+        } else {
+            // new label = smallest empty label once i is removed (mcmc.jl:199)
+            const int se = T.misc[1];
+            const int newlab = single ? min(T.label[own], se) : se;
+            changed = !(single && newlab == T.label[own]);
+        }
+        if (changed) {
+            const u64 key = ((u64)(unsigned)i << 32) | ((u64)(unsigned)own << 16) | (u64)(unsigned)(bestslot + 1);
+            atomicMin(T.blk_key, key);
+        }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Commit of the first change (i*, own slot a, target) — executed identically by every block on its LDS
+// copy of the tables; each block then corrects S for the points it owns.  Returns false on capacity
+// overflow (flag set).  mcmc.jl:250-252 plus the bookkeeping the reference does with findall each time.
+// ---------------------------------------------------------------------------------------------------
+__device__ bool commit_change(const View &V, const SweepArgs &sa, Tab &T, u64 key, int G)
+{
+    const int istar = (int)(key >> 32);
+    const int a = (int)((key >> 16) & 0xFFFFu);
+    const int tgt = (int)(key & 0xFFFFu) - 1;
+    int b = tgt;
+    bool structural = false;  // birth / death / rename: ranks and smallest-empty must be rebuilt
+    int &sh_b = T.misc[3], &sh_struct = T.misc[4], &sh_fail = T.misc[5];
+    if (threadIdx.x == 0) {
+        sh_fail = 0;
+        int st = 0;
+        if (tgt >= 0) {
+            T.size[a] -= 1;
+            T.size[b] += 1;
+            if (T.size[a] == 0) {  // death
+                const int lab = T.label[a];
+                T.used[(lab - 1) >> 5] &= ~(1u << ((lab - 1) & 31));
+                T.label[a] = 0;
+                T.misc[0] -= 1;
+                st = 1;
+            }
+        } else if (T.size[a] == 1) {  // singleton moves to a fresh label: rename the slot, S column unchanged
+            const int lab = T.label[a], nl = T.misc[1];
+            T.used[(lab - 1) >> 5] &= ~(1u << ((lab - 1) & 31));
+            T.used[(nl - 1) >> 5] |= 1u << ((nl - 1) & 31);
+            T.label[a] = nl;
+            b = a;
+            st = 1;
+        } else {  // birth
+            int f = -1;
+            for (int k = 0; k < V.kcap; ++k)
+                if (T.label[k] == 0) { f = k; break; }
+            if (f < 0) {
+                sh_fail = 1;
+            } else {
+                const int nl = T.misc[1];
+                b = f;
+                T.label[b] = nl;
+                T.size[b] = 1;
+                T.size[a] -= 1;
+                T.used[(nl - 1) >> 5] |= 1u << ((nl - 1) & 31);
+                T.misc[0] += 1;
+                st = 1;
+            }
+        }
+        sh_b = b;
+        sh_struct = st;
+    }
+    __syncthreads();
+    if (sh_fail) {
+        if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(&V.sc->err, RC_DERR_CAPACITY);
+        return false;
+    }
+    b = sh_b;
+    structural = sh_struct != 0;
+    if (structural) {
+        tab_smallest_empty(V, T);
+        tab_derive(V, sa, T);
+    } else {
+        if (threadIdx.x < 2) {
+            const int k = threadIdx.x == 0 ? a : b;
+            const int s = T.size[k];
+            T.base_o[k] = tab_base(V, sa, s);
+            T.base_s[k] = (s >= 2) ? tab_base(V, sa, s - 1) : 0.0;
+        }
+        __syncthreads();
+    }
+    // S correction for the points this block owns: S[a][i] -= D[i*,i], S[b][i] += D[i*,i] (exact)
+    if (a != b) {
+        const int nchunks = (V.n + RC_PTS - 1) / RC_PTS;
+        const int pt = threadIdx.x & (RC_PTS - 1), job = threadIdx.x >> 5;  // jobs 0..3 used
+        if (job < 4) {
+            const long long *M = (job < 2) ? V.Dq : V.Lq;
+            long long *S = (job < 2) ? V.SD : V.SL;
+            const int slot = (job & 1) ? b : a;
+            const long long sign = (job & 1) ? 1 : -1;
+            for (int c = blockIdx.x; c < nchunks; c += G) {
+                const int i = c * RC_PTS + pt;
+                if (i < V.n) S[(size_t)slot * V.ld + i] += sign * M[(size_t)istar * V.ld + i];
+            }
+        }
+    }
+    if (threadIdx.x == 0) V.slot_of[istar] = b;  // same value from every block
+    __syncthreads();
+    return true;
+}
+
+// Grid barrier: monotonic arrival counter; lane 0 of each block arrives after its (returning) atomicMin
+// on the round's key word, so every block's candidate is in the word before anyone leaves.  Bounded spin.
+__device__ bool grid_barrier(const View &V, Tab &T, unsigned target, u64 my_key, u64 *key_word)
+{
+    int &sh_ok = T.misc[6];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned inc = 1u;
+        if (my_key != RC_KEY_NONE) {
+            const u64 old = atomicMin(key_word, my_key);
+            inc += (old == 0x1234567887654321ull) ? 0u : 0u;  // data dependence: the min has been performed
+            asm volatile("" ::"v"((unsigned)old));
+        }
+        __hip_atomic_fetch_add(V.arrive, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        int ok = 1;
+        while (__hip_atomic_load(V.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > RC_SPIN_LIMIT) { ok = 0; atomicOr(&V.sc->err, RC_DERR_BARRIER); break; }
+        }
+        sh_ok = ok;
+    }
+    __syncthreads();
+    return sh_ok != 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_resolve — one persistent launch per sweep: round 0 scores every point; each further round commits the
+// first change and re-draws the points after it.  G blocks (all co-resident: G <= 256, one per CU).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RC_SCORE_THREADS) void k_resolve(View V, SweepArgs sa, int G)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Tab T = tab_carve(smem, V.kcap, V.n, blockDim.x >> 5);
+    tab_load(V, sa, T);
+    const int nchunks = (V.n + RC_PTS - 1) / RC_PTS;
+    int after = -1, round = 0, changes = 0;
+    bool ok = true;
+    for (;;) {
+        for (int c = blockIdx.x; c < nchunks; c += G)
+            if (c * RC_PTS + RC_PTS - 1 > after) score_chunk(V, sa, T, c, after);
+        __syncthreads();
+        const u64 mine = *T.blk_key;
+        ok = grid_barrier(V, T, (unsigned)G * (unsigned)(round + 1), mine, V.keys + round);
+        if (!ok) break;
+        const u64 key = __hip_atomic_load(V.keys + round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (key == RC_KEY_NONE) break;
+        if (threadIdx.x == 0) *T.blk_key = RC_KEY_NONE;
+        ok = commit_change(V, sa, T, key, G);
+        if (!ok) break;
+        after = (int)(key >> 32);
+        ++round;
+        ++changes;
+        if (round > V.n) break;  // cannot happen: each round finalises at least one more point
+    }
+    if (blockIdx.x == 0) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) {
+            V.slot_size[k] = T.size[k];
+            V.slot_label[k] = T.label[k];
+        }
+        if (threadIdx.x == 0) {
+            V.sc->K = T.misc[0];
+            V.sc->n_changes = changes;
+            V.sc->n_rounds = round + 1;
+            if (changes) V.sc->perm_valid = 0;
+        }
+        __syncthreads();
+        if (changes && ok) {
+            // rows must be regrouped before the next k_bulk; LDS tables are no longer needed
+            int *off = (int *)smem, *cur = off + V.kcap;
+            __syncthreads();
+            build_perm_block(V, off, cur);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// loglik block sums (src/mcmc.jl:26-53): B[k][t] = Σ_{i in slot k} S[t][i], accumulated as (hi, lo) halves
+// so that n² terms cannot overflow 64 bits.  One block per slot t; LDS bins per slot k.
+// out[(t*kcap + k)*4 + {0,1,2,3}] = D_hi, D_lo, L_hi, L_lo
+// ---------------------------------------------------------------------------------------------------
+#define RC_LO_BITS 24
+__global__ __launch_bounds__(256) void k_blocksums(View V, long long *out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64 *bins = (u64 *)smem;  // [kcap][4]
+    const int t = blockIdx.x;
+    if (V.slot_size[t] == 0) return;
+    for (int q = threadIdx.x; q < V.kcap * 4; q += blockDim.x) bins[q] = 0;
+    __syncthreads();
+    const long long mask = ((long long)1 << RC_LO_BITS) - 1;
+    for (int i = threadIdx.x; i < V.n; i += blockDim.x) {
+        const int k = V.slot_of[i];
+        const long long d = V.SD[(size_t)t * V.ld + i], l = V.SL[(size_t)t * V.ld + i];
+        atomicAdd(&bins[k * 4 + 0], (u64)(d >> RC_LO_BITS));
+        atomicAdd(&bins[k * 4 + 1], (u64)(d & mask));
+        atomicAdd(&bins[k * 4 + 2], (u64)(l >> RC_LO_BITS));
+        atomicAdd(&bins[k * 4 + 3], (u64)(l & mask));
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < V.kcap * 4; q += blockDim.x) out[(size_t)t * V.kcap * 4 + q] = (long long)bins[q];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Co-clustering counts: counts[i][j] += (c_i == c_j)   (adjacencymatrix, src/utils.jl:59-63; the sum of
+// src/mcmc.jl:560).  uint32 — exact.  grid (ceil(n/1024), n), 256 threads, 4 columns per thread.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cocluster_add(const int *__restrict__ slot_of, int n, int ldc,
+                                                      unsigned *__restrict__ counts)
+{
+    const int i = blockIdx.y;
+    const int j0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (j0 >= n) return;
+    const int ci = slot_of[i];
+    unsigned *row = counts + (size_t)i * ldc + j0;
+    if (j0 + 3 < n) {
+        uint4 c = *(uint4 *)row;
+        const int4 s = *(const int4 *)(slot_of + j0);
+        c.x += (s.x == ci); c.y += (s.y == ci); c.z += (s.z == ci); c.w += (s.w == ci);
+        *(uint4 *)row = c;
+    } else {
+        for (int q = 0; q < 4 && j0 + q < n; ++q) row[q] += (slot_of[j0 + q] == ci);
+    }
+}
+
+__global__ void k_cocluster_final(const unsigned *__restrict__ counts, int n, int ldc, double inv,
+                                  double *__restrict__ out)
+{
+    const size_t total = (size_t)n * n;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = t / n, j = t % n;
+        out[t] = (double)counts[i * ldc + j] * inv;  // ./ numsamples, mcmc.jl:560
+    }
+}
+
+// ===================================================================================================
+// Host side
+// ===================================================================================================
+struct rc_ctx {
+    int dev = 0;
+    int n = 0, ld = 0, kcap = 0;
+    int eD = 0, eL = 0;
+    hipStream_t stream = nullptr;
+    long long *Dq = nullptr, *Lq = nullptr, *diagq = nullptr, *SD = nullptr, *SL = nullptr;
+    int *slot_of = nullptr, *slot_size = nullptr, *slot_label = nullptr, *perm = nullptr, *pslot = nullptr;
+    double *A = nullptr;
+    u64 *keys = nullptr;
+    unsigned *arrive = nullptr;
+    DevScalars *sc = nullptr;
+    long long *blocks = nullptr;  // k_blocksums output [kcap][kcap][4]
+    unsigned *counts = nullptr;   // co-clustering counts [n][ldc]
+    int ldc = 0;
+    double *cc_out = nullptr;
+    rc_params P{};
+    bool have_params = false, have_state = false, S_valid = false;
+    int G = 256;
+    int rows_per_split = 128;
+    int num_cus = 256;
+    // timing of k_bulk
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
+    double bulk_ms = 0.0;
+    long long bulk_launches = 0;
+    DevScalars last{};
+    char err[512] = {0};
+};
+
+static thread_local char g_err[512] = {0};
+
+static int32_t fail(rc_ctx *c, int32_t code, const char *fmt, ...)
+{
+    char *dst = c ? c->err : g_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    if (c) snprintf(g_err, sizeof(g_err), "%s", c->err);
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                               \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return fail(c, (e_ == hipErrorOutOfMemory) ? RC_ERR_OOM : RC_ERR_HIP, "%s failed: %s (%s:%d)", #call, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                   \
+    } while (0)
+
+static View make_view(const rc_ctx *c)
+{
+    View V{};
+    V.n = c->n; V.ld = c->ld; V.kcap = c->kcap;
+    V.Dq = c->Dq; V.Lq = c->Lq; V.diagq = c->diagq; V.SD = c->SD; V.SL = c->SL;
+    V.slot_of = c->slot_of; V.slot_size = c->slot_size; V.slot_label = c->slot_label;
+    V.perm = c->perm; V.pslot = c->pslot; V.A = c->A; V.keys = c->keys; V.arrive = c->arrive; V.sc = c->sc;
+    V.scD = std::ldexp(1.0, -c->eD); V.scL = std::ldexp(1.0, -c->eL);
+    V.alpha = c->P.alpha; V.beta = c->P.beta; V.zeta = c->P.zeta; V.gamma = c->P.gamma;
+    V.delta1 = c->P.delta1; V.delta2 = c->P.delta2;
+    V.repulsion = c->P.repulsion ? 1 : 0;
+    V.cL = (c->P.delta1 - 1.0) - (c->P.repulsion ? (c->P.delta2 - 1.0) : 0.0);
+    V.maxK = c->P.maxK;
+    return V;
+}
+
+static int ceil_log2_ll(long long n)
+{
+    int b = 0;
+    while (((long long)1 << b) < n) ++b;
+    return b;
+}
+
+static int quant_exponent(long long n, double maxabs)
+{
+    if (maxabs == 0.0) return 0;
+    int ex;
+    std::frexp(maxabs, &ex);
+    return 62 - ex - ceil_log2_ll(n);
+}
+
+extern "C" const char *rc_last_error(const rc_ctx *ctx) { return ctx ? ctx->err : g_err; }
+
+static void free_all(rc_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->dev);
+    void *ptrs[] = {c->Dq, c->Lq, c->diagq, c->SD, c->SL, c->slot_of, c->slot_size, c->slot_label, c->perm,
+                    c->pslot, c->A, c->keys, c->arrive, c->sc, c->blocks, c->counts, c->cc_out};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto &e : c->ev_pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto &e : c->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int32_t rc_destroy(rc_ctx *ctx)
+{
+    if (!ctx) return RC_OK;
+    (void)hipSetDevice(ctx->dev);
+    (void)hipDeviceSynchronize();
+    free_all(ctx);
+    return RC_OK;
+}
+
+static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *logD)
+{
+    HIPCHK(c, hipSetDevice(c->dev));
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, c->dev));
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const size_t nn = (size_t)n * n;
+    const size_t ld = (size_t)c->ld;
+    double *tmpD = nullptr, *tmpL = nullptr;
+    unsigned *flags = nullptr;
+    u64 *mx = nullptr;
+    auto cleanup = [&]() {
+        if (tmpD) (void)hipFree(tmpD);
+        if (tmpL) (void)hipFree(tmpL);
+        if (flags) (void)hipFree(flags);
+        if (mx) (void)hipFree(mx);
+    };
+#define HIPCHK2(call)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess) {                                                                           \
+            cleanup();                                                                                    \
+            return fail(c, (e_ == hipErrorOutOfMemory) ? RC_ERR_OOM : RC_ERR_HIP, "%s failed: %s (%s:%d)", #call, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                       \
+        }                                                                                                 \
+    } while (0)
+    HIPCHK2(hipMalloc(&tmpD, nn * sizeof(double)));
+    HIPCHK2(hipMalloc(&tmpL, nn * sizeof(double)));
+    HIPCHK2(hipMalloc(&flags, 2 * sizeof(unsigned)));
+    HIPCHK2(hipMalloc(&mx, 2 * sizeof(u64)));
+    HIPCHK2(hipMalloc(&c->Dq, (size_t)n * ld * sizeof(long long)));
+    HIPCHK2(hipMalloc(&c->Lq, (size_t)n * ld * sizeof(long long)));
+    HIPCHK2(hipMalloc(&c->diagq, (size_t)n * sizeof(long long)));
+    HIPCHK2(hipMalloc(&c->SD, (size_t)c->kcap * ld * sizeof(long long)));
+    HIPCHK2(hipMalloc(&c->SL, (size_t)c->kcap * ld * sizeof(long long)));
+    HIPCHK2(hipMalloc(&c->slot_of, (size_t)n * sizeof(int)));
+    HIPCHK2(hipMalloc(&c->slot_size, (size_t)c->kcap * sizeof(int)));
+    HIPCHK2(hipMalloc(&c->slot_label, (size_t)c->kcap * sizeof(int)));
+    HIPCHK2(hipMalloc(&c->perm, (size_t)n * sizeof(int)));
+    HIPCHK2(hipMalloc(&c->pslot, (size_t)n * sizeof(int)));
+    HIPCHK2(hipMalloc(&c->A, (size_t)(n + 1) * sizeof(double)));
+    HIPCHK2(hipMalloc(&c->keys, (size_t)(n + 2) * sizeof(u64)));
+    HIPCHK2(hipMalloc(&c->arrive, 64));
+    HIPCHK2(hipMalloc(&c->sc, sizeof(DevScalars)));
+    HIPCHK2(hipMalloc(&c->blocks, (size_t)c->kcap * c->kcap * 4 * sizeof(long long)));
+    HIPCHK2(hipMemsetAsync(c->Dq, 0, (size_t)n * ld * sizeof(long long), c->stream));
+    HIPCHK2(hipMemsetAsync(c->Lq, 0, (size_t)n * ld * sizeof(long long), c->stream));
+    HIPCHK2(hipMemsetAsync(c->SD, 0, (size_t)c->kcap * ld * sizeof(long long), c->stream));
+    HIPCHK2(hipMemsetAsync(c->SL, 0, (size_t)c->kcap * ld * sizeof(long long), c->stream));
+    HIPCHK2(hipMemsetAsync(c->slot_size, 0, (size_t)c->kcap * sizeof(int), c->stream));
+    HIPCHK2(hipMemsetAsync(c->slot_label, 0, (size_t)c->kcap * sizeof(int), c->stream));
+    HIPCHK2(hipMemsetAsync(c->sc, 0, sizeof(DevScalars), c->stream));
+    HIPCHK2(hipMemsetAsync(flags, 0, 2 * sizeof(unsigned), c->stream));
+    HIPCHK2(hipMemsetAsync(mx, 0, 2 * sizeof(u64), c->stream));
+    HIPCHK2(hipMemcpyAsync(tmpD, D, nn * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const int gb = std::min<size_t>((nn + 255) / 256, 4096);
+    k_check<<<gb, 256, 0, c->stream>>>(tmpD, (int)n, flags, mx);
+    if (logD) {
+        HIPCHK2(hipMemcpyAsync(tmpL, logD, nn * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    } else {
+        k_make_log<<<gb, 256, 0, c->stream>>>(tmpD, tmpL, (int)n);
+    }
+    k_maxabs<<<gb, 256, 0, c->stream>>>(tmpL, nn, flags + 1, mx + 1);
+    unsigned hflags[2];
+    u64 hmx[2];
+    HIPCHK2(hipMemcpyAsync(hflags, flags, sizeof(hflags), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK2(hipMemcpyAsync(hmx, mx, sizeof(hmx), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK2(hipStreamSynchronize(c->stream));
+    HIPCHK2(hipGetLastError());
+    if (hflags[0] & 1u) { cleanup(); return fail(c, RC_ERR_DOMAIN, "D must be symmetric."); }
+    if (hflags[0] & 2u) { cleanup(); return fail(c, RC_ERR_DOMAIN, "D must be finite."); }
+    if (!logD && (hflags[0] & 4u)) {
+        cleanup();
+        return fail(c, RC_ERR_DOMAIN, "off-diagonal entries of D must be positive (log D = -Inf / NaN otherwise).");
+    }
+    if (hflags[1] & 2u) { cleanup(); return fail(c, RC_ERR_DOMAIN, "logD must be finite."); }
+    double maxD, maxL;
+    std::memcpy(&maxD, &hmx[0], 8);
+    std::memcpy(&maxL, &hmx[1], 8);
+    c->eD = quant_exponent(n, maxD);
+    c->eL = quant_exponent(n, maxL);
+    k_quantize<<<gb, 256, 0, c->stream>>>(tmpD, (int)n, c->ld, c->eD, c->Dq, c->diagq);
+    k_quantize<<<gb, 256, 0, c->stream>>>(tmpL, (int)n, c->ld, c->eL, c->Lq, nullptr);
+    HIPCHK2(hipStreamSynchronize(c->stream));
+    HIPCHK2(hipGetLastError());
+    cleanup();
+#undef HIPCHK2
+    return RC_OK;
+}
+
+extern "C" int32_t rc_create(int64_t n, const double *D, const double *logD_or_null, int32_t storage_bits,
+                             int32_t device_id, int64_t kcap, rc_ctx **out)
+{
+    if (!out) return fail(nullptr, RC_ERR_ARG, "rc_create: out is NULL");
+    *out = nullptr;
+    if (!D) return fail(nullptr, RC_ERR_ARG, "rc_create: D is NULL");
+    if (n < 1 || n > (1 << 20)) return fail(nullptr, RC_ERR_ARG, "rc_create: n must be in 1..2^20 (got %lld)", (long long)n);
+    if (storage_bits != 64) return fail(nullptr, RC_ERR_ARG, "rc_create: storage_bits must be 64 in this build");
+    if (kcap == 0) kcap = std::min<int64_t>(n, 256);
+    if (kcap < 1 || kcap > RC_MAX_KCAP) return fail(nullptr, RC_ERR_ARG, "rc_create: kcap must be in 1..%d", RC_MAX_KCAP);
+    if (kcap > n) kcap = n;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1) return fail(nullptr, RC_ERR_HIP, "no HIP device available (%s)", hipGetErrorString(e));
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, RC_ERR_ARG, "rc_create: device_id %d out of range (0..%d)", device_id, ndev - 1);
+    rc_ctx *c = new (std::nothrow) rc_ctx();
+    if (!c) return fail(nullptr, RC_ERR_OOM, "rc_create: host allocation failed");
+    c->dev = device_id;
+    c->n = (int)n;
+    c->ld = (int)(((n + 511) / 512) * 512);
+    c->kcap = (int)kcap;
+    int32_t rc = create_impl(c, n, D, logD_or_null);
+    if (rc != RC_OK) {
+        snprintf(g_err, sizeof(g_err), "%s", c->err);
+        free_all(c);
+        return rc;
+    }
+    const int nchunks = (c->n + RC_PTS - 1) / RC_PTS;
+    c->G = std::max(1, std::min(nchunks, c->num_cus));
+    {
+        // kernels whose dynamic LDS can exceed the 64 KiB default (large kcap)
+        const size_t lds_r = std::max(tab_bytes(c->kcap, c->n, RC_SCORE_THREADS / 32), 2 * sizeof(int) * (size_t)c->kcap);
+        const size_t lds_b = (size_t)c->kcap * 4 * sizeof(u64);
+        hipError_t e1 = hipFuncSetAttribute((const void *)k_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
+        hipError_t e2 = hipFuncSetAttribute((const void *)k_blocksums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+        if (e1 != hipSuccess || e2 != hipSuccess || lds_r > 160 * 1024 || lds_b > 160 * 1024) {
+            fail(nullptr, RC_ERR_ARG, "rc_create: kcap=%d needs more LDS than a CU has", c->kcap);
+            free_all(c);
+            return RC_ERR_ARG;
+        }
+    }
+    *out = c;
+    return RC_OK;
+}
+
+extern "C" int32_t rc_set_params(rc_ctx *c, const rc_params *P)
+{
+    if (!c || !P) return fail(c, RC_ERR_ARG, "rc_set_params: NULL argument");
+    if (!(P->delta1 > 0 && P->delta2 > 0 && P->alpha > 0 && P->beta > 0 && P->zeta > 0 && P->gamma > 0))
+        return fail(c, RC_ERR_ARG, "rc_set_params: likelihood hyperparameters must be positive");
+    if (P->maxK < 0) return fail(c, RC_ERR_ARG, "rc_set_params: maxK must be >= 0");
+    HIPCHK(c, hipSetDevice(c->dev));
+    c->P = *P;
+    // size table (see DESIGN.md "Score arithmetic"): long double on the host, once per parameter set
+    std::vector<double> A((size_t)c->n + 1);
+    const long double d1 = P->delta1, d2 = P->delta2, al = P->alpha, be = P->beta, ze = P->zeta, ga = P->gamma;
+    const long double lga = lgammal(al), lgz = lgammal(ze), lgd1 = lgammal(d1), lgd2 = lgammal(d2);
+    const long double lb = logl(be), lg = logl(ga);
+    A[0] = 0.0;
+    for (int s = 1; s <= c->n; ++s) {
+        const long double S = (long double)s;
+        const long double t1 = lgammal(al + d1 * S) - lga - d1 * S * lb - S * lgd1;
+        const long double t2 = lgammal(ze + d2 * S) - lgz - d2 * S * lg - S * lgd2;
+        A[(size_t)s] = (double)(t1 - (P->repulsion ? t2 : 0.0L) + logl((S + 1) / S));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->A, A.data(), A.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_params = true;
+    return RC_OK;
+}
+
+static int32_t drain_events(rc_ctx *c)
+{
+    for (auto &e : c->ev_pending) {
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, e.first, e.second));
+        c->bulk_ms += ms;
+        c->bulk_launches += 1;
+        c->ev_free.push_back(e);
+    }
+    c->ev_pending.clear();
+    return RC_OK;
+}
+
+static int32_t sync_and_check(rc_ctx *c)
+{
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    int32_t rc = drain_events(c);
+    if (rc != RC_OK) return rc;
+    HIPCHK(c, hipMemcpy(&c->last, c->sc, sizeof(DevScalars), hipMemcpyDeviceToHost));
+    if (c->last.err & RC_DERR_BARRIER) return fail(c, RC_ERR_HIP, "grid barrier timed out inside the sweep kernel");
+    if (c->last.err & RC_DERR_CAPACITY)
+        return fail(c, RC_ERR_CAPACITY, "number of clusters exceeded the slot capacity kcap=%d given to rc_create", c->kcap);
+    return RC_OK;
+}
+
+extern "C" int32_t rc_synchronize(rc_ctx *c)
+{
+    if (!c) return fail(c, RC_ERR_ARG, "rc_synchronize: NULL ctx");
+    HIPCHK(c, hipSetDevice(c->dev));
+    return sync_and_check(c);
+}
+
+extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
+{
+    if (!c || !clusts) return fail(c, RC_ERR_ARG, "rc_set_state: NULL argument");
+    HIPCHK(c, hipSetDevice(c->dev));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int n = c->n;
+    // clustsizes = counts(clusts, 1:n), K = sum(clustsizes .> 0)  (types.jl:135-136); slots in label order
+    std::vector<int> size_by_label((size_t)n + 1, 0);
+    for (int i = 0; i < n; ++i) {
+        if (clusts[i] < 1 || clusts[i] > n) return fail(c, RC_ERR_ARG, "rc_set_state: label %lld of point %d outside 1..n", (long long)clusts[i], i + 1);
+        size_by_label[(size_t)clusts[i]]++;
+    }
+    std::vector<int> slot_of_label((size_t)n + 1, -1), ssize((size_t)c->kcap, 0), slabel((size_t)c->kcap, 0);
+    int K = 0;
+    for (int lab = 1; lab <= n; ++lab)
+        if (size_by_label[(size_t)lab] > 0) {
+            if (K >= c->kcap) return fail(c, RC_ERR_CAPACITY, "rc_set_state: more than kcap=%d clusters", c->kcap);
+            slot_of_label[(size_t)lab] = K;
+            ssize[(size_t)K] = size_by_label[(size_t)lab];
+            slabel[(size_t)K] = lab;
+            ++K;
+        }
+    std::vector<int> so((size_t)n);
+    for (int i = 0; i < n; ++i) so[(size_t)i] = slot_of_label[(size_t)clusts[i]];
+    DevScalars s{};
+    s.K = K;
+    HIPCHK(c, hipMemcpy(c->slot_of, so.data(), so.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->slot_size, ssize.data(), ssize.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->slot_label, slabel.data(), slabel.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->sc, &s, sizeof(s), hipMemcpyHostToDevice));
+    // S of every slot may be stale: clear it all (keeps the "free slots are zero" invariant)
+    HIPCHK(c, hipMemsetAsync(c->SD, 0, (size_t)c->kcap * c->ld * sizeof(long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->SL, 0, (size_t)c->kcap * c->ld * sizeof(long long), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->last = s;
+    c->have_state = true;
+    c->S_valid = false;
+    return RC_OK;
+}
+
+// enqueue: (perm if needed) + k_zero + k_bulk
+static int32_t enqueue_bulk(rc_ctx *c, const View &V, bool perm_known_valid)
+{
+    if (!perm_known_valid) {
+        k_build_perm<<<1, 1024, 2 * sizeof(int) * (size_t)c->kcap, c->stream>>>(V);
+    }
+    dim3 gz((unsigned)(c->ld / 512), (unsigned)c->kcap);
+    k_zero<<<gz, 256, 0, c->stream>>>(V);
+    const int splits = (c->n + c->rows_per_split - 1) / c->rows_per_split;
+    dim3 gb((unsigned)(c->ld / 512), (unsigned)splits);
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    if (c->timing) {
+        if (!c->ev_free.empty()) { ev = c->ev_free.back(); c->ev_free.pop_back(); }
+        else { HIPCHK(c, hipEventCreate(&ev.first)); HIPCHK(c, hipEventCreate(&ev.second)); }
+        HIPCHK(c, hipEventRecord(ev.first, c->stream));
+    }
+    k_bulk<<<gb, 256, 0, c->stream>>>(V, c->rows_per_split);
+    if (c->timing) {
+        HIPCHK(c, hipEventRecord(ev.second, c->stream));
+        c->ev_pending.push_back(ev);
+    }
+    return RC_OK;
+}
+
+static int32_t ensure_S(rc_ctx *c)
+{
+    if (c->S_valid) return RC_OK;
+    View V = make_view(c);
+    int32_t rc = enqueue_bulk(c, V, false);
+    if (rc != RC_OK) return rc;
+    c->S_valid = true;
+    return RC_OK;
+}
+
+extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t seed, uint64_t sweep_index)
+{
+    if (!c) return fail(c, RC_ERR_ARG, "rc_gibbs_sweep: NULL ctx");
+    if (!c->have_params || !c->have_state) return fail(c, RC_ERR_STATE, "rc_gibbs_sweep: rc_set_params and rc_set_state must be called first");
+    if (!(r > 0.0) || !(p > 0.0 && p < 1.0)) return fail(c, RC_ERR_ARG, "rc_gibbs_sweep: need r > 0 and 0 < p < 1 (got r=%g p=%g)", r, p);
+    HIPCHK(c, hipSetDevice(c->dev));
+    View V = make_view(c);
+    // perm validity is tracked on the device (k_resolve rebuilds it after a sweep with changes); the first
+    // sweep after rc_set_state builds it here.
+    int32_t rc = enqueue_bulk(c, V, c->S_valid /* perm was built when S was first made valid */);
+    if (rc != RC_OK) return rc;
+    c->S_valid = true;
+    SweepArgs sa;
+    sa.r = r;
+    sa.logp = std::log(p);
+    sa.log1mp = std::log(1 - p);
+    sa.k0 = (unsigned)seed; sa.k1 = (unsigned)(seed >> 32);
+    sa.sw_lo = (unsigned)sweep_index; sa.sw_hi = (unsigned)(sweep_index >> 32);
+    const size_t lds = std::max(tab_bytes(c->kcap, c->n, RC_SCORE_THREADS / 32), 2 * sizeof(int) * (size_t)c->kcap);
+    k_resolve<<<c->G, RC_SCORE_THREADS, lds, c->stream>>>(V, sa, c->G);
+    HIPCHK(c, hipGetLastError());
+    return RC_OK;
+}
+
+extern "C" int32_t rc_gibbs_sweep(rc_ctx *c, double r, double p, uint64_t seed, uint64_t sweep_index)
+{
+    int32_t rc = rc_gibbs_sweep_async(c, r, p, seed, sweep_index);
+    if (rc != RC_OK) return rc;
+    return sync_and_check(c);
+}
+
+extern "C" int32_t rc_last_sweep_stats(rc_ctx *c, rc_sweep_stats *out)
+{
+    if (!c || !out) return fail(c, RC_ERR_ARG, "rc_last_sweep_stats: NULL argument");
+    HIPCHK(c, hipSetDevice(c->dev));
+    int32_t rc = sync_and_check(c);
+    if (rc != RC_OK) return rc;
+    out->n_changes = c->last.n_changes;
+    out->n_rounds = c->last.n_rounds;
+    out->K = c->last.K;
+    return RC_OK;
+}
+
+// labels / sizes of the current device state
+static int32_t pull_state(rc_ctx *c, std::vector<int> &so, std::vector<int> &ssize, std::vector<int> &slabel)
+{
+    int32_t rc = sync_and_check(c);
+    if (rc != RC_OK) return rc;
+    so.resize((size_t)c->n); ssize.resize((size_t)c->kcap); slabel.resize((size_t)c->kcap);
+    HIPCHK(c, hipMemcpy(so.data(), c->slot_of, so.size() * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(ssize.data(), c->slot_size, ssize.size() * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(slabel.data(), c->slot_label, slabel.size() * sizeof(int), hipMemcpyDeviceToHost));
+    return RC_OK;
+}
+
+extern "C" int32_t rc_get_state(rc_ctx *c, int64_t *clusts, int64_t *clustsizes, int64_t *K)
+{
+    if (!c) return fail(c, RC_ERR_ARG, "rc_get_state: NULL ctx");
+    if (!c->have_state) return fail(c, RC_ERR_STATE, "rc_get_state: no state set");
+    HIPCHK(c, hipSetDevice(c->dev));
+    std::vector<int> so, ssize, slabel;
+    int32_t rc = pull_state(c, so, ssize, slabel);
+    if (rc != RC_OK) return rc;
+    if (clusts)
+        for (int i = 0; i < c->n; ++i) clusts[i] = slabel[(size_t)so[(size_t)i]];
+    if (clustsizes) {
+        std::memset(clustsizes, 0, (size_t)c->n * sizeof(int64_t));
+        for (int k = 0; k < c->kcap; ++k)
+            if (slabel[(size_t)k] > 0) clustsizes[slabel[(size_t)k] - 1] = ssize[(size_t)k];
+    }
+    if (K) *K = c->last.K;
+    return RC_OK;
+}
+
+extern "C" int32_t rc_loglik(rc_ctx *c, double *out)
+{
+    if (!c || !out) return fail(c, RC_ERR_ARG, "rc_loglik: NULL argument");
+    if (!c->have_params || !c->have_state) return fail(c, RC_ERR_STATE, "rc_loglik: params and state must be set");
+    HIPCHK(c, hipSetDevice(c->dev));
+    int32_t rc = ensure_S(c);
+    if (rc != RC_OK) return rc;
+    View V = make_view(c);
+    k_blocksums<<<c->kcap, 256, (size_t)c->kcap * 4 * sizeof(u64), c->stream>>>(V, c->blocks);
+    std::vector<int> so, ssize, slabel;
+    rc = pull_state(c, so, ssize, slabel);
+    if (rc != RC_OK) return rc;
+    std::vector<long long> B((size_t)c->kcap * c->kcap * 4);
+    HIPCHK(c, hipMemcpy(B.data(), c->blocks, B.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    // scalar part of loglik (mcmc.jl:26-54) in long double, regrouped as in oracle "stable" mode
+    std::vector<int> act;
+    for (int k = 0; k < c->kcap; ++k)
+        if (ssize[(size_t)k] > 0) act.push_back(k);
+    const rc_params &P = c->P;
+    const long double d1 = P.delta1, d2 = P.delta2, al = P.alpha, be = P.beta, ze = P.zeta, ga = P.gamma;
+    const long double lga = lgammal(al), lgz = lgammal(ze), lgd1 = lgammal(d1), lgd2 = lgammal(d2);
+    const long double lb = logl(be), lg = logl(ga);
+    const long double scD = ldexpl(1.0L, -c->eD), scL = ldexpl(1.0L, -c->eL);
+    auto blk = [&](int k, int t, int which) -> long double {
+        const long long *e = &B[((size_t)t * c->kcap + k) * 4 + (which ? 2 : 0)];
+        return ((long double)e[0] * (long double)(1ll << RC_LO_BITS) + (long double)e[1]) * (which ? scL : scD);
+    };
+    long double L1 = 0, L2 = 0;
+    for (int k : act) {
+        const long double sz = ssize[(size_t)k];
+        const long double pairs = sz * (sz - 1) / 2;  // binomial(sz_k, 2)
+        const long double a = al + d1 * pairs;
+        const long double bd = blk(k, k, 0) / 2, bl = blk(k, k, 1) / 2;
+        L1 += (d1 - 1) * bl - pairs * lgd1 + (lgammal(a) - lga) - d1 * pairs * lb - a * log1pl(bd / be);
+    }
+    if (P.repulsion)
+        for (size_t x = 0; x < act.size(); ++x)
+            for (size_t y = x + 1; y < act.size(); ++y) {
+                const int k = act[x], t = act[y];
+                const long double pairs = (long double)ssize[(size_t)k] * (long double)ssize[(size_t)t];
+                const long double z = ze + d2 * pairs;
+                const long double bd = blk(k, t, 0), bl = blk(k, t, 1);
+                L2 += (d2 - 1) * bl - pairs * lgd2 + (lgammal(z) - lgz) - d2 * pairs * lg - z * log1pl(bd / ga);
+            }
+    *out = (double)(L1 + L2);
+    return RC_OK;
+}
+
+extern "C" int32_t rc_logprior(rc_ctx *c, double r, double p, double *out)
+{
+    if (!c || !out) return fail(c, RC_ERR_ARG, "rc_logprior: NULL argument");
+    if (!c->have_params || !c->have_state) return fail(c, RC_ERR_STATE, "rc_logprior: params and state must be set");
+    if (!(r > 0.0) || !(p > 0.0 && p < 1.0)) return fail(c, RC_ERR_ARG, "rc_logprior: need r > 0 and 0 < p < 1");
+    HIPCHK(c, hipSetDevice(c->dev));
+    std::vector<int> so, ssize, slabel;
+    int32_t rc = pull_state(c, so, ssize, slabel);
+    if (rc != RC_OK) return rc;
+    const rc_params &P = c->P;
+    const double n = c->n;
+    double K = 0;
+    for (int k = 0; k < c->kcap; ++k) K += ssize[(size_t)k] > 0;
+    // logpdf(Gamma(η, 1/σ), r) + logpdf(Beta(u, v), p)   (mcmc.jl:73)
+    const double lgam = P.eta * std::log(P.sigma) - std::lgamma(P.eta) + (P.eta - 1) * std::log(r) - P.sigma * r;
+    const double lbet = std::lgamma(P.u + P.v) - std::lgamma(P.u) - std::lgamma(P.v) + (P.u - 1) * std::log(p) + (P.v - 1) * std::log(1 - p);
+    double L = std::lgamma(K + 1) + (n - K) * std::log(p) + (r * K) * std::log(1 - p) - K * std::lgamma(r) + lgam + lbet;
+    // Σ_j log n_j + lgΓ(n_j + r − 1) over non-empty clusters in ascending label order (mcmc.jl:74-76)
+    std::vector<std::pair<int, int>> bylabel;
+    for (int k = 0; k < c->kcap; ++k)
+        if (ssize[(size_t)k] > 0) bylabel.push_back({slabel[(size_t)k], ssize[(size_t)k]});
+    std::sort(bylabel.begin(), bylabel.end());
+    for (auto &e : bylabel) L += std::log((double)e.second) + std::lgamma((double)e.second + r - 1);
+    *out = L;
+    return RC_OK;
+}
+
+static int32_t ensure_counts(rc_ctx *c)
+{
+    if (c->counts) return RC_OK;
+    c->ldc = ((c->n + 3) / 4) * 4;
+    HIPCHK(c, hipMalloc(&c->counts, (size_t)c->n * c->ldc * sizeof(unsigned)));
+    HIPCHK(c, hipMemsetAsync(c->counts, 0, (size_t)c->n * c->ldc * sizeof(unsigned), c->stream));
+    return RC_OK;
+}
+
+extern "C" int32_t rc_record_sample(rc_ctx *c, int64_t *canonical_out)
+{
+    if (!c) return fail(c, RC_ERR_ARG, "rc_record_sample: NULL ctx");
+    if (!c->have_state) return fail(c, RC_ERR_STATE, "rc_record_sample: no state set");
+    HIPCHK(c, hipSetDevice(c->dev));
+    int32_t rc = ensure_counts(c);
+    if (rc != RC_OK) return rc;
+    dim3 g((unsigned)((c->n + 1023) / 1024), (unsigned)c->n);
+    k_cocluster_add<<<g, 256, 0, c->stream>>>(c->slot_of, c->n, c->ldc, c->counts);
+    HIPCHK(c, hipGetLastError());
+    if (canonical_out) {
+        std::vector<int> so((size_t)c->n);
+        HIPCHK(c, hipMemcpyAsync(so.data(), c->slot_of, so.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        rc = sync_and_check(c);
+        if (rc != RC_OK) return rc;
+        // sortlabels (utils.jl:69-74): relabel by order of first appearance
+        std::vector<int> map((size_t)c->kcap, 0);
+        int next = 0;
+        for (int i = 0; i < c->n; ++i) {
+            int &m = map[(size_t)so[(size_t)i]];
+            if (m == 0) m = ++next;
+            canonical_out[i] = m;
+        }
+    }
+    return RC_OK;
+}
+
+extern "C" int32_t rc_cocluster_reset(rc_ctx *c)
+{
+    if (!c) return fail(c, RC_ERR_ARG, "rc_cocluster_reset: NULL ctx");
+    HIPCHK(c, hipSetDevice(c->dev));
+    int32_t rc = ensure_counts(c);
+    if (rc != RC_OK) return rc;
+    HIPCHK(c, hipMemsetAsync(c->counts, 0, (size_t)c->n * c->ldc * sizeof(unsigned), c->stream));
+    return RC_OK;
+}
+
+extern "C" int32_t rc_cocluster_counts(rc_ctx *c, uint32_t *out)
+{
+    if (!c || !out) return fail(c, RC_ERR_ARG, "rc_cocluster_counts: NULL argument");
+    HIPCHK(c, hipSetDevice(c->dev));
+    int32_t rc = ensure_counts(c);
+    if (rc != RC_OK) return rc;
+    rc = sync_and_check(c);
+    if (rc != RC_OK) return rc;
+    HIPCHK(c, hipMemcpy2D(out, (size_t)c->n * sizeof(unsigned), c->counts, (size_t)c->ldc * sizeof(unsigned),
+                          (size_t)c->n * sizeof(unsigned), (size_t)c->n, hipMemcpyDeviceToHost));
+    return RC_OK;
+}
+
+extern "C" int32_t rc_cocluster_device_buffer(rc_ctx *c, void **dev_ptr, int64_t *ld)
+{
+    if (!c || !dev_ptr || !ld) return fail(c, RC_ERR_ARG, "rc_cocluster_device_buffer: NULL argument");
+    HIPCHK(c, hipSetDevice(c->dev));
+    int32_t rc = ensure_counts(c);
+    if (rc != RC_OK) return rc;
+    rc = sync_and_check(c);
+    if (rc != RC_OK) return rc;
+    *dev_ptr = c->counts;
+    *ld = c->ldc;
+    return RC_OK;
+}
+
+extern "C" int32_t rc_cocluster(rc_ctx *c, double *out, int64_t numsamples)
+{
+    if (!c || !out) return fail(c, RC_ERR_ARG, "rc_cocluster: NULL argument");
+    if (numsamples < 1) return fail(c, RC_ERR_ARG, "rc_cocluster: numsamples must be >= 1");
+    HIPCHK(c, hipSetDevice(c->dev));
+    int32_t rc = ensure_counts(c);
+    if (rc != RC_OK) return rc;
+    const size_t nn = (size_t)c->n * c->n;
+    if (!c->cc_out) HIPCHK(c, hipMalloc(&c->cc_out, nn * sizeof(double)));
+    const int gb = (int)std::min<size_t>((nn + 255) / 256, 8192);
+    k_cocluster_final<<<gb, 256, 0, c->stream>>>(c->counts, c->n, c->ldc, 1.0 / (double)numsamples, c->cc_out);
+    rc = sync_and_check(c);
+    if (rc != RC_OK) return rc;
+    HIPCHK(c, hipMemcpy(out, c->cc_out, nn * sizeof(double), hipMemcpyDeviceToHost));
+    return RC_OK;
+}
+
+extern "C" int32_t rc_debug_rowsums(rc_ctx *c, int64_t label, int64_t *sumD_q, int64_t *sumL_q, int32_t *eD, int32_t *eL)
+{
+    if (!c) return fail(c, RC_ERR_ARG, "rc_debug_rowsums: NULL ctx");
+    if (!c->have_state) return fail(c, RC_ERR_STATE, "rc_debug_rowsums: no state set");
+    HIPCHK(c, hipSetDevice(c->dev));
+    int32_t rc = ensure_S(c);
+    if (rc != RC_OK) return rc;
+    std::vector<int> so, ssize, slabel;
+    rc = pull_state(c, so, ssize, slabel);
+    if (rc != RC_OK) return rc;
+    int slot = -1;
+    for (int k = 0; k < c->kcap; ++k)
+        if (slabel[(size_t)k] == (int)label) slot = k;
+    if (eD) *eD = c->eD;
+    if (eL) *eL = c->eL;
+    if (slot < 0) {
+        if (sumD_q) std::memset(sumD_q, 0, (size_t)c->n * 8);
+        if (sumL_q) std::memset(sumL_q, 0, (size_t)c->n * 8);
+        return RC_OK;
+    }
+    if (sumD_q) HIPCHK(c, hipMemcpy(sumD_q, c->SD + (size_t)slot * c->ld, (size_t)c->n * 8, hipMemcpyDeviceToHost));
+    if (sumL_q) HIPCHK(c, hipMemcpy(sumL_q, c->SL + (size_t)slot * c->ld, (size_t)c->n * 8, hipMemcpyDeviceToHost));
+    return RC_OK;
+}
+
+extern "C" int32_t rc_kernel_timing(rc_ctx *c, int32_t enable, double *bulk_ms_total, int64_t *bulk_launches)
+{
+    if (!c) return fail(c, RC_ERR_ARG, "rc_kernel_timing: NULL ctx");
+    HIPCHK(c, hipSetDevice(c->dev));
+    int32_t rc = sync_and_check(c);
+    if (rc != RC_OK) return rc;
+    if (bulk_ms_total) *bulk_ms_total = c->bulk_ms;
+    if (bulk_launches) *bulk_launches = c->bulk_launches;
+    if (enable >= 0) {
+        c->timing = enable != 0;
+        c->bulk_ms = 0.0;
+        c->bulk_launches = 0;
+    }
+    return RC_OK;
+}

@@ -47,6 +47,7 @@ def lib():
     L.orc_quant_exponent.argtypes = [i64, _dp, i64]
     L.orc_quantize.argtypes = [_dp, i64, i32, _ip]
     L.orc_sweep_literal.argtypes = [i64, _dp, _dp, _ip, _ip, C.POINTER(i64), PP, f64, f64, u64, u64, i32]
+    L.orc_sweep_literal_range.argtypes = [i64, _dp, _dp, _ip, _ip, C.POINTER(i64), PP, f64, f64, u64, u64, i32, i64, i64]
     L.orc_point_scores_literal.restype = i64
     L.orc_point_scores_literal.argtypes = [i64, _dp, _dp, _ip, _ip, PP, f64, f64, i64, _ip, _dp]
     L.orc_size_table.argtypes = [i64, PP, _dp]
@@ -118,6 +119,15 @@ class Oracle:
         K = C.c_int64()
         rc = self.L.orc_sweep_literal(self.n, self.D.reshape(-1), self.logD.reshape(-1), self.clusts, self.sizes,
                                       C.byref(K), C.byref(self.P), r, p, seed, sweep, cost_mode)
+        assert rc == 0
+        self.K = K.value
+        return self.K
+
+    def sweep_literal_range(self, r, p, seed, sweep, cost_mode, i_begin, i_end):
+        K = C.c_int64()
+        rc = self.L.orc_sweep_literal_range(self.n, self.D.reshape(-1), self.logD.reshape(-1), self.clusts,
+                                            self.sizes, C.byref(K), C.byref(self.P), r, p, seed, sweep, cost_mode,
+                                            i_begin, i_end)
         assert rc == 0
         self.K = K.value
         return self.K

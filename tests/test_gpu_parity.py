@@ -1,0 +1,265 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle and the committed
+golden vectors.  Integer outputs (labels, sizes, K, fixed-point row sums, co-clustering counts) must match
+EXACTLY; loglik / logprior within the stated relative tolerance."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import redclust_amd as rc
+from helpers import golden_case, load_golden, rp_schedule
+
+pytestmark = pytest.mark.gpu
+
+LL_RTOL = 1e-9   # loglik / logposterior vs the oracle's stable mode (north_star allows 1e-6)
+LIT_RTOL = 1e-7  # vs the literal restatement / golden vectors (cancellation noise of the literal formulas)
+
+
+def make_pair(D, P, init, kcap=0):
+    orc = O.Oracle(D, P)
+    orc.set_state(init)
+    ctx = rc.Context(D, logD=orc.logD, kcap=kcap)
+    ctx.set_params(**P)
+    ctx.set_state(init)
+    return orc, ctx
+
+
+def assert_state_equal(ctx, orc, msg=""):
+    clusts, sizes, K = ctx.get_state()
+    assert np.array_equal(clusts, orc.clusts), f"labels differ {msg}"
+    assert np.array_equal(sizes, orc.sizes), f"sizes differ {msg}"
+    assert K == orc.K, f"K differs {msg}"
+
+
+def test_fixed_point_rowsums_exact():
+    g, d = load_golden()
+    D, P, init, seed = golden_case(g, d, "d1_random")
+    orc, ctx = make_pair(D, P, init)
+    onehot = (init[:, None] == np.arange(1, 101)[None, :]).astype(np.int64)
+    SD, SL = orc.Dq @ onehot, orc.Lq @ onehot
+    for lab in np.unique(init):
+        sd, sl, eD, eL = ctx.debug_rowsums(int(lab))
+        assert (eD, eL) == (orc.eD, orc.eL)
+        assert np.array_equal(sd, SD[:, lab - 1]) and np.array_equal(sl, SL[:, lab - 1])
+    ctx.close()
+
+
+def test_device_logD_matches_host_within_one_quantum():
+    g, d = load_golden()
+    D, P, init, seed = golden_case(g, d, "d2_truth")
+    orc = O.Oracle(D, P)
+    ctx = rc.Context(D)  # logD derived on the device (types.jl:155)
+    ctx.set_params(**P)
+    ctx.set_state(init)
+    onehot = (init[:, None] == np.arange(1, 101)[None, :]).astype(np.int64)
+    SL = orc.Lq @ onehot
+    for lab in np.unique(init):
+        sd, sl, eD, eL = ctx.debug_rowsums(int(lab))
+        assert eL == orc.eL
+        # ≤ 1 quantum per summed entry
+        assert np.max(np.abs(sl - SL[:, lab - 1])) <= np.sum(init == lab)
+    ctx.close()
+
+
+@pytest.mark.parametrize("tag", ["d1_truth", "d1_random", "d1_norep", "d1_maxK6", "d1_singletons", "d2_truth",
+                                 "d2_random", "d3_truth", "d3_random"])
+def test_golden_sweeps(tag):
+    """Teacher-forced (r, p) sweeps on the paper datasets: labels/sizes/K exactly equal to the golden vectors
+    (independent NumPy transcription) and to the oracle; loglik, logprior, canonical labels too."""
+    g, d = load_golden()
+    D, P, init, seed = golden_case(g, d, tag)
+    orc, ctx = make_pair(D, P, init)
+    for t in range(4):
+        r, p = float(g["r_seq"][t]), float(g["p_seq"][t])
+        ctx.gibbs_sweep(r, p, seed, t)
+        orc.sweep_stable(r, p, seed, t)
+        assert_state_equal(ctx, orc, f"({tag}, sweep {t})")
+        clusts, sizes, K = ctx.get_state()
+        assert np.array_equal(clusts, g[f"{tag}_labels"][t]) and np.array_equal(sizes, g[f"{tag}_sizes"][t])
+        assert K == int(g[f"{tag}_K"][t])
+        assert ctx.sweep_stats()["n_changes"] == orc.last_changes
+        ll = ctx.loglik()
+        assert abs(ll - orc.loglik_stable()) <= LL_RTOL * max(1.0, abs(ll))
+        assert abs(ll - float(g[f"{tag}_loglik"][t])) <= LIT_RTOL * max(1.0, abs(ll))
+        lp = ctx.logprior(r, p)
+        assert abs(lp - float(g[f"{tag}_logprior"][t])) <= 1e-10 * max(1.0, abs(lp))
+        assert abs(lp - orc.logprior(r, p)) <= 1e-12 * max(1.0, abs(lp))
+        canon = ctx.record_sample(True)
+        assert np.array_equal(canon, g[f"{tag}_canon"][t])
+    ctx.close()
+
+
+@pytest.mark.parametrize("n,K,seed", [(257, 5, 1), (1000, 12, 2), (2000, 20, 3)])
+def test_synthetic_moving_and_stationary(n, K, seed):
+    """generatemixture-distributed data; random init (many label changes per sweep, births and deaths) and
+    the generating labels (stationary); 6 sweeps each, exact trajectory vs the oracle."""
+    data = rc.generatemixture(n, K, seed=seed, sigma=0.2)
+    D, truth = data["distancematrix"], data["clusts"]
+    P = rc.likelihood_hyperparams(D, truth)
+    rng = np.random.default_rng(seed)
+    for init in (rng.integers(1, K + 1, size=n).astype(np.int64), truth):
+        orc, ctx = make_pair(D, P, init)
+        for t in range(6):
+            r, p = rp_schedule(t)
+            ctx.gibbs_sweep(r, p, 1000 + seed, t)
+            orc.sweep_stable(r, p, 1000 + seed, t)
+            assert_state_equal(ctx, orc, f"(n={n}, sweep {t})")
+            st = ctx.sweep_stats()
+            assert st["n_changes"] == orc.last_changes and st["n_rounds"] == st["n_changes"] + 1
+        ll = ctx.loglik()
+        assert abs(ll - orc.loglik_stable()) <= LL_RTOL * abs(ll)
+        assert abs(ll - orc.loglik_literal()) <= 1e-6 * abs(ll)
+        ctx.close()
+
+
+def test_literal_restatement_trajectory():
+    """GPU vs the LITERAL restatement (reference formulas as written) on N=100: same labels for 30 sweeps."""
+    g, d = load_golden()
+    D, P, init, seed = golden_case(g, d, "d1_random")
+    orc, ctx = make_pair(D, P, init)
+    for t in range(30):
+        r, p = rp_schedule(t)
+        ctx.gibbs_sweep(r, p, 5, t)
+        orc.sweep_literal(r, p, 5, t)
+        assert_state_equal(ctx, orc, f"(literal, sweep {t})")
+    ctx.close()
+
+
+def test_cocluster_counts_and_posterior():
+    g, d = load_golden()
+    D, P, init, seed = golden_case(g, d, "d2_random")
+    orc, ctx = make_pair(D, P, init)
+    ctx.cocluster_reset()
+    ref = np.zeros((100, 100), np.uint32)
+    S = 7
+    for t in range(S):
+        r, p = rp_schedule(t)
+        ctx.gibbs_sweep(r, p, seed, t)
+        orc.sweep_stable(r, p, seed, t)
+        ctx.record_sample(False)
+        orc.L.orc_cocluster_add(100, orc.clusts, ref.reshape(-1))
+    cnt = ctx.cocluster_counts()
+    assert np.array_equal(cnt, ref)
+    post = ctx.cocluster(S)
+    assert np.array_equal(post, ref / S)  # counts ./ numsamples, mcmc.jl:560
+    assert np.all(np.diag(post) == 1.0) and np.array_equal(post, post.T)
+    ctx.close()
+
+
+def test_edge_cases_and_errors():
+    g, d = load_golden()
+    D, P, init, seed = golden_case(g, d, "d1_truth")
+    # asymmetric D is rejected like MCMCData (types.jl:149-151)
+    bad = D.copy(); bad[0, 1] += 1e-9
+    with pytest.raises(rc.RedClustHIPError, match="symmetric"):
+        rc.Context(bad)
+    z = D.copy(); z[2, 3] = z[3, 2] = 0.0
+    with pytest.raises(rc.RedClustHIPError, match="positive"):
+        rc.Context(z)
+    ctx = rc.Context(D)
+    with pytest.raises(rc.RedClustHIPError, match="RC_ERR_STATE"):
+        ctx.gibbs_sweep(1.0, 0.5, 1, 0)
+    ctx.set_params(**P)
+    with pytest.raises(rc.RedClustHIPError, match="outside 1..n"):
+        ctx.set_state(np.zeros(100, np.int64))
+    ctx.set_state(init)
+    with pytest.raises(rc.RedClustHIPError, match="RC_ERR_ARG"):
+        ctx.gibbs_sweep(-1.0, 0.5, 1, 0)
+    with pytest.raises(rc.RedClustHIPError, match="RC_ERR_ARG"):
+        ctx.gibbs_sweep(1.0, 1.0, 1, 0)
+    ctx.close()
+    # capacity: 100 singletons do not fit kcap = 16
+    ctx = rc.Context(D, kcap=16)
+    ctx.set_params(**P)
+    with pytest.raises(rc.RedClustHIPError, match="RC_ERR_CAPACITY"):
+        ctx.set_state(np.arange(1, 101, dtype=np.int64))
+    # births beyond kcap are reported, not silently dropped
+    Pn = dict(P, repulsion=False)  # without repulsion the model shatters into many clusters (golden d1_norep)
+    ctx.set_params(**Pn)
+    ctx.set_state(g["d1_norep_init"].astype(np.int64))
+    with pytest.raises(rc.RedClustHIPError, match="RC_ERR_CAPACITY"):
+        for t in range(4):
+            ctx.gibbs_sweep(1.0, 0.5, 3, t)
+    ctx.close()
+    # tiny problems: n = 1, 2, 3
+    for n in (1, 2, 3):
+        Dn = np.ascontiguousarray(D[:n, :n])
+        orc, c2 = make_pair(Dn, P, np.ones(n, np.int64))
+        for t in range(5):
+            c2.gibbs_sweep(1.0, 0.5, 11, t)
+            orc.sweep_stable(1.0, 0.5, 11, t)
+            assert_state_equal(c2, orc, f"(n={n})")
+        c2.close()
+
+
+def test_runsampler_surface():
+    """runsampler(data, options, params, init) with numMH = 0 ('pure Gibbs', test/test_sampler.jl:7): fills every
+    MCMCResult field; teacher-forced r/p reproduce the oracle's recorded trace exactly."""
+    g, d = load_golden()
+    D, P, init, seed = golden_case(g, d, "d3_random")
+    params = rc.PriorHyperparamsList(**{k: P[k] for k in ("delta1", "delta2", "alpha", "beta", "zeta", "gamma")})
+    opts = rc.MCMCOptionsList(numiters=40, burnin=10, thin=3, numMH=0)
+    rs = np.array([rp_schedule(t)[0] for t in range(40)]); ps = np.array([rp_schedule(t)[1] for t in range(40)])
+    res = rc.runsampler(rc.MCMCData(D), opts, params, rc.MCMCState(init, 1.0, 0.5), verbose=False, seed=77,
+                        rp_trace=(rs, ps))
+    assert opts.numsamples == 10 and len(res.clusts) == 10
+    orc = O.Oracle(D, P); orc.set_state(init)
+    j = 0
+    ref_counts = np.zeros((100, 100), np.uint32)
+    for i in range(1, 41):
+        orc.sweep_stable(rs[i - 1], ps[i - 1], 77, i - 1)
+        if i > 10 and (i - 10) % 3 == 0:
+            assert np.array_equal(res.clusts[j], orc.sortlabels()) and res.K[j] == orc.K
+            assert abs(res.loglik[j] - orc.loglik_stable()) <= LL_RTOL * abs(res.loglik[j])
+            lp = orc.loglik_stable() + orc.logprior(rs[i - 1], ps[i - 1])
+            assert abs(res.logposterior[j] - lp) <= 1e-6 * abs(lp)   # north_star tolerance on log-posterior
+            orc.L.orc_cocluster_add(100, orc.clusts, ref_counts.reshape(-1))
+            j += 1
+    assert j == 10 and np.array_equal(res.posterior_coclustering, ref_counts / 10)
+    # free-running r/p: smoke test as the reference's own sampler tests (@test_nothrow)
+    res2 = rc.runsampler(rc.MCMCData(D), rc.MCMCOptionsList(numiters=60, numMH=0), params,
+                         rc.MCMCState(init, 1.0, 0.5), verbose=False, seed=3)
+    assert res2.K.shape == (48,) and np.isfinite(res2.logposterior).all() and 0 <= res2.r_acceptance_rate <= 1
+    assert res2.K_ess > 0 and res2.mean_iter_time > 0 and res2.posterior_coclustering.shape == (100, 100)
+
+
+def test_full_size_properties():
+    """BASELINE config 3 (N=8192, K=50): size-independent properties — Σ sizes = n, K = #non-empty, checksum of
+    the row-sum table (Σ_k S[k][i] = Σ_j D[i,j], exact in fixed point), stationarity of the generating labels,
+    async == blocking, co-clustering diagonal/symmetry."""
+    n, K = 8192, 50
+    data = rc.generatemixture(n, K, seed=1)
+    D, truth = data["distancematrix"], data["clusts"]
+    P = rc.likelihood_hyperparams(D, truth)
+    ctx = rc.Context(D, kcap=128)
+    ctx.set_params(**P)
+    ctx.set_state(truth)
+    tot_d = np.zeros(n, np.int64); tot_l = np.zeros(n, np.int64)
+    for lab in np.unique(truth):
+        sd, sl, eD, eL = ctx.debug_rowsums(int(lab))
+        tot_d += sd; tot_l += sl
+    ref_d = np.rint(np.ldexp(D, eD)).astype(np.int64).sum(axis=1)
+    assert np.array_equal(tot_d, ref_d)
+    for t in range(3):
+        ctx.gibbs_sweep(1.0, 0.5, 42, t)
+    c1, s1, K1 = ctx.get_state()
+    assert s1.sum() == n and K1 == np.sum(s1 > 0) and np.array_equal(np.bincount(c1, minlength=n + 1)[1:], s1)
+    ll1 = ctx.loglik()
+    # same three sweeps enqueued without host synchronisation in between
+    ctx.set_state(truth)
+    for t in range(3):
+        ctx.gibbs_sweep(1.0, 0.5, 42, t, blocking=False)
+    ctx.synchronize()
+    c2, s2, K2 = ctx.get_state()
+    assert np.array_equal(c1, c2) and K1 == K2 and ctx.loglik() == ll1
+    # random init: a moving sweep keeps the invariants
+    init = np.random.default_rng(0).integers(1, K + 1, size=n).astype(np.int64)
+    ctx.set_state(init)
+    ctx.gibbs_sweep(1.0, 0.5, 43, 0)
+    c3, s3, K3 = ctx.get_state()
+    assert s3.sum() == n and K3 == np.sum(s3 > 0) and ctx.sweep_stats()["n_changes"] > 0
+    ctx.cocluster_reset()
+    ctx.record_sample(False); ctx.record_sample(False)
+    post = ctx.cocluster(2)
+    assert np.all(np.diag(post) == 1.0) and np.array_equal(post, post.T)
+    assert np.array_equal(post == 1.0, c3[:, None] == c3[None, :])
+    ctx.close()

@@ -1,0 +1,192 @@
+"""CPU tests (-m "not gpu"): the oracle against the golden vectors and against the independent NumPy
+transcription; the reference's own value tests at this boundary, restated; the host logic; the C-ABI library
+loads and exports every symbol include/redclust_hip.h declares."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import np_transcription as T
+import oracle_lib as O
+from helpers import ROOT, golden_case, load_golden, rp_schedule
+
+CASES = ["d1_truth", "d1_random", "d1_norep", "d1_maxK6", "d1_singletons", "d2_truth", "d2_random", "d3_truth",
+         "d3_random"]
+
+
+def test_philox_known_answers():
+    """Random123 kat_vectors for philox4x32-10."""
+    L = O.lib()
+    kat = [([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+            [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for ctr, key, exp in kat:
+        out = np.zeros(4, np.uint32)
+        L.orc_philox(np.array(ctr, np.uint32), np.array(key, np.uint32), out)
+        assert list(out) == exp
+        assert list(T.philox4x32_10(ctr, key)) == exp
+    g, _ = load_golden()
+    u = [L.orc_uniform(1, 0, 0, 0), L.orc_uniform(1235, 3, 99, 10), L.orc_uniform(2**40 + 7, 2**33 + 1, 8191, 50)]
+    assert np.array_equal(np.array(u), g["uniform_kat"])
+    assert all(0.0 < x < 1.0 for x in u)
+
+
+@pytest.mark.parametrize("tag", CASES)
+@pytest.mark.parametrize("mode", ["literal", "stable", "faithful"])
+def test_oracle_matches_golden(tag, mode):
+    g, d = load_golden()
+    D, P, init, seed = golden_case(g, d, tag)
+    o = O.Oracle(D, P)
+    o.set_state(init)
+    if mode == "literal":
+        for i in (0, 37, 99):
+            c, lp = o.point_scores_literal(float(g["r_seq"][0]), float(g["p_seq"][0]), i)
+            assert np.array_equal(c, g[f"{tag}_cands_pt{i}"])
+            assert np.max(np.abs(lp - g[f"{tag}_logprobs_pt{i}"])) < 1e-6  # literal formulas cancel ~1e5-sized terms
+            c2, sc = o.point_scores_stable(float(g["r_seq"][0]), float(g["p_seq"][0]), i)
+            assert np.array_equal(c, c2)
+            # stable scores = literal logprobs minus a candidate-independent shift
+            assert np.max(np.abs((sc - sc[0]) - (lp - lp[0]))) < 1e-7
+    for t in range(4):
+        r, p = float(g["r_seq"][t]), float(g["p_seq"][t])
+        if mode == "stable":
+            o.sweep_stable(r, p, seed, t)
+        else:
+            o.sweep_literal(r, p, seed, t, cost_mode=1 if mode == "faithful" else 0)
+        assert np.array_equal(o.clusts, g[f"{tag}_labels"][t]) and np.array_equal(o.sizes, g[f"{tag}_sizes"][t])
+        assert o.K == int(g[f"{tag}_K"][t])
+        ll = o.loglik_stable() if mode == "stable" else o.loglik_literal()
+        assert abs(ll - float(g[f"{tag}_loglik"][t])) <= 1e-7 * max(1.0, abs(ll))
+        assert abs(o.logprior(r, p) - float(g[f"{tag}_logprior"][t])) <= 1e-10 * max(1.0, abs(ll))
+        assert np.array_equal(o.sortlabels(), g[f"{tag}_canon"][t])
+
+
+def test_oracle_vs_transcription_fresh_run():
+    """Not only the committed vectors: a fresh run of both restatements on a new seed / schedule."""
+    g, d = load_golden()
+    D, P, init, _ = golden_case(g, d, "d2_random")
+    o = O.Oracle(D, P)
+    o.set_state(init)
+    logD = T.make_logD(D)
+    clusts = init.copy()
+    sizes, K = T.state_from_labels(clusts)
+    # numpy's SIMD log and glibc's log may differ in the last place
+    assert np.allclose(o.logD, logD, rtol=4e-16, atol=1e-300)
+    for t in range(3):
+        r, p = rp_schedule(t)
+        K = T.sweep(D, logD, clusts, sizes, P, r, p, 4242, t)
+        o.sweep_literal(r, p, 4242, t)
+        assert np.array_equal(clusts, o.clusts) and K == o.K
+    assert abs(T.loglik(D, logD, clusts, sizes, P) - o.loglik_literal()) < 1e-7 * abs(o.loglik_literal())
+
+
+def test_fixed_point_is_exact_and_order_independent():
+    g, d = load_golden()
+    D, P, init, _ = golden_case(g, d, "d1_random")
+    o = O.Oracle(D, P)
+    assert np.array_equal(o.Dq, o.Dq.T) and np.array_equal(o.Lq, o.Lq.T)
+    assert np.max(np.abs(np.ldexp(o.Dq.astype(np.float64), -o.eD) - D)) <= 2.0 ** (-o.eD - 1)
+    assert abs(int(np.abs(o.Dq).max())) * 100 < 2 ** 62 and abs(int(np.abs(o.Lq).max())) * 100 < 2 ** 62
+    perm = np.random.default_rng(0).permutation(100)
+    assert np.array_equal(o.Dq[:, perm].sum(axis=1), o.Dq.sum(axis=1))
+
+
+def test_reference_value_tests_restated():
+    """test/test_utils.jl:10-40 of the reference: matsum/vecsum ≈ sum, adjacencymatrix and sortlabels structure."""
+    L = O.lib()
+    rng = np.random.default_rng(1)
+    x = np.asfortranarray(rng.random((500, 500)))
+    v = rng.random(500)
+    inds1 = rng.integers(1, 501, 200).astype(np.int64)
+    inds2 = rng.integers(1, 501, 150).astype(np.int64)
+    xf = np.ascontiguousarray(x.T).reshape(-1)  # column-major storage of x
+    assert np.isclose(L.orc_matsum_idx(500, xf, inds1, 200, inds2, 150), x[np.ix_(inds1 - 1, inds2 - 1)].sum())
+    assert np.isclose(L.orc_vecsum_idx(v, inds1, 200), v[inds1 - 1].sum())
+    temp = rng.integers(1, 21, 500).astype(np.int64)
+    adj = T.adjacencymatrix(temp)
+    assert adj.sum() == sum(int(np.sum(temp == k)) ** 2 for k in range(1, 21))
+    y = np.zeros(500, np.int64)
+    L.orc_sortlabels(500, temp, y)
+    assert np.array_equal(T.adjacencymatrix(y), adj) and np.array_equal(y, T.sortlabels(temp))
+    first = [np.flatnonzero(y == k)[0] for k in range(1, y.max() + 1)]
+    assert first == sorted(first)  # labels numbered by order of first appearance
+    counts = np.zeros((500, 500), np.uint32)
+    L.orc_cocluster_add(500, temp, counts.reshape(-1))
+    assert np.array_equal(counts, adj.astype(np.uint32))
+
+
+def test_gumbel_max_draw_frequencies():
+    """The Gumbel-max rule of src/utils.jl:2-6 under the counter-based uniforms samples softmax(logprobs)."""
+    L = O.lib()
+    lp = np.array([0.0, -0.7, -2.0, 0.4])
+    probs = np.exp(lp) / np.exp(lp).sum()
+    N = 40000
+    cnt = np.zeros(4)
+    for i in range(N):
+        u = np.array([L.orc_uniform(9, 1, i, k) for k in range(4)])
+        cnt[int(np.argmax(-np.log(-np.log(u)) + lp))] += 1
+    assert np.max(np.abs(cnt / N - probs)) < 4 * np.sqrt(0.25 / N)
+
+
+def test_abi_library_exports_every_declared_symbol():
+    import redclust_amd as rc
+    hdr = open(os.path.join(ROOT, "include", "redclust_hip.h")).read()
+    declared = set(re.findall(r"\b(rc_[a-z_]+)\s*\(", hdr))
+    assert declared == set(rc.SIGNATURES), declared ^ set(rc.SIGNATURES)
+    so = rc.build()
+    L = C.CDLL(so)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_product_fails_loudly_without_gpu_or_library():
+    import redclust_amd as rc
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(rc.RedClustHIPError, match="RC_ERR_HIP"):
+        rc.Context(np.zeros((4, 4)))
+
+
+def test_host_structs_mirror_reference_defaults():
+    import redclust_amd as rc
+    o = rc.MCMCOptionsList()
+    assert (o.numiters, o.burnin, o.thin, o.numGibbs, o.numMH, o.numsamples) == (5000, 1000, 1, 5, 1, 4000)
+    assert rc.MCMCOptionsList(numiters=10, burnin=3, thin=2).numsamples == 3
+    for bad in (dict(numiters=0), dict(numiters=5, burnin=6), dict(thin=0), dict(numGibbs=-1), dict(numMH=-1)):
+        with pytest.raises(ValueError):
+            rc.MCMCOptionsList(**bad)
+    p = rc.PriorHyperparamsList(eta=4.0, sigma=2.0)
+    assert p.proposalsd_r == 1.0 and p.repulsion and p.maxK == 0 and p.K_initial == 1
+    s = rc.MCMCState(np.array([2, 2, 5, 1, 5]), 1.0, 0.5)
+    assert list(s.clustsizes) == [1, 2, 0, 0, 2] and s.K == 3
+    with pytest.raises(ValueError, match="symmetric"):
+        rc.MCMCData(np.array([[0.0, 1.0], [2.0, 0.0]]))
+    dat = rc.MCMCData(np.array([[0.0, 2.0], [2.0, 0.0]]))
+    assert np.array_equal(dat.logD, np.log(np.array([[1.0, 2.0], [2.0, 1.0]])))
+    iac, ess, acf = rc.iac_ess_acf(np.arange(100.0))
+    assert len(acf) == 21 and acf[0] == 1.0 and np.isclose(ess, 100 / iac)
+    rng = np.random.default_rng(0)
+    r, acc = rc.sample_r(rng, 1.0, 0.5, np.array([10, 20, 30]), 3, 1.0, 1.0, 1.0)
+    assert r > 0 and acc in (True, False)
+    assert 0 < rc.sample_p(rng, 3, 60, 1.0, 1.0, 1.0) < 1
+
+
+def test_generatemixture_shape_like_reference():
+    """test/test_datagen.jl:7-16 of the reference: shapes, symmetry, label range, sorted labels."""
+    import redclust_amd as rc
+    d = rc.generatemixture(100, 10, alpha=10, sigma=0.25, dim=10, seed=44)
+    D = d["distancematrix"]
+    assert D.shape == (100, 100) and np.array_equal(D, D.T) and np.all(np.diag(D) == 0) and np.all(D[~np.eye(100, dtype=bool)] > 0)
+    assert d["clusts"].min() >= 1 and d["clusts"].max() <= 10 and np.all(np.diff(d["clusts"]) >= 0)
+    assert np.isclose(d["probs"].sum(), 1.0) and d["points"].shape == (100, 10)
+    P = rc.likelihood_hyperparams(D, d["clusts"])
+    Pt = T.likelihood_hyperparams(D, d["clusts"])
+    for k in ("delta1", "delta2", "alpha", "beta", "zeta", "gamma"):
+        assert np.isclose(P[k], Pt[k], rtol=1e-10)
+    for bad in (dict(N=0, K=1), dict(N=5, K=6), dict(N=5, K=2, dim=1), dict(N=5, K=2, sigma=0)):
+        with pytest.raises(ValueError):
+            rc.generatemixture(**bad)
