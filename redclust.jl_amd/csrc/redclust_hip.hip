@@ -694,13 +694,13 @@ __global__ __launch_bounds__(256) void k_cocluster_add(const int *__restrict__ s
     }
 }
 
-__global__ void k_cocluster_final(const unsigned *__restrict__ counts, int n, int ldc, double inv,
+__global__ void k_cocluster_final(const unsigned *__restrict__ counts, int n, int ldc, double numsamples,
                                   double *__restrict__ out)
 {
     const size_t total = (size_t)n * n;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
         const size_t i = t / n, j = t % n;
-        out[t] = (double)counts[i * ldc + j] * inv;  // ./ numsamples, mcmc.jl:560
+        out[t] = (double)counts[i * ldc + j] / numsamples;  // ./ numsamples, mcmc.jl:560
     }
 }
 
@@ -1314,7 +1314,7 @@ extern "C" int32_t rc_cocluster(rc_ctx *c, double *out, int64_t numsamples)
     const size_t nn = (size_t)c->n * c->n;
     if (!c->cc_out) HIPCHK(c, hipMalloc(&c->cc_out, nn * sizeof(double)));
     const int gb = (int)std::min<size_t>((nn + 255) / 256, 8192);
-    k_cocluster_final<<<gb, 256, 0, c->stream>>>(c->counts, c->n, c->ldc, 1.0 / (double)numsamples, c->cc_out);
+    k_cocluster_final<<<gb, 256, 0, c->stream>>>(c->counts, c->n, c->ldc, (double)numsamples, c->cc_out);
     rc = sync_and_check(c);
     if (rc != RC_OK) return rc;
     HIPCHK(c, hipMemcpy(out, c->cc_out, nn * sizeof(double), hipMemcpyDeviceToHost));

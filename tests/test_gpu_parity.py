@@ -219,7 +219,8 @@ def test_runsampler_surface():
     res2 = rc.runsampler(rc.MCMCData(D), rc.MCMCOptionsList(numiters=60, numMH=0), params,
                          rc.MCMCState(init, 1.0, 0.5), verbose=False, seed=3)
     assert res2.K.shape == (48,) and np.isfinite(res2.logposterior).all() and 0 <= res2.r_acceptance_rate <= 1
-    assert res2.K_ess > 0 and res2.mean_iter_time > 0 and res2.posterior_coclustering.shape == (100, 100)
+    assert res2.r_ess > 0 and res2.mean_iter_time > 0 and res2.posterior_coclustering.shape == (100, 100)
+    assert len(res2.r_acf) == 18 and res2.r_acf[0] == 1.0  # autocor default lags 0:min(n-1, round(10·log10 n))
 
 
 def test_full_size_properties():
