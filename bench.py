@@ -117,12 +117,9 @@ def main():
 
     # recorded sample + the one collective of the path: sum all-reduce of the integer co-clustering counts
     ctx.record_sample(False)
-    ptr, ldc = ctx.cocluster_device_buffer()
     allreduce_ms = None
     if distributed:
-        class _Buf:
-            __cuda_array_interface__ = {"shape": (n, ldc), "typestr": "<i4", "data": (ptr, False), "version": 3}
-        counts = torch.as_tensor(_Buf(), device=torch.device("cuda", local_rank))
+        counts = rc.device_counts_tensor(ctx, local_rank)   # zero-copy view of the library's device buffer
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)

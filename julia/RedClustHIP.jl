@@ -1,0 +1,100 @@
+# RedClustHIP.jl — Julia-side binding of libredclust_hip.so (include/redclust_hip.h).
+#
+# Drop-in for the label path of RedClust.jl: defines `runsampler_hip(data, options, params, init; ...)`, which
+# has the signature and the result of `RedClust.runsampler` (src/mcmc.jl:501-590) but runs the Gibbs sweep,
+# loglik, label canonicalisation and co-clustering accumulation on an MI355X through `ccall`.  The structs
+# MCMCData / MCMCOptionsList / PriorHyperparamsList / MCMCState / MCMCResult are RedClust's own, unchanged.
+#
+# NOT TESTED IN THE BUILD IMAGE (no julia binary there) — it is the binding a maintainer would add; the same
+# C entry points are exercised by the Python host (redclust.jl_amd/) and its tests.
+module RedClustHIP
+
+using RedClust
+using RedClust: MCMCData, MCMCOptionsList, PriorHyperparamsList, MCMCState, MCMCResult,
+                sample_r!, sample_p!, iac_ess_acf
+using StatsBase: mean, mean_and_var
+
+const LIB = get(ENV, "REDCLUST_HIP_LIB", "libredclust_hip.so")
+
+struct RcParams                      # struct rc_params
+    delta1::Cdouble; delta2::Cdouble; alpha::Cdouble; beta::Cdouble; zeta::Cdouble; gamma::Cdouble
+    eta::Cdouble; sigma::Cdouble; u::Cdouble; v::Cdouble
+    maxK::Int64
+    repulsion::UInt8
+    pad::NTuple{7,UInt8}
+end
+RcParams(p::PriorHyperparamsList) = RcParams(p.δ1, p.δ2, p.α, p.β, p.ζ, p.γ, p.η, p.σ, p.u, p.v,
+                                             p.maxK, UInt8(p.repulsion), ntuple(_ -> 0x00, 7))
+
+function check(ctx::Ptr{Cvoid}, rc::Int32)
+    rc == 0 && return
+    msg = unsafe_string(ccall((:rc_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx))
+    rc == -1 ? throw(ArgumentError(msg)) : error(msg)
+end
+
+"""
+    runsampler_hip(data, options, params, init; verbose=true, seed=0, device=0, kcap=0) -> MCMCResult
+
+Same contract as `RedClust.runsampler` with `options.numMH == 0` (pure Gibbs, test/test_sampler.jl:7).
+"""
+function runsampler_hip(data::MCMCData, options::MCMCOptionsList, params::PriorHyperparamsList,
+                        init::MCMCState; verbose=true, seed::Integer=0, device::Integer=0, kcap::Integer=0)
+    options.numMH == 0 || error("split-merge steps are not offloaded yet: use MCMCOptionsList(numMH = 0)")
+    n = size(data.D, 1)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    # MCMCData keeps D and logD (src/types.jl:146-147); both are handed over so that the device copy is
+    # bit-for-bit the package's logD.  D is symmetric, so column-major == row-major.
+    GC.@preserve data begin
+        rc = ccall((:rc_create, LIB), Int32,
+                   (Int64, Ptr{Cdouble}, Ptr{Cdouble}, Int32, Int32, Int64, Ref{Ptr{Cvoid}}),
+                   n, data.D, data.logD, 64, device, kcap, h)
+    end
+    check(Ptr{Cvoid}(C_NULL), rc)
+    ctx = h[]
+    try
+        check(ctx, ccall((:rc_set_params, LIB), Int32, (Ptr{Cvoid}, Ref{RcParams}), ctx, Ref(RcParams(params))))
+        check(ctx, ccall((:rc_set_state, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), ctx, init.clusts))
+        check(ctx, ccall((:rc_cocluster_reset, LIB), Int32, (Ptr{Cvoid},), ctx))
+        result = MCMCResult(data, options, params)
+        state = init
+        K = Ref{Int64}(0)
+        ll = Ref{Cdouble}(0.0); lp = Ref{Cdouble}(0.0)
+        j = 1
+        runtime = @elapsed for i in 1:options.numiters
+            result.r_acceptances[i] = sample_r!(state, params).accept            # src/mcmc.jl:538 (host scalar)
+            sample_p!(state, params)                                             # src/mcmc.jl:539 (host scalar)
+            check(ctx, ccall((:rc_gibbs_sweep, LIB), Int32, (Ptr{Cvoid}, Cdouble, Cdouble, UInt64, UInt64),
+                             ctx, state.r, state.p, seed, i - 1))                # src/mcmc.jl:540 → :477
+            check(ctx, ccall((:rc_get_state, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ref{Int64}),
+                             ctx, state.clusts, state.clustsizes, K))
+            state.K = K[]
+            if i > options.burnin && (i - options.burnin) % options.thin == 0   # src/mcmc.jl:546
+                check(ctx, ccall((:rc_record_sample, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), ctx, result.clusts[j]))
+                result.K[j] = state.K; result.r[j] = state.r; result.p[j] = state.p
+                check(ctx, ccall((:rc_loglik, LIB), Int32, (Ptr{Cvoid}, Ref{Cdouble}), ctx, ll))
+                check(ctx, ccall((:rc_logprior, LIB), Int32, (Ptr{Cvoid}, Cdouble, Cdouble, Ref{Cdouble}),
+                                 ctx, state.r, state.p, lp))
+                result.loglik[j] = ll[]; result.logposterior[j] = ll[] + lp[]
+                j += 1
+            end
+        end
+        # row-major n×n from the library == column-major because the matrix is symmetric (src/mcmc.jl:560)
+        check(ctx, ccall((:rc_cocluster, LIB), Int32, (Ptr{Cvoid}, Ptr{Cdouble}, Int64),
+                         ctx, result.posterior_coclustering, max(options.numsamples, 1)))
+        result.K_iac, result.K_ess, result.K_acf = iac_ess_acf(result.K)        # src/mcmc.jl:564-573, unchanged
+        result.K_mean, result.K_variance = mean_and_var(result.K)
+        result.r_iac, result.r_ess, result.r_acf = iac_ess_acf(result.r)
+        result.r_mean, result.r_variance = mean_and_var(result.r)
+        result.p_iac, result.p_ess, result.p_acf = iac_ess_acf(result.p)
+        result.p_mean, result.p_variance = mean_and_var(result.p)
+        result.splitmerge_acceptance_rate = 0
+        result.r_acceptance_rate = mean(result.r_acceptances)
+        result.runtime = runtime
+        result.mean_iter_time = runtime / options.numiters
+        return result
+    finally
+        ccall((:rc_destroy, LIB), Int32, (Ptr{Cvoid},), ctx)
+    end
+end
+
+end # module

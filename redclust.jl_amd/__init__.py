@@ -9,3 +9,4 @@ from ._lib import Context, RedClustHIPError, build, lib, SIGNATURES  # noqa: F40
 from .types import MCMCData, MCMCOptionsList, MCMCResult, MCMCState, PriorHyperparamsList  # noqa: F401
 from .sampler import runsampler, sample_r, sample_p, iac_ess_acf  # noqa: F401
 from .datagen import generatemixture, likelihood_hyperparams  # noqa: F401
+from .chains import chain_seed, merge_chains, run_chains, device_counts_tensor  # noqa: F401

@@ -83,6 +83,7 @@ struct View {
 struct SweepArgs {
     double r, logp, log1mp;
     unsigned k0, k1, sw_lo, sw_hi;
+    int dbg;  // timing ablations only (RC_DEBUG_FLAGS): 1 = skip candidate loop, 2 = skip grid barrier, 4 = skip gumbel
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -254,8 +255,8 @@ __global__ __launch_bounds__(256) void k_bulk(View V, int rows_per_split)
         for (int u = 0; u < RC_BULK_U; ++u) { j[u] = perm[p + u]; s[u] = pslot[p + u]; }
 #pragma unroll
         for (int u = 0; u < RC_BULK_U; ++u) {
-            d[u] = *(const ll2 *)(Dq + (size_t)j[u] * ld);
-            l[u] = *(const ll2 *)(Lq + (size_t)j[u] * ld);
+            d[u] = __builtin_nontemporal_load((const ll2 *)(Dq + (size_t)j[u] * ld));  // streamed once per sweep
+            l[u] = __builtin_nontemporal_load((const ll2 *)(Lq + (size_t)j[u] * ld));
         }
 #pragma unroll
         for (int u = 0; u < RC_BULK_U; ++u) {
@@ -269,8 +270,8 @@ __global__ __launch_bounds__(256) void k_bulk(View V, int rows_per_split)
     }
     for (; p < p1; ++p) {
         const int j = perm[p], s = pslot[p];
-        const ll2 d = *(const ll2 *)(Dq + (size_t)j * ld);
-        const ll2 l = *(const ll2 *)(Lq + (size_t)j * ld);
+        const ll2 d = __builtin_nontemporal_load((const ll2 *)(Dq + (size_t)j * ld));
+        const ll2 l = __builtin_nontemporal_load((const ll2 *)(Lq + (size_t)j * ld));
         if (s != cur) {
             bulk_flush(V, cur, i, aD0, aD1, aL0, aL1);
             aD0 = aD1 = aL0 = aL1 = 0;
@@ -424,7 +425,7 @@ __device__ void score_chunk(const View &V, const SweepArgs &a, Tab &T, int chunk
         Ki = K - single;
         const long long dg = V.diagq[i];
         const size_t ld = (size_t)V.ld;
-        for (int pos = st; pos < K; pos += NS) {
+        for (int pos = st; pos < ((a.dbg & 1) ? 0 : K); pos += NS) {
             const int k = T.act[pos];
             const int isown = (k == own);
             const int s = T.size[k] - isown;
@@ -436,8 +437,11 @@ __device__ void score_chunk(const View &V, const SweepArgs &a, Tab &T, int chunk
             const double base = isown ? T.base_s[k] : T.base_o[k];
             double lik = V.cL * SLr - (V.alpha + V.delta1 * (double)s) * log1p(SDr / V.beta);
             if (V.repulsion) lik += (V.zeta + V.delta2 * (double)s) * log1p(SDr / V.gamma);
-            const double u = rc_uniform(a, (unsigned)i, (unsigned)pe);
-            const double v = (base + lik) + (-log(-log(u)));
+            double v = base + lik;
+            if (!(a.dbg & 4)) {
+                const double u = rc_uniform(a, (unsigned)i, (unsigned)pe);
+                v = v + (-log(-log(u)));
+            }
             if (v > bestv) { bestv = v; bestpos = pe; bestslot = k; }
         }
         // new-cluster candidate, last position (mcmc.jl:198-203, 228-230); one stream handles it
@@ -611,6 +615,7 @@ __global__ __launch_bounds__(RC_SCORE_THREADS) void k_resolve(View V, SweepArgs 
             if (c * RC_PTS + RC_PTS - 1 > after) score_chunk(V, sa, T, c, after);
         __syncthreads();
         const u64 mine = *T.blk_key;
+        if (sa.dbg & 2) break;
         ok = grid_barrier(V, T, (unsigned)G * (unsigned)(round + 1), mine, V.keys + round);
         if (!ok) break;
         const u64 key = __hip_atomic_load(V.keys + round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -725,7 +730,7 @@ struct rc_ctx {
     rc_params P{};
     bool have_params = false, have_state = false, S_valid = false;
     int G = 256;
-    int rows_per_split = 128;
+    int rows_per_split = 256;  // tools/bulk_tune.hip: fewer, longer splits = fewer 64-bit atomic flushes
     int num_cus = 256;
     // timing of k_bulk
     bool timing = false;
@@ -935,6 +940,13 @@ extern "C" int32_t rc_create(int64_t n, const double *D, const double *logD_or_n
     const int nchunks = (c->n + RC_PTS - 1) / RC_PTS;
     c->G = std::max(1, std::min(nchunks, c->num_cus));
     {
+        // k_bulk split length: aim for >= 512 workgroups, but keep splits long (each split boundary costs a
+        // round of 64-bit atomic flushes): 256 rows at n = 8192 (tools/bulk_tune.hip)
+        const int col_chunks = c->ld / 512;
+        const int splits_target = std::max(1, 512 / col_chunks);
+        c->rows_per_split = std::max(16, std::min(512, (c->n + splits_target - 1) / splits_target));
+    }
+    {
         // kernels whose dynamic LDS can exceed the 64 KiB default (large kcap)
         const size_t lds_r = std::max(tab_bytes(c->kcap, c->n, RC_SCORE_THREADS / 32), 2 * sizeof(int) * (size_t)c->kcap);
         const size_t lds_b = (size_t)c->kcap * 4 * sizeof(u64);
@@ -1101,6 +1113,10 @@ extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t 
     sa.log1mp = std::log(1 - p);
     sa.k0 = (unsigned)seed; sa.k1 = (unsigned)(seed >> 32);
     sa.sw_lo = (unsigned)sweep_index; sa.sw_hi = (unsigned)(sweep_index >> 32);
+    {
+        static const int dbg = getenv("RC_DEBUG_FLAGS") ? atoi(getenv("RC_DEBUG_FLAGS")) : 0;
+        sa.dbg = dbg;
+    }
     const size_t lds = std::max(tab_bytes(c->kcap, c->n, RC_SCORE_THREADS / 32), 2 * sizeof(int) * (size_t)c->kcap);
     k_resolve<<<c->G, RC_SCORE_THREADS, lds, c->stream>>>(V, sa, c->G);
     HIPCHK(c, hipGetLastError());
