@@ -103,7 +103,7 @@ def main():
         ctx.gibbs_sweep(r, p, chain_seed, sweep, blocking=False)
         sweep += 1
     ctx.synchronize()
-    ctx.kernel_timing(enable=1)
+    ctx.kernel_timing(enable=0 if os.environ.get('RC_BENCH_NO_TIMING') else int(os.environ.get('RC_BENCH_TIME_EVERY', 8)))
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -137,6 +137,12 @@ def main():
         value = world * args.steps / dt
         bulk_avg_ms = bulk_ms / max(bulk_launches, 1)
         achieved = alg_bytes / (bulk_avg_ms * 1e-3) / 1e9 if bulk_launches else None
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01", f"pmc_traffic_n{n}.json")
+        if os.path.exists(pmc):
+            # HBM bytes per k_bulk launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950
+            # FETCH_SIZE correction applied); collected offline with the same command, see the file's "source"
+            traffic = json.load(open(pmc))["k_bulk_hbm_bytes_per_launch"]
         out = {
             "metric": "Gibbs sweeps/sec (n×n distM)", "value": value, "unit": "sweeps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -150,7 +156,7 @@ def main():
             "label_changes_last_sweep": stats["n_changes"], "K_final": stats["K"],
             "coclustering_allreduce_ms": allreduce_ms, "coclustering_diag_ok": diag_ok,
             "roofline": {"kernel": "k_bulk", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": None,
+                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
                          "avg_launch_ms": bulk_avg_ms, "launches": bulk_launches, "algorithmic_bytes_per_launch": alg_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -109,8 +109,10 @@ int32_t rc_cocluster_reset(rc_ctx *ctx);
 int32_t rc_debug_rowsums(rc_ctx *ctx, int64_t label, int64_t *sumD_q /* n */, int64_t *sumL_q /* n */,
                          int32_t *eD, int32_t *eL);
 
-/* Timing of the dominant kernel (row-bucket reduction) measured with HIP events on the context's own
- * stream: accumulated milliseconds and launch count since the last reset. */
+/* Timing of the dominant kernel (row-bucket reduction) measured with HIP events on the stream it is launched
+ * on: accumulated milliseconds and number of timed launches since the last reset.  enable: 0 = off, 1 = time
+ * every launch, N > 1 = time every N-th launch (each timed launch costs a few microseconds of stream time),
+ * negative = just read the counters. */
 int32_t rc_kernel_timing(rc_ctx *ctx, int32_t enable, double *bulk_ms_total, int64_t *bulk_launches);
 
 #ifdef __cplusplus

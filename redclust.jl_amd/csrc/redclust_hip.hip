@@ -22,6 +22,10 @@
 //     re-drawn.  Draws are deterministic functions of (state, counter-based uniforms), so the result
 //     is identical to the sequential loop.  k_resolve runs this loop inside ONE persistent launch (one
 //     grid barrier per change); at stationarity it is a single scoring pass.
+//   * Sweeps are software-pipelined over two streams: k_resolve of sweep t runs concurrently with
+//     k_bulk of sweep t+1, which reduces the rows under the labels known before sweep t; the label
+//     changes of sweep t are added to that table by k_resolve with the same commutative integer atomics,
+//     so the table k_resolve(t+1) reads is exactly the row sums under the labels after sweep t.
 //   * Scores use the regrouped arithmetic of SURVEY.md §7 H2 (size-only lgamma terms tabulated on the
 //     host in long double; log(β+S) = log β + log1p(S/β)); terms common to all candidates (L2_i, the
 //     subtracted minimum) are dropped — they cannot change the Gumbel-max argmax.
@@ -42,22 +46,24 @@ typedef long long ll2 __attribute__((ext_vector_type(2)));
 typedef unsigned long long u64;
 
 #define RC_KEY_NONE 0xFFFFFFFFFFFFFFFFull
-#define RC_SCORE_THREADS 1024
-#define RC_PTS 32          // points per chunk (lanes of a half wave)
+#define RC_RES_THREADS 512  // k_resolve block: 32 points x 16 candidate streams; 2 waves/SIMD so it co-resides with k_bulk
+#define RC_PTS 32           // points per chunk (lanes of a half wave)
 #define RC_MAX_KCAP 4096
-#define RC_SPIN_LIMIT (1u << 22)
+#define RC_SPIN_LIMIT (1u << 23)
 
 // error bits in DevScalars.err
 #define RC_DERR_CAPACITY 1
 #define RC_DERR_BARRIER 2
 
 struct DevScalars {
-    int K;              // number of non-empty clusters
-    int n_changes;      // label changes committed in the last sweep
-    int n_rounds;       // scoring passes of the last sweep
-    int err;            // RC_DERR_* bits
-    int perm_valid;     // perm/pslot describe the current slot_of
-    int pad[3];
+    int K;                  // number of non-empty clusters
+    int n_changes;          // label changes committed in the last sweep
+    int n_rounds;           // scoring passes of the last sweep
+    int err;                // RC_DERR_* bits
+    int smallest_empty;     // smallest empty label (1-based), n+1 if none   (findfirst(clustsizes .== 0), mcmc.jl:199)
+    int slot_hi;            // 1 + highest slot index used since rc_set_state (rows >= slot_hi of every S buffer are zero)
+    int last_change_sweep;  // internal index of the last sweep that changed a label (-1: none)
+    int pad;
 };
 
 // Everything a kernel needs, passed by value.
@@ -65,14 +71,16 @@ struct View {
     int n, ld, kcap;
     const long long *Dq, *Lq;  // [n][ld] fixed point
     const long long *diagq;    // [n] Dq[i][i]
-    long long *SD, *SL;        // [kcap][ld]
+    long long *SD[3], *SL[3];  // three generations of the [kcap][ld] row-sum table (software pipelining)
     int *slot_of;              // [n]
     int *slot_size;            // [kcap]
     int *slot_label;           // [kcap] 1-based label, 0 = free slot
-    int *perm, *pslot;         // [n] rows grouped by slot, and the slot of each sorted position
+    short *slot_pos;           // [kcap] rank of the slot's label among active labels
+    short *slot_act;           // [kcap] slot_act[pos] = slot
+    int *perm[2], *pslot[2];   // [n] rows grouped by slot, and the slot of each sorted position (two generations)
     const double *A;           // [n+1] size table
-    u64 *keys;                 // [n+2] one first-change word per round
-    unsigned *arrive;          // grid-barrier arrival counter
+    u64 *keys[2];              // [n+2] one first-change word per round (two generations)
+    unsigned *arrive[2];       // grid-barrier arrival counters (two generations)
     DevScalars *sc;
     double scD, scL;           // 2^-eD, 2^-eL
     double alpha, beta, zeta, gamma, delta1, delta2, cL;
@@ -83,6 +91,7 @@ struct View {
 struct SweepArgs {
     double r, logp, log1mp;
     unsigned k0, k1, sw_lo, sw_hi;
+    int t;    // internal sweep index since rc_set_state: selects buffer generations
     int dbg;  // timing ablations only (RC_DEBUG_FLAGS): 1 = skip candidate loop, 2 = skip grid barrier, 4 = skip gumbel
 };
 
@@ -165,8 +174,9 @@ __global__ void k_quantize(const double *__restrict__ X, int n, int ld, int e, l
 // perm / pslot: rows grouped by slot (order inside a group is irrelevant — sums are exact integers).
 // One block.  LDS: 2*kcap ints.
 // ---------------------------------------------------------------------------------------------------
-__device__ void build_perm_block(const View &V, int *lds_off /*kcap*/, int *lds_cur /*kcap*/)
+__device__ void build_perm_block(const View &V, int gen, int *lds_off /*kcap*/, int *lds_cur /*kcap*/)
 {
+    int *perm = V.perm[gen], *pslot = V.pslot[gen];
     for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) lds_cur[k] = 0;
     __syncthreads();
     for (int i = threadIdx.x; i < V.n; i += blockDim.x) atomicAdd(&lds_cur[V.slot_of[i]], 1);
@@ -181,52 +191,25 @@ __device__ void build_perm_block(const View &V, int *lds_off /*kcap*/, int *lds_
     for (int i = threadIdx.x; i < V.n; i += blockDim.x) {
         const int s = V.slot_of[i];
         const int p = lds_off[s] + atomicAdd(&lds_cur[s], 1);
-        V.perm[p] = i;
-        V.pslot[p] = s;
+        perm[p] = i;
+        pslot[p] = s;
     }
     __syncthreads();
-    if (threadIdx.x == 0) V.sc->perm_valid = 1;
-}
-
-__global__ __launch_bounds__(1024) void k_build_perm(View V)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int *off = (int *)smem, *cur = off + V.kcap;
-    build_perm_block(V, off, cur);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// k_zero: clears the S rows of the active slots (free slots are all-zero by invariant: a cluster that
-// dies has had every contribution subtracted exactly), the per-round key words and the barrier counter.
-// grid (ld/512, kcap), 256 threads.
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_zero(View V)
-{
-    const int k = blockIdx.y;
-    if (k == 0) {
-        const int t = blockIdx.x * 256 + threadIdx.x;
-        for (int q = t; q < V.n + 2; q += gridDim.x * 256) V.keys[q] = RC_KEY_NONE;
-        if (t == 0) *V.arrive = 0u;
-    }
-    if (V.slot_size[k] == 0) return;
-    const size_t o = (size_t)k * V.ld + (size_t)(blockIdx.x * 256 + threadIdx.x) * 2;
-    const ll2 z = {0, 0};
-    *(ll2 *)(V.SD + o) = z;
-    *(ll2 *)(V.SL + o) = z;
 }
 
 // ---------------------------------------------------------------------------------------------------
 // k_bulk — THE HBM-BOUND KERNEL.  Row-bucket reduction of D and logD into S (matsum(D,[i],clust_k) and
 // matsum(logD,[i],clust_k), src/mcmc.jl:210-213, for all i and k).  Algorithmic traffic 2·n²·8 bytes.
-//   block = 256 threads = 512 consecutive columns i (2 per lane, 16-byte loads, 4 KiB contiguous per row);
-//   blockIdx.y = split of the cluster-sorted row list; rows of one cluster accumulate in registers and are
-//   flushed with exact 64-bit integer atomics when the cluster changes.
+//   block = 256 threads = 512 consecutive columns i (2 per lane, 16-byte non-temporal loads, 4 KiB contiguous
+//   per row and matrix); blockIdx.y = split of the cluster-sorted row list; rows of one cluster accumulate in
+//   registers and are flushed with exact 64-bit integer atomics when the cluster changes.
+//   Prologue: clears the S generation that the sweep after next will fill (nobody reads it any more).
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bulk_flush(const View &V, int slot, int i, long long d0, long long d1,
-                                           long long l0, long long l1)
+__device__ __forceinline__ void bulk_flush(long long *SD, long long *SL, size_t ld, int slot, int i, long long d0,
+                                           long long d1, long long l0, long long l1)
 {
-    u64 *pd = (u64 *)(V.SD + (size_t)slot * V.ld + i);
-    u64 *pl = (u64 *)(V.SL + (size_t)slot * V.ld + i);
+    u64 *pd = (u64 *)(SD + (size_t)slot * ld + i);
+    u64 *pl = (u64 *)(SL + (size_t)slot * ld + i);
     __hip_atomic_fetch_add(pd, (u64)d0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_add(pd + 1, (u64)d1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_add(pl, (u64)l0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -234,17 +217,27 @@ __device__ __forceinline__ void bulk_flush(const View &V, int slot, int i, long 
 }
 
 #define RC_BULK_U 8
-__global__ __launch_bounds__(256) void k_bulk(View V, int rows_per_split)
+__global__ __launch_bounds__(256) void k_bulk(View V, int rows_per_split, int wgen, int zgen, int pgen)
 {
+    const size_t ld = (size_t)V.ld;
+    {   // clear generation zgen, rows < slot_hi (rows above are zero by invariant)
+        const int hi = V.sc->slot_hi;
+        const size_t total2 = (size_t)hi * ld / 2;
+        const size_t nthreads = (size_t)gridDim.x * gridDim.y * 256;
+        const size_t me = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        ll2 *zd = (ll2 *)V.SD[zgen], *zl = (ll2 *)V.SL[zgen];
+        const ll2 z = {0, 0};
+        for (size_t q = me; q < total2; q += nthreads) { zd[q] = z; zl[q] = z; }
+    }
     const int i = (blockIdx.x * 256 + threadIdx.x) * 2;
     const int p0 = blockIdx.y * rows_per_split;
     const int p1 = min(V.n, p0 + rows_per_split);
     if (p0 >= p1) return;
-    const int *__restrict__ perm = V.perm;
-    const int *__restrict__ pslot = V.pslot;
+    const int *__restrict__ perm = V.perm[pgen];
+    const int *__restrict__ pslot = V.pslot[pgen];
     const long long *__restrict__ Dq = V.Dq + i;
     const long long *__restrict__ Lq = V.Lq + i;
-    const size_t ld = (size_t)V.ld;
+    long long *SD = V.SD[wgen], *SL = V.SL[wgen];
     long long aD0 = 0, aD1 = 0, aL0 = 0, aL1 = 0;
     int cur = pslot[p0];
     int p = p0;
@@ -261,7 +254,7 @@ __global__ __launch_bounds__(256) void k_bulk(View V, int rows_per_split)
 #pragma unroll
         for (int u = 0; u < RC_BULK_U; ++u) {
             if (s[u] != cur) {
-                bulk_flush(V, cur, i, aD0, aD1, aL0, aL1);
+                bulk_flush(SD, SL, ld, cur, i, aD0, aD1, aL0, aL1);
                 aD0 = aD1 = aL0 = aL1 = 0;
                 cur = s[u];
             }
@@ -273,13 +266,13 @@ __global__ __launch_bounds__(256) void k_bulk(View V, int rows_per_split)
         const ll2 d = __builtin_nontemporal_load((const ll2 *)(Dq + (size_t)j * ld));
         const ll2 l = __builtin_nontemporal_load((const ll2 *)(Lq + (size_t)j * ld));
         if (s != cur) {
-            bulk_flush(V, cur, i, aD0, aD1, aL0, aL1);
+            bulk_flush(SD, SL, ld, cur, i, aD0, aD1, aL0, aL1);
             aD0 = aD1 = aL0 = aL1 = 0;
             cur = s;
         }
         aD0 += d.x; aD1 += d.y; aL0 += l.x; aL1 += l.y;
     }
-    bulk_flush(V, cur, i, aD0, aD1, aL0, aL1);
+    bulk_flush(SD, SL, ld, cur, i, aD0, aD1, aL0, aL1);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -292,74 +285,62 @@ struct Tab {
     short *act;      // [kcap] act[pos] = slot
     double *base_o;  // [kcap] A[s] + log p + log(s-1+r), s = size          (candidate cluster of another point)
     double *base_s;  // [kcap] same with s = size-1                          (the point's own cluster, itself removed)
-    unsigned *used;  // [(n+31)/32] label occupancy bitset, bit (label-1)
-    double *red_v;   // [NS][32] reduction scratch
+    unsigned *used;  // [(n+31)/32] label occupancy bitset, bit (label-1); built only when a birth/death/rename needs it
+    double *red_v;   // [NW][32] reduction scratch (NW = waves per block)
     int *red_pos, *red_slot;
-    int *misc;       // [0]=K [1]=smallest_empty(1-based, n+1 if none) [2]=scratch min [3]=b [4]=structural [5]=fail [6]=barrier ok
+    int *misc;       // [0]=K [1]=smallest_empty [2]=scratch min [3]=b [4]=structural [5]=fail [6]=barrier ok [7]=slot_hi
     u64 *blk_key;    // block-local first-change key
 };
 
-__device__ __forceinline__ size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
-
-__device__ Tab tab_carve(char *smem, int kcap, int n, int ns)
+#define RC_A16(x) (((x) + 15) & ~(size_t)15)
+__host__ __device__ inline size_t tab_layout(int kcap, int n, int nw, size_t *off /*12*/)
 {
-    Tab T;
     size_t o = 0;
-    T.base_o = (double *)(smem + o); o = align16(o + sizeof(double) * kcap);
-    T.base_s = (double *)(smem + o); o = align16(o + sizeof(double) * kcap);
-    T.red_v = (double *)(smem + o); o = align16(o + sizeof(double) * ns * RC_PTS);
-    T.blk_key = (u64 *)(smem + o); o = align16(o + sizeof(u64));
-    T.size = (int *)(smem + o); o = align16(o + sizeof(int) * kcap);
-    T.label = (int *)(smem + o); o = align16(o + sizeof(int) * kcap);
-    T.red_pos = (int *)(smem + o); o = align16(o + sizeof(int) * ns * RC_PTS);
-    T.red_slot = (int *)(smem + o); o = align16(o + sizeof(int) * ns * RC_PTS);
-    T.used = (unsigned *)(smem + o); o = align16(o + sizeof(unsigned) * ((n + 31) / 32));
-    T.misc = (int *)(smem + o); o = align16(o + sizeof(int) * 8);
-    T.pos = (short *)(smem + o); o = align16(o + sizeof(short) * kcap);
-    T.act = (short *)(smem + o); o = align16(o + sizeof(short) * kcap);
+    off[0] = o; o = RC_A16(o + sizeof(double) * kcap);          // base_o
+    off[1] = o; o = RC_A16(o + sizeof(double) * kcap);          // base_s
+    off[2] = o; o = RC_A16(o + sizeof(double) * nw * RC_PTS);   // red_v
+    off[3] = o; o = RC_A16(o + sizeof(u64));                    // blk_key
+    off[4] = o; o = RC_A16(o + sizeof(int) * kcap);             // size
+    off[5] = o; o = RC_A16(o + sizeof(int) * kcap);             // label
+    off[6] = o; o = RC_A16(o + sizeof(int) * nw * RC_PTS);      // red_pos
+    off[7] = o; o = RC_A16(o + sizeof(int) * nw * RC_PTS);      // red_slot
+    off[8] = o; o = RC_A16(o + sizeof(unsigned) * ((n + 31) / 32));  // used
+    off[9] = o; o = RC_A16(o + sizeof(int) * 8);                // misc
+    off[10] = o; o = RC_A16(o + sizeof(short) * kcap);          // pos
+    off[11] = o; o = RC_A16(o + sizeof(short) * kcap);          // act
+    return o;
+}
+
+__device__ Tab tab_carve(char *smem, int kcap, int n, int nw)
+{
+    size_t off[12];
+    tab_layout(kcap, n, nw, off);
+    Tab T;
+    T.base_o = (double *)(smem + off[0]); T.base_s = (double *)(smem + off[1]); T.red_v = (double *)(smem + off[2]);
+    T.blk_key = (u64 *)(smem + off[3]); T.size = (int *)(smem + off[4]); T.label = (int *)(smem + off[5]);
+    T.red_pos = (int *)(smem + off[6]); T.red_slot = (int *)(smem + off[7]); T.used = (unsigned *)(smem + off[8]);
+    T.misc = (int *)(smem + off[9]); T.pos = (short *)(smem + off[10]); T.act = (short *)(smem + off[11]);
     return T;
 }
 
-static size_t tab_bytes(int kcap, int n, int ns)
+static size_t tab_bytes(int kcap, int n, int nw)
 {
-    auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    size_t o = 0;
-    o = a16(o + sizeof(double) * kcap);
-    o = a16(o + sizeof(double) * kcap);
-    o = a16(o + sizeof(double) * ns * RC_PTS);
-    o = a16(o + sizeof(u64));
-    o = a16(o + sizeof(int) * kcap);
-    o = a16(o + sizeof(int) * kcap);
-    o = a16(o + sizeof(int) * ns * RC_PTS);
-    o = a16(o + sizeof(int) * ns * RC_PTS);
-    o = a16(o + sizeof(unsigned) * ((n + 31) / 32));
-    o = a16(o + sizeof(int) * 8);
-    o = a16(o + sizeof(short) * kcap);
-    o = a16(o + sizeof(short) * kcap);
-    return o;
+    size_t off[12];
+    return tab_layout(kcap, n, nw, off);
 }
 
 __device__ __forceinline__ double tab_base(const View &V, const SweepArgs &a, int s)
 {
-    // A[s] + (log p + log(s - 1 + r)): size-only terms of mcmc.jl:223-226,240-241 (see orc_size_table)
+    // A[s] + (log p + log(s - 1 + r)): size-only terms of mcmc.jl:223-226,240-241
     return V.A[s] + (a.logp + log((double)s - 1.0 + a.r));
 }
 
-// ranks (candidate order = ascending label), act list, base constants.  All threads; ends synchronised.
-__device__ void tab_derive(const View &V, const SweepArgs &a, Tab &T)
+// per-slot score constants of the active slots.  All threads; ends synchronised.
+__device__ void tab_bases(const View &V, const SweepArgs &a, Tab &T)
 {
-    const int kcap = V.kcap;
-    for (int k = threadIdx.x; k < kcap; k += blockDim.x) {
-        const int lab = T.label[k];
-        if (lab > 0) {
-            int c = 0;
-            for (int q = 0; q < kcap; ++q) {
-                const int lq = T.label[q];
-                c += (lq > 0 && lq < lab);
-            }
-            T.pos[k] = (short)c;
-            T.act[c] = (short)k;
-            const int s = T.size[k];
+    for (int k = threadIdx.x; k < T.misc[7]; k += blockDim.x) {
+        const int s = T.size[k];
+        if (T.label[k] > 0) {
             T.base_o[k] = tab_base(V, a, s);
             T.base_s[k] = (s >= 2) ? tab_base(V, a, s - 1) : 0.0;
         }
@@ -367,12 +348,18 @@ __device__ void tab_derive(const View &V, const SweepArgs &a, Tab &T)
     __syncthreads();
 }
 
-// smallest empty label from the bitset (findfirst(clustsizes .== 0), mcmc.jl:199).  Ends synchronised.
-__device__ void tab_smallest_empty(const View &V, Tab &T)
+// After a birth / death / rename: label bitset, smallest empty label, candidate ranks.  Ends synchronised.
+__device__ void tab_structural(const View &V, Tab &T)
 {
+    const int nw = (V.n + 31) / 32, hi = T.misc[7];
+    for (int w = threadIdx.x; w < nw; w += blockDim.x) T.used[w] = 0u;
     if (threadIdx.x == 0) T.misc[2] = V.n + 1;
     __syncthreads();
-    const int nw = (V.n + 31) / 32;
+    for (int k = threadIdx.x; k < hi; k += blockDim.x) {
+        const int lab = T.label[k];
+        if (lab > 0) atomicOr(&T.used[(lab - 1) >> 5], 1u << ((lab - 1) & 31));
+    }
+    __syncthreads();
     for (int w = threadIdx.x; w < nw; w += blockDim.x) {
         const unsigned inv = ~T.used[w];
         if (inv) {
@@ -380,28 +367,69 @@ __device__ void tab_smallest_empty(const View &V, Tab &T)
             if (lab <= V.n) atomicMin(&T.misc[2], lab);
         }
     }
+    for (int k = threadIdx.x; k < hi; k += blockDim.x) {
+        const int lab = T.label[k];
+        if (lab > 0) {
+            int c = 0;
+            for (int q = 0; q < hi; ++q) {
+                const int lq = T.label[q];
+                c += (lq > 0 && lq < lab);
+            }
+            T.pos[k] = (short)c;
+            T.act[c] = (short)k;
+        }
+    }
     __syncthreads();
     if (threadIdx.x == 0) T.misc[1] = T.misc[2];
     __syncthreads();
 }
 
-__device__ void tab_load(const View &V, const SweepArgs &a, Tab &T)
+__device__ void tab_load(const View &V, Tab &T)
 {
-    const int nw = (V.n + 31) / 32;
-    for (int w = threadIdx.x; w < nw; w += blockDim.x) T.used[w] = 0u;
     for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) {
         T.size[k] = V.slot_size[k];
         T.label[k] = V.slot_label[k];
+        T.pos[k] = V.slot_pos[k];
+        T.act[k] = V.slot_act[k];
     }
-    if (threadIdx.x == 0) { T.misc[0] = V.sc->K; *T.blk_key = RC_KEY_NONE; }
+    if (threadIdx.x == 0) {
+        T.misc[0] = V.sc->K;
+        T.misc[1] = V.sc->smallest_empty;
+        T.misc[7] = V.sc->slot_hi;
+        *T.blk_key = RC_KEY_NONE;
+    }
     __syncthreads();
+}
+
+__device__ void tab_store(const View &V, const Tab &T)
+{
     for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) {
-        const int lab = T.label[k];
-        if (lab > 0) atomicOr(&T.used[(lab - 1) >> 5], 1u << ((lab - 1) & 31));
+        V.slot_size[k] = T.size[k];
+        V.slot_label[k] = T.label[k];
+        V.slot_pos[k] = T.pos[k];
+        V.slot_act[k] = T.act[k];
     }
+    if (threadIdx.x == 0) {
+        V.sc->K = T.misc[0];
+        V.sc->smallest_empty = T.misc[1];
+        V.sc->slot_hi = T.misc[7];
+    }
+}
+
+// After rc_set_state: derive ranks / smallest empty label / perm (both generations) from slot_size, slot_label, slot_of.
+__global__ __launch_bounds__(1024) void k_derive(View V)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Tab T = tab_carve(smem, V.kcap, V.n, 1);
+    for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) { T.size[k] = V.slot_size[k]; T.label[k] = V.slot_label[k]; T.pos[k] = 0; T.act[k] = 0; }
+    if (threadIdx.x == 0) { T.misc[0] = V.sc->K; T.misc[7] = V.sc->slot_hi; }
     __syncthreads();
-    tab_smallest_empty(V, T);
-    tab_derive(V, a, T);
+    tab_structural(V, T);
+    tab_store(V, T);
+    __syncthreads();
+    int *off = (int *)smem, *cur = off + V.kcap;
+    build_perm_block(V, 0, off, cur);
+    for (int p = threadIdx.x; p < V.n; p += blockDim.x) { V.perm[1][p] = V.perm[0][p]; V.pslot[1][p] = V.pslot[0][p]; }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -409,9 +437,17 @@ __device__ void tab_load(const View &V, const SweepArgs &a, Tab &T)
 // src/utils.jl:2-6 for the draw), under the state held in T.  Thread (pt, st): point pt of the chunk,
 // candidate positions st, st+NS, ...  Points with index <= after_i are skipped (already final).
 // ---------------------------------------------------------------------------------------------------
-__device__ void score_chunk(const View &V, const SweepArgs &a, Tab &T, int chunk, int after_i)
+__device__ __forceinline__ void best_merge(double &bv, int &bp, int &bs, double v, int p, int s)
+{
+    // first-index tie rule of argmax (utils.jl:5): larger value wins, equal values -> smaller candidate position
+    if (s != -2 && (bs == -2 || v > bv || (v == bv && p < bp))) { bv = v; bp = p; bs = s; }
+}
+
+__device__ void score_chunk(const View &V, const SweepArgs &a, Tab &T, const long long *SD, const long long *SL,
+                            int chunk, int after_i)
 {
     const int pt = threadIdx.x & (RC_PTS - 1), st = threadIdx.x >> 5, NS = blockDim.x >> 5;
+    const int wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
     const int i = chunk * RC_PTS + pt;
     const bool valid = (i < V.n) && (i > after_i);
     const int K = T.misc[0];
@@ -431,8 +467,8 @@ __device__ void score_chunk(const View &V, const SweepArgs &a, Tab &T, int chunk
             const int s = T.size[k] - isown;
             if (s == 0) continue;  // own singleton cluster: not a candidate once i is removed (mcmc.jl:193-196)
             const int pe = pos - (single && pos > pown);
-            const long long sd = V.SD[(size_t)k * ld + i] - (isown ? dg : 0);  // i itself excluded (clusts[i] = -1)
-            const long long sl = V.SL[(size_t)k * ld + i];                      // logD diagonal is 0 (types.jl:155)
+            const long long sd = SD[(size_t)k * ld + i] - (isown ? dg : 0);  // i itself excluded (clusts[i] = -1)
+            const long long sl = SL[(size_t)k * ld + i];                      // logD diagonal is 0 (types.jl:155)
             const double SDr = (double)sd * V.scD, SLr = (double)sl * V.scL;
             const double base = isown ? T.base_s[k] : T.base_o[k];
             double lik = V.cL * SLr - (V.alpha + V.delta1 * (double)s) * log1p(SDr / V.beta);
@@ -451,30 +487,41 @@ __device__ void score_chunk(const View &V, const SweepArgs &a, Tab &T, int chunk
             if (v > bestv || bestslot == -2) { bestv = v; bestpos = Ki; bestslot = -1; }
         }
     }
-    T.red_v[st * RC_PTS + pt] = bestv;
-    T.red_pos[st * RC_PTS + pt] = bestpos;
-    T.red_slot[st * RC_PTS + pt] = bestslot;
+    // reduce over the candidate streams: the two halves of each wave by shuffle, then the waves through LDS
+    {
+        const double ov = __shfl_xor(bestv, 32);
+        const int op = __shfl_xor(bestpos, 32), os = __shfl_xor(bestslot, 32);
+        best_merge(bestv, bestpos, bestslot, ov, op, os);
+    }
+    if ((threadIdx.x & 63) < RC_PTS) {
+        T.red_v[wave * RC_PTS + pt] = bestv;
+        T.red_pos[wave * RC_PTS + pt] = bestpos;
+        T.red_slot[wave * RC_PTS + pt] = bestslot;
+    }
     __syncthreads();
-    if (st == 0 && valid) {
-        for (int q = 1; q < NS; ++q) {
-            const int sl = T.red_slot[q * RC_PTS + pt];
-            if (sl == -2) continue;
-            const double v = T.red_v[q * RC_PTS + pt];
-            const int ps = T.red_pos[q * RC_PTS + pt];
-            if (bestslot == -2 || v > bestv || (v == bestv && ps < bestpos)) { bestv = v; bestpos = ps; bestslot = sl; }
-        }
-        bool changed;
-        if (bestslot >= 0) {
-            changed = (bestslot != own);
-        } else {
-            // new label = smallest empty label once i is removed (mcmc.jl:199)
-            const int se = T.misc[1];
-            const int newlab = single ? min(T.label[own], se) : se;
-            changed = !(single && newlab == T.label[own]);
-        }
-        if (changed) {
-            const u64 key = ((u64)(unsigned)i << 32) | ((u64)(unsigned)own << 16) | (u64)(unsigned)(bestslot + 1);
-            atomicMin(T.blk_key, key);
+    if (wave == 0) {
+        const int half = (threadIdx.x >> 5) & 1;  // lanes 0-31: waves [0, NW/2), lanes 32-63: the rest
+        const int w0 = half ? (NW + 1) / 2 : 0, w1 = half ? NW : (NW + 1) / 2;
+        double bv = -INFINITY;
+        int bp = 0x7fffffff, bs = -2;
+        for (int w = w0; w < w1; ++w) best_merge(bv, bp, bs, T.red_v[w * RC_PTS + pt], T.red_pos[w * RC_PTS + pt], T.red_slot[w * RC_PTS + pt]);
+        const double ov = __shfl_xor(bv, 32);
+        const int op = __shfl_xor(bp, 32), os = __shfl_xor(bs, 32);
+        best_merge(bv, bp, bs, ov, op, os);
+        if (half == 0 && valid) {
+            bool changed;
+            if (bs >= 0) {
+                changed = (bs != own);
+            } else {
+                // new label = smallest empty label once i is removed (mcmc.jl:199)
+                const int se = T.misc[1];
+                const int newlab = single ? min(T.label[own], se) : se;
+                changed = !(single && newlab == T.label[own]);
+            }
+            if (changed) {
+                const u64 key = ((u64)(unsigned)i << 32) | ((u64)(unsigned)own << 16) | (u64)(unsigned)(bs + 1);
+                atomicMin(T.blk_key, key);
+            }
         }
     }
     __syncthreads();
@@ -482,35 +529,31 @@ __device__ void score_chunk(const View &V, const SweepArgs &a, Tab &T, int chunk
 
 // ---------------------------------------------------------------------------------------------------
 // Commit of the first change (i*, own slot a, target) — executed identically by every block on its LDS
-// copy of the tables; each block then corrects S for the points it owns.  Returns false on capacity
-// overflow (flag set).  mcmc.jl:250-252 plus the bookkeeping the reference does with findall each time.
+// copy of the tables; each block then corrects S for the points it owns: the generation it is reading
+// (plain read-modify-write: nobody else touches those words) and the NEXT generation, which the
+// concurrently running k_bulk of the following sweep is filling from the pre-change labels (64-bit integer
+// atomics commute with k_bulk's, so the sum is exact whatever the interleaving).
+// Returns false on capacity overflow (flag set).  mcmc.jl:250-252 plus the findall bookkeeping.
 // ---------------------------------------------------------------------------------------------------
-__device__ bool commit_change(const View &V, const SweepArgs &sa, Tab &T, u64 key, int G)
+__device__ bool commit_change(const View &V, const SweepArgs &sa, Tab &T, u64 key, int G, int own_gen, int next_gen)
 {
     const int istar = (int)(key >> 32);
     const int a = (int)((key >> 16) & 0xFFFFu);
     const int tgt = (int)(key & 0xFFFFu) - 1;
-    int b = tgt;
-    bool structural = false;  // birth / death / rename: ranks and smallest-empty must be rebuilt
     int &sh_b = T.misc[3], &sh_struct = T.misc[4], &sh_fail = T.misc[5];
     if (threadIdx.x == 0) {
         sh_fail = 0;
-        int st = 0;
+        int st = 0, b = tgt;
         if (tgt >= 0) {
             T.size[a] -= 1;
             T.size[b] += 1;
             if (T.size[a] == 0) {  // death
-                const int lab = T.label[a];
-                T.used[(lab - 1) >> 5] &= ~(1u << ((lab - 1) & 31));
                 T.label[a] = 0;
                 T.misc[0] -= 1;
                 st = 1;
             }
-        } else if (T.size[a] == 1) {  // singleton moves to a fresh label: rename the slot, S column unchanged
-            const int lab = T.label[a], nl = T.misc[1];
-            T.used[(lab - 1) >> 5] &= ~(1u << ((lab - 1) & 31));
-            T.used[(nl - 1) >> 5] |= 1u << ((nl - 1) & 31);
-            T.label[a] = nl;
+        } else if (T.size[a] == 1) {  // singleton moves to a fresh (smaller) label: rename the slot, S column unchanged
+            T.label[a] = T.misc[1];
             b = a;
             st = 1;
         } else {  // birth
@@ -520,13 +563,12 @@ __device__ bool commit_change(const View &V, const SweepArgs &sa, Tab &T, u64 ke
             if (f < 0) {
                 sh_fail = 1;
             } else {
-                const int nl = T.misc[1];
                 b = f;
-                T.label[b] = nl;
+                T.label[b] = T.misc[1];
                 T.size[b] = 1;
                 T.size[a] -= 1;
-                T.used[(nl - 1) >> 5] |= 1u << ((nl - 1) & 31);
                 T.misc[0] += 1;
+                if (b + 1 > T.misc[7]) T.misc[7] = b + 1;
                 st = 1;
             }
         }
@@ -538,11 +580,10 @@ __device__ bool commit_change(const View &V, const SweepArgs &sa, Tab &T, u64 ke
         if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(&V.sc->err, RC_DERR_CAPACITY);
         return false;
     }
-    b = sh_b;
-    structural = sh_struct != 0;
-    if (structural) {
-        tab_smallest_empty(V, T);
-        tab_derive(V, sa, T);
+    const int b = sh_b;
+    if (sh_struct) {
+        tab_structural(V, T);
+        tab_bases(V, sa, T);
     } else {
         if (threadIdx.x < 2) {
             const int k = threadIdx.x == 0 ? a : b;
@@ -552,18 +593,23 @@ __device__ bool commit_change(const View &V, const SweepArgs &sa, Tab &T, u64 ke
         }
         __syncthreads();
     }
-    // S correction for the points this block owns: S[a][i] -= D[i*,i], S[b][i] += D[i*,i] (exact)
+    // S correction for the points this block owns: S[a][i] -= x[i*,i], S[b][i] += x[i*,i] (exact)
     if (a != b) {
         const int nchunks = (V.n + RC_PTS - 1) / RC_PTS;
-        const int pt = threadIdx.x & (RC_PTS - 1), job = threadIdx.x >> 5;  // jobs 0..3 used
+        const int pt = threadIdx.x & (RC_PTS - 1), job = threadIdx.x >> 5;  // jobs 0..3: (D,a) (D,b) (L,a) (L,b)
         if (job < 4) {
             const long long *M = (job < 2) ? V.Dq : V.Lq;
-            long long *S = (job < 2) ? V.SD : V.SL;
+            long long *So = (job < 2) ? V.SD[own_gen] : V.SL[own_gen];
+            long long *Sn = (job < 2) ? V.SD[next_gen] : V.SL[next_gen];
             const int slot = (job & 1) ? b : a;
-            const long long sign = (job & 1) ? 1 : -1;
             for (int c = blockIdx.x; c < nchunks; c += G) {
                 const int i = c * RC_PTS + pt;
-                if (i < V.n) S[(size_t)slot * V.ld + i] += sign * M[(size_t)istar * V.ld + i];
+                if (i < V.n) {
+                    const long long x = M[(size_t)istar * V.ld + i];
+                    const long long dx = (job & 1) ? x : -x;
+                    So[(size_t)slot * V.ld + i] += dx;
+                    __hip_atomic_fetch_add((u64 *)(Sn + (size_t)slot * V.ld + i), (u64)dx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
     }
@@ -574,21 +620,19 @@ __device__ bool commit_change(const View &V, const SweepArgs &sa, Tab &T, u64 ke
 
 // Grid barrier: monotonic arrival counter; lane 0 of each block arrives after its (returning) atomicMin
 // on the round's key word, so every block's candidate is in the word before anyone leaves.  Bounded spin.
-__device__ bool grid_barrier(const View &V, Tab &T, unsigned target, u64 my_key, u64 *key_word)
+__device__ bool grid_barrier(const View &V, Tab &T, unsigned *arrive, unsigned target, u64 my_key, u64 *key_word)
 {
     int &sh_ok = T.misc[6];
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned inc = 1u;
         if (my_key != RC_KEY_NONE) {
             const u64 old = atomicMin(key_word, my_key);
-            inc += (old == 0x1234567887654321ull) ? 0u : 0u;  // data dependence: the min has been performed
-            asm volatile("" ::"v"((unsigned)old));
+            asm volatile("" ::"v"((unsigned)old));  // data dependence: the min has been performed before we arrive
         }
-        __hip_atomic_fetch_add(V.arrive, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
         int ok = 1;
-        while (__hip_atomic_load(V.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(2);
             if (++spins > RC_SPIN_LIMIT) { ok = 0; atomicOr(&V.sc->err, RC_DERR_BARRIER); break; }
         }
@@ -600,28 +644,36 @@ __device__ bool grid_barrier(const View &V, Tab &T, unsigned target, u64 my_key,
 
 // ---------------------------------------------------------------------------------------------------
 // k_resolve — one persistent launch per sweep: round 0 scores every point; each further round commits the
-// first change and re-draws the points after it.  G blocks (all co-resident: G <= 256, one per CU).
+// first change and re-draws the points after it.  G blocks (G <= #CUs; they need not start together: the
+// spin is bounded only by a generous timeout, and k_bulk never waits on this kernel).
+// Sweep t reads S generation t%3, corrects generations t%3 and (t+1)%3, uses key/barrier generation t%2
+// (and re-arms generation (t+1)%2), and leaves perm generation t%2 describing the labels after the sweep.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(RC_SCORE_THREADS) void k_resolve(View V, SweepArgs sa, int G)
+__global__ __launch_bounds__(RC_RES_THREADS) void k_resolve(View V, SweepArgs sa, int G)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    Tab T = tab_carve(smem, V.kcap, V.n, blockDim.x >> 5);
-    tab_load(V, sa, T);
+    Tab T = tab_carve(smem, V.kcap, V.n, blockDim.x >> 6);
+    const int t = sa.t, own_gen = t % 3, next_gen = (t + 1) % 3, kg = t & 1;
+    const long long *SD = V.SD[own_gen], *SL = V.SL[own_gen];
+    u64 *keys = V.keys[kg];
+    unsigned *arrive = V.arrive[kg];
+    tab_load(V, T);
+    tab_bases(V, sa, T);
     const int nchunks = (V.n + RC_PTS - 1) / RC_PTS;
     int after = -1, round = 0, changes = 0;
     bool ok = true;
     for (;;) {
         for (int c = blockIdx.x; c < nchunks; c += G)
-            if (c * RC_PTS + RC_PTS - 1 > after) score_chunk(V, sa, T, c, after);
+            if (c * RC_PTS + RC_PTS - 1 > after) score_chunk(V, sa, T, SD, SL, c, after);
         __syncthreads();
         const u64 mine = *T.blk_key;
         if (sa.dbg & 2) break;
-        ok = grid_barrier(V, T, (unsigned)G * (unsigned)(round + 1), mine, V.keys + round);
+        ok = grid_barrier(V, T, arrive, (unsigned)G * (unsigned)(round + 1), mine, keys + round);
         if (!ok) break;
-        const u64 key = __hip_atomic_load(V.keys + round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64 key = __hip_atomic_load(keys + round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (key == RC_KEY_NONE) break;
         if (threadIdx.x == 0) *T.blk_key = RC_KEY_NONE;
-        ok = commit_change(V, sa, T, key, G);
+        ok = commit_change(V, sa, T, key, G, own_gen, next_gen);
         if (!ok) break;
         after = (int)(key >> 32);
         ++round;
@@ -630,22 +682,24 @@ __global__ __launch_bounds__(RC_SCORE_THREADS) void k_resolve(View V, SweepArgs 
     }
     if (blockIdx.x == 0) {
         __syncthreads();
-        for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) {
-            V.slot_size[k] = T.size[k];
-            V.slot_label[k] = T.label[k];
-        }
+        // re-arm the other key/barrier generation for the next sweep (its last user, sweep t-1, has finished)
+        for (int q = threadIdx.x; q < V.n + 2; q += blockDim.x) V.keys[kg ^ 1][q] = RC_KEY_NONE;
+        if (threadIdx.x == 0) *V.arrive[kg ^ 1] = 0u;
+        tab_store(V, T);
+        const int last = V.sc->last_change_sweep;
+        __syncthreads();
         if (threadIdx.x == 0) {
-            V.sc->K = T.misc[0];
             V.sc->n_changes = changes;
             V.sc->n_rounds = round + 1;
-            if (changes) V.sc->perm_valid = 0;
+            if (changes) V.sc->last_change_sweep = t;
         }
-        __syncthreads();
+        // perm generation t%2 must describe the labels after this sweep (k_bulk of sweep t+2 reads it)
         if (changes && ok) {
-            // rows must be regrouped before the next k_bulk; LDS tables are no longer needed
-            int *off = (int *)smem, *cur = off + V.kcap;
+            int *off = (int *)smem, *cur = off + V.kcap;  // LDS tables are no longer needed
             __syncthreads();
-            build_perm_block(V, off, cur);
+            build_perm_block(V, kg, off, cur);
+        } else if (last == t - 1 && t >= 1) {
+            for (int p = threadIdx.x; p < V.n; p += blockDim.x) { V.perm[kg][p] = V.perm[kg ^ 1][p]; V.pslot[kg][p] = V.pslot[kg ^ 1][p]; }
         }
     }
 }
@@ -656,7 +710,7 @@ __global__ __launch_bounds__(RC_SCORE_THREADS) void k_resolve(View V, SweepArgs 
 // out[(t*kcap + k)*4 + {0,1,2,3}] = D_hi, D_lo, L_hi, L_lo
 // ---------------------------------------------------------------------------------------------------
 #define RC_LO_BITS 24
-__global__ __launch_bounds__(256) void k_blocksums(View V, long long *out)
+__global__ __launch_bounds__(256) void k_blocksums(View V, int gen, long long *out)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u64 *bins = (u64 *)smem;  // [kcap][4]
@@ -667,7 +721,7 @@ __global__ __launch_bounds__(256) void k_blocksums(View V, long long *out)
     const long long mask = ((long long)1 << RC_LO_BITS) - 1;
     for (int i = threadIdx.x; i < V.n; i += blockDim.x) {
         const int k = V.slot_of[i];
-        const long long d = V.SD[(size_t)t * V.ld + i], l = V.SL[(size_t)t * V.ld + i];
+        const long long d = V.SD[gen][(size_t)t * V.ld + i], l = V.SL[gen][(size_t)t * V.ld + i];
         atomicAdd(&bins[k * 4 + 0], (u64)(d >> RC_LO_BITS));
         atomicAdd(&bins[k * 4 + 1], (u64)(d & mask));
         atomicAdd(&bins[k * 4 + 2], (u64)(l >> RC_LO_BITS));
@@ -709,6 +763,7 @@ __global__ void k_cocluster_final(const unsigned *__restrict__ counts, int n, in
     }
 }
 
+
 // ===================================================================================================
 // Host side
 // ===================================================================================================
@@ -716,29 +771,41 @@ struct rc_ctx {
     int dev = 0;
     int n = 0, ld = 0, kcap = 0;
     int eD = 0, eL = 0;
-    hipStream_t stream = nullptr;
-    long long *Dq = nullptr, *Lq = nullptr, *diagq = nullptr, *SD = nullptr, *SL = nullptr;
-    int *slot_of = nullptr, *slot_size = nullptr, *slot_label = nullptr, *perm = nullptr, *pslot = nullptr;
+    hipStream_t sA = nullptr;  // resolve + observables (high priority)
+    hipStream_t sB = nullptr;  // row-bucket reduction (k_bulk)
+    long long *Dq = nullptr, *Lq = nullptr, *diagq = nullptr;
+    long long *SD[3] = {nullptr, nullptr, nullptr}, *SL[3] = {nullptr, nullptr, nullptr};
+    int *slot_of = nullptr, *slot_size = nullptr, *slot_label = nullptr;
+    short *slot_pos = nullptr, *slot_act = nullptr;
+    int *perm[2] = {nullptr, nullptr}, *pslot[2] = {nullptr, nullptr};
     double *A = nullptr;
-    u64 *keys = nullptr;
-    unsigned *arrive = nullptr;
+    u64 *keys[2] = {nullptr, nullptr};
+    unsigned *arrive[2] = {nullptr, nullptr};
     DevScalars *sc = nullptr;
     long long *blocks = nullptr;  // k_blocksums output [kcap][kcap][4]
     unsigned *counts = nullptr;   // co-clustering counts [n][ldc]
     int ldc = 0;
     double *cc_out = nullptr;
     rc_params P{};
-    bool have_params = false, have_state = false, S_valid = false;
+    bool have_params = false, have_state = false;
     int G = 256;
-    int rows_per_split = 256;  // tools/bulk_tune.hip: fewer, longer splits = fewer 64-bit atomic flushes
+    int rows_per_split = 256;
     int num_cus = 256;
+    // software pipeline
+    long long t_next = 0;     // internal index of the next sweep (0 after rc_set_state)
+    long long bulk_enq = -1;  // highest sweep index whose k_bulk has been enqueued
+    bool prefetch = true;     // enqueue k_bulk(t+1) together with k_resolve(t)
+    hipEvent_t ev_bulk[4] = {nullptr, nullptr, nullptr, nullptr}, ev_res[4] = {nullptr, nullptr, nullptr, nullptr};
     // timing of k_bulk
     bool timing = false;
+    int timing_every = 1;     // time every N-th k_bulk launch (HIP timing events cost a few us each)
+    size_t bulk_lds = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
     double bulk_ms = 0.0;
     long long bulk_launches = 0;
     DevScalars last{};
+    int dbg = 0;
     char err[512] = {0};
 };
 
@@ -767,9 +834,12 @@ static View make_view(const rc_ctx *c)
 {
     View V{};
     V.n = c->n; V.ld = c->ld; V.kcap = c->kcap;
-    V.Dq = c->Dq; V.Lq = c->Lq; V.diagq = c->diagq; V.SD = c->SD; V.SL = c->SL;
+    V.Dq = c->Dq; V.Lq = c->Lq; V.diagq = c->diagq;
+    for (int g = 0; g < 3; ++g) { V.SD[g] = c->SD[g]; V.SL[g] = c->SL[g]; }
+    for (int g = 0; g < 2; ++g) { V.perm[g] = c->perm[g]; V.pslot[g] = c->pslot[g]; V.keys[g] = c->keys[g]; V.arrive[g] = c->arrive[g]; }
     V.slot_of = c->slot_of; V.slot_size = c->slot_size; V.slot_label = c->slot_label;
-    V.perm = c->perm; V.pslot = c->pslot; V.A = c->A; V.keys = c->keys; V.arrive = c->arrive; V.sc = c->sc;
+    V.slot_pos = c->slot_pos; V.slot_act = c->slot_act;
+    V.A = c->A; V.sc = c->sc;
     V.scD = std::ldexp(1.0, -c->eD); V.scL = std::ldexp(1.0, -c->eL);
     V.alpha = c->P.alpha; V.beta = c->P.beta; V.zeta = c->P.zeta; V.gamma = c->P.gamma;
     V.delta1 = c->P.delta1; V.delta2 = c->P.delta2;
@@ -800,13 +870,20 @@ static void free_all(rc_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->dev);
-    void *ptrs[] = {c->Dq, c->Lq, c->diagq, c->SD, c->SL, c->slot_of, c->slot_size, c->slot_label, c->perm,
-                    c->pslot, c->A, c->keys, c->arrive, c->sc, c->blocks, c->counts, c->cc_out};
+    void *ptrs[] = {c->Dq, c->Lq, c->diagq, c->SD[0], c->SD[1], c->SD[2], c->SL[0], c->SL[1], c->SL[2], c->slot_of,
+                    c->slot_size, c->slot_label, c->slot_pos, c->slot_act, c->perm[0], c->perm[1], c->pslot[0],
+                    c->pslot[1], c->A, c->keys[0], c->keys[1], c->arrive[0], c->arrive[1], c->sc, c->blocks,
+                    c->counts, c->cc_out};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &e : c->ev_pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &e : c->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    for (int q = 0; q < 4; ++q) {
+        if (c->ev_bulk[q]) (void)hipEventDestroy(c->ev_bulk[q]);
+        if (c->ev_res[q]) (void)hipEventDestroy(c->ev_res[q]);
+    }
+    if (c->sA) (void)hipStreamDestroy(c->sA);
+    if (c->sB) (void)hipStreamDestroy(c->sB);
     delete c;
 }
 
@@ -814,7 +891,8 @@ extern "C" int32_t rc_destroy(rc_ctx *ctx)
 {
     if (!ctx) return RC_OK;
     (void)hipSetDevice(ctx->dev);
-    (void)hipDeviceSynchronize();
+    if (ctx->sA) (void)hipStreamSynchronize(ctx->sA);
+    if (ctx->sB) (void)hipStreamSynchronize(ctx->sB);
     free_all(ctx);
     return RC_OK;
 }
@@ -825,7 +903,14 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     hipDeviceProp_t prop;
     HIPCHK(c, hipGetDeviceProperties(&prop, c->dev));
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    int pr_least = 0, pr_greatest = 0;
+    HIPCHK(c, hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
+    HIPCHK(c, hipStreamCreateWithPriority(&c->sA, hipStreamNonBlocking, pr_greatest));
+    HIPCHK(c, hipStreamCreateWithPriority(&c->sB, hipStreamNonBlocking, pr_least));
+    for (int q = 0; q < 4; ++q) {
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_bulk[q], hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_res[q], hipEventDisableTiming));
+    }
     const size_t nn = (size_t)n * n;
     const size_t ld = (size_t)c->ld;
     double *tmpD = nullptr, *tmpL = nullptr;
@@ -846,6 +931,7 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
                         hipGetErrorString(e_), __FILE__, __LINE__);                                       \
         }                                                                                                 \
     } while (0)
+    hipStream_t s = c->sA;
     HIPCHK2(hipMalloc(&tmpD, nn * sizeof(double)));
     HIPCHK2(hipMalloc(&tmpL, nn * sizeof(double)));
     HIPCHK2(hipMalloc(&flags, 2 * sizeof(unsigned)));
@@ -853,41 +939,45 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     HIPCHK2(hipMalloc(&c->Dq, (size_t)n * ld * sizeof(long long)));
     HIPCHK2(hipMalloc(&c->Lq, (size_t)n * ld * sizeof(long long)));
     HIPCHK2(hipMalloc(&c->diagq, (size_t)n * sizeof(long long)));
-    HIPCHK2(hipMalloc(&c->SD, (size_t)c->kcap * ld * sizeof(long long)));
-    HIPCHK2(hipMalloc(&c->SL, (size_t)c->kcap * ld * sizeof(long long)));
+    for (int g = 0; g < 3; ++g) {
+        HIPCHK2(hipMalloc(&c->SD[g], (size_t)c->kcap * ld * sizeof(long long)));
+        HIPCHK2(hipMalloc(&c->SL[g], (size_t)c->kcap * ld * sizeof(long long)));
+    }
+    for (int g = 0; g < 2; ++g) {
+        HIPCHK2(hipMalloc(&c->perm[g], (size_t)n * sizeof(int)));
+        HIPCHK2(hipMalloc(&c->pslot[g], (size_t)n * sizeof(int)));
+        HIPCHK2(hipMalloc(&c->keys[g], (size_t)(n + 2) * sizeof(u64)));
+        HIPCHK2(hipMalloc(&c->arrive[g], 64));
+    }
     HIPCHK2(hipMalloc(&c->slot_of, (size_t)n * sizeof(int)));
     HIPCHK2(hipMalloc(&c->slot_size, (size_t)c->kcap * sizeof(int)));
     HIPCHK2(hipMalloc(&c->slot_label, (size_t)c->kcap * sizeof(int)));
-    HIPCHK2(hipMalloc(&c->perm, (size_t)n * sizeof(int)));
-    HIPCHK2(hipMalloc(&c->pslot, (size_t)n * sizeof(int)));
+    HIPCHK2(hipMalloc(&c->slot_pos, (size_t)c->kcap * sizeof(short)));
+    HIPCHK2(hipMalloc(&c->slot_act, (size_t)c->kcap * sizeof(short)));
     HIPCHK2(hipMalloc(&c->A, (size_t)(n + 1) * sizeof(double)));
-    HIPCHK2(hipMalloc(&c->keys, (size_t)(n + 2) * sizeof(u64)));
-    HIPCHK2(hipMalloc(&c->arrive, 64));
     HIPCHK2(hipMalloc(&c->sc, sizeof(DevScalars)));
     HIPCHK2(hipMalloc(&c->blocks, (size_t)c->kcap * c->kcap * 4 * sizeof(long long)));
-    HIPCHK2(hipMemsetAsync(c->Dq, 0, (size_t)n * ld * sizeof(long long), c->stream));
-    HIPCHK2(hipMemsetAsync(c->Lq, 0, (size_t)n * ld * sizeof(long long), c->stream));
-    HIPCHK2(hipMemsetAsync(c->SD, 0, (size_t)c->kcap * ld * sizeof(long long), c->stream));
-    HIPCHK2(hipMemsetAsync(c->SL, 0, (size_t)c->kcap * ld * sizeof(long long), c->stream));
-    HIPCHK2(hipMemsetAsync(c->slot_size, 0, (size_t)c->kcap * sizeof(int), c->stream));
-    HIPCHK2(hipMemsetAsync(c->slot_label, 0, (size_t)c->kcap * sizeof(int), c->stream));
-    HIPCHK2(hipMemsetAsync(c->sc, 0, sizeof(DevScalars), c->stream));
-    HIPCHK2(hipMemsetAsync(flags, 0, 2 * sizeof(unsigned), c->stream));
-    HIPCHK2(hipMemsetAsync(mx, 0, 2 * sizeof(u64), c->stream));
-    HIPCHK2(hipMemcpyAsync(tmpD, D, nn * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK2(hipMemsetAsync(c->Dq, 0, (size_t)n * ld * sizeof(long long), s));
+    HIPCHK2(hipMemsetAsync(c->Lq, 0, (size_t)n * ld * sizeof(long long), s));
+    HIPCHK2(hipMemsetAsync(c->slot_size, 0, (size_t)c->kcap * sizeof(int), s));
+    HIPCHK2(hipMemsetAsync(c->slot_label, 0, (size_t)c->kcap * sizeof(int), s));
+    HIPCHK2(hipMemsetAsync(c->sc, 0, sizeof(DevScalars), s));
+    HIPCHK2(hipMemsetAsync(flags, 0, 2 * sizeof(unsigned), s));
+    HIPCHK2(hipMemsetAsync(mx, 0, 2 * sizeof(u64), s));
+    HIPCHK2(hipMemcpyAsync(tmpD, D, nn * sizeof(double), hipMemcpyHostToDevice, s));
     const int gb = std::min<size_t>((nn + 255) / 256, 4096);
-    k_check<<<gb, 256, 0, c->stream>>>(tmpD, (int)n, flags, mx);
+    k_check<<<gb, 256, 0, s>>>(tmpD, (int)n, flags, mx);
     if (logD) {
-        HIPCHK2(hipMemcpyAsync(tmpL, logD, nn * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK2(hipMemcpyAsync(tmpL, logD, nn * sizeof(double), hipMemcpyHostToDevice, s));
     } else {
-        k_make_log<<<gb, 256, 0, c->stream>>>(tmpD, tmpL, (int)n);
+        k_make_log<<<gb, 256, 0, s>>>(tmpD, tmpL, (int)n);
     }
-    k_maxabs<<<gb, 256, 0, c->stream>>>(tmpL, nn, flags + 1, mx + 1);
+    k_maxabs<<<gb, 256, 0, s>>>(tmpL, nn, flags + 1, mx + 1);
     unsigned hflags[2];
     u64 hmx[2];
-    HIPCHK2(hipMemcpyAsync(hflags, flags, sizeof(hflags), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK2(hipMemcpyAsync(hmx, mx, sizeof(hmx), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK2(hipStreamSynchronize(c->stream));
+    HIPCHK2(hipMemcpyAsync(hflags, flags, sizeof(hflags), hipMemcpyDeviceToHost, s));
+    HIPCHK2(hipMemcpyAsync(hmx, mx, sizeof(hmx), hipMemcpyDeviceToHost, s));
+    HIPCHK2(hipStreamSynchronize(s));
     HIPCHK2(hipGetLastError());
     if (hflags[0] & 1u) { cleanup(); return fail(c, RC_ERR_DOMAIN, "D must be symmetric."); }
     if (hflags[0] & 2u) { cleanup(); return fail(c, RC_ERR_DOMAIN, "D must be finite."); }
@@ -901,9 +991,9 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     std::memcpy(&maxL, &hmx[1], 8);
     c->eD = quant_exponent(n, maxD);
     c->eL = quant_exponent(n, maxL);
-    k_quantize<<<gb, 256, 0, c->stream>>>(tmpD, (int)n, c->ld, c->eD, c->Dq, c->diagq);
-    k_quantize<<<gb, 256, 0, c->stream>>>(tmpL, (int)n, c->ld, c->eL, c->Lq, nullptr);
-    HIPCHK2(hipStreamSynchronize(c->stream));
+    k_quantize<<<gb, 256, 0, s>>>(tmpD, (int)n, c->ld, c->eD, c->Dq, c->diagq);
+    k_quantize<<<gb, 256, 0, s>>>(tmpL, (int)n, c->ld, c->eL, c->Lq, nullptr);
+    HIPCHK2(hipStreamSynchronize(s));
     HIPCHK2(hipGetLastError());
     cleanup();
 #undef HIPCHK2
@@ -931,6 +1021,8 @@ extern "C" int32_t rc_create(int64_t n, const double *D, const double *logD_or_n
     c->n = (int)n;
     c->ld = (int)(((n + 511) / 512) * 512);
     c->kcap = (int)kcap;
+    c->dbg = getenv("RC_DEBUG_FLAGS") ? atoi(getenv("RC_DEBUG_FLAGS")) : 0;
+    c->prefetch = !(getenv("RC_NO_PREFETCH") && atoi(getenv("RC_NO_PREFETCH")));
     int32_t rc = create_impl(c, n, D, logD_or_null);
     if (rc != RC_OK) {
         snprintf(g_err, sizeof(g_err), "%s", c->err);
@@ -945,14 +1037,21 @@ extern "C" int32_t rc_create(int64_t n, const double *D, const double *logD_or_n
         const int col_chunks = c->ld / 512;
         const int splits_target = std::max(1, 512 / col_chunks);
         c->rows_per_split = std::max(16, std::min(512, (c->n + splits_target - 1) / splits_target));
+        if (getenv("RC_BULK_ROWS")) c->rows_per_split = std::max(1, atoi(getenv("RC_BULK_ROWS")));
+        const int per_cu = getenv("RC_BULK_PER_CU") ? atoi(getenv("RC_BULK_PER_CU")) : 2;
+        c->bulk_lds = per_cu > 0 ? (size_t)((150 * 1024 / per_cu) & ~1023) : 0;
+        if (c->bulk_lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void *)k_bulk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->bulk_lds);
     }
     {
         // kernels whose dynamic LDS can exceed the 64 KiB default (large kcap)
-        const size_t lds_r = std::max(tab_bytes(c->kcap, c->n, RC_SCORE_THREADS / 32), 2 * sizeof(int) * (size_t)c->kcap);
+        const size_t lds_r = std::max(tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64), 2 * sizeof(int) * (size_t)c->kcap);
+        const size_t lds_d = std::max(tab_bytes(c->kcap, c->n, 1), 2 * sizeof(int) * (size_t)c->kcap);
         const size_t lds_b = (size_t)c->kcap * 4 * sizeof(u64);
         hipError_t e1 = hipFuncSetAttribute((const void *)k_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
         hipError_t e2 = hipFuncSetAttribute((const void *)k_blocksums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
-        if (e1 != hipSuccess || e2 != hipSuccess || lds_r > 160 * 1024 || lds_b > 160 * 1024) {
+        hipError_t e3 = hipFuncSetAttribute((const void *)k_derive, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || lds_r > 160 * 1024 || lds_b > 160 * 1024) {
             fail(nullptr, RC_ERR_ARG, "rc_create: kcap=%d needs more LDS than a CU has", c->kcap);
             free_all(c);
             return RC_ERR_ARG;
@@ -969,6 +1068,8 @@ extern "C" int32_t rc_set_params(rc_ctx *c, const rc_params *P)
         return fail(c, RC_ERR_ARG, "rc_set_params: likelihood hyperparameters must be positive");
     if (P->maxK < 0) return fail(c, RC_ERR_ARG, "rc_set_params: maxK must be >= 0");
     HIPCHK(c, hipSetDevice(c->dev));
+    HIPCHK(c, hipStreamSynchronize(c->sA));
+    HIPCHK(c, hipStreamSynchronize(c->sB));
     c->P = *P;
     // size table (see DESIGN.md "Score arithmetic"): long double on the host, once per parameter set
     std::vector<double> A((size_t)c->n + 1);
@@ -982,8 +1083,8 @@ extern "C" int32_t rc_set_params(rc_ctx *c, const rc_params *P)
         const long double t2 = lgammal(ze + d2 * S) - lgz - d2 * S * lg - S * lgd2;
         A[(size_t)s] = (double)(t1 - (P->repulsion ? t2 : 0.0L) + logl((S + 1) / S));
     }
-    HIPCHK(c, hipMemcpyAsync(c->A, A.data(), A.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->A, A.data(), A.size() * sizeof(double), hipMemcpyHostToDevice, c->sA));
+    HIPCHK(c, hipStreamSynchronize(c->sA));
     c->have_params = true;
     return RC_OK;
 }
@@ -1001,12 +1102,16 @@ static int32_t drain_events(rc_ctx *c)
     return RC_OK;
 }
 
-static int32_t sync_and_check(rc_ctx *c)
+// Waits for the resolve/observable stream (and for the k_bulk stream too when `both`), then surfaces device errors.
+static int32_t sync_and_check(rc_ctx *c, bool both = false)
 {
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->sA));
+    if (both) {
+        HIPCHK(c, hipStreamSynchronize(c->sB));
+        int32_t rc = drain_events(c);
+        if (rc != RC_OK) return rc;
+    }
     HIPCHK(c, hipGetLastError());
-    int32_t rc = drain_events(c);
-    if (rc != RC_OK) return rc;
     HIPCHK(c, hipMemcpy(&c->last, c->sc, sizeof(DevScalars), hipMemcpyDeviceToHost));
     if (c->last.err & RC_DERR_BARRIER) return fail(c, RC_ERR_HIP, "grid barrier timed out inside the sweep kernel");
     if (c->last.err & RC_DERR_CAPACITY)
@@ -1018,14 +1123,15 @@ extern "C" int32_t rc_synchronize(rc_ctx *c)
 {
     if (!c) return fail(c, RC_ERR_ARG, "rc_synchronize: NULL ctx");
     HIPCHK(c, hipSetDevice(c->dev));
-    return sync_and_check(c);
+    return sync_and_check(c, true);
 }
 
 extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
 {
     if (!c || !clusts) return fail(c, RC_ERR_ARG, "rc_set_state: NULL argument");
     HIPCHK(c, hipSetDevice(c->dev));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->sA));
+    HIPCHK(c, hipStreamSynchronize(c->sB));
     const int n = c->n;
     // clustsizes = counts(clusts, 1:n), K = sum(clustsizes .> 0)  (types.jl:135-136); slots in label order
     std::vector<int> size_by_label((size_t)n + 1, 0);
@@ -1047,51 +1153,73 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
     for (int i = 0; i < n; ++i) so[(size_t)i] = slot_of_label[(size_t)clusts[i]];
     DevScalars s{};
     s.K = K;
+    s.slot_hi = K;
+    s.last_change_sweep = -1;
     HIPCHK(c, hipMemcpy(c->slot_of, so.data(), so.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->slot_size, ssize.data(), ssize.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->slot_label, slabel.data(), slabel.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->sc, &s, sizeof(s), hipMemcpyHostToDevice));
-    // S of every slot may be stale: clear it all (keeps the "free slots are zero" invariant)
-    HIPCHK(c, hipMemsetAsync(c->SD, 0, (size_t)c->kcap * c->ld * sizeof(long long), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->SL, 0, (size_t)c->kcap * c->ld * sizeof(long long), c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->last = s;
+    // every S generation may be stale: clear them all (keeps the "rows of free slots are zero" invariant)
+    for (int g = 0; g < 3; ++g) {
+        HIPCHK(c, hipMemsetAsync(c->SD[g], 0, (size_t)c->kcap * c->ld * sizeof(long long), c->sA));
+        HIPCHK(c, hipMemsetAsync(c->SL[g], 0, (size_t)c->kcap * c->ld * sizeof(long long), c->sA));
+    }
+    for (int g = 0; g < 2; ++g) {
+        HIPCHK(c, hipMemsetAsync(c->keys[g], 0xFF, (size_t)(n + 2) * sizeof(u64), c->sA));
+        HIPCHK(c, hipMemsetAsync(c->arrive[g], 0, 64, c->sA));
+    }
+    View V = make_view(c);
+    const size_t lds = std::max(tab_bytes(c->kcap, c->n, 1), 2 * sizeof(int) * (size_t)c->kcap);
+    k_derive<<<1, 1024, lds, c->sA>>>(V);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->sA));
+    HIPCHK(c, hipMemcpy(&c->last, c->sc, sizeof(DevScalars), hipMemcpyDeviceToHost));
+    c->t_next = 0;
+    c->bulk_enq = -1;
     c->have_state = true;
-    c->S_valid = false;
     return RC_OK;
 }
 
-// enqueue: (perm if needed) + k_zero + k_bulk
-static int32_t enqueue_bulk(rc_ctx *c, const View &V, bool perm_known_valid)
+// k_bulk of sweep t on stream B: fills S generation t%3 from perm generation t%2 (labels after sweep t-2),
+// clears generation (t+1)%3.  Needs k_resolve(t-2) (perm, and the last reader of the generation being cleared).
+static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
 {
-    if (!perm_known_valid) {
-        k_build_perm<<<1, 1024, 2 * sizeof(int) * (size_t)c->kcap, c->stream>>>(V);
-    }
-    dim3 gz((unsigned)(c->ld / 512), (unsigned)c->kcap);
-    k_zero<<<gz, 256, 0, c->stream>>>(V);
+    if (t >= 2) HIPCHK(c, hipStreamWaitEvent(c->sB, c->ev_res[(t - 2) & 3], 0));
     const int splits = (c->n + c->rows_per_split - 1) / c->rows_per_split;
     dim3 gb((unsigned)(c->ld / 512), (unsigned)splits);
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
-    if (c->timing) {
+    const bool timed = c->timing && (c->timing_every <= 1 || (t % c->timing_every) == 0);
+    if (timed) {
         if (!c->ev_free.empty()) { ev = c->ev_free.back(); c->ev_free.pop_back(); }
         else { HIPCHK(c, hipEventCreate(&ev.first)); HIPCHK(c, hipEventCreate(&ev.second)); }
-        HIPCHK(c, hipEventRecord(ev.first, c->stream));
+        HIPCHK(c, hipEventRecord(ev.first, c->sB));
     }
-    k_bulk<<<gb, 256, 0, c->stream>>>(V, c->rows_per_split);
-    if (c->timing) {
-        HIPCHK(c, hipEventRecord(ev.second, c->stream));
+    // bulk_lds: unused dynamic LDS that caps k_bulk at bulk_blocks_per_cu workgroups per CU, which (i) spreads the
+    // grid evenly over the CUs and (ii) leaves registers/wave slots on every CU for the concurrent k_resolve
+    k_bulk<<<gb, 256, c->bulk_lds, c->sB>>>(V, c->rows_per_split, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1));
+    if (timed) {
+        HIPCHK(c, hipEventRecord(ev.second, c->sB));
         c->ev_pending.push_back(ev);
     }
+    HIPCHK(c, hipEventRecord(c->ev_bulk[t & 3], c->sB));
+    c->bulk_enq = t;
     return RC_OK;
 }
 
-static int32_t ensure_S(rc_ctx *c)
+// Makes the S generation of the CURRENT labels available to work enqueued on stream A; returns its index.
+static int32_t ensure_S(rc_ctx *c, int *gen)
 {
-    if (c->S_valid) return RC_OK;
-    View V = make_view(c);
-    int32_t rc = enqueue_bulk(c, V, false);
-    if (rc != RC_OK) return rc;
-    c->S_valid = true;
+    if (c->t_next == 0) {
+        if (c->bulk_enq < 0) {
+            View V = make_view(c);
+            int32_t rc = enqueue_bulk(c, V, 0);
+            if (rc != RC_OK) return rc;
+        }
+        HIPCHK(c, hipStreamWaitEvent(c->sA, c->ev_bulk[0], 0));
+        *gen = 0;
+    } else {
+        *gen = (int)((c->t_next - 1) % 3);  // corrected in place by k_resolve(t_next-1), already ordered on stream A
+    }
     return RC_OK;
 }
 
@@ -1102,24 +1230,33 @@ extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t 
     if (!(r > 0.0) || !(p > 0.0 && p < 1.0)) return fail(c, RC_ERR_ARG, "rc_gibbs_sweep: need r > 0 and 0 < p < 1 (got r=%g p=%g)", r, p);
     HIPCHK(c, hipSetDevice(c->dev));
     View V = make_view(c);
-    // perm validity is tracked on the device (k_resolve rebuilds it after a sweep with changes); the first
-    // sweep after rc_set_state builds it here.
-    int32_t rc = enqueue_bulk(c, V, c->S_valid /* perm was built when S was first made valid */);
-    if (rc != RC_OK) return rc;
-    c->S_valid = true;
+    const long long t = c->t_next;
+    int32_t rc;
+    if (c->bulk_enq < t) {
+        rc = enqueue_bulk(c, V, t);
+        if (rc != RC_OK) return rc;
+    }
     SweepArgs sa;
     sa.r = r;
     sa.logp = std::log(p);
     sa.log1mp = std::log(1 - p);
     sa.k0 = (unsigned)seed; sa.k1 = (unsigned)(seed >> 32);
     sa.sw_lo = (unsigned)sweep_index; sa.sw_hi = (unsigned)(sweep_index >> 32);
-    {
-        static const int dbg = getenv("RC_DEBUG_FLAGS") ? atoi(getenv("RC_DEBUG_FLAGS")) : 0;
-        sa.dbg = dbg;
-    }
-    const size_t lds = std::max(tab_bytes(c->kcap, c->n, RC_SCORE_THREADS / 32), 2 * sizeof(int) * (size_t)c->kcap);
-    k_resolve<<<c->G, RC_SCORE_THREADS, lds, c->stream>>>(V, sa, c->G);
+    if (t >= 0x7ffffff0ll) return fail(c, RC_ERR_STATE, "rc_gibbs_sweep: internal sweep counter exhausted; call rc_set_state");
+    sa.t = (int)t;
+    sa.dbg = c->dbg;
+    const size_t lds = std::max(tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64), 2 * sizeof(int) * (size_t)c->kcap);
+    HIPCHK(c, hipStreamWaitEvent(c->sA, c->ev_bulk[t & 3], 0));
+    k_resolve<<<c->G, RC_RES_THREADS, lds, c->sA>>>(V, sa, c->G);
     HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev_res[t & 3], c->sA));
+    c->t_next = t + 1;
+    if (c->prefetch) {
+        // software pipeline: the row reduction of the next sweep starts now, under the labels known before
+        // this sweep; k_resolve adds this sweep's label changes to it (exact integer atomics)
+        rc = enqueue_bulk(c, V, t + 1);
+        if (rc != RC_OK) return rc;
+    }
     return RC_OK;
 }
 
@@ -1153,7 +1290,6 @@ static int32_t pull_state(rc_ctx *c, std::vector<int> &so, std::vector<int> &ssi
     HIPCHK(c, hipMemcpy(slabel.data(), c->slot_label, slabel.size() * sizeof(int), hipMemcpyDeviceToHost));
     return RC_OK;
 }
-
 extern "C" int32_t rc_get_state(rc_ctx *c, int64_t *clusts, int64_t *clustsizes, int64_t *K)
 {
     if (!c) return fail(c, RC_ERR_ARG, "rc_get_state: NULL ctx");
@@ -1178,10 +1314,11 @@ extern "C" int32_t rc_loglik(rc_ctx *c, double *out)
     if (!c || !out) return fail(c, RC_ERR_ARG, "rc_loglik: NULL argument");
     if (!c->have_params || !c->have_state) return fail(c, RC_ERR_STATE, "rc_loglik: params and state must be set");
     HIPCHK(c, hipSetDevice(c->dev));
-    int32_t rc = ensure_S(c);
+    int gen = 0;
+    int32_t rc = ensure_S(c, &gen);
     if (rc != RC_OK) return rc;
     View V = make_view(c);
-    k_blocksums<<<c->kcap, 256, (size_t)c->kcap * 4 * sizeof(u64), c->stream>>>(V, c->blocks);
+    k_blocksums<<<c->kcap, 256, (size_t)c->kcap * 4 * sizeof(u64), c->sA>>>(V, gen, c->blocks);
     std::vector<int> so, ssize, slabel;
     rc = pull_state(c, so, ssize, slabel);
     if (rc != RC_OK) return rc;
@@ -1253,7 +1390,7 @@ static int32_t ensure_counts(rc_ctx *c)
     if (c->counts) return RC_OK;
     c->ldc = ((c->n + 3) / 4) * 4;
     HIPCHK(c, hipMalloc(&c->counts, (size_t)c->n * c->ldc * sizeof(unsigned)));
-    HIPCHK(c, hipMemsetAsync(c->counts, 0, (size_t)c->n * c->ldc * sizeof(unsigned), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->counts, 0, (size_t)c->n * c->ldc * sizeof(unsigned), c->sA));
     return RC_OK;
 }
 
@@ -1265,11 +1402,11 @@ extern "C" int32_t rc_record_sample(rc_ctx *c, int64_t *canonical_out)
     int32_t rc = ensure_counts(c);
     if (rc != RC_OK) return rc;
     dim3 g((unsigned)((c->n + 1023) / 1024), (unsigned)c->n);
-    k_cocluster_add<<<g, 256, 0, c->stream>>>(c->slot_of, c->n, c->ldc, c->counts);
+    k_cocluster_add<<<g, 256, 0, c->sA>>>(c->slot_of, c->n, c->ldc, c->counts);
     HIPCHK(c, hipGetLastError());
     if (canonical_out) {
         std::vector<int> so((size_t)c->n);
-        HIPCHK(c, hipMemcpyAsync(so.data(), c->slot_of, so.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(so.data(), c->slot_of, so.size() * sizeof(int), hipMemcpyDeviceToHost, c->sA));
         rc = sync_and_check(c);
         if (rc != RC_OK) return rc;
         // sortlabels (utils.jl:69-74): relabel by order of first appearance
@@ -1290,7 +1427,7 @@ extern "C" int32_t rc_cocluster_reset(rc_ctx *c)
     HIPCHK(c, hipSetDevice(c->dev));
     int32_t rc = ensure_counts(c);
     if (rc != RC_OK) return rc;
-    HIPCHK(c, hipMemsetAsync(c->counts, 0, (size_t)c->n * c->ldc * sizeof(unsigned), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->counts, 0, (size_t)c->n * c->ldc * sizeof(unsigned), c->sA));
     return RC_OK;
 }
 
@@ -1330,7 +1467,7 @@ extern "C" int32_t rc_cocluster(rc_ctx *c, double *out, int64_t numsamples)
     const size_t nn = (size_t)c->n * c->n;
     if (!c->cc_out) HIPCHK(c, hipMalloc(&c->cc_out, nn * sizeof(double)));
     const int gb = (int)std::min<size_t>((nn + 255) / 256, 8192);
-    k_cocluster_final<<<gb, 256, 0, c->stream>>>(c->counts, c->n, c->ldc, (double)numsamples, c->cc_out);
+    k_cocluster_final<<<gb, 256, 0, c->sA>>>(c->counts, c->n, c->ldc, (double)numsamples, c->cc_out);
     rc = sync_and_check(c);
     if (rc != RC_OK) return rc;
     HIPCHK(c, hipMemcpy(out, c->cc_out, nn * sizeof(double), hipMemcpyDeviceToHost));
@@ -1342,7 +1479,8 @@ extern "C" int32_t rc_debug_rowsums(rc_ctx *c, int64_t label, int64_t *sumD_q, i
     if (!c) return fail(c, RC_ERR_ARG, "rc_debug_rowsums: NULL ctx");
     if (!c->have_state) return fail(c, RC_ERR_STATE, "rc_debug_rowsums: no state set");
     HIPCHK(c, hipSetDevice(c->dev));
-    int32_t rc = ensure_S(c);
+    int gen = 0;
+    int32_t rc = ensure_S(c, &gen);
     if (rc != RC_OK) return rc;
     std::vector<int> so, ssize, slabel;
     rc = pull_state(c, so, ssize, slabel);
@@ -1357,8 +1495,8 @@ extern "C" int32_t rc_debug_rowsums(rc_ctx *c, int64_t label, int64_t *sumD_q, i
         if (sumL_q) std::memset(sumL_q, 0, (size_t)c->n * 8);
         return RC_OK;
     }
-    if (sumD_q) HIPCHK(c, hipMemcpy(sumD_q, c->SD + (size_t)slot * c->ld, (size_t)c->n * 8, hipMemcpyDeviceToHost));
-    if (sumL_q) HIPCHK(c, hipMemcpy(sumL_q, c->SL + (size_t)slot * c->ld, (size_t)c->n * 8, hipMemcpyDeviceToHost));
+    if (sumD_q) HIPCHK(c, hipMemcpy(sumD_q, c->SD[gen] + (size_t)slot * c->ld, (size_t)c->n * 8, hipMemcpyDeviceToHost));
+    if (sumL_q) HIPCHK(c, hipMemcpy(sumL_q, c->SL[gen] + (size_t)slot * c->ld, (size_t)c->n * 8, hipMemcpyDeviceToHost));
     return RC_OK;
 }
 
@@ -1366,12 +1504,13 @@ extern "C" int32_t rc_kernel_timing(rc_ctx *c, int32_t enable, double *bulk_ms_t
 {
     if (!c) return fail(c, RC_ERR_ARG, "rc_kernel_timing: NULL ctx");
     HIPCHK(c, hipSetDevice(c->dev));
-    int32_t rc = sync_and_check(c);
+    int32_t rc = sync_and_check(c, true);
     if (rc != RC_OK) return rc;
     if (bulk_ms_total) *bulk_ms_total = c->bulk_ms;
     if (bulk_launches) *bulk_launches = c->bulk_launches;
     if (enable >= 0) {
         c->timing = enable != 0;
+        c->timing_every = enable > 1 ? enable : 1;
         c->bulk_ms = 0.0;
         c->bulk_launches = 0;
     }
