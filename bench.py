@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 N_POINTS = int(os.environ.get("RC_BENCH_N", 8192))
 N_CLUST = int(os.environ.get("RC_BENCH_K", 50))
+BITS = int(os.environ.get("RC_BENCH_BITS", 64))  # 32: int32 fixed-point storage (BASELINE config 5 style)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ≈6300 GB/s is the measured copy ceiling
 
 
@@ -88,7 +89,7 @@ def main():
     r, p = 1.0, 0.5
     chain_seed = 1 + rank                             # chain seeds 1..N
 
-    ctx = rc.Context(D, device=local_rank, kcap=max(128, 2 * K))
+    ctx = rc.Context(D, device=local_rank, kcap=max(128, 2 * K), storage_bits=BITS)
     ctx.set_params(**P)
     ctx.set_state(truth)                              # stationary regime: generating labels
     ctx.cocluster_reset()
@@ -133,22 +134,22 @@ def main():
         diag_ok = True
 
     if rank == 0:
-        alg_bytes = 2.0 * n * n * 8.0                 # every row of D and of logD read once per sweep
+        alg_bytes = 2.0 * n * n * (BITS / 8.0)        # every row of D and of logD read once per sweep
         value = world * args.steps / dt
         bulk_avg_ms = bulk_ms / max(bulk_launches, 1)
         achieved = alg_bytes / (bulk_avg_ms * 1e-3) / 1e9 if bulk_launches else None
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01", f"pmc_traffic_n{n}.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and BITS == 64:
             # HBM bytes per k_bulk launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950
             # FETCH_SIZE correction applied); collected offline with the same command, see the file's "source"
             traffic = json.load(open(pmc))["k_bulk_hbm_bytes_per_launch"]
         out = {
             "metric": "Gibbs sweeps/sec (n×n distM)", "value": value, "unit": "sweeps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i64 fixed-point sums, f64 scores",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": f"i{BITS} fixed-point storage, i64 exact sums, f64 scores",
             "data": "synthetic",
-            "config": {"workload": f"generatemixture N={n} K={K} dim={K} sigma=0.1 dense Float64 distM, 1 chain per GPU, "
+            "config": {"workload": f"generatemixture N={n} K={K} dim={K} sigma=0.1 dense Float64 distM ({BITS}-bit fixed-point storage), 1 chain per GPU, "
                                    "numMH=0 Gibbs sweep, init = generating labels (stationary), r=1 p=0.5",
                        "chains": world, "n": n, "K": K, "parallelism": f"chains x{world}"},
             "sweep_GBps_algorithmic": value / world * alg_bytes / 1e9,

@@ -58,8 +58,10 @@ typedef struct rc_sweep_stats {
 /* MCMCData constructor, src/types.jl:145-157.  Copies the n×n matrix D to HBM once, checks symmetry
  * (types.jl:149-151) and derives logD = log.(D - Diagonal(D) + I) on the device (types.jl:155; diagonal 0,
  * D's own diagonal kept as stored) unless the caller passes its own logD (e.g. MCMCData.logD).
- * storage_bits: 64 (int64 fixed point, the Float64 path) or 32 (int32 fixed point, half the HBM traffic).
- * kcap: slot capacity = most clusters the state may hold at once (0 = default min(n, 1024)).
+ * storage_bits: 64 (int64 fixed point; the Float64 path) or 32 (int32 fixed point: every entry rounded to
+ * 2^-30 of the largest magnitude, half the HBM traffic; all sums stay exact 64-bit integers and scores stay f64
+ * — the counterpart of BASELINE config 5's Float32 storage, which the reference itself does not have).
+ * kcap: slot capacity = most clusters the state may hold at once (0 = default min(n, 1024); at most 4096).
  * device_id: HIP device ordinal. */
 int32_t rc_create(int64_t n, const double *D, const double *logD_or_null, int32_t storage_bits,
                   int32_t device_id, int64_t kcap, rc_ctx **out);

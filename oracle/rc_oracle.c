@@ -131,6 +131,21 @@ int orc_quant_exponent(int64_t n, const double *x, int64_t count)
     return 62 - ex - ceil_log2_i64(n);
 }
 
+/* 32-bit storage variant of the HIP path: every entry fits int32 (|q| < 2^30), sums are 64-bit. */
+int orc_quant_exponent32(const double *x, int64_t count)
+{
+    double m = 0.0;
+    for (int64_t t = 0; t < count; ++t) {
+        double a = fabs(x[t]);
+        if (!(a <= 1.79769313486231570e308)) return -10000;
+        if (a > m) m = a;
+    }
+    if (m == 0.0) return 0;
+    int ex;
+    frexp(m, &ex);
+    return 30 - ex;
+}
+
 void orc_quantize(const double *x, int64_t count, int e, int64_t *q)
 {
     for (int64_t t = 0; t < count; ++t) q[t] = llrint(ldexp(x[t], e));

@@ -69,7 +69,8 @@ struct DevScalars {
 // Everything a kernel needs, passed by value.
 struct View {
     int n, ld, kcap;
-    const long long *Dq, *Lq;  // [n][ld] fixed point
+    const void *Dq, *Lq;       // [n][ld] fixed point: int64 (bits = 64) or int32 (bits = 32)
+    int bits;
     const long long *diagq;    // [n] Dq[i][i]
     long long *SD[3], *SL[3];  // three generations of the [kcap][ld] row-sum table (software pipelining)
     int *slot_of;              // [n]
@@ -158,14 +159,15 @@ __global__ void k_maxabs(const double *__restrict__ X, size_t total, unsigned *f
     atomicMax(maxabs_bits, m);
 }
 
-__global__ void k_quantize(const double *__restrict__ X, int n, int ld, int e, long long *__restrict__ Q,
+template <typename T>
+__global__ void k_quantize(const double *__restrict__ X, int n, int ld, int e, T *__restrict__ Q,
                            long long *__restrict__ diag_or_null)
 {
     const size_t total = (size_t)n * n;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
         const int i = (int)(t / n), j = (int)(t % n);
         const long long q = __double2ll_rn(scalbn(X[t], e));
-        Q[(size_t)i * ld + j] = q;
+        Q[(size_t)i * ld + j] = (T)q;
         if (diag_or_null && i == j) diag_or_null[i] = q;
     }
 }
@@ -217,8 +219,16 @@ __device__ __forceinline__ void bulk_flush(long long *SD, long long *SL, size_t 
 }
 
 #define RC_BULK_U 8
+// 16-byte row segment per lane: two int64 columns or four int32 columns
+template <typename T> struct Seg;
+template <> struct Seg<long long> { typedef ll2 vec; static constexpr int C = 2; };
+template <> struct Seg<int> { typedef int vec __attribute__((ext_vector_type(4))); static constexpr int C = 4; };
+
+template <typename T>
 __global__ __launch_bounds__(256) void k_bulk(View V, int rows_per_split, int wgen, int zgen, int pgen)
 {
+    typedef typename Seg<T>::vec vec;
+    constexpr int C = Seg<T>::C;
     const size_t ld = (size_t)V.ld;
     {   // clear generation zgen, rows < slot_hi (rows above are zero by invariant)
         const int hi = V.sc->slot_hi;
@@ -229,50 +239,52 @@ __global__ __launch_bounds__(256) void k_bulk(View V, int rows_per_split, int wg
         const ll2 z = {0, 0};
         for (size_t q = me; q < total2; q += nthreads) { zd[q] = z; zl[q] = z; }
     }
-    const int i = (blockIdx.x * 256 + threadIdx.x) * 2;
+    const int i = (blockIdx.x * 256 + threadIdx.x) * C;
     const int p0 = blockIdx.y * rows_per_split;
     const int p1 = min(V.n, p0 + rows_per_split);
     if (p0 >= p1) return;
     const int *__restrict__ perm = V.perm[pgen];
     const int *__restrict__ pslot = V.pslot[pgen];
-    const long long *__restrict__ Dq = V.Dq + i;
-    const long long *__restrict__ Lq = V.Lq + i;
+    const T *__restrict__ Dq = (const T *)V.Dq + i;
+    const T *__restrict__ Lq = (const T *)V.Lq + i;
     long long *SD = V.SD[wgen], *SL = V.SL[wgen];
-    long long aD0 = 0, aD1 = 0, aL0 = 0, aL1 = 0;
+    long long aD[C], aL[C];
+#pragma unroll
+    for (int q = 0; q < C; ++q) { aD[q] = 0; aL[q] = 0; }
+    auto flush = [&](int slot) {
+#pragma unroll
+        for (int q = 0; q < C; q += 2) bulk_flush(SD, SL, ld, slot, i + q, aD[q], aD[q + 1], aL[q], aL[q + 1]);
+#pragma unroll
+        for (int q = 0; q < C; ++q) { aD[q] = 0; aL[q] = 0; }
+    };
     int cur = pslot[p0];
     int p = p0;
     for (; p + RC_BULK_U <= p1; p += RC_BULK_U) {
         int j[RC_BULK_U], s[RC_BULK_U];
-        ll2 d[RC_BULK_U], l[RC_BULK_U];
+        vec d[RC_BULK_U], l[RC_BULK_U];
 #pragma unroll
         for (int u = 0; u < RC_BULK_U; ++u) { j[u] = perm[p + u]; s[u] = pslot[p + u]; }
 #pragma unroll
         for (int u = 0; u < RC_BULK_U; ++u) {
-            d[u] = __builtin_nontemporal_load((const ll2 *)(Dq + (size_t)j[u] * ld));  // streamed once per sweep
-            l[u] = __builtin_nontemporal_load((const ll2 *)(Lq + (size_t)j[u] * ld));
+            d[u] = __builtin_nontemporal_load((const vec *)(Dq + (size_t)j[u] * ld));  // streamed once per sweep
+            l[u] = __builtin_nontemporal_load((const vec *)(Lq + (size_t)j[u] * ld));
         }
 #pragma unroll
         for (int u = 0; u < RC_BULK_U; ++u) {
-            if (s[u] != cur) {
-                bulk_flush(SD, SL, ld, cur, i, aD0, aD1, aL0, aL1);
-                aD0 = aD1 = aL0 = aL1 = 0;
-                cur = s[u];
-            }
-            aD0 += d[u].x; aD1 += d[u].y; aL0 += l[u].x; aL1 += l[u].y;
+            if (s[u] != cur) { flush(cur); cur = s[u]; }
+#pragma unroll
+            for (int q = 0; q < C; ++q) { aD[q] += (long long)d[u][q]; aL[q] += (long long)l[u][q]; }
         }
     }
     for (; p < p1; ++p) {
-        const int j = perm[p], s = pslot[p];
-        const ll2 d = __builtin_nontemporal_load((const ll2 *)(Dq + (size_t)j * ld));
-        const ll2 l = __builtin_nontemporal_load((const ll2 *)(Lq + (size_t)j * ld));
-        if (s != cur) {
-            bulk_flush(SD, SL, ld, cur, i, aD0, aD1, aL0, aL1);
-            aD0 = aD1 = aL0 = aL1 = 0;
-            cur = s;
-        }
-        aD0 += d.x; aD1 += d.y; aL0 += l.x; aL1 += l.y;
+        const int j = perm[p], sl = pslot[p];
+        const vec d = __builtin_nontemporal_load((const vec *)(Dq + (size_t)j * ld));
+        const vec l = __builtin_nontemporal_load((const vec *)(Lq + (size_t)j * ld));
+        if (sl != cur) { flush(cur); cur = sl; }
+#pragma unroll
+        for (int q = 0; q < C; ++q) { aD[q] += (long long)d[q]; aL[q] += (long long)l[q]; }
     }
-    bulk_flush(SD, SL, ld, cur, i, aD0, aD1, aL0, aL1);
+    flush(cur);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -598,14 +610,15 @@ __device__ bool commit_change(const View &V, const SweepArgs &sa, Tab &T, u64 ke
         const int nchunks = (V.n + RC_PTS - 1) / RC_PTS;
         const int pt = threadIdx.x & (RC_PTS - 1), job = threadIdx.x >> 5;  // jobs 0..3: (D,a) (D,b) (L,a) (L,b)
         if (job < 4) {
-            const long long *M = (job < 2) ? V.Dq : V.Lq;
+            const void *M = (job < 2) ? V.Dq : V.Lq;
             long long *So = (job < 2) ? V.SD[own_gen] : V.SL[own_gen];
             long long *Sn = (job < 2) ? V.SD[next_gen] : V.SL[next_gen];
             const int slot = (job & 1) ? b : a;
             for (int c = blockIdx.x; c < nchunks; c += G) {
                 const int i = c * RC_PTS + pt;
                 if (i < V.n) {
-                    const long long x = M[(size_t)istar * V.ld + i];
+                    const size_t e = (size_t)istar * V.ld + i;
+                    const long long x = (V.bits == 64) ? ((const long long *)M)[e] : (long long)((const int *)M)[e];
                     const long long dx = (job & 1) ? x : -x;
                     So[(size_t)slot * V.ld + i] += dx;
                     __hip_atomic_fetch_add((u64 *)(Sn + (size_t)slot * V.ld + i), (u64)dx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -707,16 +720,16 @@ __global__ __launch_bounds__(RC_RES_THREADS) void k_resolve(View V, SweepArgs sa
 // ---------------------------------------------------------------------------------------------------
 // loglik block sums (src/mcmc.jl:26-53): B[k][t] = Σ_{i in slot k} S[t][i], accumulated as (hi, lo) halves
 // so that n² terms cannot overflow 64 bits.  One block per slot t; LDS bins per slot k.
-// out[(t*kcap + k)*4 + {0,1,2,3}] = D_hi, D_lo, L_hi, L_lo
+// out[(t*hi + k)*4 + {0,1,2,3}] = D_hi, D_lo, L_hi, L_lo   (hi = slot high-water mark; slots >= hi are free)
 // ---------------------------------------------------------------------------------------------------
 #define RC_LO_BITS 24
-__global__ __launch_bounds__(256) void k_blocksums(View V, int gen, long long *out)
+__global__ __launch_bounds__(256) void k_blocksums(View V, int gen, int hi, long long *out)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    u64 *bins = (u64 *)smem;  // [kcap][4]
+    u64 *bins = (u64 *)smem;  // [hi][4]
     const int t = blockIdx.x;
     if (V.slot_size[t] == 0) return;
-    for (int q = threadIdx.x; q < V.kcap * 4; q += blockDim.x) bins[q] = 0;
+    for (int q = threadIdx.x; q < hi * 4; q += blockDim.x) bins[q] = 0;
     __syncthreads();
     const long long mask = ((long long)1 << RC_LO_BITS) - 1;
     for (int i = threadIdx.x; i < V.n; i += blockDim.x) {
@@ -728,28 +741,55 @@ __global__ __launch_bounds__(256) void k_blocksums(View V, int gen, long long *o
         atomicAdd(&bins[k * 4 + 3], (u64)(l & mask));
     }
     __syncthreads();
-    for (int q = threadIdx.x; q < V.kcap * 4; q += blockDim.x) out[(size_t)t * V.kcap * 4 + q] = (long long)bins[q];
+    for (int q = threadIdx.x; q < hi * 4; q += blockDim.x) out[(size_t)t * hi * 4 + q] = (long long)bins[q];
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Co-clustering counts: counts[i][j] += (c_i == c_j)   (adjacencymatrix, src/utils.jl:59-63; the sum of
-// src/mcmc.jl:560).  uint32 — exact.  grid (ceil(n/1024), n), 256 threads, 4 columns per thread.
+// Co-clustering counts: counts[i][j] += (c_i == c_j) per recorded sample (adjacencymatrix, src/utils.jl:59-63;
+// the sum of src/mcmc.jl:560).  uint32 — exact.  A read-modify-write of the n×n matrix per sample would cost
+// as much HBM traffic as half a sweep, so recorded label vectors are queued as 16-bit slot
+// ids (RC_CC_BATCH of them) and added in ONE pass over the matrix: tile = 16 rows × 1024 columns per block,
+// 64 register counters per thread, row labels broadcast from LDS.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_cocluster_add(const int *__restrict__ slot_of, int n, int ldc,
-                                                      unsigned *__restrict__ counts)
+#define RC_CC_BATCH 32
+#define RC_CC_ROWS 16
+__global__ __launch_bounds__(256) void k_snapshot(const int *__restrict__ slot_of, int n, int ldn, unsigned short *__restrict__ snap)
 {
-    const int i = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < ldn) snap[i] = (i < n) ? (unsigned short)slot_of[i] : (unsigned short)0xFFFE;
+}
+
+__global__ __launch_bounds__(256) void k_cocluster_batch(const unsigned short *__restrict__ snap, int cnt, int n, int ldn,
+                                                        int ldc, unsigned *__restrict__ counts)
+{
+    __shared__ unsigned short ci[RC_CC_BATCH][RC_CC_ROWS];
+    const int i0 = blockIdx.y * RC_CC_ROWS;
     const int j0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (j0 >= n) return;
-    const int ci = slot_of[i];
-    unsigned *row = counts + (size_t)i * ldc + j0;
-    if (j0 + 3 < n) {
-        uint4 c = *(uint4 *)row;
-        const int4 s = *(const int4 *)(slot_of + j0);
-        c.x += (s.x == ci); c.y += (s.y == ci); c.z += (s.z == ci); c.w += (s.w == ci);
-        *(uint4 *)row = c;
-    } else {
-        for (int q = 0; q < 4 && j0 + q < n; ++q) row[q] += (slot_of[j0 + q] == ci);
+    for (int q = threadIdx.x; q < cnt * RC_CC_ROWS; q += 256) {
+        const int t = q / RC_CC_ROWS, r = q % RC_CC_ROWS;
+        ci[t][r] = (i0 + r < n) ? snap[(size_t)t * ldn + i0 + r] : (unsigned short)0xFFFF;
+    }
+    __syncthreads();
+    if (j0 >= ldn) return;
+    unsigned acc[RC_CC_ROWS][4];
+#pragma unroll
+    for (int r = 0; r < RC_CC_ROWS; ++r) { acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0; }
+    for (int t = 0; t < cnt; ++t) {
+        const ushort4 cj = *(const ushort4 *)(snap + (size_t)t * ldn + j0);
+#pragma unroll
+        for (int r = 0; r < RC_CC_ROWS; ++r) {
+            const unsigned short c = ci[t][r];
+            acc[r][0] += (c == cj.x); acc[r][1] += (c == cj.y); acc[r][2] += (c == cj.z); acc[r][3] += (c == cj.w);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RC_CC_ROWS; ++r) {
+        if (i0 + r < n) {
+            uint4 *row = (uint4 *)(counts + (size_t)(i0 + r) * ldc + j0);
+            uint4 v = *row;
+            v.x += acc[r][0]; v.y += acc[r][1]; v.z += acc[r][2]; v.w += acc[r][3];
+            *row = v;
+        }
     }
 }
 
@@ -773,7 +813,9 @@ struct rc_ctx {
     int eD = 0, eL = 0;
     hipStream_t sA = nullptr;  // resolve + observables (high priority)
     hipStream_t sB = nullptr;  // row-bucket reduction (k_bulk)
-    long long *Dq = nullptr, *Lq = nullptr, *diagq = nullptr;
+    void *Dq = nullptr, *Lq = nullptr;  // int64 or int32 fixed point
+    long long *diagq = nullptr;
+    int bits = 64;
     long long *SD[3] = {nullptr, nullptr, nullptr}, *SL[3] = {nullptr, nullptr, nullptr};
     int *slot_of = nullptr, *slot_size = nullptr, *slot_label = nullptr;
     short *slot_pos = nullptr, *slot_act = nullptr;
@@ -785,6 +827,8 @@ struct rc_ctx {
     long long *blocks = nullptr;  // k_blocksums output [kcap][kcap][4]
     unsigned *counts = nullptr;   // co-clustering counts [n][ldc]
     int ldc = 0;
+    unsigned short *snap = nullptr;  // queued label snapshots [RC_CC_BATCH][ldc]
+    int snap_cnt = 0;
     double *cc_out = nullptr;
     rc_params P{};
     bool have_params = false, have_state = false;
@@ -834,7 +878,7 @@ static View make_view(const rc_ctx *c)
 {
     View V{};
     V.n = c->n; V.ld = c->ld; V.kcap = c->kcap;
-    V.Dq = c->Dq; V.Lq = c->Lq; V.diagq = c->diagq;
+    V.Dq = c->Dq; V.Lq = c->Lq; V.bits = c->bits; V.diagq = c->diagq;
     for (int g = 0; g < 3; ++g) { V.SD[g] = c->SD[g]; V.SL[g] = c->SL[g]; }
     for (int g = 0; g < 2; ++g) { V.perm[g] = c->perm[g]; V.pslot[g] = c->pslot[g]; V.keys[g] = c->keys[g]; V.arrive[g] = c->arrive[g]; }
     V.slot_of = c->slot_of; V.slot_size = c->slot_size; V.slot_label = c->slot_label;
@@ -856,12 +900,13 @@ static int ceil_log2_ll(long long n)
     return b;
 }
 
-static int quant_exponent(long long n, double maxabs)
+// 64-bit storage: any sum of n entries fits int64.  32-bit storage: every entry fits int32 (sums are 64-bit).
+static int quant_exponent(long long n, double maxabs, int bits)
 {
     if (maxabs == 0.0) return 0;
     int ex;
     std::frexp(maxabs, &ex);
-    return 62 - ex - ceil_log2_ll(n);
+    return bits == 64 ? 62 - ex - ceil_log2_ll(n) : 30 - ex;
 }
 
 extern "C" const char *rc_last_error(const rc_ctx *ctx) { return ctx ? ctx->err : g_err; }
@@ -873,7 +918,7 @@ static void free_all(rc_ctx *c)
     void *ptrs[] = {c->Dq, c->Lq, c->diagq, c->SD[0], c->SD[1], c->SD[2], c->SL[0], c->SL[1], c->SL[2], c->slot_of,
                     c->slot_size, c->slot_label, c->slot_pos, c->slot_act, c->perm[0], c->perm[1], c->pslot[0],
                     c->pslot[1], c->A, c->keys[0], c->keys[1], c->arrive[0], c->arrive[1], c->sc, c->blocks,
-                    c->counts, c->cc_out};
+                    c->counts, c->cc_out, c->snap};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &e : c->ev_pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -936,8 +981,9 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     HIPCHK2(hipMalloc(&tmpL, nn * sizeof(double)));
     HIPCHK2(hipMalloc(&flags, 2 * sizeof(unsigned)));
     HIPCHK2(hipMalloc(&mx, 2 * sizeof(u64)));
-    HIPCHK2(hipMalloc(&c->Dq, (size_t)n * ld * sizeof(long long)));
-    HIPCHK2(hipMalloc(&c->Lq, (size_t)n * ld * sizeof(long long)));
+    const size_t esz = (size_t)c->bits / 8;
+    HIPCHK2(hipMalloc(&c->Dq, (size_t)n * ld * esz));
+    HIPCHK2(hipMalloc(&c->Lq, (size_t)n * ld * esz));
     HIPCHK2(hipMalloc(&c->diagq, (size_t)n * sizeof(long long)));
     for (int g = 0; g < 3; ++g) {
         HIPCHK2(hipMalloc(&c->SD[g], (size_t)c->kcap * ld * sizeof(long long)));
@@ -957,8 +1003,8 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     HIPCHK2(hipMalloc(&c->A, (size_t)(n + 1) * sizeof(double)));
     HIPCHK2(hipMalloc(&c->sc, sizeof(DevScalars)));
     HIPCHK2(hipMalloc(&c->blocks, (size_t)c->kcap * c->kcap * 4 * sizeof(long long)));
-    HIPCHK2(hipMemsetAsync(c->Dq, 0, (size_t)n * ld * sizeof(long long), s));
-    HIPCHK2(hipMemsetAsync(c->Lq, 0, (size_t)n * ld * sizeof(long long), s));
+    HIPCHK2(hipMemsetAsync(c->Dq, 0, (size_t)n * ld * esz, s));
+    HIPCHK2(hipMemsetAsync(c->Lq, 0, (size_t)n * ld * esz, s));
     HIPCHK2(hipMemsetAsync(c->slot_size, 0, (size_t)c->kcap * sizeof(int), s));
     HIPCHK2(hipMemsetAsync(c->slot_label, 0, (size_t)c->kcap * sizeof(int), s));
     HIPCHK2(hipMemsetAsync(c->sc, 0, sizeof(DevScalars), s));
@@ -989,10 +1035,15 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     double maxD, maxL;
     std::memcpy(&maxD, &hmx[0], 8);
     std::memcpy(&maxL, &hmx[1], 8);
-    c->eD = quant_exponent(n, maxD);
-    c->eL = quant_exponent(n, maxL);
-    k_quantize<<<gb, 256, 0, s>>>(tmpD, (int)n, c->ld, c->eD, c->Dq, c->diagq);
-    k_quantize<<<gb, 256, 0, s>>>(tmpL, (int)n, c->ld, c->eL, c->Lq, nullptr);
+    c->eD = quant_exponent(n, maxD, c->bits);
+    c->eL = quant_exponent(n, maxL, c->bits);
+    if (c->bits == 64) {
+        k_quantize<long long><<<gb, 256, 0, s>>>(tmpD, (int)n, c->ld, c->eD, (long long *)c->Dq, c->diagq);
+        k_quantize<long long><<<gb, 256, 0, s>>>(tmpL, (int)n, c->ld, c->eL, (long long *)c->Lq, nullptr);
+    } else {
+        k_quantize<int><<<gb, 256, 0, s>>>(tmpD, (int)n, c->ld, c->eD, (int *)c->Dq, c->diagq);
+        k_quantize<int><<<gb, 256, 0, s>>>(tmpL, (int)n, c->ld, c->eL, (int *)c->Lq, nullptr);
+    }
     HIPCHK2(hipStreamSynchronize(s));
     HIPCHK2(hipGetLastError());
     cleanup();
@@ -1007,8 +1058,8 @@ extern "C" int32_t rc_create(int64_t n, const double *D, const double *logD_or_n
     *out = nullptr;
     if (!D) return fail(nullptr, RC_ERR_ARG, "rc_create: D is NULL");
     if (n < 1 || n > (1 << 20)) return fail(nullptr, RC_ERR_ARG, "rc_create: n must be in 1..2^20 (got %lld)", (long long)n);
-    if (storage_bits != 64) return fail(nullptr, RC_ERR_ARG, "rc_create: storage_bits must be 64 in this build");
-    if (kcap == 0) kcap = std::min<int64_t>(n, 256);
+    if (storage_bits != 64 && storage_bits != 32) return fail(nullptr, RC_ERR_ARG, "rc_create: storage_bits must be 64 or 32");
+    if (kcap == 0) kcap = std::min<int64_t>(n, 1024);
     if (kcap < 1 || kcap > RC_MAX_KCAP) return fail(nullptr, RC_ERR_ARG, "rc_create: kcap must be in 1..%d", RC_MAX_KCAP);
     if (kcap > n) kcap = n;
     int ndev = 0;
@@ -1019,7 +1070,8 @@ extern "C" int32_t rc_create(int64_t n, const double *D, const double *logD_or_n
     if (!c) return fail(nullptr, RC_ERR_OOM, "rc_create: host allocation failed");
     c->dev = device_id;
     c->n = (int)n;
-    c->ld = (int)(((n + 511) / 512) * 512);
+    c->ld = (int)(((n + 1023) / 1024) * 1024);
+    c->bits = storage_bits;
     c->kcap = (int)kcap;
     c->dbg = getenv("RC_DEBUG_FLAGS") ? atoi(getenv("RC_DEBUG_FLAGS")) : 0;
     c->prefetch = !(getenv("RC_NO_PREFETCH") && atoi(getenv("RC_NO_PREFETCH")));
@@ -1034,14 +1086,15 @@ extern "C" int32_t rc_create(int64_t n, const double *D, const double *logD_or_n
     {
         // k_bulk split length: aim for >= 512 workgroups, but keep splits long (each split boundary costs a
         // round of 64-bit atomic flushes): 256 rows at n = 8192 (tools/bulk_tune.hip)
-        const int col_chunks = c->ld / 512;
+        const int col_chunks = c->ld / (c->bits == 64 ? 512 : 1024);
         const int splits_target = std::max(1, 512 / col_chunks);
         c->rows_per_split = std::max(16, std::min(512, (c->n + splits_target - 1) / splits_target));
         if (getenv("RC_BULK_ROWS")) c->rows_per_split = std::max(1, atoi(getenv("RC_BULK_ROWS")));
         const int per_cu = getenv("RC_BULK_PER_CU") ? atoi(getenv("RC_BULK_PER_CU")) : 2;
         c->bulk_lds = per_cu > 0 ? (size_t)((150 * 1024 / per_cu) & ~1023) : 0;
         if (c->bulk_lds > 64 * 1024)
-            (void)hipFuncSetAttribute((const void *)k_bulk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->bulk_lds);
+            (void)hipFuncSetAttribute(c->bits == 64 ? (const void *)k_bulk<long long> : (const void *)k_bulk<int>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->bulk_lds);
     }
     {
         // kernels whose dynamic LDS can exceed the 64 KiB default (large kcap)
@@ -1186,7 +1239,7 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
 {
     if (t >= 2) HIPCHK(c, hipStreamWaitEvent(c->sB, c->ev_res[(t - 2) & 3], 0));
     const int splits = (c->n + c->rows_per_split - 1) / c->rows_per_split;
-    dim3 gb((unsigned)(c->ld / 512), (unsigned)splits);
+    dim3 gb((unsigned)(c->ld / (c->bits == 64 ? 512 : 1024)), (unsigned)splits);
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     const bool timed = c->timing && (c->timing_every <= 1 || (t % c->timing_every) == 0);
     if (timed) {
@@ -1196,7 +1249,10 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
     }
     // bulk_lds: unused dynamic LDS that caps k_bulk at bulk_blocks_per_cu workgroups per CU, which (i) spreads the
     // grid evenly over the CUs and (ii) leaves registers/wave slots on every CU for the concurrent k_resolve
-    k_bulk<<<gb, 256, c->bulk_lds, c->sB>>>(V, c->rows_per_split, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1));
+    if (c->bits == 64)
+        k_bulk<long long><<<gb, 256, c->bulk_lds, c->sB>>>(V, c->rows_per_split, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1));
+    else
+        k_bulk<int><<<gb, 256, c->bulk_lds, c->sB>>>(V, c->rows_per_split, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1));
     if (timed) {
         HIPCHK(c, hipEventRecord(ev.second, c->sB));
         c->ev_pending.push_back(ev);
@@ -1317,13 +1373,16 @@ extern "C" int32_t rc_loglik(rc_ctx *c, double *out)
     int gen = 0;
     int32_t rc = ensure_S(c, &gen);
     if (rc != RC_OK) return rc;
-    View V = make_view(c);
-    k_blocksums<<<c->kcap, 256, (size_t)c->kcap * 4 * sizeof(u64), c->sA>>>(V, gen, c->blocks);
     std::vector<int> so, ssize, slabel;
-    rc = pull_state(c, so, ssize, slabel);
+    rc = pull_state(c, so, ssize, slabel);  // also refreshes c->last (slot_hi)
     if (rc != RC_OK) return rc;
-    std::vector<long long> B((size_t)c->kcap * c->kcap * 4);
-    HIPCHK(c, hipMemcpy(B.data(), c->blocks, B.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    const int hi = std::max(1, std::min(c->kcap, c->last.slot_hi));
+    View V = make_view(c);
+    k_blocksums<<<hi, 256, (size_t)hi * 4 * sizeof(u64), c->sA>>>(V, gen, hi, c->blocks);
+    HIPCHK(c, hipGetLastError());
+    std::vector<long long> B((size_t)hi * hi * 4);
+    HIPCHK(c, hipMemcpyAsync(B.data(), c->blocks, B.size() * sizeof(long long), hipMemcpyDeviceToHost, c->sA));
+    HIPCHK(c, hipStreamSynchronize(c->sA));
     // scalar part of loglik (mcmc.jl:26-54) in long double, regrouped as in oracle "stable" mode
     std::vector<int> act;
     for (int k = 0; k < c->kcap; ++k)
@@ -1334,7 +1393,7 @@ extern "C" int32_t rc_loglik(rc_ctx *c, double *out)
     const long double lb = logl(be), lg = logl(ga);
     const long double scD = ldexpl(1.0L, -c->eD), scL = ldexpl(1.0L, -c->eL);
     auto blk = [&](int k, int t, int which) -> long double {
-        const long long *e = &B[((size_t)t * c->kcap + k) * 4 + (which ? 2 : 0)];
+        const long long *e = &B[((size_t)t * hi + k) * 4 + (which ? 2 : 0)];
         return ((long double)e[0] * (long double)(1ll << RC_LO_BITS) + (long double)e[1]) * (which ? scL : scD);
     };
     long double L1 = 0, L2 = 0;
@@ -1390,7 +1449,20 @@ static int32_t ensure_counts(rc_ctx *c)
     if (c->counts) return RC_OK;
     c->ldc = ((c->n + 3) / 4) * 4;
     HIPCHK(c, hipMalloc(&c->counts, (size_t)c->n * c->ldc * sizeof(unsigned)));
+    HIPCHK(c, hipMalloc(&c->snap, (size_t)RC_CC_BATCH * c->ldc * sizeof(unsigned short)));
     HIPCHK(c, hipMemsetAsync(c->counts, 0, (size_t)c->n * c->ldc * sizeof(unsigned), c->sA));
+    c->snap_cnt = 0;
+    return RC_OK;
+}
+
+// adds the queued label snapshots to the count matrix (one pass over the matrix for up to RC_CC_BATCH samples)
+static int32_t flush_counts(rc_ctx *c)
+{
+    if (!c->counts || c->snap_cnt == 0) return RC_OK;
+    dim3 g((unsigned)((c->ldc + 1023) / 1024), (unsigned)((c->n + RC_CC_ROWS - 1) / RC_CC_ROWS));
+    k_cocluster_batch<<<g, 256, 0, c->sA>>>(c->snap, c->snap_cnt, c->n, c->ldc, c->ldc, c->counts);
+    HIPCHK(c, hipGetLastError());
+    c->snap_cnt = 0;
     return RC_OK;
 }
 
@@ -1401,9 +1473,12 @@ extern "C" int32_t rc_record_sample(rc_ctx *c, int64_t *canonical_out)
     HIPCHK(c, hipSetDevice(c->dev));
     int32_t rc = ensure_counts(c);
     if (rc != RC_OK) return rc;
-    dim3 g((unsigned)((c->n + 1023) / 1024), (unsigned)c->n);
-    k_cocluster_add<<<g, 256, 0, c->sA>>>(c->slot_of, c->n, c->ldc, c->counts);
+    k_snapshot<<<(c->ldc + 255) / 256, 256, 0, c->sA>>>(c->slot_of, c->n, c->ldc, c->snap + (size_t)c->snap_cnt * c->ldc);
     HIPCHK(c, hipGetLastError());
+    if (++c->snap_cnt == RC_CC_BATCH) {
+        rc = flush_counts(c);
+        if (rc != RC_OK) return rc;
+    }
     if (canonical_out) {
         std::vector<int> so((size_t)c->n);
         HIPCHK(c, hipMemcpyAsync(so.data(), c->slot_of, so.size() * sizeof(int), hipMemcpyDeviceToHost, c->sA));
@@ -1427,6 +1502,7 @@ extern "C" int32_t rc_cocluster_reset(rc_ctx *c)
     HIPCHK(c, hipSetDevice(c->dev));
     int32_t rc = ensure_counts(c);
     if (rc != RC_OK) return rc;
+    c->snap_cnt = 0;
     HIPCHK(c, hipMemsetAsync(c->counts, 0, (size_t)c->n * c->ldc * sizeof(unsigned), c->sA));
     return RC_OK;
 }
@@ -1436,6 +1512,8 @@ extern "C" int32_t rc_cocluster_counts(rc_ctx *c, uint32_t *out)
     if (!c || !out) return fail(c, RC_ERR_ARG, "rc_cocluster_counts: NULL argument");
     HIPCHK(c, hipSetDevice(c->dev));
     int32_t rc = ensure_counts(c);
+    if (rc != RC_OK) return rc;
+    rc = flush_counts(c);
     if (rc != RC_OK) return rc;
     rc = sync_and_check(c);
     if (rc != RC_OK) return rc;
@@ -1450,6 +1528,8 @@ extern "C" int32_t rc_cocluster_device_buffer(rc_ctx *c, void **dev_ptr, int64_t
     HIPCHK(c, hipSetDevice(c->dev));
     int32_t rc = ensure_counts(c);
     if (rc != RC_OK) return rc;
+    rc = flush_counts(c);
+    if (rc != RC_OK) return rc;
     rc = sync_and_check(c);
     if (rc != RC_OK) return rc;
     *dev_ptr = c->counts;
@@ -1463,6 +1543,8 @@ extern "C" int32_t rc_cocluster(rc_ctx *c, double *out, int64_t numsamples)
     if (numsamples < 1) return fail(c, RC_ERR_ARG, "rc_cocluster: numsamples must be >= 1");
     HIPCHK(c, hipSetDevice(c->dev));
     int32_t rc = ensure_counts(c);
+    if (rc != RC_OK) return rc;
+    rc = flush_counts(c);
     if (rc != RC_OK) return rc;
     const size_t nn = (size_t)c->n * c->n;
     if (!c->cc_out) HIPCHK(c, hipMalloc(&c->cc_out, nn * sizeof(double)));

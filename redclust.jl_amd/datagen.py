@@ -27,14 +27,31 @@ def generatemixture(N: int, K: int, *, alpha: float | None = None, dim: int | No
     clusts = np.sort(rng.choice(K, size=N, p=probs)) + 1          # utils.jl:114 (sorted labels)
     pts = rng.normal(0.0, sigma, size=(N, dim))                   # utils.jl:123-128
     pts[np.arange(N), clusts - 1] += radius                       # centre k = radius·e_k, utils.jl:117-120
-    g = pts @ pts.T
+    # pairwise Euclidean distances (utils.jl:144-145), built block-row-wise so that N = 32768 needs one N×N array
     sq = np.einsum("ij,ij->i", pts, pts)
-    D2 = sq[:, None] + sq[None, :] - 2 * g
-    np.maximum(D2, 0, out=D2)
-    D = np.sqrt(D2)
-    D = (D + D.T) * 0.5                                           # exact symmetry (types.jl:149-151)
+    D = np.empty((N, N), dtype=np.float64)
+    B = 2048
+    for i0 in range(0, N, B):
+        i1 = min(N, i0 + B)
+        blk = pts[i0:i1] @ pts.T
+        blk *= -2.0
+        blk += sq[i0:i1, None]
+        blk += sq[None, :]
+        np.maximum(blk, 0.0, out=blk)
+        np.sqrt(blk, out=D[i0:i1])
+    # exact symmetry (types.jl:149-151 requires it): mirror the upper triangle, zero diagonal
+    for i0 in range(0, N, B):
+        i1 = min(N, i0 + B)
+        for j0 in range(i0, N, B):
+            j1 = min(N, j0 + B)
+            if i0 == j0:
+                t = D[i0:i1, j0:j1]
+                iu = np.triu_indices(i1 - i0, 1)
+                t.T[iu] = t[iu]
+            else:
+                D[j0:j1, i0:i1] = D[i0:i1, j0:j1].T
     np.fill_diagonal(D, 0.0)
-    return dict(points=pts, distancematrix=D.astype(dtype), clusts=clusts.astype(np.int64), probs=probs)
+    return dict(points=pts, distancematrix=D if dtype == np.float64 else D.astype(dtype), clusts=clusts.astype(np.int64), probs=probs)
 
 
 def _gamma_shape_mle(mean_x, mean_logx):

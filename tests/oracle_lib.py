@@ -46,6 +46,7 @@ def lib():
     L.orc_state_from_labels.argtypes = [i64, _ip, _ip, C.POINTER(i64)]
     L.orc_quant_exponent.argtypes = [i64, _dp, i64]
     L.orc_quantize.argtypes = [_dp, i64, i32, _ip]
+    L.orc_quant_exponent32.argtypes = [_dp, i64]
     L.orc_sweep_literal.argtypes = [i64, _dp, _dp, _ip, _ip, C.POINTER(i64), PP, f64, f64, u64, u64, i32]
     L.orc_sweep_literal_range.argtypes = [i64, _dp, _dp, _ip, _ip, C.POINTER(i64), PP, f64, f64, u64, u64, i32, i64, i64]
     L.orc_point_scores_literal.restype = i64
@@ -80,7 +81,7 @@ def params(P: dict) -> OrcParams:
 class Oracle:
     """Convenience wrapper holding one dataset (D, logD, fixed-point copies) and one label state."""
 
-    def __init__(self, D: np.ndarray, P: dict, logD: np.ndarray | None = None):
+    def __init__(self, D: np.ndarray, P: dict, logD: np.ndarray | None = None, bits: int = 64):
         self.L = lib()
         self.n = int(D.shape[0])
         self.D = np.ascontiguousarray(D, dtype=np.float64)
@@ -91,8 +92,12 @@ class Oracle:
         self.logD = np.ascontiguousarray(logD, dtype=np.float64)
         self.set_params(P)
         nn = self.n * self.n
-        self.eD = self.L.orc_quant_exponent(self.n, self.D.ravel(), nn)
-        self.eL = self.L.orc_quant_exponent(self.n, self.logD.ravel(), nn)
+        if bits == 64:
+            self.eD = self.L.orc_quant_exponent(self.n, self.D.ravel(), nn)
+            self.eL = self.L.orc_quant_exponent(self.n, self.logD.ravel(), nn)
+        else:
+            self.eD = self.L.orc_quant_exponent32(self.D.ravel(), nn)
+            self.eL = self.L.orc_quant_exponent32(self.logD.ravel(), nn)
         self.Dq = np.empty((self.n, self.n), np.int64)
         self.Lq = np.empty((self.n, self.n), np.int64)
         self.L.orc_quantize(self.D.ravel(), nn, self.eD, self.Dq.reshape(-1))

@@ -1,6 +1,8 @@
 """GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle and the committed
 golden vectors.  Integer outputs (labels, sizes, K, fixed-point row sums, co-clustering counts) must match
 EXACTLY; loglik / logprior within the stated relative tolerance."""
+import os
+
 import numpy as np
 import pytest
 
@@ -14,10 +16,10 @@ LL_RTOL = 1e-9   # loglik / logposterior vs the oracle's stable mode (north_star
 LIT_RTOL = 1e-7  # vs the literal restatement / golden vectors (cancellation noise of the literal formulas)
 
 
-def make_pair(D, P, init, kcap=0):
-    orc = O.Oracle(D, P)
+def make_pair(D, P, init, kcap=0, bits=64):
+    orc = O.Oracle(D, P, bits=bits)
     orc.set_state(init)
-    ctx = rc.Context(D, logD=orc.logD, kcap=kcap)
+    ctx = rc.Context(D, logD=orc.logD, kcap=kcap, storage_bits=bits)
     ctx.set_params(**P)
     ctx.set_state(init)
     return orc, ctx
@@ -111,6 +113,44 @@ def test_synthetic_moving_and_stationary(n, K, seed):
         ctx.close()
 
 
+@pytest.mark.parametrize("tag", ["d1_random", "d2_truth", "d1_singletons"])
+def test_storage32_golden_cases(tag):
+    """32-bit fixed-point storage (config-5 style): exact parity with the oracle's stable mode on the same 32-bit
+    quantised matrices; row sums exact; loglik within 1e-9 of that oracle and within 1e-6 of the Float64 literal."""
+    g, d = load_golden()
+    D, P, init, seed = golden_case(g, d, tag)
+    orc, ctx = make_pair(D, P, init, bits=32)
+    assert int(np.abs(orc.Dq).max()) < 2 ** 30 and int(np.abs(orc.Lq).max()) < 2 ** 30
+    onehot = (init[:, None] == np.arange(1, 101)[None, :]).astype(np.int64)
+    for lab in np.unique(init)[:5]:
+        sd, sl, eD, eL = ctx.debug_rowsums(int(lab))
+        assert (eD, eL) == (orc.eD, orc.eL)
+        assert np.array_equal(sd, (orc.Dq @ onehot)[:, lab - 1]) and np.array_equal(sl, (orc.Lq @ onehot)[:, lab - 1])
+    for t in range(6):
+        r, p = rp_schedule(t)
+        ctx.gibbs_sweep(r, p, seed, t)
+        orc.sweep_stable(r, p, seed, t)
+        assert_state_equal(ctx, orc, f"(32-bit {tag}, sweep {t})")
+    ll = ctx.loglik()
+    assert abs(ll - orc.loglik_stable()) <= LL_RTOL * max(1.0, abs(ll))
+    assert abs(ll - orc.loglik_literal()) <= 1e-6 * max(1.0, abs(ll))
+    ctx.close()
+
+
+def test_storage32_synthetic():
+    data = rc.generatemixture(1500, 40, seed=5, sigma=0.2)
+    D, truth = data["distancematrix"], data["clusts"]
+    P = rc.likelihood_hyperparams(D, truth)
+    init = np.random.default_rng(5).integers(1, 41, size=1500).astype(np.int64)
+    orc, ctx = make_pair(D, P, init, bits=32, kcap=512)  # the first sweep from a random init shatters into ~300 clusters
+    for t in range(5):
+        r, p = rp_schedule(t)
+        ctx.gibbs_sweep(r, p, 77, t)
+        orc.sweep_stable(r, p, 77, t)
+        assert_state_equal(ctx, orc, f"(32-bit synthetic, sweep {t})")
+    ctx.close()
+
+
 def test_literal_restatement_trajectory():
     """GPU vs the LITERAL restatement (reference formulas as written) on N=100: same labels for 30 sweeps."""
     g, d = load_golden()
@@ -142,6 +182,32 @@ def test_cocluster_counts_and_posterior():
     post = ctx.cocluster(S)
     assert np.array_equal(post, ref / S)  # counts ./ numsamples, mcmc.jl:560
     assert np.all(np.diag(post) == 1.0) and np.array_equal(post, post.T)
+    ctx.close()
+
+
+def test_cocluster_many_samples_batched():
+    """More recorded samples than one accumulation batch (32): full flushes + a partial one, odd n (padding)."""
+    g, d = load_golden()
+    D, P, init, seed = golden_case(g, d, "d1_random")
+    n = 97
+    D = np.ascontiguousarray(D[:n, :n]); init = init[:n].copy()
+    orc, ctx = make_pair(D, P, init)
+    ctx.cocluster_reset()
+    ref = np.zeros((n, n), np.uint32)
+    S = 75
+    for t in range(S):
+        r, p = rp_schedule(t)
+        ctx.gibbs_sweep(r, p, seed, t)
+        orc.sweep_stable(r, p, seed, t)
+        ctx.record_sample(t % 10 == 0)
+        orc.L.orc_cocluster_add(n, orc.clusts, ref.reshape(-1))
+        if t == 40:
+            assert np.array_equal(ctx.cocluster_counts(), ref)  # reading flushes the queue; accumulation continues
+    assert_state_equal(ctx, orc)
+    assert np.array_equal(ctx.cocluster_counts(), ref)
+    assert np.array_equal(ctx.cocluster(S), ref / S)
+    ctx.cocluster_reset()
+    assert not ctx.cocluster_counts().any()
     ctx.close()
 
 
@@ -263,4 +329,45 @@ def test_full_size_properties():
     post = ctx.cocluster(2)
     assert np.all(np.diag(post) == 1.0) and np.array_equal(post, post.T)
     assert np.array_equal(post == 1.0, c3[:, None] == c3[None, :])
+    ctx.close()
+
+
+@pytest.mark.skipif(not os.environ.get("RC_TEST_BIG"), reason="BASELINE config 5 (N=32768, K=200, 8 GiB host matrix): set RC_TEST_BIG=1")
+def test_config5_properties():
+    """BASELINE config 5: N=32768, K=200, 32-bit storage.  Size-independent properties (no oracle at this size)."""
+    n, K = 32768, 200
+    data = rc.generatemixture(n, K, seed=1)
+    D, truth = data["distancematrix"], data["clusts"]
+    P = rc.likelihood_hyperparams(D, truth)
+    ctx = rc.Context(D, kcap=512, storage_bits=32)
+    ctx.set_params(**P)
+    ctx.set_state(truth)
+    tot = np.zeros(n, np.int64)
+    eD = None
+    for lab in np.unique(truth):
+        sd, sl, eD, eL = ctx.debug_rowsums(int(lab))
+        tot += sd
+    ref = np.zeros(n, np.int64)
+    for i0 in range(0, n, 2048):
+        ref[i0:i0 + 2048] = np.rint(np.ldexp(D[i0:i0 + 2048], eD)).astype(np.int64).sum(axis=1)
+    assert np.array_equal(tot, ref)                       # checksum of the whole row-sum table, exact
+    for t in range(3):
+        ctx.gibbs_sweep(1.0, 0.5, 42, t)
+    c1, s1, K1 = ctx.get_state()
+    assert s1.sum() == n and K1 == np.sum(s1 > 0) and np.array_equal(np.bincount(c1, minlength=n + 1)[1:], s1)
+    ll1 = ctx.loglik()
+    ctx.set_state(truth)
+    for t in range(3):
+        ctx.gibbs_sweep(1.0, 0.5, 42, t, blocking=False)
+    ctx.synchronize()
+    c2, s2, K2 = ctx.get_state()
+    assert np.array_equal(c1, c2) and ctx.loglik() == ll1
+    # perturb 500 labels: the sweep must move points and keep the invariants
+    init = truth.copy()
+    idx = np.random.default_rng(0).choice(n, 500, replace=False)
+    init[idx] = np.random.default_rng(1).integers(1, K + 1, size=500)
+    ctx.set_state(init)
+    ctx.gibbs_sweep(1.0, 0.5, 43, 0)
+    c3, s3, K3 = ctx.get_state()
+    assert s3.sum() == n and K3 == np.sum(s3 > 0) and ctx.sweep_stats()["n_changes"] > 0
     ctx.close()
