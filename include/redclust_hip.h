@@ -74,6 +74,8 @@ int32_t rc_set_params(rc_ctx *ctx, const rc_params *params);
 
 /* MCMCState, src/types.jl:131-137: clustsizes and K are derived from the labels (types.jl:135-136). */
 int32_t rc_set_state(rc_ctx *ctx, const int64_t *clusts /* n, 1-based */);
+/* Any of the three outputs may be NULL.  With clusts == NULL nothing is copied from the device: sizes and K come
+ * from the summary the sweep kernel leaves in host-mapped memory (the per-iteration need of sample_r!/sample_p!). */
 int32_t rc_get_state(rc_ctx *ctx, int64_t *clusts /* n */, int64_t *clustsizes /* n, by label */, int64_t *K);
 
 /* sample_labels_Gibbs!(data, state, params), src/mcmc.jl:158-256 — one full sequential sweep with the

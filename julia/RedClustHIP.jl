@@ -65,10 +65,13 @@ function runsampler_hip(data::MCMCData, options::MCMCOptionsList, params::PriorH
             sample_p!(state, params)                                             # src/mcmc.jl:539 (host scalar)
             check(ctx, ccall((:rc_gibbs_sweep, LIB), Int32, (Ptr{Cvoid}, Cdouble, Cdouble, UInt64, UInt64),
                              ctx, state.r, state.p, seed, i - 1))                # src/mcmc.jl:540 → :477
+            record = i > options.burnin && (i - options.burnin) % options.thin == 0   # src/mcmc.jl:546
+            # sizes and K for the next sample_r!/sample_p! come from the sweep's host-mapped summary (no device copy);
+            # the label vector itself is pulled only when a sample is recorded
             check(ctx, ccall((:rc_get_state, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ref{Int64}),
-                             ctx, state.clusts, state.clustsizes, K))
+                             ctx, record ? pointer(state.clusts) : Ptr{Int64}(C_NULL), state.clustsizes, K))
             state.K = K[]
-            if i > options.burnin && (i - options.burnin) % options.thin == 0   # src/mcmc.jl:546
+            if record
                 check(ctx, ccall((:rc_record_sample, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), ctx, result.clusts[j]))
                 result.K[j] = state.K; result.r[j] = state.r; result.p[j] = state.p
                 check(ctx, ccall((:rc_loglik, LIB), Int32, (Ptr{Cvoid}, Ref{Cdouble}), ctx, ll))

@@ -58,7 +58,7 @@ SIGNATURES = {
     "rc_last_error": (C.c_char_p, [C.c_void_p]),
     "rc_set_params": (C.c_int32, [C.c_void_p, C.POINTER(RcParams)]),
     "rc_set_state": (C.c_int32, [C.c_void_p, _ip]),
-    "rc_get_state": (C.c_int32, [C.c_void_p, _ip, _ip, C.POINTER(C.c_int64)]),
+    "rc_get_state": (C.c_int32, [C.c_void_p, C.c_void_p, _ip, C.POINTER(C.c_int64)]),
     "rc_gibbs_sweep": (C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_uint64, C.c_uint64]),
     "rc_gibbs_sweep_async": (C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_uint64, C.c_uint64]),
     "rc_last_sweep_stats": (C.c_int32, [C.c_void_p, C.POINTER(RcSweepStats)]),
@@ -140,11 +140,13 @@ class Context:
             raise ValueError("clusts must have length n")
         self._chk(self.L.rc_set_state(self.h, c))
 
-    def get_state(self):
-        clusts = np.zeros(self.n, np.int64)
+    def get_state(self, want_labels=True):
+        """(clusts, clustsizes, K); with want_labels=False clusts is None and nothing is copied from the device."""
+        clusts = np.zeros(self.n, np.int64) if want_labels else None
         sizes = np.zeros(self.n, np.int64)
         K = C.c_int64()
-        self._chk(self.L.rc_get_state(self.h, clusts, sizes, C.byref(K)))
+        self._chk(self.L.rc_get_state(self.h, clusts.ctypes.data_as(C.c_void_p) if want_labels else None, sizes,
+                                      C.byref(K)))
         return clusts, sizes, K.value
 
     def gibbs_sweep(self, r, p, seed, sweep_index, blocking=True):

@@ -66,6 +66,14 @@ struct DevScalars {
     int pad;
 };
 
+// Per-sweep summary written by block 0 of k_resolve straight into host-mapped pinned memory: the host needs K and
+// the cluster sizes after every sweep for the scalar r / p updates (src/mcmc.jl:84-89,139-144) —
+// one stream synchronisation and no copy call.
+struct HostSummary {
+    int K, n_changes, n_rounds, err, slot_hi, seq, pad0, pad1;
+    int size_label[2 * RC_MAX_KCAP];  // [2k] = size of slot k, [2k+1] = its 1-based label (0 = free)
+};
+
 // Everything a kernel needs, passed by value.
 struct View {
     int n, ld, kcap;
@@ -83,6 +91,7 @@ struct View {
     u64 *keys[2];              // [n+2] one first-change word per round (two generations)
     unsigned *arrive[2];       // grid-barrier arrival counters (two generations)
     DevScalars *sc;
+    HostSummary *hsum;         // device address of the host-mapped summary
     double scD, scL;           // 2^-eD, 2^-eL
     double alpha, beta, zeta, gamma, delta1, delta2, cL;
     int repulsion;
@@ -428,6 +437,22 @@ __device__ void tab_store(const View &V, const Tab &T)
     }
 }
 
+__device__ void write_summary(const View &V, int n_changes, int n_rounds)
+{
+    for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) {
+        V.hsum->size_label[2 * k] = V.slot_size[k];
+        V.hsum->size_label[2 * k + 1] = V.slot_label[k];
+    }
+    if (threadIdx.x == 0) {
+        V.hsum->K = V.sc->K;
+        V.hsum->n_changes = n_changes;
+        V.hsum->n_rounds = n_rounds;
+        V.hsum->slot_hi = V.sc->slot_hi;
+        V.hsum->err = __hip_atomic_load(&V.sc->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        V.hsum->seq += 1;
+    }
+}
+
 // After rc_set_state: derive ranks / smallest empty label / perm (both generations) from slot_size, slot_label, slot_of.
 __global__ __launch_bounds__(1024) void k_derive(View V)
 {
@@ -438,6 +463,8 @@ __global__ __launch_bounds__(1024) void k_derive(View V)
     __syncthreads();
     tab_structural(V, T);
     tab_store(V, T);
+    __syncthreads();
+    write_summary(V, 0, 0);
     __syncthreads();
     int *off = (int *)smem, *cur = off + V.kcap;
     build_perm_block(V, 0, off, cur);
@@ -706,6 +733,8 @@ __global__ __launch_bounds__(RC_RES_THREADS) void k_resolve(View V, SweepArgs sa
             V.sc->n_rounds = round + 1;
             if (changes) V.sc->last_change_sweep = t;
         }
+        __syncthreads();
+        write_summary(V, changes, round + 1);
         // perm generation t%2 must describe the labels after this sweep (k_bulk of sweep t+2 reads it)
         if (changes && ok) {
             int *off = (int *)smem, *cur = off + V.kcap;  // LDS tables are no longer needed
@@ -824,6 +853,8 @@ struct rc_ctx {
     u64 *keys[2] = {nullptr, nullptr};
     unsigned *arrive[2] = {nullptr, nullptr};
     DevScalars *sc = nullptr;
+    HostSummary *hsum = nullptr;      // pinned, host-mapped
+    HostSummary *hsum_dev = nullptr;  // its device address
     long long *blocks = nullptr;  // k_blocksums output [kcap][kcap][4]
     unsigned *counts = nullptr;   // co-clustering counts [n][ldc]
     int ldc = 0;
@@ -883,7 +914,7 @@ static View make_view(const rc_ctx *c)
     for (int g = 0; g < 2; ++g) { V.perm[g] = c->perm[g]; V.pslot[g] = c->pslot[g]; V.keys[g] = c->keys[g]; V.arrive[g] = c->arrive[g]; }
     V.slot_of = c->slot_of; V.slot_size = c->slot_size; V.slot_label = c->slot_label;
     V.slot_pos = c->slot_pos; V.slot_act = c->slot_act;
-    V.A = c->A; V.sc = c->sc;
+    V.A = c->A; V.sc = c->sc; V.hsum = c->hsum_dev;
     V.scD = std::ldexp(1.0, -c->eD); V.scL = std::ldexp(1.0, -c->eL);
     V.alpha = c->P.alpha; V.beta = c->P.beta; V.zeta = c->P.zeta; V.gamma = c->P.gamma;
     V.delta1 = c->P.delta1; V.delta2 = c->P.delta2;
@@ -921,6 +952,7 @@ static void free_all(rc_ctx *c)
                     c->counts, c->cc_out, c->snap};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (c->hsum) (void)hipHostFree(c->hsum);
     for (auto &e : c->ev_pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &e : c->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (int q = 0; q < 4; ++q) {
@@ -1002,6 +1034,9 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     HIPCHK2(hipMalloc(&c->slot_act, (size_t)c->kcap * sizeof(short)));
     HIPCHK2(hipMalloc(&c->A, (size_t)(n + 1) * sizeof(double)));
     HIPCHK2(hipMalloc(&c->sc, sizeof(DevScalars)));
+    HIPCHK2(hipHostMalloc((void **)&c->hsum, sizeof(HostSummary), hipHostMallocMapped));
+    std::memset(c->hsum, 0, sizeof(HostSummary));
+    HIPCHK2(hipHostGetDevicePointer((void **)&c->hsum_dev, c->hsum, 0));
     HIPCHK2(hipMalloc(&c->blocks, (size_t)c->kcap * c->kcap * 4 * sizeof(long long)));
     HIPCHK2(hipMemsetAsync(c->Dq, 0, (size_t)n * ld * esz, s));
     HIPCHK2(hipMemsetAsync(c->Lq, 0, (size_t)n * ld * esz, s));
@@ -1165,7 +1200,8 @@ static int32_t sync_and_check(rc_ctx *c, bool both = false)
         if (rc != RC_OK) return rc;
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpy(&c->last, c->sc, sizeof(DevScalars), hipMemcpyDeviceToHost));
+    c->last.K = c->hsum->K; c->last.n_changes = c->hsum->n_changes; c->last.n_rounds = c->hsum->n_rounds;
+    c->last.err = c->hsum->err; c->last.slot_hi = c->hsum->slot_hi;
     if (c->last.err & RC_DERR_BARRIER) return fail(c, RC_ERR_HIP, "grid barrier timed out inside the sweep kernel");
     if (c->last.err & RC_DERR_CAPACITY)
         return fail(c, RC_ERR_CAPACITY, "number of clusters exceeded the slot capacity kcap=%d given to rc_create", c->kcap);
@@ -1226,7 +1262,7 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
     k_derive<<<1, 1024, lds, c->sA>>>(V);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->sA));
-    HIPCHK(c, hipMemcpy(&c->last, c->sc, sizeof(DevScalars), hipMemcpyDeviceToHost));
+    c->last = s;
     c->t_next = 0;
     c->bulk_enq = -1;
     c->have_state = true;
@@ -1336,14 +1372,21 @@ extern "C" int32_t rc_last_sweep_stats(rc_ctx *c, rc_sweep_stats *out)
 }
 
 // labels / sizes of the current device state
-static int32_t pull_state(rc_ctx *c, std::vector<int> &so, std::vector<int> &ssize, std::vector<int> &slabel)
+static int32_t pull_state(rc_ctx *c, std::vector<int> &so, std::vector<int> &ssize, std::vector<int> &slabel,
+                          bool want_points = true)
 {
     int32_t rc = sync_and_check(c);
     if (rc != RC_OK) return rc;
-    so.resize((size_t)c->n); ssize.resize((size_t)c->kcap); slabel.resize((size_t)c->kcap);
-    HIPCHK(c, hipMemcpy(so.data(), c->slot_of, so.size() * sizeof(int), hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(ssize.data(), c->slot_size, ssize.size() * sizeof(int), hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(slabel.data(), c->slot_label, slabel.size() * sizeof(int), hipMemcpyDeviceToHost));
+    ssize.resize((size_t)c->kcap); slabel.resize((size_t)c->kcap);
+    for (int k = 0; k < c->kcap; ++k) {  // host-mapped summary written by the last kernel: no device copy
+        ssize[(size_t)k] = c->hsum->size_label[2 * k];
+        slabel[(size_t)k] = c->hsum->size_label[2 * k + 1];
+    }
+    if (want_points) {
+        so.resize((size_t)c->n);
+        HIPCHK(c, hipMemcpyAsync(so.data(), c->slot_of, so.size() * sizeof(int), hipMemcpyDeviceToHost, c->sA));
+        HIPCHK(c, hipStreamSynchronize(c->sA));
+    }
     return RC_OK;
 }
 extern "C" int32_t rc_get_state(rc_ctx *c, int64_t *clusts, int64_t *clustsizes, int64_t *K)
@@ -1352,7 +1395,7 @@ extern "C" int32_t rc_get_state(rc_ctx *c, int64_t *clusts, int64_t *clustsizes,
     if (!c->have_state) return fail(c, RC_ERR_STATE, "rc_get_state: no state set");
     HIPCHK(c, hipSetDevice(c->dev));
     std::vector<int> so, ssize, slabel;
-    int32_t rc = pull_state(c, so, ssize, slabel);
+    int32_t rc = pull_state(c, so, ssize, slabel, clusts != nullptr);
     if (rc != RC_OK) return rc;
     if (clusts)
         for (int i = 0; i < c->n; ++i) clusts[i] = slabel[(size_t)so[(size_t)i]];
@@ -1374,7 +1417,7 @@ extern "C" int32_t rc_loglik(rc_ctx *c, double *out)
     int32_t rc = ensure_S(c, &gen);
     if (rc != RC_OK) return rc;
     std::vector<int> so, ssize, slabel;
-    rc = pull_state(c, so, ssize, slabel);  // also refreshes c->last (slot_hi)
+    rc = pull_state(c, so, ssize, slabel, false);  // also refreshes c->last (slot_hi)
     if (rc != RC_OK) return rc;
     const int hi = std::max(1, std::min(c->kcap, c->last.slot_hi));
     View V = make_view(c);
@@ -1424,7 +1467,7 @@ extern "C" int32_t rc_logprior(rc_ctx *c, double r, double p, double *out)
     if (!(r > 0.0) || !(p > 0.0 && p < 1.0)) return fail(c, RC_ERR_ARG, "rc_logprior: need r > 0 and 0 < p < 1");
     HIPCHK(c, hipSetDevice(c->dev));
     std::vector<int> so, ssize, slabel;
-    int32_t rc = pull_state(c, so, ssize, slabel);
+    int32_t rc = pull_state(c, so, ssize, slabel, false);
     if (rc != RC_OK) return rc;
     const rc_params &P = c->P;
     const double n = c->n;

@@ -112,8 +112,9 @@ def runsampler(data: MCMCData, options: MCMCOptionsList | None = None, params: P
             ctx.gibbs_sweep(state.r, state.p, seed, i - 1)                         # mcmc.jl:540 → :477
             record = i > burnin and (i - burnin) % thin == 0                       # mcmc.jl:546
             if record or rp_trace is None:
-                # sample_r!/sample_p! of the next iteration need K and the cluster sizes (mcmc.jl:84-89,139)
-                state.clusts, state.clustsizes, state.K = ctx.get_state()
+                # sample_r!/sample_p! of the next iteration need K and the cluster sizes (mcmc.jl:84-89,139): read
+                # from the host-mapped sweep summary, no device copy; labels are pulled only with a recorded sample
+                _, state.clustsizes, state.K = ctx.get_state(want_labels=False)
             if record:
                 result.clusts[j][:] = ctx.record_sample(True)                      # sortlabels, mcmc.jl:547
                 result.K[j], result.r[j], result.p[j] = state.K, state.r, state.p  # mcmc.jl:548-550
@@ -133,6 +134,7 @@ def runsampler(data: MCMCData, options: MCMCOptionsList | None = None, params: P
         result.r_acceptance_rate = float(np.mean(result.r_acceptances))
         result.runtime = runtime
         result.mean_iter_time = runtime / numiters
+        state.clusts, state.clustsizes, state.K = ctx.get_state()
         result.final_state = state
         return result
     finally:

@@ -14,8 +14,9 @@ params = rc.PriorHyperparamsList(**{k: P[k] for k in ("delta1", "delta2", "alpha
 init = truth if mode == "truth" else np.random.default_rng(0).integers(1, K + 1, size=N).astype(np.int64)
 ctx = rc.Context(D, kcap=max(128, 2 * K))
 opts = rc.MCMCOptionsList(numiters=iters, burnin=0, thin=thin, numMH=0)
+data = rc.MCMCData(D)
 t0 = time.perf_counter()
-res = rc.runsampler(rc.MCMCData(D), opts, params, rc.MCMCState(init, 1.0, 0.5), verbose=False, seed=1, ctx=ctx)
+res = rc.runsampler(data, opts, params, rc.MCMCState(init, 1.0, 0.5), verbose=False, seed=1, ctx=ctx)
 dt = time.perf_counter() - t0
 print(f"N={N} K={K} iters={iters} thin={thin} init={mode}: {iters/dt:.1f} it/s ({dt/iters*1e3:.3f} ms/it), K trace {res.K[:3]}..{res.K[-3:]}, "
       f"loglik {res.loglik[-1]:.3f}, r_acc {res.r_acceptance_rate:.2f}")
