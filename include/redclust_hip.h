@@ -108,6 +108,22 @@ int32_t rc_cocluster_counts(rc_ctx *ctx, uint32_t *out_n_by_n);
 int32_t rc_cocluster_device_buffer(rc_ctx *ctx, void **dev_ptr, int64_t *ld);
 int32_t rc_cocluster_reset(rc_ctx *ctx);
 
+/* ---- split–merge step -------------------------------------------------------------------
+ * One proposal of the MH loop of sample_labels!, src/mcmc.jl:374-473 (chaperones, launch state, numGibbs
+ * restricted scans sample_labels_Gibbs_restricted! src/mcmc.jl:259-354, split or merge bookkeeping, prior /
+ * likelihood / proposal ratios, acceptance), restated as written including quirks Q2/Q3.  The
+ * scalar scans run on the host on matrices borrowed with rc_attach_host_matrices (MCMCData.D and .logD; logD may
+ * be NULL — the library then derives it); both log-likelihoods of mcmc.jl:462-464 come from the device.
+ * Uniforms: Philox keyed (seed_lo, seed_hi ^ 0x4D485F52), counter (draw, mh_counter, iter_lo, iter_hi) — DESIGN.md.
+ * On acceptance the device state becomes the proposed state.  The reference's `state = finalstate` (mcmc.jl:470)
+ * only rebinds a local name (quirk Q1): a host loop that wants the reference's behaviour as written brackets the
+ * iteration with rc_state_checkpoint / rc_state_restore and skips the Gibbs sweep after an acceptance. */
+int32_t rc_attach_host_matrices(rc_ctx *ctx, const double *D, const double *logD_or_null);
+int32_t rc_splitmerge(rc_ctx *ctx, double r, double p, int64_t numGibbs, uint64_t seed, uint64_t iter,
+                      uint64_t mh_counter, uint8_t *accept_out, uint8_t *split_out);
+int32_t rc_state_checkpoint(rc_ctx *ctx);
+int32_t rc_state_restore(rc_ctx *ctx);
+
 /* Introspection used by the parity tests: exact fixed-point row sums Σ_j D[i,j]·[c_j = label] of the
  * current state (the matsum(D,[i],clust_k) of src/mcmc.jl:210-213 before β is added), value = q·2^-e. */
 int32_t rc_debug_rowsums(rc_ctx *ctx, int64_t label, int64_t *sumD_q /* n */, int64_t *sumL_q /* n */,

@@ -615,3 +615,249 @@ double orc_vecsum_idx(const double *x, const int64_t *inds, int64_t m)
     for (int64_t i = 0; i < m; ++i) ans += x[inds[i] - 1];
     return ans;
 }
+
+/* ================================================================================================
+ * Split–merge step: sample_labels! (src/mcmc.jl:356-479) and sample_labels_Gibbs_restricted!
+ * (src/mcmc.jl:259-354), restated AS WRITTEN, including
+ *   Q1  `state = finalstate` (mcmc.jl:470) rebinds the local name only: an accepted proposal, later proposals
+ *       of the same iteration and the closing Gibbs sweep act on an object the caller never sees;
+ *   Q2  `logprobs .+= minimum(logprobs)` (mcmc.jl:348): a no-op after sample_logweights' in-place shift in
+ *       free mode (exp overflows beyond a gap of ~709), doubles the magnitude in forced mode;
+ *   Q3  `L2_i = L2_ik_prime[1] + L2_ik_prime[2]` (mcmc.jl:331): the first two non-empty clusters.
+ * Uniform stream of the MH block: Philox4x32-10 keyed (seed_lo, seed_hi ^ 0x4D485F52) with counter
+ * (draw, mh_counter, iter_lo, iter_hi); draw 0/1 = chaperones (i = floor(u0 n); j = floor(u1 (n-1)), +1 if >= i),
+ * 2 = acceptance, 4+q = launch assignment of the q-th element of S, 4+|S|+2|S|s+2q+k = k-th uniform of item q
+ * in restricted scan s.
+ * ============================================================================================== */
+double orc_uniform_mh(uint64_t seed, uint64_t iter, uint64_t mh, uint64_t draw)
+{
+    uint32_t c[4] = {(uint32_t)draw, (uint32_t)mh, (uint32_t)iter, (uint32_t)(iter >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x4D485F52u);
+    uint64_t bits = (((uint64_t)c[0] << 32) | c[1]) >> 12;
+    return ((double)bits + 0.5) * 0x1p-52;
+}
+
+/* sum over the members (ascending index) of cluster `lab` of row x of M */
+static double row_member_sum(int64_t n, const double *M, const int64_t *clusts, int64_t x, int64_t lab)
+{
+    double s = 0;
+    for (int64_t y = 0; y < n; ++y)
+        if (clusts[y] == lab) s += M[x * n + y];
+    return s;
+}
+
+/* sample_labels_Gibbs_restricted! (mcmc.jl:259-354).  items: 0-based indices; cand: two 1-based labels;
+ * final_clusts: NULL (free allocation) or the forced labels.  Returns log_transition_prob. */
+static double restricted_scan(int64_t n, const double *D, const double *logD, int64_t *clusts, int64_t *clustsizes,
+                              const orc_params *P, double r, double p, const int64_t *items, int64_t m,
+                              const int64_t cand[2], const int64_t *final_clusts, uint64_t seed, uint64_t iter,
+                              uint64_t mh, int64_t scan)
+{
+    const double d1 = P->delta1, d2 = P->delta2, al = P->alpha, be = P->beta, ze = P->zeta, ga = P->gamma;
+    const double abratio = al * log(be) - lgamma(al), zgratio = ze * log(ga) - lgamma(ze);   /* :293-294 */
+    const double lg_d1 = lgamma(d1), lg_d2 = lgamma(d2), logp = log(p);                     /* :295-297 */
+    const double rep = P->repulsion ? 1.0 : 0.0;
+    /* C = findall(clustsizes .> 0), frozen at entry (:273); only C[1], C[2] and the candidates are ever used */
+    int64_t C1 = 0, C2 = 0;
+    for (int64_t k = 0; k < n && C2 == 0; ++k)
+        if (clustsizes[k] > 0) { if (C1 == 0) C1 = k + 1; else C2 = k + 1; }
+    double ltp = 0;                                                                        /* :285 */
+    for (int64_t q = 0; q < m; ++q) {
+        const int64_t x = items[q];
+        clustsizes[clusts[x] - 1] -= 1;                                                    /* :303 */
+        clusts[x] = -1;                                                                    /* :304 */
+        double L1[2], lpr[2], L2[2], logprobs[2], L2p_c[2];
+        for (int k = 0; k < 2; ++k) {                                                      /* :307-312, :321-326 */
+            const int64_t lab = cand[k];
+            const double sz = (double)clustsizes[lab - 1];
+            const double sD = row_member_sum(n, D, clusts, x, lab);
+            const double sL = row_member_sum(n, logD, clusts, x, lab);
+            const double a_i = al + d1 * sz, b_i = be + sD;
+            const double z_i = ze + d2 * sz, g_i = ga + sD;
+            L1[k] = lgamma(a_i) + abratio - a_i * log(b_i) + (d1 - 1) * sL - sz * lg_d1;
+            lpr[k] = log(sz + 1) + logp + log(sz - 1 + r) - log(sz);
+            L2p_c[k] = lgamma(z_i) - z_i * log(g_i) + zgratio + (d2 - 1) * sL - sz * lg_d2;  /* :328-329 for this label */
+        }
+        double L2p_first[2];
+        const int64_t firsts[2] = {C1, C2};
+        for (int t = 0; t < 2; ++t) {                                                      /* :313-319, :327-331 */
+            const int64_t lab = firsts[t];
+            if (lab == 0) { L2p_first[t] = 0; continue; }  /* fewer than two clusters: BoundsError in Julia; unreachable */
+            if (lab == cand[0]) { L2p_first[t] = L2p_c[0]; continue; }
+            if (lab == cand[1]) { L2p_first[t] = L2p_c[1]; continue; }
+            const double sz = (double)clustsizes[lab - 1];
+            const double sD = row_member_sum(n, D, clusts, x, lab);
+            const double sL = row_member_sum(n, logD, clusts, x, lab);
+            const double z_i = ze + d2 * sz, g_i = ga + sD;
+            L2p_first[t] = lgamma(z_i) - z_i * log(g_i) + zgratio + (d2 - 1) * sL - sz * lg_d2;
+        }
+        const double L2_i = L2p_first[0] + L2p_first[1];                                   /* :331 (Q3) */
+        for (int k = 0; k < 2; ++k) {
+            L2[k] = L2_i - L2p_c[k];                                                       /* :333 */
+            logprobs[k] = lpr[k] + (L1[k] + (rep != 0.0 ? L2[k] : 0.0));                   /* :335 */
+        }
+        int k;
+        if (!final_clusts) {                                                               /* :336-338 */
+            /* sample_logweights mutates its argument (utils.jl:3) */
+            const double mn = logprobs[0] < logprobs[1] ? logprobs[0] : logprobs[1];
+            logprobs[0] -= mn; logprobs[1] -= mn;
+            const uint64_t base = 4 + (uint64_t)m + 2 * (uint64_t)m * (uint64_t)scan + 2 * (uint64_t)q;
+            const double g0 = -log(-log(orc_uniform_mh(seed, iter, mh, base))) + logprobs[0];
+            const double g1 = -log(-log(orc_uniform_mh(seed, iter, mh, base + 1))) + logprobs[1];
+            k = (g1 > g0) ? 1 : 0;                                                         /* argmax, first wins ties */
+        } else {                                                                           /* :339-342 */
+            k = (final_clusts[x] == cand[0]) ? 0 : 1;
+        }
+        clusts[x] = cand[k];                                                               /* :344 */
+        clustsizes[cand[k] - 1] += 1;                                                      /* :345 */
+        const double mn = logprobs[0] < logprobs[1] ? logprobs[0] : logprobs[1];          /* :348 (Q2) */
+        /* Julia's minimum propagates NaN */
+        const double mnn = (logprobs[0] != logprobs[0] || logprobs[1] != logprobs[1]) ? NAN : mn;
+        double pr[2] = {exp(logprobs[0] + mnn), exp(logprobs[1] + mnn)};                   /* :349 */
+        const double tot = pr[0] + pr[1];
+        ltp += log(pr[k] / tot);                                                           /* :350-351 */
+    }
+    return ltp;
+}
+
+typedef struct {
+    int32_t accept, split, skipped, pad;
+    int64_t i, j, nS;
+    double log_prior_ratio, log_lik_ratio, log_proposal_ratio, log_u;
+} orc_mh_info;
+
+/* One proposal of the MH loop body (mcmc.jl:374-473) on (clusts, clustsizes, K).  On acceptance the arrays are
+ * REPLACED by the final state (the caller decides what that means: Q1).  loglik_mode 0 = literal, 1 = stable
+ * (needs Dq/Lq; pass NULL otherwise). */
+int orc_mh_proposal(int64_t n, const double *D, const double *logD, const int64_t *Dq, const int64_t *Lq, int eD, int eL,
+                    int64_t *clusts, int64_t *clustsizes, int64_t *K, const orc_params *P, double r, double p,
+                    int64_t numGibbs, uint64_t seed, uint64_t iter, uint64_t mh, int loglik_mode, orc_mh_info *info)
+{
+    memset(info, 0, sizeof(*info));
+    /* i, j = sample(1:n, 2, replace=false)  (:379) */
+    int64_t i = (int64_t)floor(orc_uniform_mh(seed, iter, mh, 0) * (double)n);
+    int64_t j = (int64_t)floor(orc_uniform_mh(seed, iter, mh, 1) * (double)(n - 1));
+    if (i >= n) i = n - 1;
+    if (j >= n - 1) j = n - 2;
+    if (j >= i) j += 1;
+    info->i = i; info->j = j;
+    const int64_t ci = clusts[i], cj = clusts[j];
+    int64_t nonempty = 0;
+    for (int64_t k = 0; k < n; ++k) nonempty += clustsizes[k] > 0;
+    if (P->maxK > 0 && ci == cj && nonempty >= P->maxK) { info->skipped = 1; return 0; }   /* :384-386 */
+    int64_t *S = malloc((size_t)n * sizeof(int64_t));
+    int64_t m = 0;
+    for (int64_t k = 0; k < n; ++k)
+        if ((clusts[k] == ci || clusts[k] == cj) && k != i && k != j) S[m++] = k;          /* :389-390 */
+    info->nS = m;
+    int64_t *claunch = malloc((size_t)n * sizeof(int64_t)), *szlaunch = malloc((size_t)n * sizeof(int64_t));
+    memcpy(claunch, clusts, (size_t)n * sizeof(int64_t));
+    memcpy(szlaunch, clustsizes, (size_t)n * sizeof(int64_t));
+    int64_t Klaunch = *K;
+    if (ci == cj) {                                                                         /* :396-401 */
+        int64_t e = 0;
+        while (clustsizes[e] != 0) ++e;
+        claunch[i] = e + 1;
+        szlaunch[ci - 1] -= 1;
+        szlaunch[e] += 1;
+        Klaunch = *K + 1;
+    }
+    const int64_t cand[2] = {claunch[i], claunch[j]};                                       /* :402 */
+    for (int64_t q = 0; q < m; ++q) {                                                       /* :403-407 */
+        const int64_t k = S[q];
+        claunch[k] = cand[orc_uniform_mh(seed, iter, mh, 4 + (uint64_t)q) < 0.5 ? 0 : 1];
+        szlaunch[clusts[k] - 1] -= 1;
+        szlaunch[claunch[k] - 1] += 1;
+    }
+    for (int64_t s = 0; s < numGibbs; ++s)                                                  /* :411-414 */
+        restricted_scan(n, D, logD, claunch, szlaunch, P, r, p, S, m, cand, NULL, seed, iter, mh, s);
+    int64_t *cfinal, *szfinal, Kfinal;
+    double log_prior_ratio, log_proposal_ratio;
+    if (ci == cj) {                                                                         /* split :416-434 */
+        info->split = 1;
+        const double ltp = restricted_scan(n, D, logD, claunch, szlaunch, P, r, p, S, m, cand, NULL, seed, iter, mh, numGibbs);
+        cfinal = claunch; szfinal = szlaunch; Kfinal = Klaunch;
+        log_prior_ratio = log((double)(*K + 1)) + r * log(1 - p) - log(p) - lgamma(r) +
+                          lgamma((double)szfinal[cfinal[i] - 1] - 1 + r) + lgamma((double)szfinal[cfinal[j] - 1] - 1 + r) +
+                          log((double)szfinal[cfinal[i] - 1]) + log((double)szfinal[cfinal[j] - 1]) +
+                          -(lgamma((double)clustsizes[ci - 1] - 1 + r) + log((double)clustsizes[ci - 1]));
+        log_proposal_ratio = ltp;
+    } else {                                                                                /* merge :435-459 */
+        cfinal = malloc((size_t)n * sizeof(int64_t)); szfinal = malloc((size_t)n * sizeof(int64_t));
+        memcpy(cfinal, claunch, (size_t)n * sizeof(int64_t));
+        memcpy(szfinal, szlaunch, (size_t)n * sizeof(int64_t));
+        Kfinal = Klaunch;
+        int64_t sz_clust_i = 0;
+        for (int64_t k = 0; k < n; ++k)
+            if (cfinal[k] == ci) { cfinal[k] = cj; ++sz_clust_i; }
+        szfinal[ci - 1] = 0;
+        szfinal[cj - 1] += sz_clust_i;
+        Kfinal -= 1;
+        log_prior_ratio = -(log((double)*K) + r * log(1 - p) - log(p) - lgamma(r)) +
+                          lgamma((double)szfinal[cj - 1] - 1 + r) + log((double)szfinal[cj - 1]) +
+                          -(lgamma((double)clustsizes[ci - 1] - 1 + r) + lgamma((double)clustsizes[cj - 1] - 1 + r) +
+                            log((double)clustsizes[ci - 1]) + log((double)clustsizes[cj - 1]));
+        const double ltp = restricted_scan(n, D, logD, claunch, szlaunch, P, r, p, S, m, cand, clusts, seed, iter, mh, numGibbs);
+        log_proposal_ratio = -ltp;
+    }
+    double llr;                                                                             /* :462-464 */
+    if (loglik_mode == 0)
+        llr = orc_loglik_literal(n, D, logD, cfinal, szfinal, P) - orc_loglik_literal(n, D, logD, clusts, clustsizes, P);
+    else
+        llr = orc_loglik_stable(n, Dq, Lq, eD, eL, cfinal, szfinal, P) - orc_loglik_stable(n, Dq, Lq, eD, eL, clusts, clustsizes, P);
+    const double x = log_prior_ratio + llr - log_proposal_ratio;
+    /* minimum([0, x]) propagates NaN (:467-468); log(u) < NaN is false */
+    const double lar = (x != x) ? NAN : (x < 0 ? x : 0.0);
+    const double lu = log(orc_uniform_mh(seed, iter, mh, 2));
+    info->log_prior_ratio = log_prior_ratio; info->log_lik_ratio = llr; info->log_proposal_ratio = log_proposal_ratio;
+    info->log_u = lu;
+    if (lu < lar) {                                                                         /* :469-472 */
+        memcpy(clusts, cfinal, (size_t)n * sizeof(int64_t));
+        memcpy(clustsizes, szfinal, (size_t)n * sizeof(int64_t));
+        *K = Kfinal;
+        info->accept = 1;
+    }
+    if (cfinal != claunch) { free(cfinal); free(szfinal); }
+    free(claunch); free(szlaunch); free(S);
+    return 0;
+}
+
+/* sample_labels!(data, state, params, options) AS WRITTEN (mcmc.jl:356-479): numMH proposals, then the full
+ * Gibbs sweep.  Because of Q1 the caller's (clusts, clustsizes, K) are mutated by the sweep only when NO proposal
+ * was accepted; after an acceptance everything (later proposals, the sweep) happens on a private object.
+ * sweep_mode: 0 literal, 1 stable (fixed-point).  accept/split: numMH flags each (undefined entries stay 0, as the
+ * reference's `fill(false, numMH)`).  Returns the number of accepted proposals. */
+int orc_sample_labels(int64_t n, const double *D, const double *logD, const int64_t *Dq, const int64_t *Lq, int eD, int eL,
+                      const double *A, int64_t *clusts, int64_t *clustsizes, int64_t *K, const orc_params *P, double r,
+                      double p, int64_t numMH, int64_t numGibbs, uint64_t seed, uint64_t iter, int mode, uint8_t *accept,
+                      uint8_t *split)
+{
+    int64_t *c = clusts, *s = clustsizes, Kloc = *K;
+    int64_t *pc = NULL, *ps = NULL;
+    int naccept = 0;
+    for (int64_t mh = 0; mh < numMH; ++mh) {
+        accept[mh] = 0; split[mh] = 0;
+        if (!pc) {  /* still the caller's object: propose on a scratch copy so that an acceptance can rebind */
+            pc = malloc((size_t)n * sizeof(int64_t)); ps = malloc((size_t)n * sizeof(int64_t));
+            memcpy(pc, c, (size_t)n * sizeof(int64_t)); memcpy(ps, s, (size_t)n * sizeof(int64_t));
+        }
+        orc_mh_info info;
+        int64_t Ktmp = Kloc;
+        int64_t *wc = (c == clusts) ? pc : c, *ws = (s == clustsizes) ? ps : s;
+        if (c == clusts) { memcpy(pc, c, (size_t)n * sizeof(int64_t)); memcpy(ps, s, (size_t)n * sizeof(int64_t)); }
+        orc_mh_proposal(n, D, logD, Dq, Lq, eD, eL, wc, ws, &Ktmp, P, r, p, numGibbs, seed, iter, (uint64_t)mh, mode, &info);
+        split[mh] = (uint8_t)info.split;
+        if (info.accept) {
+            accept[mh] = 1;
+            ++naccept;
+            c = wc; s = ws; Kloc = Ktmp;   /* `state = finalstate`: the local name now refers to the private object */
+        }
+    }
+    /* final Gibbs scan on whatever `state` names now (:477) */
+    int64_t Ksw = Kloc;
+    if (mode == 0) orc_sweep_literal(n, D, logD, c, s, &Ksw, P, r, p, seed, iter, 0);
+    else orc_sweep_stable(n, Dq, Lq, eD, eL, A, c, s, &Ksw, P, r, p, seed, iter, NULL);
+    if (c == clusts) *K = Ksw;  /* the caller's object was swept; otherwise it is untouched (Q1) */
+    free(pc); free(ps);
+    return naccept;
+}

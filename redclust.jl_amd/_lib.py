@@ -70,6 +70,11 @@ SIGNATURES = {
     "rc_cocluster_counts": (C.c_int32, [C.c_void_p, _up]),
     "rc_cocluster_device_buffer": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "rc_cocluster_reset": (C.c_int32, [C.c_void_p]),
+    "rc_attach_host_matrices": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rc_splitmerge": (C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint64,
+                                  C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]),
+    "rc_state_checkpoint": (C.c_int32, [C.c_void_p]),
+    "rc_state_restore": (C.c_int32, [C.c_void_p]),
     "rc_debug_rowsums": (C.c_int32, [C.c_void_p, C.c_int64, _ip, _ip, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rc_kernel_timing": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
@@ -197,6 +202,25 @@ class Context:
 
     def cocluster_reset(self):
         self._chk(self.L.rc_cocluster_reset(self.h))
+
+    def attach_host_matrices(self, D, logD=None):
+        """Borrow the caller's host matrices for the split–merge scans; they must outlive the context's use."""
+        self._hostD = np.ascontiguousarray(D, dtype=np.float64)
+        self._hostL = None if logD is None else np.ascontiguousarray(logD, dtype=np.float64)
+        self._chk(self.L.rc_attach_host_matrices(self.h, self._hostD.ctypes.data_as(C.c_void_p),
+                                                 None if self._hostL is None else self._hostL.ctypes.data_as(C.c_void_p)))
+
+    def splitmerge(self, r, p, numGibbs, seed, it, mh_counter):
+        a, s = C.c_uint8(), C.c_uint8()
+        self._chk(self.L.rc_splitmerge(self.h, float(r), float(p), int(numGibbs), int(seed), int(it), int(mh_counter),
+                                       C.byref(a), C.byref(s)))
+        return bool(a.value), bool(s.value)
+
+    def checkpoint(self):
+        self._chk(self.L.rc_state_checkpoint(self.h))
+
+    def restore(self):
+        self._chk(self.L.rc_state_restore(self.h))
 
     def debug_rowsums(self, label):
         sd = np.zeros(self.n, np.int64)

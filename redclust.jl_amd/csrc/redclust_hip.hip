@@ -454,7 +454,40 @@ __device__ void write_summary(const View &V, int n_changes, int n_rounds)
 }
 
 // After rc_set_state: derive ranks / smallest empty label / perm (both generations) from slot_size, slot_label, slot_of.
-__global__ __launch_bounds__(1024) void k_derive(View V)
+// Exact S correction for a batch of label moves made outside a sweep (split–merge proposals, state restore):
+// for every move (point x: slot a -> slot b) and every column i: S[a][i] -= x_row[i], S[b][i] += x_row[i], in each
+// listed S generation.  256 threads x 2 columns; moves are applied in order, no atomics (the caller has drained
+// both streams).
+struct MoveList { const int *mv; int count; int gens[2]; int ngens; };
+__global__ __launch_bounds__(256) void k_apply_moves(View V, MoveList ML)
+{
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 2;
+    if (i >= V.ld) return;
+    for (int m = 0; m < ML.count; ++m) {
+        const int x = ML.mv[3 * m], a = ML.mv[3 * m + 1], b = ML.mv[3 * m + 2];
+        if (a == b) continue;
+        const size_t e = (size_t)x * V.ld + i;
+        long long d0, d1, l0, l1;
+        if (V.bits == 64) {
+            const ll2 d = *(const ll2 *)((const long long *)V.Dq + e), l = *(const ll2 *)((const long long *)V.Lq + e);
+            d0 = d.x; d1 = d.y; l0 = l.x; l1 = l.y;
+        } else {
+            const int2 d = *(const int2 *)((const int *)V.Dq + e), l = *(const int2 *)((const int *)V.Lq + e);
+            d0 = d.x; d1 = d.y; l0 = l.x; l1 = l.y;
+        }
+        for (int g = 0; g < ML.ngens; ++g) {
+            long long *SD = V.SD[ML.gens[g]], *SL = V.SL[ML.gens[g]];
+            ll2 *pa = (ll2 *)(SD + (size_t)a * V.ld + i), *pb = (ll2 *)(SD + (size_t)b * V.ld + i);
+            ll2 *qa = (ll2 *)(SL + (size_t)a * V.ld + i), *qb = (ll2 *)(SL + (size_t)b * V.ld + i);
+            ll2 va = *pa, vb = *pb, wa = *qa, wb = *qb;
+            va.x -= d0; va.y -= d1; vb.x += d0; vb.y += d1;
+            wa.x -= l0; wa.y -= l1; wb.x += l0; wb.y += l1;
+            *pa = va; *pb = vb; *qa = wa; *qb = wb;
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_derive(View V, int rebuild_perm)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Tab T = tab_carve(smem, V.kcap, V.n, 1);
@@ -466,6 +499,7 @@ __global__ __launch_bounds__(1024) void k_derive(View V)
     __syncthreads();
     write_summary(V, 0, 0);
     __syncthreads();
+    if (!rebuild_perm) return;
     int *off = (int *)smem, *cur = off + V.kcap;
     build_perm_block(V, 0, off, cur);
     for (int p = threadIdx.x; p < V.n; p += blockDim.x) { V.perm[1][p] = V.perm[0][p]; V.pslot[1][p] = V.pslot[0][p]; }
@@ -881,6 +915,12 @@ struct rc_ctx {
     long long bulk_launches = 0;
     DevScalars last{};
     int dbg = 0;
+    // split–merge support (host-side proposal logic on borrowed host matrices)
+    const double *hostD = nullptr, *hostL = nullptr;
+    std::vector<double> ownL;            // host logD computed by the library when the caller passes none
+    std::vector<int64_t> checkpoint;     // labels saved by rc_state_checkpoint
+    int *d_moves = nullptr;
+    size_t d_moves_cap = 0;
     char err[512] = {0};
 };
 
@@ -949,7 +989,7 @@ static void free_all(rc_ctx *c)
     void *ptrs[] = {c->Dq, c->Lq, c->diagq, c->SD[0], c->SD[1], c->SD[2], c->SL[0], c->SL[1], c->SL[2], c->slot_of,
                     c->slot_size, c->slot_label, c->slot_pos, c->slot_act, c->perm[0], c->perm[1], c->pslot[0],
                     c->pslot[1], c->A, c->keys[0], c->keys[1], c->arrive[0], c->arrive[1], c->sc, c->blocks,
-                    c->counts, c->cc_out, c->snap};
+                    c->counts, c->cc_out, c->snap, c->d_moves};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->hsum) (void)hipHostFree(c->hsum);
@@ -1259,7 +1299,7 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
     }
     View V = make_view(c);
     const size_t lds = std::max(tab_bytes(c->kcap, c->n, 1), 2 * sizeof(int) * (size_t)c->kcap);
-    k_derive<<<1, 1024, lds, c->sA>>>(V);
+    k_derive<<<1, 1024, lds, c->sA>>>(V, 1);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->sA));
     c->last = s;
@@ -1640,4 +1680,374 @@ extern "C" int32_t rc_kernel_timing(rc_ctx *c, int32_t enable, double *bulk_ms_t
         c->bulk_launches = 0;
     }
     return RC_OK;
+}
+
+// ===================================================================================================
+// Split–merge step (src/mcmc.jl:356-479) — SURVEY.md §8f-1.
+// The proposal is a short sequential scalar computation over the |S| members of two clusters (restricted Gibbs
+// scans, src/mcmc.jl:259-354): it runs on the host, as it does in the reference, on host matrices borrowed from
+// the caller (MCMCData.D / .logD), in the reference's literal arithmetic including its quirks Q1–Q3 (SURVEY.md
+// §3.2).  The device supplies what is data-parallel: both log-likelihoods of the acceptance ratio (mcmc.jl:462-464)
+// from the exact S table — the proposed state is applied with k_apply_moves and, unless accepted, reverted
+// bit-exactly (integer corrections).
+// ===================================================================================================
+static double rc_uniform_mh(uint64_t seed, uint64_t iter, uint64_t mh, uint64_t draw)
+{
+    uint32_t c[4] = {(uint32_t)draw, (uint32_t)mh, (uint32_t)iter, (uint32_t)(iter >> 32)};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ 0x4D485F52u;
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const uint64_t bits = (((uint64_t)c[0] << 32) | c[1]) >> 12;
+    return ((double)bits + 0.5) * 0x1p-52;
+}
+
+extern "C" int32_t rc_attach_host_matrices(rc_ctx *c, const double *D, const double *logD_or_null)
+{
+    if (!c || !D) return fail(c, RC_ERR_ARG, "rc_attach_host_matrices: NULL argument");
+    c->hostD = D;
+    if (logD_or_null) {
+        c->hostL = logD_or_null;
+        c->ownL.clear();
+        c->ownL.shrink_to_fit();
+    } else {
+        const size_t n = (size_t)c->n;
+        c->ownL.resize(n * n);
+        for (size_t i = 0; i < n; ++i)
+            for (size_t j = 0; j < n; ++j) c->ownL[i * n + j] = (i == j) ? 0.0 : std::log(D[i * n + j]);  // types.jl:155
+        c->hostL = c->ownL.data();
+    }
+    return RC_OK;
+}
+
+// labels (1-based, by point), sizes by label (length n), K of the current device state
+static int32_t pull_labels(rc_ctx *c, std::vector<int64_t> &labels, std::vector<int64_t> &sizes, int64_t &K)
+{
+    std::vector<int> so, ssize, slabel;
+    int32_t rc = pull_state(c, so, ssize, slabel, true);
+    if (rc != RC_OK) return rc;
+    labels.resize((size_t)c->n);
+    sizes.assign((size_t)c->n, 0);
+    for (int i = 0; i < c->n; ++i) labels[(size_t)i] = slabel[(size_t)so[(size_t)i]];
+    K = 0;
+    for (int k = 0; k < c->kcap; ++k)
+        if (slabel[(size_t)k] > 0) { sizes[(size_t)slabel[(size_t)k] - 1] = ssize[(size_t)k]; ++K; }
+    return RC_OK;
+}
+
+// Moves the device state from labelling `cur` (which it currently holds) to `next`: slot tables, slot_of, exact S
+// corrections in every S generation that is valid, derived tables and both perm generations.
+static int32_t apply_labels(rc_ctx *c, const std::vector<int64_t> &cur, const std::vector<int64_t> &next)
+{
+    // perm / pslot hold slot ids, and a revert may re-create a dead cluster in a different slot: both perm
+    // generations are always rebuilt (k_derive) and the sweep pipeline's change marker is reset accordingly
+    const bool persist = true;
+    const int n = c->n;
+    HIPCHK(c, hipStreamSynchronize(c->sA));
+    HIPCHK(c, hipStreamSynchronize(c->sB));
+    int32_t rc = drain_events(c);
+    if (rc != RC_OK) return rc;
+    std::vector<int> ssize((size_t)c->kcap), slabel((size_t)c->kcap);
+    for (int k = 0; k < c->kcap; ++k) { ssize[(size_t)k] = c->hsum->size_label[2 * k]; slabel[(size_t)k] = c->hsum->size_label[2 * k + 1]; }
+    std::vector<int> slot_of_label((size_t)n + 1, -1);
+    for (int k = 0; k < c->kcap; ++k)
+        if (slabel[(size_t)k] > 0) slot_of_label[(size_t)slabel[(size_t)k]] = k;
+    // new sizes; births take the lowest slot that is free now, before any slot freed by this batch
+    std::vector<int> moved;
+    for (int i = 0; i < n; ++i)
+        if (cur[(size_t)i] != next[(size_t)i]) {
+            if (next[(size_t)i] < 1 || next[(size_t)i] > n) return fail(c, RC_ERR_ARG, "apply_labels: label outside 1..n");
+            moved.push_back(i);
+        }
+    if (moved.empty()) return RC_OK;
+    int free_scan = 0;
+    for (int i : moved) {
+        const int lab = (int)next[(size_t)i];
+        if (slot_of_label[(size_t)lab] < 0) {
+            while (free_scan < c->kcap && slabel[(size_t)free_scan] != 0) ++free_scan;
+            if (free_scan >= c->kcap) return fail(c, RC_ERR_CAPACITY, "split-merge: more than kcap=%d clusters", c->kcap);
+            slot_of_label[(size_t)lab] = free_scan;
+            slabel[(size_t)free_scan] = lab;
+            ssize[(size_t)free_scan] = 0;
+        }
+    }
+    std::vector<int> mv;
+    mv.reserve(moved.size() * 3);
+    for (int i : moved) {
+        const int a = slot_of_label[(size_t)cur[(size_t)i]], b = slot_of_label[(size_t)next[(size_t)i]];
+        ssize[(size_t)a] -= 1;
+        ssize[(size_t)b] += 1;
+        mv.push_back(i); mv.push_back(a); mv.push_back(b);
+    }
+    int K = 0, hi = c->last.slot_hi;
+    for (int k = 0; k < c->kcap; ++k) {
+        if (slabel[(size_t)k] > 0 && ssize[(size_t)k] == 0) slabel[(size_t)k] = 0;  // death: its S row is now exactly zero
+        if (slabel[(size_t)k] > 0) { ++K; hi = std::max(hi, k + 1); }
+    }
+    // S generations that currently hold valid sums
+    MoveList ML{};
+    if (c->bulk_enq >= 0) {
+        if (c->t_next == 0) ML.gens[ML.ngens++] = 0;
+        else {
+            ML.gens[ML.ngens++] = (int)((c->t_next - 1) % 3);
+            if (c->bulk_enq >= c->t_next) ML.gens[ML.ngens++] = (int)(c->t_next % 3);
+        }
+    }
+    View V = make_view(c);
+    if (mv.size() > c->d_moves_cap) {
+        if (c->d_moves) (void)hipFree(c->d_moves);
+        c->d_moves = nullptr;
+        c->d_moves_cap = std::max(mv.size(), (size_t)3 * 4096);
+        HIPCHK(c, hipMalloc(&c->d_moves, c->d_moves_cap * sizeof(int)));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_moves, mv.data(), mv.size() * sizeof(int), hipMemcpyHostToDevice, c->sA));
+    if (ML.ngens > 0) {
+        ML.mv = c->d_moves;
+        ML.count = (int)moved.size();
+        k_apply_moves<<<c->ld / 512, 256, 0, c->sA>>>(V, ML);
+        HIPCHK(c, hipGetLastError());
+    }
+    // tables
+    std::vector<int> so((size_t)n);
+    HIPCHK(c, hipMemcpyAsync(so.data(), c->slot_of, so.size() * sizeof(int), hipMemcpyDeviceToHost, c->sA));
+    HIPCHK(c, hipStreamSynchronize(c->sA));
+    for (size_t q = 0; q < moved.size(); ++q) so[(size_t)moved[q]] = mv[3 * q + 2];
+    // only K / slot_hi (and, when the change persists and both perm generations are rebuilt, last_change_sweep) are
+    // touched: the other device scalars belong to the sweep pipeline
+    const int kv[2] = {K, hi}, minus1 = -1;
+    HIPCHK(c, hipMemcpyAsync(&c->sc->K, &kv[0], sizeof(int), hipMemcpyHostToDevice, c->sA));
+    HIPCHK(c, hipMemcpyAsync(&c->sc->slot_hi, &kv[1], sizeof(int), hipMemcpyHostToDevice, c->sA));
+    if (persist) HIPCHK(c, hipMemcpyAsync(&c->sc->last_change_sweep, &minus1, sizeof(int), hipMemcpyHostToDevice, c->sA));
+    HIPCHK(c, hipMemcpyAsync(c->slot_of, so.data(), so.size() * sizeof(int), hipMemcpyHostToDevice, c->sA));
+    HIPCHK(c, hipMemcpyAsync(c->slot_size, ssize.data(), ssize.size() * sizeof(int), hipMemcpyHostToDevice, c->sA));
+    HIPCHK(c, hipMemcpyAsync(c->slot_label, slabel.data(), slabel.size() * sizeof(int), hipMemcpyHostToDevice, c->sA));
+    const size_t lds = std::max(tab_bytes(c->kcap, c->n, 1), 2 * sizeof(int) * (size_t)c->kcap);
+    k_derive<<<1, 1024, lds, c->sA>>>(V, persist ? 1 : 0);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->sA));  // also keeps the stack buffers above alive until the copies are done
+    c->last.K = K; c->last.slot_hi = hi;
+    return RC_OK;
+}
+
+extern "C" int32_t rc_state_checkpoint(rc_ctx *c)
+{
+    if (!c) return fail(c, RC_ERR_ARG, "rc_state_checkpoint: NULL ctx");
+    if (!c->have_state) return fail(c, RC_ERR_STATE, "rc_state_checkpoint: no state set");
+    HIPCHK(c, hipSetDevice(c->dev));
+    std::vector<int64_t> sizes;
+    int64_t K;
+    return pull_labels(c, c->checkpoint, sizes, K);
+}
+
+extern "C" int32_t rc_state_restore(rc_ctx *c)
+{
+    if (!c) return fail(c, RC_ERR_ARG, "rc_state_restore: NULL ctx");
+    if (c->checkpoint.size() != (size_t)c->n) return fail(c, RC_ERR_STATE, "rc_state_restore: no checkpoint");
+    HIPCHK(c, hipSetDevice(c->dev));
+    std::vector<int64_t> cur, sizes;
+    int64_t K;
+    int32_t rc = pull_labels(c, cur, sizes, K);
+    if (rc != RC_OK) return rc;
+    return apply_labels(c, cur, c->checkpoint);
+}
+
+namespace {
+// literal arithmetic of sample_labels_Gibbs_restricted! on the host matrices
+struct Restricted {
+    const rc_ctx *c;
+    const double *D, *L;
+    int64_t n;
+    double r, p;
+    uint64_t seed, iter, mh;
+    double abratio, zgratio, lg_d1, lg_d2, logp;
+    const std::vector<int64_t> *U;  // sorted indices of i, j and S: every member of the two candidate clusters
+    std::vector<std::vector<int64_t>> fixed_members;  // members of C[1] / C[2] when they are not candidates
+
+    double member_sum(const double *M, int64_t x, const std::vector<int64_t> &clusts, int64_t lab) const
+    {
+        double s = 0;  // ascending member order, as findall + matsum (mcmc.jl:308-311, utils.jl:9-17)
+        for (int64_t y : *U)
+            if (clusts[(size_t)y] == lab) s += M[(size_t)x * (size_t)n + (size_t)y];
+        return s;
+    }
+    static double list_sum(const double *M, int64_t x, int64_t n, const std::vector<int64_t> &mem)
+    {
+        double s = 0;
+        for (int64_t y : mem) s += M[(size_t)x * (size_t)n + (size_t)y];
+        return s;
+    }
+
+    // one scan (mcmc.jl:302-352); returns log_transition_prob
+    double scan(std::vector<int64_t> &clusts, std::vector<int64_t> &sizes, const std::vector<int64_t> &items,
+                const int64_t cand[2], const std::vector<int64_t> *final_clusts, int64_t scan_index)
+    {
+        const rc_params &P = c->P;
+        const double d1 = P.delta1, d2 = P.delta2, al = P.alpha, be = P.beta, ze = P.zeta, ga = P.gamma;
+        // C = findall(clustsizes .> 0), frozen at entry (mcmc.jl:273); only C[1], C[2] are ever read (Q3)
+        int64_t firsts[2] = {0, 0};
+        for (int64_t k = 0, f = 0; k < n && f < 2; ++k)
+            if (sizes[(size_t)k] > 0) firsts[f++] = k + 1;
+        fixed_members.assign(2, {});
+        for (int t = 0; t < 2; ++t)
+            if (firsts[t] != 0 && firsts[t] != cand[0] && firsts[t] != cand[1])
+                for (int64_t y = 0; y < n; ++y)
+                    if (clusts[(size_t)y] == firsts[t]) fixed_members[(size_t)t].push_back(y);
+        const int64_t m = (int64_t)items.size();
+        double ltp = 0;
+        for (int64_t q = 0; q < m; ++q) {
+            const int64_t x = items[(size_t)q];
+            sizes[(size_t)clusts[(size_t)x] - 1] -= 1;                                   // mcmc.jl:303
+            clusts[(size_t)x] = -1;                                                      // mcmc.jl:304
+            double L1[2], lpr[2], L2p_c[2], logprobs[2];
+            for (int k = 0; k < 2; ++k) {                                                // mcmc.jl:307-326
+                const double sz = (double)sizes[(size_t)cand[k] - 1];
+                const double sD = member_sum(D, x, clusts, cand[k]);
+                const double sL = member_sum(L, x, clusts, cand[k]);
+                const double a_i = al + d1 * sz, b_i = be + sD, z_i = ze + d2 * sz, g_i = ga + sD;
+                L1[k] = std::lgamma(a_i) + abratio - a_i * std::log(b_i) + (d1 - 1) * sL - sz * lg_d1;
+                lpr[k] = std::log(sz + 1) + logp + std::log(sz - 1 + r) - std::log(sz);
+                L2p_c[k] = std::lgamma(z_i) - z_i * std::log(g_i) + zgratio + (d2 - 1) * sL - sz * lg_d2;
+            }
+            double L2p_first[2];
+            for (int t = 0; t < 2; ++t) {                                                // mcmc.jl:327-331
+                if (firsts[t] == 0) { L2p_first[t] = 0; continue; }
+                if (firsts[t] == cand[0]) { L2p_first[t] = L2p_c[0]; continue; }
+                if (firsts[t] == cand[1]) { L2p_first[t] = L2p_c[1]; continue; }
+                const double sz = (double)sizes[(size_t)firsts[t] - 1];
+                const double sD = list_sum(D, x, n, fixed_members[(size_t)t]), sL = list_sum(L, x, n, fixed_members[(size_t)t]);
+                const double z_i = ze + d2 * sz, g_i = ga + sD;
+                L2p_first[t] = std::lgamma(z_i) - z_i * std::log(g_i) + zgratio + (d2 - 1) * sL - sz * lg_d2;
+            }
+            const double L2_i = L2p_first[0] + L2p_first[1];                             // Q3
+            for (int k = 0; k < 2; ++k)
+                logprobs[k] = lpr[k] + (L1[k] + (P.repulsion ? (L2_i - L2p_c[k]) : 0.0)); // mcmc.jl:333-335
+            int k;
+            if (!final_clusts) {                                                         // mcmc.jl:336-338
+                const double mn = logprobs[0] < logprobs[1] ? logprobs[0] : logprobs[1];
+                logprobs[0] -= mn; logprobs[1] -= mn;                                    // utils.jl:3 mutates its argument
+                const uint64_t base = 4 + (uint64_t)m + 2 * (uint64_t)m * (uint64_t)scan_index + 2 * (uint64_t)q;
+                const double g0 = -std::log(-std::log(rc_uniform_mh(seed, iter, mh, base))) + logprobs[0];
+                const double g1 = -std::log(-std::log(rc_uniform_mh(seed, iter, mh, base + 1))) + logprobs[1];
+                k = (g1 > g0) ? 1 : 0;
+            } else {
+                k = ((*final_clusts)[(size_t)x] == cand[0]) ? 0 : 1;                     // mcmc.jl:340-341
+            }
+            clusts[(size_t)x] = cand[k];                                                 // mcmc.jl:344-345
+            sizes[(size_t)cand[k] - 1] += 1;
+            double mn = logprobs[0] < logprobs[1] ? logprobs[0] : logprobs[1];           // mcmc.jl:348 (Q2)
+            if (logprobs[0] != logprobs[0] || logprobs[1] != logprobs[1]) mn = NAN;      // minimum() propagates NaN
+            const double p0 = std::exp(logprobs[0] + mn), p1 = std::exp(logprobs[1] + mn);
+            ltp += std::log((k ? p1 : p0) / (p0 + p1));                                  // mcmc.jl:349-351
+        }
+        return ltp;
+    }
+};
+}  // namespace
+
+// One proposal of the MH loop of sample_labels! (src/mcmc.jl:374-473) on the current device state.  On acceptance
+// the device state BECOMES the proposed state (what the reference's rebinding `state = finalstate`, mcmc.jl:470,
+// means for its caller is the host loop's business: rc_state_checkpoint / rc_state_restore).
+extern "C" int32_t rc_splitmerge(rc_ctx *c, double r, double p, int64_t numGibbs, uint64_t seed, uint64_t iter,
+                                 uint64_t mh_counter, uint8_t *accept_out, uint8_t *split_out)
+{
+    if (!c || !accept_out || !split_out) return fail(c, RC_ERR_ARG, "rc_splitmerge: NULL argument");
+    if (!c->have_params || !c->have_state) return fail(c, RC_ERR_STATE, "rc_splitmerge: params and state must be set");
+    if (!c->hostD || !c->hostL) return fail(c, RC_ERR_STATE, "rc_splitmerge: call rc_attach_host_matrices first");
+    if (!(r > 0.0) || !(p > 0.0 && p < 1.0) || numGibbs < 0) return fail(c, RC_ERR_ARG, "rc_splitmerge: need r > 0, 0 < p < 1, numGibbs >= 0");
+    if (c->n < 2) return fail(c, RC_ERR_ARG, "rc_splitmerge: needs n >= 2 (sample(1:n, 2, replace=false))");
+    HIPCHK(c, hipSetDevice(c->dev));
+    *accept_out = 0; *split_out = 0;
+    const int64_t n = c->n;
+    std::vector<int64_t> clusts, sizes;
+    int64_t K;
+    int32_t rc = pull_labels(c, clusts, sizes, K);
+    if (rc != RC_OK) return rc;
+    // chaperones (mcmc.jl:379)
+    int64_t i = (int64_t)std::floor(rc_uniform_mh(seed, iter, mh_counter, 0) * (double)n);
+    int64_t j = (int64_t)std::floor(rc_uniform_mh(seed, iter, mh_counter, 1) * (double)(n - 1));
+    if (i >= n) i = n - 1;
+    if (j >= n - 1) j = n - 2;
+    if (j >= i) j += 1;
+    const int64_t ci = clusts[(size_t)i], cj = clusts[(size_t)j];
+    if (c->P.maxK > 0 && ci == cj && K >= c->P.maxK) return RC_OK;                      // mcmc.jl:384-386
+    std::vector<int64_t> S, U;
+    for (int64_t k = 0; k < n; ++k)
+        if (clusts[(size_t)k] == ci || clusts[(size_t)k] == cj) {
+            U.push_back(k);
+            if (k != i && k != j) S.push_back(k);                                        // mcmc.jl:389-390
+        }
+    if ((uint64_t)S.size() * (uint64_t)(2 * numGibbs + 4) + 8 > 0xFFFFFFFFull)
+        return fail(c, RC_ERR_ARG, "rc_splitmerge: uniform counter overflow (|S| * numGibbs too large)");
+    std::vector<int64_t> claunch = clusts, szlaunch = sizes;
+    int64_t Klaunch = K;
+    if (ci == cj) {                                                                      // mcmc.jl:396-401
+        int64_t e = 0;
+        while (e < n && sizes[(size_t)e] != 0) ++e;
+        if (e >= n) return fail(c, RC_ERR_STATE, "rc_splitmerge: no empty label for a split");
+        claunch[(size_t)i] = e + 1;
+        szlaunch[(size_t)ci - 1] -= 1;
+        szlaunch[(size_t)e] += 1;
+        Klaunch = K + 1;
+    }
+    const int64_t cand[2] = {claunch[(size_t)i], claunch[(size_t)j]};                    // mcmc.jl:402
+    for (size_t q = 0; q < S.size(); ++q) {                                              // mcmc.jl:403-407
+        const int64_t k = S[q];
+        claunch[(size_t)k] = cand[rc_uniform_mh(seed, iter, mh_counter, 4 + (uint64_t)q) < 0.5 ? 0 : 1];
+        szlaunch[(size_t)clusts[(size_t)k] - 1] -= 1;
+        szlaunch[(size_t)claunch[(size_t)k] - 1] += 1;
+    }
+    const rc_params &P = c->P;
+    Restricted R;
+    R.c = c; R.D = c->hostD; R.L = c->hostL; R.n = n; R.r = r; R.p = p; R.seed = seed; R.iter = iter; R.mh = mh_counter;
+    R.abratio = P.alpha * std::log(P.beta) - std::lgamma(P.alpha);                       // mcmc.jl:293-297
+    R.zgratio = P.zeta * std::log(P.gamma) - std::lgamma(P.zeta);
+    R.lg_d1 = std::lgamma(P.delta1); R.lg_d2 = std::lgamma(P.delta2); R.logp = std::log(p);
+    R.U = &U;
+    for (int64_t s = 0; s < numGibbs; ++s) R.scan(claunch, szlaunch, S, cand, nullptr, s);  // mcmc.jl:411-414
+    std::vector<int64_t> cfinal, szfinal;
+    double log_prior_ratio, log_proposal_ratio;
+    if (ci == cj) {                                                                      // split, mcmc.jl:416-434
+        *split_out = 1;
+        const double ltp = R.scan(claunch, szlaunch, S, cand, nullptr, numGibbs);
+        cfinal = claunch; szfinal = szlaunch;
+        const double sfi = (double)szfinal[(size_t)cfinal[(size_t)i] - 1], sfj = (double)szfinal[(size_t)cfinal[(size_t)j] - 1];
+        const double sci = (double)sizes[(size_t)ci - 1];
+        log_prior_ratio = std::log((double)(K + 1)) + r * std::log(1 - p) - std::log(p) - std::lgamma(r) +
+                          std::lgamma(sfi - 1 + r) + std::lgamma(sfj - 1 + r) + std::log(sfi) + std::log(sfj) +
+                          -(std::lgamma(sci - 1 + r) + std::log(sci));
+        log_proposal_ratio = ltp;
+    } else {                                                                             // merge, mcmc.jl:435-459
+        cfinal = claunch; szfinal = szlaunch;
+        int64_t sz_clust_i = 0;
+        for (int64_t k : U)
+            if (cfinal[(size_t)k] == ci) { cfinal[(size_t)k] = cj; ++sz_clust_i; }
+        szfinal[(size_t)ci - 1] = 0;
+        szfinal[(size_t)cj - 1] += sz_clust_i;
+        const double sfj = (double)szfinal[(size_t)cj - 1], sci = (double)sizes[(size_t)ci - 1], scj = (double)sizes[(size_t)cj - 1];
+        log_prior_ratio = -(std::log((double)K) + r * std::log(1 - p) - std::log(p) - std::lgamma(r)) +
+                          std::lgamma(sfj - 1 + r) + std::log(sfj) +
+                          -(std::lgamma(sci - 1 + r) + std::lgamma(scj - 1 + r) + std::log(sci) + std::log(scj));
+        const double ltp = R.scan(claunch, szlaunch, S, cand, &clusts, numGibbs);
+        log_proposal_ratio = -ltp;
+    }
+    (void)Klaunch;
+    // likelihood ratio (mcmc.jl:462-464): both states evaluated on the device from the exact S table
+    double ll_cur = 0, ll_fin = 0;
+    rc = rc_loglik(c, &ll_cur);
+    if (rc != RC_OK) return rc;
+    rc = apply_labels(c, clusts, cfinal);
+    if (rc != RC_OK) return rc;
+    rc = rc_loglik(c, &ll_fin);
+    if (rc != RC_OK) return rc;
+    const double x = log_prior_ratio + (ll_fin - ll_cur) - log_proposal_ratio;
+    const double lar = (x != x) ? NAN : (x < 0 ? x : 0.0);                                // minimum([0, x]) propagates NaN
+    const double lu = std::log(rc_uniform_mh(seed, iter, mh_counter, 2));
+    if (lu < lar) {                                                                      // mcmc.jl:469-472
+        *accept_out = 1;  // the proposed state stays on the device (tables and perm generations already follow it)
+        return RC_OK;
+    }
+    return apply_labels(c, cfinal, clusts);                                              // rejected: revert, bit-exactly
 }

@@ -4,8 +4,13 @@ Kept on the host, as in the reference: the scalar r / p updates (mcmc.jl:80-155)
 (mcmc.jl:546-553) and the diagnostics (mcmc.jl:564-587).  On the device behind the C ABI: the Gibbs sweep,
 loglik, logprior's size terms, label canonicalisation and the co-clustering accumulation.
 
-Not in this build: the split–merge step (numMH must be 0), fitprior (params must be given)
-and the k-medoids initialisation (init must be given)."""
+The split–merge step (numMH > 0, src/mcmc.jl:356-474) runs through rc_splitmerge: scalar scans on the host as
+in the reference, both log-likelihoods on the device.  `splitmerge="as_written"` reproduces the reference
+literally, including its rebinding quirk (after an accepted proposal the iteration leaves
+the caller's labels untouched); `splitmerge="intended"` keeps accepted proposals and sweeps them.
+
+Not in this build: fitprior (params must be given) and the k-medoids initialisation (init must be
+given)."""
 from __future__ import annotations
 
 import math
@@ -71,7 +76,8 @@ def _mean_and_var(x):
 
 def runsampler(data: MCMCData, options: MCMCOptionsList | None = None, params: PriorHyperparamsList | None = None,
                init: MCMCState | None = None, *, verbose: bool = True, seed: int = 0, rng=None, device: int = 0,
-               kcap: int = 0, ctx: Context | None = None, rp_trace=None) -> MCMCResult:
+               kcap: int = 0, ctx: Context | None = None, rp_trace=None, splitmerge: str = "as_written",
+               host_logD=None) -> MCMCResult:
     """runsampler(data, options, params, init; verbose) — src/mcmc.jl:501-590.
 
     seed keys the counter-based uniform stream of the label draws; rng (numpy Generator) drives
@@ -81,9 +87,8 @@ def runsampler(data: MCMCData, options: MCMCOptionsList | None = None, params: P
         raise NotImplementedError("fitprior is outside this build's scope (SURVEY.md §8): pass params explicitly")
     if init is None:
         raise NotImplementedError("k-medoids initialisation is outside this build's scope (SURVEY.md §8): pass init")
-    if options.numMH != 0:
-        raise NotImplementedError("the split–merge step (numMH > 0) is not in this build yet (SURVEY.md §8f-1); "
-                                  "use MCMCOptionsList(numMH=0) — 'pure Gibbs sampling', test/test_sampler.jl:7")
+    if splitmerge not in ("as_written", "intended"):
+        raise ValueError("splitmerge must be 'as_written' or 'intended'")
     out = print if verbose else (lambda *a, **k: None)
     rng = rng or np.random.default_rng(seed)
     n = data.D.shape[0]
@@ -95,6 +100,9 @@ def runsampler(data: MCMCData, options: MCMCOptionsList | None = None, params: P
         ctx.set_params(**params.as_dict())
         ctx.set_state(init.clusts)
         ctx.cocluster_reset()
+        numMH = options.numMH
+        if numMH > 0:
+            ctx.attach_host_matrices(data.D, data.logD if host_logD is None else host_logD)
         result = MCMCResult.allocate(data, options, params)
         state = MCMCState(init.clusts, init.r, init.p)
         out("Run MCMC")
@@ -109,7 +117,21 @@ def runsampler(data: MCMCData, options: MCMCOptionsList | None = None, params: P
                 state.p = sample_p(rng, state.K, n, state.r, params.u, params.v)    # mcmc.jl:539
             else:
                 state.r, state.p = float(rp_trace[0][i - 1]), float(rp_trace[1][i - 1])
-            ctx.gibbs_sweep(state.r, state.p, seed, i - 1)                         # mcmc.jl:540 → :477
+            accepted_any = False
+            if numMH > 0:                                                          # sample_labels!, mcmc.jl:372-474
+                if splitmerge == "as_written":
+                    ctx.checkpoint()
+                for mh in range(numMH):
+                    acc, spl = ctx.splitmerge(state.r, state.p, options.numGibbs, seed, i - 1, mh)
+                    result.splitmerge_acceptances[(i - 1) * numMH + mh] = acc      # mcmc.jl:541-543
+                    result.splitmerge_splits[(i - 1) * numMH + mh] = spl
+                    accepted_any |= acc
+            if accepted_any and splitmerge == "as_written":
+                # Q1: `state = finalstate` (mcmc.jl:470) rebound a local name; the accepted proposal and the closing
+                # Gibbs scan (mcmc.jl:477) acted on an object the caller never sees
+                ctx.restore()
+            else:
+                ctx.gibbs_sweep(state.r, state.p, seed, i - 1)                     # mcmc.jl:540 → :477
             record = i > burnin and (i - burnin) % thin == 0                       # mcmc.jl:546
             if record or rp_trace is None:
                 # sample_r!/sample_p! of the next iteration need K and the cluster sizes (mcmc.jl:84-89,139): read
@@ -130,7 +152,7 @@ def runsampler(data: MCMCData, options: MCMCOptionsList | None = None, params: P
         result.r_mean, result.r_variance = _mean_and_var(result.r)
         result.p_iac, result.p_ess, result.p_acf = iac_ess_acf(result.p)
         result.p_mean, result.p_variance = _mean_and_var(result.p)
-        result.splitmerge_acceptance_rate = 0.0                                    # mcmc.jl:576-580 (numMH = 0)
+        result.splitmerge_acceptance_rate = float(np.mean(result.splitmerge_acceptances)) if numMH > 0 else 0.0  # :576-580
         result.r_acceptance_rate = float(np.mean(result.r_acceptances))
         result.runtime = runtime
         result.mean_iter_time = runtime / numiters

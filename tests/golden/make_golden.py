@@ -100,7 +100,42 @@ def main():
     gold["uniform_kat"] = np.array([T.uniform(1, 0, 0, 0), T.uniform(1235, 3, 99, 10),
                                     T.uniform(2**40 + 7, 2**33 + 1, 8191, 50)])
     np.savez_compressed(os.path.join(HERE, "golden_sweeps.npz"), **gold)
+    make_golden_mh(data)
     print("wrote", HERE)
+
+
+def make_golden_mh(data):
+    """Split–merge step as written (sample_labels!, mcmc.jl:356-479): accept / split flags and the caller's labels
+    after each of 20 iterations (numMH=3, numGibbs=5) from inits with merged and with split true clusters."""
+    gold = {}
+    cases = []
+    for d, kind in ((1, "merged"), (3, "merged"), (3, "splitup"), (2, "truth")):
+        D, truth = data[f"D{d}"], data[f"labels{d}"]
+        P = T.likelihood_hyperparams(D, truth)
+        init = truth.copy()
+        if kind == "merged":
+            init[init == 2] = 1; init[init == 4] = 3; init[init == 9] = 8
+        elif kind == "splitup":
+            m = np.flatnonzero(init == 5); init[m[: len(m) // 2]] = 11
+            m = np.flatnonzero(init == 7); init[m[::2]] = 12
+        logD = T.make_logD(D)
+        cl = init.copy()
+        sz, K = T.state_from_labels(cl)
+        acc, spl, labs, Ks = [], [], [], []
+        for it in range(20):
+            a, s, K = T.sample_labels(D, logD, cl, sz, K, P, 1.0 + 0.05 * it, 0.5, 3, 5, 4321 + d, it)
+            acc.append(a); spl.append(s); labs.append(cl.copy()); Ks.append(K)
+        tag = f"d{d}_{kind}"
+        cases.append(tag)
+        gold[f"{tag}_init"] = init
+        gold[f"{tag}_accept"] = np.array(acc)
+        gold[f"{tag}_split"] = np.array(spl)
+        gold[f"{tag}_labels"] = np.array(labs)
+        gold[f"{tag}_K"] = np.array(Ks)
+        gold[f"{tag}_seed"] = np.array(4321 + d)
+        print(tag, "accepted", int(np.sum(acc)), "splits proposed", int(np.sum(spl)), "K", Ks[0], "->", Ks[-1])
+    gold["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "golden_mh.npz"), **gold)
 
 
 if __name__ == "__main__":

@@ -208,3 +208,140 @@ def sortlabels(x):
 
 def adjacencymatrix(x):
     return x[:, None] == x[None, :]
+
+
+# ------------------------------------------------------------------------------------------------------
+# Split–merge step, as written: sample_labels! (mcmc.jl:356-479), sample_labels_Gibbs_restricted! (:259-354)
+# ------------------------------------------------------------------------------------------------------
+def uniform_mh(seed: int, it: int, mh: int, draw: int) -> float:
+    c = philox4x32_10((draw, mh, it & M32, (it >> 32) & M32), (seed & M32, ((seed >> 32) & M32) ^ 0x4D485F52))
+    bits = ((c[0] << 32) | c[1]) >> 12
+    return (bits + 0.5) * 2.0 ** -52
+
+
+def _seqsum(M, x, mem):
+    s = 0.0
+    for y in mem:
+        s += M[x, y]
+    return s
+
+
+def restricted_scan(D, logD, clusts, sizes, P, r, p, items, cand, final_clusts, seed, it, mh, scan):
+    d1, d2, al, be, ze, ga = (P[k] for k in ("delta1", "delta2", "alpha", "beta", "zeta", "gamma"))
+    abratio = al * np.log(be) - gammaln(al)
+    zgratio = ze * np.log(ga) - gammaln(ze)
+    C = np.flatnonzero(sizes > 0) + 1                       # frozen at entry (:273)
+    cinds = [int(np.flatnonzero(C == c)[0]) for c in cand]  # indexin(candidate_clusts, C)
+    m = len(items)
+    ltp = 0.0
+    with np.errstate(all="ignore"):
+        for q, x in enumerate(items):
+            sizes[clusts[x] - 1] -= 1
+            clusts[x] = -1
+            a_i = np.zeros(2); b_i = np.zeros(2)
+            for k in range(2):
+                mem = np.flatnonzero(clusts == cand[k])
+                a_i[k] = al + d1 * sizes[cand[k] - 1]
+                b_i[k] = be + _seqsum(D, x, mem)
+            need = sorted(set([0, 1] + cinds))              # only these entries of the K-vectors are ever read
+            z_i = {}; g_i = {}; sl = {}
+            for t in need:
+                mem = np.flatnonzero(clusts == C[t])
+                z_i[t] = ze + d2 * sizes[C[t] - 1]
+                g_i[t] = ga + _seqsum(D, x, mem)
+                sl[t] = _seqsum(logD, x, mem)
+            L1 = np.zeros(2); lpr = np.zeros(2)
+            for k in range(2):
+                sz = sizes[cand[k] - 1]
+                L1[k] = gammaln(a_i[k]) + abratio - a_i[k] * np.log(b_i[k]) + (d1 - 1) * sl[cinds[k]] - sz * gammaln(d1)
+                lpr[k] = np.log(sz + 1) + np.log(p) + np.log(sz - 1 + r) - np.log(sz)
+            L2p = {t: gammaln(z_i[t]) - z_i[t] * np.log(g_i[t]) + zgratio + (d2 - 1) * sl[t] - sizes[C[t] - 1] * gammaln(d2)
+                   for t in need}
+            L2_i = L2p[0] + L2p[1]                          # Q3
+            L2 = np.array([L2_i - L2p[cinds[0]], L2_i - L2p[cinds[1]]])
+            logprobs = lpr + (L1 + (L2 if P["repulsion"] else 0.0))
+            if final_clusts is None:
+                logprobs = logprobs - logprobs.min()        # sample_logweights mutates its argument
+                base = 4 + m + 2 * m * scan + 2 * q
+                g = np.array([-np.log(-np.log(uniform_mh(seed, it, mh, base + k))) for k in range(2)]) + logprobs
+                k = int(np.argmax(g))
+            else:
+                k = 0 if final_clusts[x] == cand[0] else 1
+            clusts[x] = cand[k]
+            sizes[cand[k] - 1] += 1
+            logprobs = logprobs + logprobs.min()            # Q2 (np.min propagates NaN like Julia's minimum)
+            probs = np.exp(logprobs)
+            probs = probs / (probs[0] + probs[1])
+            ltp += np.log(probs[k])
+    return float(ltp)
+
+
+def mh_proposal(D, logD, clusts, sizes, K, P, r, p, numGibbs, seed, it, mh):
+    """One proposal (mcmc.jl:374-473).  Returns (accept, split, skipped, final (clusts, sizes, K) or None, info)."""
+    n = len(clusts)
+    i = min(int(np.floor(uniform_mh(seed, it, mh, 0) * n)), n - 1)
+    j = min(int(np.floor(uniform_mh(seed, it, mh, 1) * (n - 1))), n - 2)
+    if j >= i:
+        j += 1
+    ci, cj = int(clusts[i]), int(clusts[j])
+    if P["maxK"] > 0 and ci == cj and int(np.sum(sizes > 0)) >= P["maxK"]:
+        return False, False, True, None, {}
+    S = [k for k in np.flatnonzero((clusts == ci) | (clusts == cj)) if k != i and k != j]
+    claunch, szlaunch, Klaunch = clusts.copy(), sizes.copy(), K
+    if ci == cj:
+        new = int(np.flatnonzero(sizes == 0)[0]) + 1
+        claunch[i] = new
+        szlaunch[ci - 1] -= 1
+        szlaunch[new - 1] += 1
+        Klaunch = K + 1
+    cand = (int(claunch[i]), int(claunch[j]))
+    for q, k in enumerate(S):
+        claunch[k] = cand[0 if uniform_mh(seed, it, mh, 4 + q) < 0.5 else 1]
+        szlaunch[clusts[k] - 1] -= 1
+        szlaunch[claunch[k] - 1] += 1
+    for s in range(numGibbs):
+        restricted_scan(D, logD, claunch, szlaunch, P, r, p, S, cand, None, seed, it, mh, s)
+    lg = gammaln
+    if ci == cj:
+        split = True
+        ltp = restricted_scan(D, logD, claunch, szlaunch, P, r, p, S, cand, None, seed, it, mh, numGibbs)
+        cfinal, szfinal, Kfinal = claunch, szlaunch, Klaunch
+        lpr = (np.log(K + 1) + r * np.log(1 - p) - np.log(p) - lg(r) + lg(szfinal[cfinal[i] - 1] - 1 + r)
+               + lg(szfinal[cfinal[j] - 1] - 1 + r) + np.log(szfinal[cfinal[i] - 1]) + np.log(szfinal[cfinal[j] - 1])
+               - (lg(sizes[ci - 1] - 1 + r) + np.log(sizes[ci - 1])))
+        lprop = ltp
+    else:
+        split = False
+        cfinal, szfinal, Kfinal = claunch.copy(), szlaunch.copy(), Klaunch
+        mem = np.flatnonzero(cfinal == ci)
+        cfinal[mem] = cj
+        szfinal[ci - 1] = 0
+        szfinal[cj - 1] += len(mem)
+        Kfinal -= 1
+        lpr = (-(np.log(K) + r * np.log(1 - p) - np.log(p) - lg(r)) + lg(szfinal[cj - 1] - 1 + r) + np.log(szfinal[cj - 1])
+               - (lg(sizes[ci - 1] - 1 + r) + lg(sizes[cj - 1] - 1 + r) + np.log(sizes[ci - 1]) + np.log(sizes[cj - 1])))
+        ltp = restricted_scan(D, logD, claunch, szlaunch, P, r, p, S, cand, clusts, seed, it, mh, numGibbs)
+        lprop = -ltp
+    llr = loglik(D, logD, cfinal, szfinal, P) - loglik(D, logD, clusts, sizes, P)
+    x = lpr + llr - lprop
+    lar = np.nan if np.isnan(x) else min(0.0, x)
+    lu = np.log(uniform_mh(seed, it, mh, 2))
+    accept = bool(lu < lar)
+    info = dict(i=i, j=j, nS=len(S), log_prior_ratio=float(lpr), log_lik_ratio=float(llr), log_proposal_ratio=float(lprop))
+    return accept, split, False, (cfinal, szfinal, Kfinal), info
+
+
+def sample_labels(D, logD, clusts, sizes, K, P, r, p, numMH, numGibbs, seed, it):
+    """sample_labels! as written (Q1): returns (accept flags, split flags, K of the caller's state afterwards);
+    the caller's clusts/sizes are swept in place only if no proposal was accepted."""
+    state = (clusts, sizes, K)
+    accept = [False] * numMH
+    split = [False] * numMH
+    for mh in range(numMH):
+        a, s, skipped, final, _ = mh_proposal(D, logD, state[0], state[1], state[2], P, r, p, numGibbs, seed, it, mh)
+        split[mh] = s
+        if a:
+            accept[mh] = True
+            state = final                                   # rebinding: the caller's arrays are not touched
+    Knew = sweep(D, logD, state[0], state[1], P, r, p, seed, it)
+    return accept, split, (Knew if state[0] is clusts else K)

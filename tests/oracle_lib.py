@@ -19,6 +19,12 @@ class OrcParams(C.Structure):
                                           "sigma", "u", "v")] + [("repulsion", C.c_int32), ("maxK", C.c_int64)]
 
 
+class OrcMHInfo(C.Structure):
+    _fields_ = [("accept", C.c_int32), ("split", C.c_int32), ("skipped", C.c_int32), ("pad", C.c_int32),
+                ("i", C.c_int64), ("j", C.c_int64), ("nS", C.c_int64), ("log_prior_ratio", C.c_double),
+                ("log_lik_ratio", C.c_double), ("log_proposal_ratio", C.c_double), ("log_u", C.c_double)]
+
+
 def build(force: bool = False) -> str:
     src = os.path.join(ORACLE_DIR, "rc_oracle.c")
     if force or not os.path.exists(SO) or os.path.getmtime(SO) < os.path.getmtime(src):
@@ -68,6 +74,13 @@ def lib():
     L.orc_matsum_idx.argtypes = [i64, _dp, _ip, i64, _ip, i64]
     L.orc_vecsum_idx.restype = f64
     L.orc_vecsum_idx.argtypes = [_dp, _ip, i64]
+    _bp = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+    L.orc_uniform_mh.restype = f64
+    L.orc_uniform_mh.argtypes = [u64, u64, u64, u64]
+    L.orc_mh_proposal.argtypes = [i64, _dp, _dp, C.c_void_p, C.c_void_p, i32, i32, _ip, _ip, C.POINTER(i64), PP, f64, f64,
+                                  i64, u64, u64, u64, i32, C.POINTER(OrcMHInfo)]
+    L.orc_sample_labels.argtypes = [i64, _dp, _dp, C.c_void_p, C.c_void_p, i32, i32, C.c_void_p, _ip, _ip,
+                                    C.POINTER(i64), PP, f64, f64, i64, i64, u64, u64, i32, _bp, _bp]
     _lib = L
     return L
 
@@ -136,6 +149,31 @@ class Oracle:
         assert rc == 0
         self.K = K.value
         return self.K
+
+    def mh_proposal(self, r, p, numGibbs, seed, it, mh, mode=0):
+        """One split–merge proposal on the oracle's state (replaced by the final state on acceptance)."""
+        info = OrcMHInfo()
+        K = C.c_int64(self.K)
+        dq = self.Dq.ctypes.data_as(C.c_void_p) if mode else None
+        lq = self.Lq.ctypes.data_as(C.c_void_p) if mode else None
+        self.L.orc_mh_proposal(self.n, self.D.reshape(-1), self.logD.reshape(-1), dq, lq, self.eD, self.eL, self.clusts,
+                               self.sizes, C.byref(K), C.byref(self.P), r, p, numGibbs, seed, it, mh, mode, C.byref(info))
+        self.K = K.value
+        return info
+
+    def sample_labels(self, r, p, numMH, numGibbs, seed, it, mode=0):
+        """sample_labels! as written (numMH proposals + the Gibbs sweep, quirk Q1).  mode 0 literal, 1 stable."""
+        acc = np.zeros(max(numMH, 1), np.uint8)
+        spl = np.zeros(max(numMH, 1), np.uint8)
+        K = C.c_int64(self.K)
+        dq = self.Dq.ctypes.data_as(C.c_void_p) if mode else None
+        lq = self.Lq.ctypes.data_as(C.c_void_p) if mode else None
+        A = self.A.ctypes.data_as(C.c_void_p) if mode else None
+        na = self.L.orc_sample_labels(self.n, self.D.reshape(-1), self.logD.reshape(-1), dq, lq, self.eD, self.eL, A,
+                                      self.clusts, self.sizes, C.byref(K), C.byref(self.P), r, p, numMH, numGibbs, seed,
+                                      it, mode, acc, spl)
+        self.K = K.value
+        return na, acc[:numMH].astype(bool), spl[:numMH].astype(bool)
 
     def sweep_stable(self, r, p, seed, sweep):
         K = C.c_int64()

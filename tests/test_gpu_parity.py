@@ -289,6 +289,63 @@ def test_runsampler_surface():
     assert len(res2.r_acf) == 18 and res2.r_acf[0] == 1.0  # autocor default lags 0:min(n-1, round(10·log10 n))
 
 
+@pytest.mark.parametrize("tag", ["d1_merged", "d3_merged", "d3_splitup", "d2_truth"])
+def test_splitmerge_as_written(tag):
+    """sample_labels! as written (numMH=3, numGibbs=5; quirks Q1–Q3): rc_splitmerge + checkpoint/restore + sweep
+    against the oracle (literal restricted scans, stable loglik and sweep) and the golden flags; the S table must
+    survive every apply / revert bit-exactly (the sweeps after it stay on the oracle's trajectory)."""
+    from test_splitmerge_cpu import mh_case
+    gm, D, P, init, seed = mh_case(tag)
+    orc, ctx = make_pair(D, P, init)
+    ctx.attach_host_matrices(D, orc.logD)
+    for it in range(20):
+        r, p = 1.0 + 0.05 * it, 0.5
+        na, acc_ref, spl_ref = orc.sample_labels(r, p, 3, 5, seed, it, mode=1)
+        ctx.checkpoint()
+        acc, spl = [], []
+        for mh in range(3):
+            a, s = ctx.splitmerge(r, p, 5, seed, it, mh)
+            acc.append(a); spl.append(s)
+        if any(acc):
+            ctx.restore()
+        else:
+            ctx.gibbs_sweep(r, p, seed, it)
+        assert acc == list(acc_ref) and spl == list(spl_ref), (tag, it)
+        assert acc == list(gm[f"{tag}_accept"][it]) and spl == list(gm[f"{tag}_split"][it])
+        assert_state_equal(ctx, orc, f"({tag}, iteration {it})")
+        assert abs(ctx.loglik() - orc.loglik_stable()) <= LL_RTOL * max(1.0, abs(orc.loglik_stable()))
+    ctx.close()
+
+
+def test_splitmerge_intended_mode_and_runsampler_defaults():
+    """'intended' semantics (accepted proposals are kept and swept) proposal by proposal against the oracle, then the
+    reference's default options (numMH = 1, numGibbs = 5) through runsampler in both modes."""
+    from test_splitmerge_cpu import mh_case
+    gm, D, P, init, seed = mh_case("d1_merged")
+    orc, ctx = make_pair(D, P, init)
+    ctx.attach_host_matrices(D, orc.logD)
+    accepted = 0
+    for it in range(25):
+        for mh in range(2):
+            inf = orc.mh_proposal(1.0, 0.5, 5, seed, it, mh, mode=1)   # replaces the oracle's state on acceptance
+            a, s = ctx.splitmerge(1.0, 0.5, 5, seed, it, mh)
+            assert (a, s) == (bool(inf.accept), bool(inf.split)), (it, mh)
+            accepted += a
+            assert_state_equal(ctx, orc, f"(intended, {it}, {mh})")
+        ctx.gibbs_sweep(1.0, 0.5, seed, it)
+        orc.sweep_stable(1.0, 0.5, seed, it)
+        assert_state_equal(ctx, orc, f"(intended sweep {it})")
+    assert accepted >= 1
+    ctx.close()
+    params = rc.PriorHyperparamsList(**{k: P[k] for k in ("delta1", "delta2", "alpha", "beta", "zeta", "gamma")})
+    for mode in ("as_written", "intended"):
+        res = rc.runsampler(rc.MCMCData(D), rc.MCMCOptionsList(numiters=60), params, rc.MCMCState(init, 1.0, 0.5),
+                            verbose=False, seed=5, splitmerge=mode)
+        assert res.splitmerge_acceptances.shape == (60,) and res.splitmerge_splits.shape == (60,)
+        assert 0.0 <= res.splitmerge_acceptance_rate <= 1.0 and np.isfinite(res.logposterior).all()
+        assert res.K.shape == (48,) and res.posterior_coclustering.shape == (100, 100)
+
+
 def test_full_size_properties():
     """BASELINE config 3 (N=8192, K=50): size-independent properties — Σ sizes = n, K = #non-empty, checksum of
     the row-sum table (Σ_k S[k][i] = Σ_j D[i,j], exact in fixed point), stationarity of the generating labels,
