@@ -116,6 +116,20 @@ def main():
     bulk_ms, bulk_launches = ctx.kernel_timing(enable=0)
     stats = ctx.sweep_stats()
 
+    # same workload in the exact incremental mode (no row reduction while labels are stable) — reported as an extra
+    inc_sweeps_per_s = None
+    if not os.environ.get("RC_BENCH_NO_INCREMENTAL"):
+        ctx.set_mode("incremental")
+        for _ in range(args.warmup):
+            ctx.gibbs_sweep(r, p, chain_seed, sweep, blocking=False); sweep += 1
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.gibbs_sweep(r, p, chain_seed, sweep, blocking=False); sweep += 1
+        ctx.synchronize()
+        inc_sweeps_per_s = args.steps / (time.perf_counter() - t1)
+        ctx.set_mode("full")
+
     # recorded sample + the one collective of the path: sum all-reduce of the integer co-clustering counts
     ctx.record_sample(False)
     allreduce_ms = None
@@ -155,6 +169,7 @@ def main():
             "sweep_GBps_algorithmic": value / world * alg_bytes / 1e9,
             "sweep_frac_of_hbm_peak": value / world * alg_bytes / 1e9 / HBM_PEAK_GBPS,
             "label_changes_last_sweep": stats["n_changes"], "K_final": stats["K"],
+            "incremental_mode_sweeps_per_s_rank0": inc_sweeps_per_s,
             "coclustering_allreduce_ms": allreduce_ms, "coclustering_diag_ok": diag_ok,
             "roofline": {"kernel": "k_bulk", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,

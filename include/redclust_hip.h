@@ -84,6 +84,15 @@ int32_t rc_get_state(rc_ctx *ctx, int64_t *clusts /* n */, int64_t *clustsizes /
 int32_t rc_gibbs_sweep(rc_ctx *ctx, double r, double p, uint64_t seed, uint64_t sweep_index);
 int32_t rc_last_sweep_stats(rc_ctx *ctx, rc_sweep_stats *out);
 
+/* Data flow of the sweep.  RC_MODE_FULL (default) recomputes the row-sum table S[k][i] = Σ_j D[i,j]·[c_j = k] from
+ * the matrices in every sweep — what the reference does (src/mcmc.jl:206-214) and what the HBM roofline metric
+ * is defined on.  RC_MODE_INCREMENTAL computes it once and then only corrects it for label changes; because the
+ * sums are exact integers both modes give bit-identical results, and a sweep that changes no label reads no
+ * matrix data at all.  Can be switched at any time. */
+#define RC_MODE_FULL 0
+#define RC_MODE_INCREMENTAL 1
+int32_t rc_set_mode(rc_ctx *ctx, int32_t mode);
+
 /* Non-blocking sweep for the stationary fast path and for benchmarking: enqueues one sweep on the
  * context's stream and returns; label changes are resolved on the device.  rc_synchronize() (or any
  * blocking call) waits for completion. */

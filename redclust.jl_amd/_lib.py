@@ -70,6 +70,7 @@ SIGNATURES = {
     "rc_cocluster_counts": (C.c_int32, [C.c_void_p, _up]),
     "rc_cocluster_device_buffer": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "rc_cocluster_reset": (C.c_int32, [C.c_void_p]),
+    "rc_set_mode": (C.c_int32, [C.c_void_p, C.c_int32]),
     "rc_attach_host_matrices": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "rc_splitmerge": (C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint64,
                                   C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]),
@@ -157,6 +158,11 @@ class Context:
     def gibbs_sweep(self, r, p, seed, sweep_index, blocking=True):
         fn = self.L.rc_gibbs_sweep if blocking else self.L.rc_gibbs_sweep_async
         self._chk(fn(self.h, float(r), float(p), int(seed), int(sweep_index)))
+
+    def set_mode(self, mode):
+        """'full' (recompute the row-sum table every sweep, the reference's data flow) or 'incremental' (maintain it
+        by exact corrections only); results are bit-identical."""
+        self._chk(self.L.rc_set_mode(self.h, {"full": 0, "incremental": 1}[mode]))
 
     def synchronize(self):
         self._chk(self.L.rc_synchronize(self.h))

@@ -101,7 +101,8 @@ struct View {
 struct SweepArgs {
     double r, logp, log1mp;
     unsigned k0, k1, sw_lo, sw_hi;
-    int t;    // internal sweep index since rc_set_state: selects buffer generations
+    int t;    // internal sweep index since rc_set_state: selects key / perm generations
+    int own_gen, next_gen;  // S generation read (and corrected in place); generation being filled for the next sweep (-1: none)
     int dbg;  // timing ablations only (RC_DEBUG_FLAGS): 1 = skip candidate loop, 2 = skip grid barrier, 4 = skip gumbel
 };
 
@@ -673,7 +674,7 @@ __device__ bool commit_change(const View &V, const SweepArgs &sa, Tab &T, u64 ke
         if (job < 4) {
             const void *M = (job < 2) ? V.Dq : V.Lq;
             long long *So = (job < 2) ? V.SD[own_gen] : V.SL[own_gen];
-            long long *Sn = (job < 2) ? V.SD[next_gen] : V.SL[next_gen];
+            long long *Sn = (job < 2) ? V.SD[next_gen < 0 ? own_gen : next_gen] : V.SL[next_gen < 0 ? own_gen : next_gen];
             const int slot = (job & 1) ? b : a;
             for (int c = blockIdx.x; c < nchunks; c += G) {
                 const int i = c * RC_PTS + pt;
@@ -682,7 +683,8 @@ __device__ bool commit_change(const View &V, const SweepArgs &sa, Tab &T, u64 ke
                     const long long x = (V.bits == 64) ? ((const long long *)M)[e] : (long long)((const int *)M)[e];
                     const long long dx = (job & 1) ? x : -x;
                     So[(size_t)slot * V.ld + i] += dx;
-                    __hip_atomic_fetch_add((u64 *)(Sn + (size_t)slot * V.ld + i), (u64)dx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (next_gen >= 0)
+                        __hip_atomic_fetch_add((u64 *)(Sn + (size_t)slot * V.ld + i), (u64)dx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
@@ -727,7 +729,7 @@ __global__ __launch_bounds__(RC_RES_THREADS) void k_resolve(View V, SweepArgs sa
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Tab T = tab_carve(smem, V.kcap, V.n, blockDim.x >> 6);
-    const int t = sa.t, own_gen = t % 3, next_gen = (t + 1) % 3, kg = t & 1;
+    const int t = sa.t, own_gen = sa.own_gen, next_gen = sa.next_gen, kg = t & 1;
     const long long *SD = V.SD[own_gen], *SL = V.SL[own_gen];
     u64 *keys = V.keys[kg];
     unsigned *arrive = V.arrive[kg];
@@ -904,6 +906,8 @@ struct rc_ctx {
     long long t_next = 0;     // internal index of the next sweep (0 after rc_set_state)
     long long bulk_enq = -1;  // highest sweep index whose k_bulk has been enqueued
     bool prefetch = true;     // enqueue k_bulk(t+1) together with k_resolve(t)
+    bool incremental = false; // RC_MODE_INCREMENTAL: S is only maintained by exact corrections, never recomputed
+    int inc_gen = 0;          // the S generation that incremental mode keeps current
     hipEvent_t ev_bulk[4] = {nullptr, nullptr, nullptr, nullptr}, ev_res[4] = {nullptr, nullptr, nullptr, nullptr};
     // timing of k_bulk
     bool timing = false;
@@ -1341,6 +1345,10 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
 // Makes the S generation of the CURRENT labels available to work enqueued on stream A; returns its index.
 static int32_t ensure_S(rc_ctx *c, int *gen)
 {
+    if (c->incremental && c->bulk_enq >= 0 && c->t_next > 0) {
+        *gen = c->inc_gen;
+        return RC_OK;
+    }
     if (c->t_next == 0) {
         if (c->bulk_enq < 0) {
             View V = make_view(c);
@@ -1364,20 +1372,39 @@ extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t 
     View V = make_view(c);
     const long long t = c->t_next;
     int32_t rc;
-    if (c->bulk_enq < t) {
-        rc = enqueue_bulk(c, V, t);
-        if (rc != RC_OK) return rc;
-    }
+    if (t >= 0x7ffffff0ll) return fail(c, RC_ERR_STATE, "rc_gibbs_sweep: internal sweep counter exhausted; call rc_set_state");
     SweepArgs sa;
     sa.r = r;
     sa.logp = std::log(p);
     sa.log1mp = std::log(1 - p);
     sa.k0 = (unsigned)seed; sa.k1 = (unsigned)(seed >> 32);
     sa.sw_lo = (unsigned)sweep_index; sa.sw_hi = (unsigned)(sweep_index >> 32);
-    if (t >= 0x7ffffff0ll) return fail(c, RC_ERR_STATE, "rc_gibbs_sweep: internal sweep counter exhausted; call rc_set_state");
     sa.t = (int)t;
     sa.dbg = c->dbg;
     const size_t lds = std::max(tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64), 2 * sizeof(int) * (size_t)c->kcap);
+    if (c->incremental) {
+        // exact incremental mode: the row-sum table of the current labels already exists (one k_bulk after
+        // rc_set_state) and every label change corrects it in place — no matrix traffic at all in this sweep
+        int gen = 0;
+        if (t == 0 || c->bulk_enq < 0) {
+            rc = ensure_S(c, &gen);
+            if (rc != RC_OK) return rc;
+            c->inc_gen = gen;
+        }
+        sa.own_gen = c->inc_gen;
+        sa.next_gen = -1;
+        k_resolve<<<c->G, RC_RES_THREADS, lds, c->sA>>>(V, sa, c->G);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(c->ev_res[t & 3], c->sA));
+        c->t_next = t + 1;
+        return RC_OK;
+    }
+    if (c->bulk_enq < t) {
+        rc = enqueue_bulk(c, V, t);
+        if (rc != RC_OK) return rc;
+    }
+    sa.own_gen = (int)(t % 3);
+    sa.next_gen = (int)((t + 1) % 3);
     HIPCHK(c, hipStreamWaitEvent(c->sA, c->ev_bulk[t & 3], 0));
     k_resolve<<<c->G, RC_RES_THREADS, lds, c->sA>>>(V, sa, c->G);
     HIPCHK(c, hipGetLastError());
@@ -1789,7 +1816,9 @@ static int32_t apply_labels(rc_ctx *c, const std::vector<int64_t> &cur, const st
     }
     // S generations that currently hold valid sums
     MoveList ML{};
-    if (c->bulk_enq >= 0) {
+    if (c->incremental && c->bulk_enq >= 0 && c->t_next > 0) {
+        ML.gens[ML.ngens++] = c->inc_gen;
+    } else if (c->bulk_enq >= 0) {
         if (c->t_next == 0) ML.gens[ML.ngens++] = 0;
         else {
             ML.gens[ML.ngens++] = (int)((c->t_next - 1) % 3);
@@ -2050,4 +2079,52 @@ extern "C" int32_t rc_splitmerge(rc_ctx *c, double r, double p, int64_t numGibbs
         return RC_OK;
     }
     return apply_labels(c, cfinal, clusts);                                              // rejected: revert, bit-exactly
+}
+
+
+// RC_MODE_FULL (default): every sweep recomputes the row-sum table from the matrices, as the reference re-reads
+// D and logD in every sweep (src/mcmc.jl:206-214) — the HBM-bound data flow the roofline metric is defined on.
+// RC_MODE_INCREMENTAL: the table is computed once and then only corrected for label changes.  Both modes give
+// bit-identical results (exact integer sums); the incremental one does no matrix traffic while labels are stable.
+extern "C" int32_t rc_set_mode(rc_ctx *c, int32_t mode)
+{
+    if (!c) return fail(c, RC_ERR_ARG, "rc_set_mode: NULL ctx");
+    if (mode != RC_MODE_FULL && mode != RC_MODE_INCREMENTAL) return fail(c, RC_ERR_ARG, "rc_set_mode: unknown mode %d", mode);
+    HIPCHK(c, hipSetDevice(c->dev));
+    const bool inc = (mode == RC_MODE_INCREMENTAL);
+    if (inc == c->incremental) return RC_OK;
+    int32_t rc = sync_and_check(c, true);
+    if (rc != RC_OK) return rc;
+    if (inc) {
+        if (c->have_state) {
+            int gen = 0;
+            rc = ensure_S(c, &gen);  // the generation holding the sums of the current labels
+            if (rc != RC_OK) return rc;
+            c->inc_gen = gen;
+        }
+        c->incremental = true;
+        return RC_OK;
+    }
+    // back to full recomputation: restart the sweep pipeline from the current labels
+    c->incremental = false;
+    if (c->have_state) {
+        for (int g = 0; g < 3; ++g) {
+            HIPCHK(c, hipMemsetAsync(c->SD[g], 0, (size_t)c->kcap * c->ld * sizeof(long long), c->sA));
+            HIPCHK(c, hipMemsetAsync(c->SL[g], 0, (size_t)c->kcap * c->ld * sizeof(long long), c->sA));
+        }
+        for (int g = 0; g < 2; ++g) {
+            HIPCHK(c, hipMemsetAsync(c->keys[g], 0xFF, (size_t)(c->n + 2) * sizeof(u64), c->sA));
+            HIPCHK(c, hipMemsetAsync(c->arrive[g], 0, 64, c->sA));
+        }
+        const int minus1 = -1;
+        HIPCHK(c, hipMemcpyAsync(&c->sc->last_change_sweep, &minus1, sizeof(int), hipMemcpyHostToDevice, c->sA));
+        View V = make_view(c);
+        const size_t lds = std::max(tab_bytes(c->kcap, c->n, 1), 2 * sizeof(int) * (size_t)c->kcap);
+        k_derive<<<1, 1024, lds, c->sA>>>(V, 1);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->sA));
+        c->t_next = 0;
+        c->bulk_enq = -1;
+    }
+    return RC_OK;
 }

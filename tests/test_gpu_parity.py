@@ -346,6 +346,46 @@ def test_splitmerge_intended_mode_and_runsampler_defaults():
         assert res.K.shape == (48,) and res.posterior_coclustering.shape == (100, 100)
 
 
+def test_incremental_mode_is_bit_identical():
+    """RC_MODE_INCREMENTAL (row-sum table maintained by exact corrections only) vs RC_MODE_FULL (recomputed every
+    sweep) vs the oracle: same labels every sweep, identical loglik bits, identical row sums; switching modes
+    mid-run and split–merge moves in incremental mode keep the trajectory."""
+    data = rc.generatemixture(1200, 15, seed=9, sigma=0.22)
+    D, truth = data["distancematrix"], data["clusts"]
+    P = rc.likelihood_hyperparams(D, truth)
+    init = np.random.default_rng(9).integers(1, 16, size=1200).astype(np.int64)
+    orc, full = make_pair(D, P, init, kcap=512)
+    inc = rc.Context(D, logD=orc.logD, kcap=512)
+    inc.set_params(**P); inc.set_state(init); inc.set_mode("incremental")
+    mixed = rc.Context(D, logD=orc.logD, kcap=512)
+    mixed.set_params(**P); mixed.set_state(init)
+    for t in range(12):
+        r, p = rp_schedule(t)
+        if t == 4:
+            mixed.set_mode("incremental")
+        if t == 9:
+            mixed.set_mode("full")
+        for c in (full, inc, mixed):
+            c.gibbs_sweep(r, p, 31, t)
+        orc.sweep_stable(r, p, 31, t)
+        for c in (full, inc, mixed):
+            assert_state_equal(c, orc, f"(mode test, sweep {t})")
+        assert full.loglik() == inc.loglik() == mixed.loglik()
+    lab = int(orc.clusts[0])
+    a, b = full.debug_rowsums(lab), inc.debug_rowsums(lab)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # split–merge proposals (apply / revert of moves) on the incrementally maintained table
+    inc.attach_host_matrices(D, orc.logD)
+    for it in range(6):
+        inf = orc.mh_proposal(1.0, 0.5, 3, 8, it, 0, mode=1)
+        a_, s_ = inc.splitmerge(1.0, 0.5, 3, 8, it, 0)
+        assert (a_, s_) == (bool(inf.accept), bool(inf.split))
+        inc.gibbs_sweep(1.0, 0.5, 8, 100 + it); orc.sweep_stable(1.0, 0.5, 8, 100 + it)
+        assert_state_equal(inc, orc, f"(incremental + MH, {it})")
+    for c in (full, inc, mixed):
+        c.close()
+
+
 def test_full_size_properties():
     """BASELINE config 3 (N=8192, K=50): size-independent properties — Σ sizes = n, K = #non-empty, checksum of
     the row-sum table (Σ_k S[k][i] = Σ_j D[i,j], exact in fixed point), stationarity of the generating labels,
