@@ -65,6 +65,13 @@ typedef struct rc_sweep_stats {
  * device_id: HIP device ordinal. */
 int32_t rc_create(int64_t n, const double *D, const double *logD_or_null, int32_t storage_bits,
                   int32_t device_id, int64_t kcap, rc_ctx **out);
+/* MCMCData(points) constructor, src/types.jl:159-162: D = pairwise(Euclidean(), makematrix(pnts), dims=2) is
+ * computed on the device from the n×dim row-major points (the n×n matrix never exists on the host), then
+ * everything proceeds as in rc_create.  SURVEY.md §8f-2. */
+int32_t rc_create_from_points(int64_t n, int64_t dim, const double *points, int32_t storage_bits, int32_t device_id,
+                              int64_t kcap, rc_ctx **out);
+/* The matrix the device actually holds (which = 0: D, 1: logD), as doubles: value = q·2^-e exactly. */
+int32_t rc_get_matrix(rc_ctx *ctx, int32_t which, double *out_n_by_n);
 int32_t rc_destroy(rc_ctx *ctx);
 
 /* Last error text of ctx (or of the calling thread's last failed rc_create when ctx == NULL). */

@@ -861,3 +861,30 @@ int orc_sample_labels(int64_t n, const double *D, const double *logD, const int6
     free(pc); free(ps);
     return naccept;
 }
+
+
+/* MCMCData(points) (src/types.jl:159-162): D = pairwise(Euclidean(), makematrix(pnts), dims=2).  Distances.jl
+ * (third party, not under the reference checkout; restated from its published algorithm for a single matrix):
+ * sa2[i] = Σ_k a[k,i]², R = a'a, r[i,j] = sqrt(max(sa2[i] + sa2[j] − 2R[i,j], 0)) for i > j, mirrored, diagonal 0.
+ * pts: n×dim row-major (point i = pts[i*dim .. ]).  R's BLAS summation order is unspecified; plain ascending here. */
+void orc_pairwise_euclidean(int64_t n, int64_t dim, const double *pts, double *D)
+{
+    double *sa2 = malloc((size_t)n * sizeof(double));
+    for (int64_t i = 0; i < n; ++i) {
+        double s = 0;
+        for (int64_t k = 0; k < dim; ++k) s += pts[i * dim + k] * pts[i * dim + k];
+        sa2[i] = s;
+    }
+    for (int64_t j = 0; j < n; ++j) {
+        D[j * n + j] = 0;
+        for (int64_t i = j + 1; i < n; ++i) {
+            double r = 0;
+            for (int64_t k = 0; k < dim; ++k) r += pts[i * dim + k] * pts[j * dim + k];
+            double d2 = sa2[i] + sa2[j] - 2 * r;
+            double d = sqrt(d2 > 0 ? d2 : 0);
+            D[i * n + j] = d;
+            D[j * n + i] = d;
+        }
+    }
+    free(sa2);
+}

@@ -54,6 +54,8 @@ _up = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
 # every symbol include/redclust_hip.h declares, with its ctypes signature
 SIGNATURES = {
     "rc_create": (C.c_int32, [C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_void_p)]),
+    "rc_create_from_points": (C.c_int32, [C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_void_p)]),
+    "rc_get_matrix": (C.c_int32, [C.c_void_p, C.c_int32, _dp]),
     "rc_destroy": (C.c_int32, [C.c_void_p]),
     "rc_last_error": (C.c_char_p, [C.c_void_p]),
     "rc_set_params": (C.c_int32, [C.c_void_p, C.POINTER(RcParams)]),
@@ -119,6 +121,28 @@ class Context:
         if rc != RC_OK:
             raise RedClustHIPError(rc, self.L.rc_last_error(None).decode())
         self.h = h
+
+    @classmethod
+    def from_points(cls, points, device: int = 0, kcap: int = 0, storage_bits: int = 64):
+        """MCMCData(points) on the device: pairwise Euclidean distances are computed there (types.jl:159-162)."""
+        self = cls.__new__(cls)
+        self.L = lib()
+        pts = np.ascontiguousarray(points, dtype=np.float64)
+        if pts.ndim != 2:
+            raise ValueError("points must be an n×dim array (one observation per row)")
+        self.n = int(pts.shape[0])
+        h = C.c_void_p()
+        rc = self.L.rc_create_from_points(self.n, int(pts.shape[1]), pts.ctypes.data_as(C.c_void_p), storage_bits, device,
+                                          kcap, C.byref(h))
+        if rc != RC_OK:
+            raise RedClustHIPError(rc, self.L.rc_last_error(None).decode())
+        self.h = h
+        return self
+
+    def get_matrix(self, which=0):
+        out = np.zeros((self.n, self.n))
+        self._chk(self.L.rc_get_matrix(self.h, int(which), out.reshape(-1)))
+        return out
 
     def _chk(self, rc):
         if rc != RC_OK:

@@ -49,14 +49,15 @@ def run_chains(data, options, params, init, *, base_seed: int = 1, verbose: bool
     from .sampler import runsampler
     rank = dist.get_rank() if dist.is_initialized() else 0
     local = int(os.environ.get("LOCAL_RANK", 0))
-    ctx = Context(data.D, device=local, kcap=kcap)
+    ctx = (Context.from_points(data.points, device=local, kcap=kcap) if data.points is not None
+           else Context(data.D, device=local, kcap=kcap))
     try:
         res = runsampler(data, options, params, init, verbose=verbose and rank == 0,
                          seed=chain_seed(base_seed, rank), ctx=ctx)
         counts = device_counts_tensor(ctx, local)
         traces = dict(rank=rank, K=res.K, r=res.r, p=res.p, loglik=res.loglik, logposterior=res.logposterior)
         counts, total, chains = merge_chains(counts, options.numsamples, traces)
-        n = data.D.shape[0]
+        n = data.n
         merged = counts[:, :n].to(torch.float64).cpu().numpy() / max(total, 1)
         return res, merged, chains
     finally:

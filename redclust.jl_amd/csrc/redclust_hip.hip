@@ -169,6 +169,70 @@ __global__ void k_maxabs(const double *__restrict__ X, size_t total, unsigned *f
     atomicMax(maxabs_bits, m);
 }
 
+// Pairwise Euclidean distances of n points in R^dim (MCMCData(points), src/types.jl:159-162:
+// pairwise(Euclidean(), makematrix(pnts), dims=2); Distances.jl evaluates sqrt(max(|a_i|² + |a_j|² − 2 a_i·a_j, 0)),
+// mirrors the triangle and zeroes the diagonal).  pts is n×dim row-major (= the dim×N column-major matrix of
+// makematrix).  64×64 pairs per block, 4×4 per thread, dim tiled by 16 through LDS; the dot product runs in
+// ascending coordinate order for both (i,j) and (j,i), so the result is exactly symmetric.
+__global__ __launch_bounds__(256) void k_pairwise(const double *__restrict__ pts, int n, int dim, double *__restrict__ D)
+{
+    const int tj = blockIdx.x, ti = blockIdx.y;
+    if (ti < tj) return;  // lower block triangle (incl. diagonal blocks); mirrored on store
+    __shared__ double A[16][65], B[16][65];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    double acc[4][4], sa[4], sb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { sa[u] = 0; sb[u] = 0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = 0; }
+    for (int k0 = 0; k0 < dim; k0 += 16) {
+        for (int q = threadIdx.x; q < 16 * 64; q += 256) {
+            const int kk = q & 15, r = q >> 4;
+            const int gi = ti * 64 + r, gj = tj * 64 + r, k = k0 + kk;
+            A[kk][r] = (gi < n && k < dim) ? pts[(size_t)gi * dim + k] : 0.0;
+            B[kk][r] = (gj < n && k < dim) ? pts[(size_t)gj * dim + k] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = A[kk][ty * 4 + u]; b[u] = B[kk][tx * 4 + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                sa[u] += a[u] * a[u];
+                sb[u] += b[u] * b[u];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] += a[u] * b[v];
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int i = ti * 64 + ty * 4 + u, j = tj * 64 + tx * 4 + v;
+            if (i < n && j < n) {
+                const double d2 = sa[u] + sb[v] - 2.0 * acc[u][v];
+                const double d = (i == j) ? 0.0 : sqrt(d2 > 0.0 ? d2 : 0.0);
+                D[(size_t)i * n + j] = d;
+                if (ti != tj) D[(size_t)j * n + i] = d;
+            }
+        }
+}
+
+// fixed-point matrix back to doubles (value = q·2^-e), for checks
+template <typename T>
+__global__ void k_dequantize(const T *__restrict__ Q, int n, int ld, double scale, double *__restrict__ out)
+{
+    const size_t total = (size_t)n * n;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = t / n, j = t % n;
+        out[t] = (double)Q[i * ld + j] * scale;
+    }
+}
+
 template <typename T>
 __global__ void k_quantize(const double *__restrict__ X, int n, int ld, int e, T *__restrict__ Q,
                            long long *__restrict__ diag_or_null)
@@ -1018,7 +1082,8 @@ extern "C" int32_t rc_destroy(rc_ctx *ctx)
     return RC_OK;
 }
 
-static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *logD)
+static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *logD, const double *points = nullptr,
+                           int64_t dim = 0)
 {
     HIPCHK(c, hipSetDevice(c->dev));
     hipDeviceProp_t prop;
@@ -1054,7 +1119,7 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     } while (0)
     hipStream_t s = c->sA;
     HIPCHK2(hipMalloc(&tmpD, nn * sizeof(double)));
-    HIPCHK2(hipMalloc(&tmpL, nn * sizeof(double)));
+    HIPCHK2(hipMalloc(&tmpL, std::max(nn, (size_t)n * (size_t)std::max<int64_t>(dim, 1)) * sizeof(double)));
     HIPCHK2(hipMalloc(&flags, 2 * sizeof(unsigned)));
     HIPCHK2(hipMalloc(&mx, 2 * sizeof(u64)));
     const size_t esz = (size_t)c->bits / 8;
@@ -1089,8 +1154,15 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     HIPCHK2(hipMemsetAsync(c->sc, 0, sizeof(DevScalars), s));
     HIPCHK2(hipMemsetAsync(flags, 0, 2 * sizeof(unsigned), s));
     HIPCHK2(hipMemsetAsync(mx, 0, 2 * sizeof(u64), s));
-    HIPCHK2(hipMemcpyAsync(tmpD, D, nn * sizeof(double), hipMemcpyHostToDevice, s));
     const int gb = std::min<size_t>((nn + 255) / 256, 4096);
+    if (points) {
+        // MCMCData(points): distances are computed on the device, no n×n host matrix is involved
+        HIPCHK2(hipMemcpyAsync(tmpL, points, (size_t)n * (size_t)dim * sizeof(double), hipMemcpyHostToDevice, s));  // tmpL as staging
+        const unsigned nt = (unsigned)((n + 63) / 64);
+        k_pairwise<<<dim3(nt, nt), 256, 0, s>>>(tmpL, (int)n, (int)dim, tmpD);
+    } else {
+        HIPCHK2(hipMemcpyAsync(tmpD, D, nn * sizeof(double), hipMemcpyHostToDevice, s));
+    }
     k_check<<<gb, 256, 0, s>>>(tmpD, (int)n, flags, mx);
     if (logD) {
         HIPCHK2(hipMemcpyAsync(tmpL, logD, nn * sizeof(double), hipMemcpyHostToDevice, s));
@@ -1130,12 +1202,8 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     return RC_OK;
 }
 
-extern "C" int32_t rc_create(int64_t n, const double *D, const double *logD_or_null, int32_t storage_bits,
-                             int32_t device_id, int64_t kcap, rc_ctx **out)
+static int32_t alloc_ctx(int64_t n, int32_t storage_bits, int32_t device_id, int64_t kcap, rc_ctx **out)
 {
-    if (!out) return fail(nullptr, RC_ERR_ARG, "rc_create: out is NULL");
-    *out = nullptr;
-    if (!D) return fail(nullptr, RC_ERR_ARG, "rc_create: D is NULL");
     if (n < 1 || n > (1 << 20)) return fail(nullptr, RC_ERR_ARG, "rc_create: n must be in 1..2^20 (got %lld)", (long long)n);
     if (storage_bits != 64 && storage_bits != 32) return fail(nullptr, RC_ERR_ARG, "rc_create: storage_bits must be 64 or 32");
     if (kcap == 0) kcap = std::min<int64_t>(n, 1024);
@@ -1154,12 +1222,13 @@ extern "C" int32_t rc_create(int64_t n, const double *D, const double *logD_or_n
     c->kcap = (int)kcap;
     c->dbg = getenv("RC_DEBUG_FLAGS") ? atoi(getenv("RC_DEBUG_FLAGS")) : 0;
     c->prefetch = !(getenv("RC_NO_PREFETCH") && atoi(getenv("RC_NO_PREFETCH")));
-    int32_t rc = create_impl(c, n, D, logD_or_null);
-    if (rc != RC_OK) {
-        snprintf(g_err, sizeof(g_err), "%s", c->err);
-        free_all(c);
-        return rc;
-    }
+    *out = c;
+    return RC_OK;
+}
+
+// launch geometry and LDS attributes that depend on (n, kcap, bits)
+static int32_t finish_create(rc_ctx *c)
+{
     const int nchunks = (c->n + RC_PTS - 1) / RC_PTS;
     c->G = std::max(1, std::min(nchunks, c->num_cus));
     {
@@ -1175,21 +1244,81 @@ extern "C" int32_t rc_create(int64_t n, const double *D, const double *logD_or_n
             (void)hipFuncSetAttribute(c->bits == 64 ? (const void *)k_bulk<long long> : (const void *)k_bulk<int>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->bulk_lds);
     }
+    // kernels whose dynamic LDS can exceed the 64 KiB default (large kcap)
+    const size_t lds_r = std::max(tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64), 2 * sizeof(int) * (size_t)c->kcap);
+    const size_t lds_d = std::max(tab_bytes(c->kcap, c->n, 1), 2 * sizeof(int) * (size_t)c->kcap);
+    const size_t lds_b = (size_t)c->kcap * 4 * sizeof(u64);
+    hipError_t e1 = hipFuncSetAttribute((const void *)k_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
+    hipError_t e2 = hipFuncSetAttribute((const void *)k_blocksums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+    hipError_t e3 = hipFuncSetAttribute((const void *)k_derive, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || lds_r > 160 * 1024 || lds_b > 160 * 1024)
+        return fail(c, RC_ERR_ARG, "rc_create: kcap=%d needs more LDS than a CU has", c->kcap);
+    return RC_OK;
+}
+
+extern "C" int32_t rc_create(int64_t n, const double *D, const double *logD_or_null, int32_t storage_bits,
+                             int32_t device_id, int64_t kcap, rc_ctx **out)
+{
+    if (!out) return fail(nullptr, RC_ERR_ARG, "rc_create: out is NULL");
+    *out = nullptr;
+    if (!D) return fail(nullptr, RC_ERR_ARG, "rc_create: D is NULL");
+    rc_ctx *c = nullptr;
     {
-        // kernels whose dynamic LDS can exceed the 64 KiB default (large kcap)
-        const size_t lds_r = std::max(tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64), 2 * sizeof(int) * (size_t)c->kcap);
-        const size_t lds_d = std::max(tab_bytes(c->kcap, c->n, 1), 2 * sizeof(int) * (size_t)c->kcap);
-        const size_t lds_b = (size_t)c->kcap * 4 * sizeof(u64);
-        hipError_t e1 = hipFuncSetAttribute((const void *)k_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
-        hipError_t e2 = hipFuncSetAttribute((const void *)k_blocksums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
-        hipError_t e3 = hipFuncSetAttribute((const void *)k_derive, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d);
-        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || lds_r > 160 * 1024 || lds_b > 160 * 1024) {
-            fail(nullptr, RC_ERR_ARG, "rc_create: kcap=%d needs more LDS than a CU has", c->kcap);
-            free_all(c);
-            return RC_ERR_ARG;
-        }
+        int32_t rc0 = alloc_ctx(n, storage_bits, device_id, kcap, &c);
+        if (rc0 != RC_OK) return rc0;
+    }
+    int32_t rc = create_impl(c, n, D, logD_or_null);
+    if (rc == RC_OK) rc = finish_create(c);
+    if (rc != RC_OK) {
+        snprintf(g_err, sizeof(g_err), "%s", c->err);
+        free_all(c);
+        return rc;
     }
     *out = c;
+    return RC_OK;
+}
+
+// MCMCData(points) constructor, src/types.jl:159-162: D = pairwise(Euclidean(), makematrix(pnts), dims=2), computed
+// on the device (k_pairwise) — the n×n matrix never exists on the host.  points: n×dim row-major.
+extern "C" int32_t rc_create_from_points(int64_t n, int64_t dim, const double *points, int32_t storage_bits,
+                                         int32_t device_id, int64_t kcap, rc_ctx **out)
+{
+    if (!out) return fail(nullptr, RC_ERR_ARG, "rc_create_from_points: out is NULL");
+    *out = nullptr;
+    if (!points) return fail(nullptr, RC_ERR_ARG, "rc_create_from_points: points is NULL");
+    if (dim < 1 || dim > (1 << 20)) return fail(nullptr, RC_ERR_ARG, "rc_create_from_points: dim must be in 1..2^20");
+    rc_ctx *c = nullptr;
+    int32_t rc = alloc_ctx(n, storage_bits, device_id, kcap, &c);
+    if (rc != RC_OK) return rc;
+    rc = create_impl(c, n, nullptr, nullptr, points, dim);
+    if (rc == RC_OK) rc = finish_create(c);
+    if (rc != RC_OK) {
+        snprintf(g_err, sizeof(g_err), "%s", c->err);
+        free_all(c);
+        return rc;
+    }
+    *out = c;
+    return RC_OK;
+}
+
+// The fixed-point matrix held on the device, as doubles (which = 0: D, 1: logD); value = q·2^-e exactly.
+extern "C" int32_t rc_get_matrix(rc_ctx *c, int32_t which, double *out_n_by_n)
+{
+    if (!c || !out_n_by_n) return fail(c, RC_ERR_ARG, "rc_get_matrix: NULL argument");
+    if (which != 0 && which != 1) return fail(c, RC_ERR_ARG, "rc_get_matrix: which must be 0 (D) or 1 (logD)");
+    HIPCHK(c, hipSetDevice(c->dev));
+    const size_t nn = (size_t)c->n * c->n;
+    double *tmp = nullptr;
+    HIPCHK(c, hipMalloc(&tmp, nn * sizeof(double)));
+    const int gb = (int)std::min<size_t>((nn + 255) / 256, 8192);
+    const void *Q = which ? c->Lq : c->Dq;
+    const double scale = std::ldexp(1.0, -(which ? c->eL : c->eD));
+    if (c->bits == 64) k_dequantize<long long><<<gb, 256, 0, c->sA>>>((const long long *)Q, c->n, c->ld, scale, tmp);
+    else k_dequantize<int><<<gb, 256, 0, c->sA>>>((const int *)Q, c->n, c->ld, scale, tmp);
+    hipError_t e = hipMemcpyAsync(out_n_by_n, tmp, nn * sizeof(double), hipMemcpyDeviceToHost, c->sA);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->sA);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(c, RC_ERR_HIP, "rc_get_matrix: %s", hipGetErrorString(e));
     return RC_OK;
 }
 

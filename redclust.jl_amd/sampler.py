@@ -91,11 +91,12 @@ def runsampler(data: MCMCData, options: MCMCOptionsList | None = None, params: P
         raise ValueError("splitmerge must be 'as_written' or 'intended'")
     out = print if verbose else (lambda *a, **k: None)
     rng = rng or np.random.default_rng(seed)
-    n = data.D.shape[0]
+    n = data.n
     numiters, burnin, thin, numsamples = options.numiters, options.burnin, options.thin, options.numsamples
     own_ctx = ctx is None
     if own_ctx:
-        ctx = Context(data.D, device=device, kcap=kcap)
+        ctx = (Context.from_points(data.points, device=device, kcap=kcap) if data.points is not None
+               else Context(data.D, device=device, kcap=kcap))
     try:
         ctx.set_params(**params.as_dict())
         ctx.set_state(init.clusts)

@@ -83,21 +83,39 @@ class MCMCData:
 
     def __init__(self, D_or_points):
         x = D_or_points
+        self.points = None
+        self._D = None
+        self._logD = None
         if isinstance(x, (list, tuple)) or (isinstance(x, np.ndarray) and x.ndim == 2 and x.shape[0] != x.shape[1]):
-            pts = np.asarray(x, dtype=np.float64)  # one observation per row (makematrix + pairwise, types.jl:159-162)
-            g = pts @ pts.T
-            sq = np.diag(g)
-            D = np.sqrt(np.maximum(sq[:, None] + sq[None, :] - 2 * g, 0.0))
-            D = (D + D.T) / 2
-            np.fill_diagonal(D, 0.0)
-        else:
-            D = np.asarray(x, dtype=np.float64)
+            # points (one observation per row): the device computes the distances (rc_create_from_points); the host
+            # matrix is only materialised if somebody reads .D (e.g. the split–merge step)
+            self.points = np.ascontiguousarray(x, dtype=np.float64)
+            if self.points.ndim != 2:
+                raise ValueError("points must be a vector of equal-length vectors")
+            return
+        D = np.asarray(x, dtype=np.float64)
         if D.ndim != 2 or D.shape[0] != D.shape[1]:
             raise ValueError("D must be a square matrix.")
         if np.any(D != D.T):
             raise ValueError("D must be symmetric.")
-        self.D = np.ascontiguousarray(D)
-        self._logD = None
+        self._D = np.ascontiguousarray(D)
+
+    @property
+    def n(self):
+        return self.points.shape[0] if self._D is None else self._D.shape[0]
+
+    @property
+    def D(self):
+        if self._D is None:  # pairwise(Euclidean(), makematrix(pnts), dims=2), types.jl:159-162
+            pts = self.points
+            sq = np.einsum("ij,ij->i", pts, pts)
+            D2 = sq[:, None] + sq[None, :] - 2 * (pts @ pts.T)
+            np.maximum(D2, 0.0, out=D2)
+            D = np.sqrt(D2)
+            D = np.minimum(D, D.T)
+            np.fill_diagonal(D, 0.0)
+            self._D = np.ascontiguousarray(D)
+        return self._D
 
     @property
     def logD(self):
@@ -109,7 +127,7 @@ class MCMCData:
         return self._logD
 
     def __repr__(self):
-        return f"MCMC data : {self.D.shape[0]}×{self.D.shape[0]} dissimilarity matrix."
+        return f"MCMC data : {self.n}×{self.n} dissimilarity matrix."
 
 
 @dataclass
@@ -149,7 +167,7 @@ class MCMCResult:
 
     @classmethod
     def allocate(cls, data: MCMCData, options: MCMCOptionsList, params: PriorHyperparamsList):
-        n, ns = data.D.shape[0], options.numsamples
+        n, ns = data.n, options.numsamples
         return cls(options=options, params=params, clusts=[np.zeros(n, np.int64) for _ in range(ns)],
                    posterior_coclustering=None, K=np.zeros(ns, np.int64), K_acf=np.zeros(ns), r=np.zeros(ns),
                    r_acf=np.zeros(ns), p=np.zeros(ns), p_acf=np.zeros(ns), loglik=np.zeros(ns),

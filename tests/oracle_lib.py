@@ -75,6 +75,7 @@ def lib():
     L.orc_vecsum_idx.restype = f64
     L.orc_vecsum_idx.argtypes = [_dp, _ip, i64]
     _bp = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+    L.orc_pairwise_euclidean.argtypes = [i64, i64, _dp, _dp]
     L.orc_uniform_mh.restype = f64
     L.orc_uniform_mh.argtypes = [u64, u64, u64, u64]
     L.orc_mh_proposal.argtypes = [i64, _dp, _dp, C.c_void_p, C.c_void_p, i32, i32, _ip, _ip, C.POINTER(i64), PP, f64, f64,

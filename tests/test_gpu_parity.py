@@ -346,6 +346,41 @@ def test_splitmerge_intended_mode_and_runsampler_defaults():
         assert res.K.shape == (48,) and res.posterior_coclustering.shape == (100, 100)
 
 
+def test_device_pairwise_distances():
+    """MCMCData(points) on the device (rc_create_from_points, types.jl:159-162) vs the oracle's restatement of
+    Distances.jl's pairwise Euclidean: exact symmetry and zero diagonal, values within 1e-12 relative (the dot
+    products' summation order is unspecified in the reference too), and the same sweep trajectory as a context
+    built from the resulting matrices."""
+    data = rc.generatemixture(777, 9, seed=4, sigma=0.2, dim=37)
+    pts, truth = data["points"], data["clusts"]
+    ref = np.zeros((777, 777))
+    O.lib().orc_pairwise_euclidean(777, 37, np.ascontiguousarray(pts), ref.reshape(-1))
+    ctx = rc.Context.from_points(pts)
+    Dd, Ld = ctx.get_matrix(0), ctx.get_matrix(1)
+    assert np.array_equal(Dd, Dd.T) and np.all(np.diag(Dd) == 0) and np.all(np.diag(Ld) == 0)
+    assert np.max(np.abs(Dd - ref)) <= 1e-12 * ref.max()
+    off = ~np.eye(777, dtype=bool)
+    assert np.max(np.abs(Ld[off] - np.log(ref[off]))) <= 1e-11
+    P = rc.likelihood_hyperparams(ref, truth)
+    ctx2 = rc.Context(Dd, logD=Ld)           # re-quantises to the same integers
+    init = np.random.default_rng(4).integers(1, 10, size=777).astype(np.int64)
+    for c in (ctx, ctx2):
+        c.set_params(**P); c.set_state(init)
+    for t in range(5):
+        r, p = rp_schedule(t)
+        ctx.gibbs_sweep(r, p, 3, t); ctx2.gibbs_sweep(r, p, 3, t)
+        a, b = ctx.get_state(), ctx2.get_state()
+        assert np.array_equal(a[0], b[0]) and a[2] == b[2]
+    assert ctx.loglik() == ctx2.loglik()
+    ctx.close(); ctx2.close()
+    # the host surface: MCMCData(points) + runsampler never builds the n×n matrix on the host for numMH = 0
+    md = rc.MCMCData(pts)
+    params = rc.PriorHyperparamsList(**{k: P[k] for k in ("delta1", "delta2", "alpha", "beta", "zeta", "gamma")})
+    res = rc.runsampler(md, rc.MCMCOptionsList(numiters=20, numMH=0), params, rc.MCMCState(truth, 1.0, 0.5), verbose=False)
+    assert md._D is None and res.K.shape == (16,) and np.isfinite(res.logposterior).all()
+    assert np.max(np.abs(md.D - ref)) <= 1e-12 * ref.max() and np.array_equal(md.D, md.D.T)
+
+
 def test_incremental_mode_is_bit_identical():
     """RC_MODE_INCREMENTAL (row-sum table maintained by exact corrections only) vs RC_MODE_FULL (recomputed every
     sweep) vs the oracle: same labels every sweep, identical loglik bits, identical row sums; switching modes
