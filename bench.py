@@ -73,7 +73,7 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    distributed = world > 1
+    distributed = world > 1 or bool(os.environ.get("RC_BENCH_FORCE_DIST"))  # force: exercise the RCCL path on one GPU
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -148,12 +148,15 @@ def main():
         diag_ok = True
 
     if rank == 0:
-        alg_bytes = 2.0 * n * n * (BITS / 8.0)        # every row of D and of logD read once per sweep
+        # bytes of matrix data the selected row-reduction kernel has to read per sweep: k_bulk reads every entry of D
+        # and logD (2·n²·sizeof); k_bulk_sym exploits symmetry and reads the upper triangle only
+        kernel_name, alg_bytes = ctx.bulk_kernel_info()
+        full_bytes = 2.0 * n * n * (BITS / 8.0)
         value = world * args.steps / dt
         bulk_avg_ms = bulk_ms / max(bulk_launches, 1)
         achieved = alg_bytes / (bulk_avg_ms * 1e-3) / 1e9 if bulk_launches else None
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01", f"pmc_traffic_n{n}.json")
+        pmc = os.path.join(ROOT, "profiles", "r01", f"pmc_traffic_n{n}_{kernel_name}.json")
         if os.path.exists(pmc) and BITS == 64:
             # HBM bytes per k_bulk launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950
             # FETCH_SIZE correction applied); collected offline with the same command, see the file's "source"
@@ -168,10 +171,11 @@ def main():
                        "chains": world, "n": n, "K": K, "parallelism": f"chains x{world}"},
             "sweep_GBps_algorithmic": value / world * alg_bytes / 1e9,
             "sweep_frac_of_hbm_peak": value / world * alg_bytes / 1e9 / HBM_PEAK_GBPS,
+            "sweep_GBps_vs_reference_dataflow": value / world * full_bytes / 1e9,  # 2·n²·sizeof per sweep, what the reference reads
             "label_changes_last_sweep": stats["n_changes"], "K_final": stats["K"],
             "incremental_mode_sweeps_per_s_rank0": inc_sweeps_per_s,
             "coclustering_allreduce_ms": allreduce_ms, "coclustering_diag_ok": diag_ok,
-            "roofline": {"kernel": "k_bulk", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"kernel": kernel_name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
                          "avg_launch_ms": bulk_avg_ms, "launches": bulk_launches, "algorithmic_bytes_per_launch": alg_bytes},
         }

@@ -151,6 +151,12 @@ int32_t rc_debug_rowsums(rc_ctx *ctx, int64_t label, int64_t *sumD_q /* n */, in
  * negative = just read the counters. */
 int32_t rc_kernel_timing(rc_ctx *ctx, int32_t enable, double *bulk_ms_total, int64_t *bulk_launches);
 
+/* Which row-reduction kernel the last enqueued sweep used — 0: k_bulk (reads every entry of D and logD, any point
+ * order), 1: k_bulk_sym (reads only the upper triangle; chosen automatically when the points of a cluster are
+ * contiguous in the point order, override with RC_BULK_KERNEL=perm|sym|auto) — and the matrix bytes that kernel
+ * has to read per launch. */
+int32_t rc_bulk_kernel_info(rc_ctx *ctx, int32_t *which, double *algorithmic_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,6 +79,7 @@ SIGNATURES = {
     "rc_state_checkpoint": (C.c_int32, [C.c_void_p]),
     "rc_state_restore": (C.c_int32, [C.c_void_p]),
     "rc_debug_rowsums": (C.c_int32, [C.c_void_p, C.c_int64, _ip, _ip, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "rc_bulk_kernel_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "rc_kernel_timing": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 
@@ -258,6 +259,11 @@ class Context:
         eD, eL = C.c_int32(), C.c_int32()
         self._chk(self.L.rc_debug_rowsums(self.h, int(label), sd, sl, C.byref(eD), C.byref(eL)))
         return sd, sl, eD.value, eL.value
+
+    def bulk_kernel_info(self):
+        w, b = C.c_int32(), C.c_double()
+        self._chk(self.L.rc_bulk_kernel_info(self.h, C.byref(w), C.byref(b)))
+        return ("k_bulk_sym" if w.value else "k_bulk"), b.value
 
     def kernel_timing(self, enable=-1):
         ms = C.c_double()

@@ -63,14 +63,14 @@ struct DevScalars {
     int smallest_empty;     // smallest empty label (1-based), n+1 if none   (findfirst(clustsizes .== 0), mcmc.jl:199)
     int slot_hi;            // 1 + highest slot index used since rc_set_state (rows >= slot_hi of every S buffer are zero)
     int last_change_sweep;  // internal index of the last sweep that changed a label (-1: none)
-    int pad;
+    int runs;               // number of label runs in natural point order (#{i : slot[i] != slot[i-1]} + 1)
 };
 
 // Per-sweep summary written by block 0 of k_resolve straight into host-mapped pinned memory: the host needs K and
 // the cluster sizes after every sweep for the scalar r / p updates (src/mcmc.jl:84-89,139-144) —
 // one stream synchronisation and no copy call.
 struct HostSummary {
-    int K, n_changes, n_rounds, err, slot_hi, seq, pad0, pad1;
+    int K, n_changes, n_rounds, err, slot_hi, seq, runs, pad1;
     int size_label[2 * RC_MAX_KCAP];  // [2k] = size of slot k, [2k+1] = its 1-based label (0 = free)
 };
 
@@ -87,6 +87,8 @@ struct View {
     short *slot_pos;           // [kcap] rank of the slot's label among active labels
     short *slot_act;           // [kcap] slot_act[pos] = slot
     int *perm[2], *pslot[2];   // [n] rows grouped by slot, and the slot of each sorted position (two generations)
+    int *snap[2];              // [n] slot of every point as it was when the generation was written (k_bulk_sym reads these)
+    int *work[2];              // work-item counters of k_bulk_sym (two generations)
     const double *A;           // [n+1] size table
     u64 *keys[2];              // [n+2] one first-change word per round (two generations)
     unsigned *arrive[2];       // grid-barrier arrival counters (two generations)
@@ -312,6 +314,7 @@ __global__ __launch_bounds__(256) void k_bulk(View V, int rows_per_split, int wg
         ll2 *zd = (ll2 *)V.SD[zgen], *zl = (ll2 *)V.SL[zgen];
         const ll2 z = {0, 0};
         for (size_t q = me; q < total2; q += nthreads) { zd[q] = z; zl[q] = z; }
+        if (me == 0) { *V.work[0] = 0; *V.work[1] = 0; }  // keep k_bulk_sym's work counters armed if the kernels alternate
     }
     const int i = (blockIdx.x * 256 + threadIdx.x) * C;
     const int p0 = blockIdx.y * rows_per_split;
@@ -359,6 +362,199 @@ __global__ __launch_bounds__(256) void k_bulk(View V, int rows_per_split, int wg
         for (int q = 0; q < C; ++q) { aD[q] += (long long)d[q]; aL[q] += (long long)l[q]; }
     }
     flush(cur);
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// k_bulk_sym — symmetric row-bucket reduction (64-bit storage): reads only the upper triangle of D and logD.
+// Every entry x = X[a][b], a < b, contributes to S[slot_a][b] (direction 1) and to S[slot_b][a] (direction 2); the
+// diagonal goes to S[slot_a][a].  Algorithmic traffic n²·8 B (both matrices) instead of 2·n²·8 B.
+//   A 32-row × 128-column tile of each matrix (strictly-upper entries, others zeroed) is staged in LDS.
+//   Waves 0-1: one column per lane, accumulate DOWN the rows in registers carried across the tiles of a work item;
+//   waves 2-3: one (row, matrix) per lane, accumulate ALONG 64 columns.  Rows/columns are taken 8 at a time; an
+//   8-chunk whose points share a slot is summed without looking at labels (fast path), a mixed chunk element by
+//   element.  Flushes are coalesced 64-bit integer atomics, so the result is exact for ANY labelling; the kernel is
+//   merely fastest when points of a cluster are contiguous (few label runs) — the host picks k_bulk otherwise.
+//   Persistent blocks pull work items (column block J, range of row tiles) from an atomic counter, heavy column
+//   blocks first.  Labels come from the snapshot generation written two sweeps ago (see software pipelining).
+// ---------------------------------------------------------------------------------------------------
+#define RC_SYM_TR 32
+#define RC_SYM_TC 128
+#define RC_SYM_TP (RC_SYM_TC + 2)  // row pitch in elements: row threads hit distinct LDS banks
+__global__ __launch_bounds__(256) void k_bulk_sym(View V, int wgen, int zgen, int sgen, int cgen, int item_tiles, int nitems)
+{
+    __shared__ __attribute__((aligned(16))) long long tt[2][RC_SYM_TR][RC_SYM_TP];  // [matrix][row][col]
+    __shared__ int item_sh, J_sh;
+    __shared__ int cslot[RC_SYM_TC], rslot[RC_SYM_TR];
+    __shared__ int cchk[RC_SYM_TC / 8], rchk[RC_SYM_TR / 8];  // slot of an 8-wide chunk if uniform, else -2
+    const int tid = threadIdx.x;
+    const size_t ld = (size_t)V.ld;
+    {   // clear generation zgen, rows < slot_hi (rows above are zero by invariant); re-arm the other work counter
+        const int hi = V.sc->slot_hi;
+        const size_t total2 = (size_t)hi * ld / 2;
+        const size_t nthreads = (size_t)gridDim.x * 256;
+        ll2 *zd = (ll2 *)V.SD[zgen], *zl = (ll2 *)V.SL[zgen];
+        const ll2 z = {0, 0};
+        for (size_t q = (size_t)blockIdx.x * 256 + tid; q < total2; q += nthreads) { zd[q] = z; zl[q] = z; }
+        if (blockIdx.x == 0 && tid == 0) *V.work[cgen ^ 1] = 0;
+    }
+    const long long *__restrict__ Dq = (const long long *)V.Dq;
+    const long long *__restrict__ Lq = (const long long *)V.Lq;
+    const int *__restrict__ slot = V.snap[sgen];
+    long long *SD = V.SD[wgen], *SL = V.SL[wgen];
+    const int n = V.n;
+    const int ncb = (n + RC_SYM_TC - 1) / RC_SYM_TC;
+    int *counter = V.work[cgen];
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) {
+            int item = atomicAdd(counter, 1);
+            int J = -1;
+            if (item < nitems) {
+                for (J = ncb - 1;; --J) {
+                    const int ntile = (min(RC_SYM_TC * J + RC_SYM_TC, n) + RC_SYM_TR - 1) / RC_SYM_TR;
+                    const int cnt = (ntile + item_tiles - 1) / item_tiles;
+                    if (item < cnt) break;
+                    item -= cnt;
+                }
+            }
+            item_sh = item; J_sh = J;
+        }
+        __syncthreads();
+        const int J = J_sh, item = item_sh;
+        if (J < 0) break;
+        const int c0 = J * RC_SYM_TC;
+        const int ntile = (min(c0 + RC_SYM_TC, n) + RC_SYM_TR - 1) / RC_SYM_TR;   // rows a >= c0+128 have no column b > a here
+        const int t_begin = item * item_tiles, t_end = min(ntile, t_begin + item_tiles);
+        if (tid < RC_SYM_TC) cslot[tid] = (c0 + tid < n) ? slot[c0 + tid] : -1;
+        __syncthreads();
+        if (tid < RC_SYM_TC / 8) {
+            const int s0 = cslot[tid * 8];
+            bool u = true;
+            for (int q = 1; q < 8; ++q) u = u && (cslot[tid * 8 + q] == s0);
+            cchk[tid] = u ? s0 : -2;
+        }
+        // loader role: 32 rows x 64 sixteen-byte pieces per matrix = 8 pieces per thread and matrix
+        ll2 d[8], l[8];
+        auto issue = [&](int t) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int piece = q * 256 + tid, lr = piece >> 6, lp = piece & 63;
+                const int r = min(t * RC_SYM_TR + lr, n - 1);
+                d[q] = __builtin_nontemporal_load((const ll2 *)(Dq + (size_t)r * ld + c0 + lp * 2));
+                l[q] = __builtin_nontemporal_load((const ll2 *)(Lq + (size_t)r * ld + c0 + lp * 2));
+            }
+        };
+        issue(t_begin);
+        long long accD = 0, accL = 0;
+        int cur = -1;
+        for (int t = t_begin; t < t_end; ++t) {
+            const int r0 = t * RC_SYM_TR;
+            __syncthreads();  // the previous tile has been consumed
+            if (tid < RC_SYM_TR) rslot[tid] = (r0 + tid < n) ? slot[r0 + tid] : -1;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int piece = q * 256 + tid, lr = piece >> 6, lp = piece & 63;
+                const int r = r0 + lr, b = c0 + lp * 2;
+                const bool live = r < n;
+                ll2 x = d[q], y = l[q];
+                if (!(live && b > r)) { x.x = 0; y.x = 0; }
+                if (!(live && b + 1 > r)) { x.y = 0; y.y = 0; }
+                *(ll2 *)&tt[0][lr][lp * 2] = x;
+                *(ll2 *)&tt[1][lr][lp * 2] = y;
+            }
+            if (t + 1 < t_end) issue(t + 1);  // in flight while this tile is reduced
+            __syncthreads();
+            if (tid < RC_SYM_TR / 8) {
+                const int s0 = rslot[tid * 8];
+                bool u = true;
+                for (int q = 1; q < 8; ++q) u = u && (rslot[tid * 8 + q] == s0);
+                rchk[tid] = u ? s0 : -2;
+            }
+            __syncthreads();
+            if (tid < RC_SYM_TC) {
+                // direction 1: column b = c0 + tid gathers the rows of the tile, grouped by the rows' slots
+                const int b = c0 + tid;
+#pragma unroll
+                for (int ch = 0; ch < RC_SYM_TR / 8; ++ch) {
+                    long long xd[8], xl[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { xd[q] = tt[0][ch * 8 + q][tid]; xl[q] = tt[1][ch * 8 + q][tid]; }
+                    const int cs_ = __builtin_amdgcn_readfirstlane(rchk[ch]);
+                    if (cs_ != -2) {
+                        if (cs_ != cur) {
+                            if (cur >= 0) {
+                                if (accD) __hip_atomic_fetch_add((u64 *)(SD + (size_t)cur * ld + b), (u64)accD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (accL) __hip_atomic_fetch_add((u64 *)(SL + (size_t)cur * ld + b), (u64)accL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            accD = accL = 0; cur = cs_;
+                        }
+                        accD += ((xd[0] + xd[1]) + (xd[2] + xd[3])) + ((xd[4] + xd[5]) + (xd[6] + xd[7]));
+                        accL += ((xl[0] + xl[1]) + (xl[2] + xl[3])) + ((xl[4] + xl[5]) + (xl[6] + xl[7]));
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int sr = __builtin_amdgcn_readfirstlane(rslot[ch * 8 + q]);
+                            if (sr != cur) {
+                                if (cur >= 0) {
+                                    if (accD) __hip_atomic_fetch_add((u64 *)(SD + (size_t)cur * ld + b), (u64)accD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    if (accL) __hip_atomic_fetch_add((u64 *)(SL + (size_t)cur * ld + b), (u64)accL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
+                                accD = accL = 0; cur = sr;
+                            }
+                            accD += xd[q]; accL += xl[q];
+                        }
+                    }
+                }
+            } else {
+                // direction 2: wave 2 -> columns 0..63, wave 3 -> 64..127; lanes 0-31 rows of D, lanes 32-63 rows of logD
+                const int q2 = tid - RC_SYM_TC, half = q2 >> 6, r = q2 & 31, mat = (q2 >> 5) & 1;
+                long long *S = mat ? SL : SD;
+                const int arow = r0 + r;
+                long long acc = 0;
+                int cc = -1;
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch) {
+                    const int cb = half * 64 + ch * 8;
+                    const ll2 x0 = *(const ll2 *)&tt[mat][r][cb], x1 = *(const ll2 *)&tt[mat][r][cb + 2];
+                    const ll2 x2 = *(const ll2 *)&tt[mat][r][cb + 4], x3 = *(const ll2 *)&tt[mat][r][cb + 6];
+                    const int cs_ = __builtin_amdgcn_readfirstlane(cchk[cb >> 3]);
+                    if (cs_ != -2) {
+                        if (cs_ != cc) {
+                            if (cc >= 0 && acc && arow < n) __hip_atomic_fetch_add((u64 *)(S + (size_t)cc * ld + arow), (u64)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            acc = 0; cc = cs_;
+                        }
+                        acc += ((x0.x + x0.y) + (x1.x + x1.y)) + ((x2.x + x2.y) + (x3.x + x3.y));
+                    } else {
+                        const long long xs[8] = {x0.x, x0.y, x1.x, x1.y, x2.x, x2.y, x3.x, x3.y};
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int sc = __builtin_amdgcn_readfirstlane(cslot[cb + q]);
+                            if (sc != cc) {
+                                if (cc >= 0 && acc && arow < n) __hip_atomic_fetch_add((u64 *)(S + (size_t)cc * ld + arow), (u64)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                acc = 0; cc = sc;
+                            }
+                            acc += xs[q];
+                        }
+                    }
+                }
+                if (cc >= 0 && acc && arow < n) __hip_atomic_fetch_add((u64 *)(S + (size_t)cc * ld + arow), (u64)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (tid < RC_SYM_TC && cur >= 0) {
+            const int b = c0 + tid;
+            if (accD) __hip_atomic_fetch_add((u64 *)(SD + (size_t)cur * ld + b), (u64)accD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (accL) __hip_atomic_fetch_add((u64 *)(SL + (size_t)cur * ld + b), (u64)accL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // diagonal (S includes j = i): D[a][a] -> S[slot_a][a]; logD's diagonal is 0 (types.jl:155)
+        if (t_begin == 0 && tid < RC_SYM_TC) {
+            const int a_ = c0 + tid;
+            if (a_ < n) {
+                const long long x = V.diagq[a_];
+                if (x) __hip_atomic_fetch_add((u64 *)(SD + (size_t)slot[a_] * ld + a_), (u64)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -502,6 +698,23 @@ __device__ void tab_store(const View &V, const Tab &T)
     }
 }
 
+// label snapshot of generation g and the run count of the labels in natural point order.  One block.
+__device__ void snapshot_labels(const View &V, int g, int *lds_cnt)
+{
+    if (threadIdx.x == 0) *lds_cnt = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int i = threadIdx.x; i < V.n; i += blockDim.x) {
+        const int s = V.slot_of[i];
+        V.snap[g][i] = s;
+        mine += (i == 0) || (s != V.slot_of[i - 1]);
+    }
+    atomicAdd(lds_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) V.sc->runs = *lds_cnt;
+    __syncthreads();
+}
+
 __device__ void write_summary(const View &V, int n_changes, int n_rounds)
 {
     for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) {
@@ -513,6 +726,7 @@ __device__ void write_summary(const View &V, int n_changes, int n_rounds)
         V.hsum->n_changes = n_changes;
         V.hsum->n_rounds = n_rounds;
         V.hsum->slot_hi = V.sc->slot_hi;
+        V.hsum->runs = V.sc->runs;
         V.hsum->err = __hip_atomic_load(&V.sc->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         V.hsum->seq += 1;
     }
@@ -561,6 +775,9 @@ __global__ __launch_bounds__(1024) void k_derive(View V, int rebuild_perm)
     __syncthreads();
     tab_structural(V, T);
     tab_store(V, T);
+    __syncthreads();
+    snapshot_labels(V, 0, &T.misc[2]);
+    for (int i = threadIdx.x; i < V.n; i += blockDim.x) V.snap[1][i] = V.snap[0][i];
     __syncthreads();
     write_summary(V, 0, 0);
     __syncthreads();
@@ -834,6 +1051,8 @@ __global__ __launch_bounds__(RC_RES_THREADS) void k_resolve(View V, SweepArgs sa
             if (changes) V.sc->last_change_sweep = t;
         }
         __syncthreads();
+        // label snapshot of this generation: k_bulk_sym of sweep t+2 reads it (as the perm generation below)
+        if (changes || last == t - 1 || t < 2) snapshot_labels(V, kg, &T.misc[2]);
         write_summary(V, changes, round + 1);
         // perm generation t%2 must describe the labels after this sweep (k_bulk of sweep t+2 reads it)
         if (changes && ok) {
@@ -949,6 +1168,10 @@ struct rc_ctx {
     int *slot_of = nullptr, *slot_size = nullptr, *slot_label = nullptr;
     short *slot_pos = nullptr, *slot_act = nullptr;
     int *perm[2] = {nullptr, nullptr}, *pslot[2] = {nullptr, nullptr};
+    int *lsnap[2] = {nullptr, nullptr}, *work[2] = {nullptr, nullptr};  // label snapshots / work counters of k_bulk_sym
+    int bulk_kernel = -1;      // RC_BULK_KERNEL: -1 auto, 0 k_bulk (full read, any layout), 1 k_bulk_sym (upper triangle)
+    int last_bulk_kernel = 0;  // what the last enqueue chose
+    int sym_item_tiles = 4;
     double *A = nullptr;
     u64 *keys[2] = {nullptr, nullptr};
     unsigned *arrive[2] = {nullptr, nullptr};
@@ -1019,7 +1242,7 @@ static View make_view(const rc_ctx *c)
     V.n = c->n; V.ld = c->ld; V.kcap = c->kcap;
     V.Dq = c->Dq; V.Lq = c->Lq; V.bits = c->bits; V.diagq = c->diagq;
     for (int g = 0; g < 3; ++g) { V.SD[g] = c->SD[g]; V.SL[g] = c->SL[g]; }
-    for (int g = 0; g < 2; ++g) { V.perm[g] = c->perm[g]; V.pslot[g] = c->pslot[g]; V.keys[g] = c->keys[g]; V.arrive[g] = c->arrive[g]; }
+    for (int g = 0; g < 2; ++g) { V.perm[g] = c->perm[g]; V.pslot[g] = c->pslot[g]; V.keys[g] = c->keys[g]; V.arrive[g] = c->arrive[g]; V.snap[g] = c->lsnap[g]; V.work[g] = c->work[g]; }
     V.slot_of = c->slot_of; V.slot_size = c->slot_size; V.slot_label = c->slot_label;
     V.slot_pos = c->slot_pos; V.slot_act = c->slot_act;
     V.A = c->A; V.sc = c->sc; V.hsum = c->hsum_dev;
@@ -1056,7 +1279,7 @@ static void free_all(rc_ctx *c)
     (void)hipSetDevice(c->dev);
     void *ptrs[] = {c->Dq, c->Lq, c->diagq, c->SD[0], c->SD[1], c->SD[2], c->SL[0], c->SL[1], c->SL[2], c->slot_of,
                     c->slot_size, c->slot_label, c->slot_pos, c->slot_act, c->perm[0], c->perm[1], c->pslot[0],
-                    c->pslot[1], c->A, c->keys[0], c->keys[1], c->arrive[0], c->arrive[1], c->sc, c->blocks,
+                    c->pslot[1], c->lsnap[0], c->lsnap[1], c->work[0], c->work[1], c->A, c->keys[0], c->keys[1], c->arrive[0], c->arrive[1], c->sc, c->blocks,
                     c->counts, c->cc_out, c->snap, c->d_moves};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1133,6 +1356,9 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     for (int g = 0; g < 2; ++g) {
         HIPCHK2(hipMalloc(&c->perm[g], (size_t)n * sizeof(int)));
         HIPCHK2(hipMalloc(&c->pslot[g], (size_t)n * sizeof(int)));
+        HIPCHK2(hipMalloc(&c->lsnap[g], (size_t)n * sizeof(int)));
+        HIPCHK2(hipMalloc(&c->work[g], 64));
+        HIPCHK2(hipMemsetAsync(c->work[g], 0, 64, s));
         HIPCHK2(hipMalloc(&c->keys[g], (size_t)(n + 2) * sizeof(u64)));
         HIPCHK2(hipMalloc(&c->arrive[g], 64));
     }
@@ -1222,6 +1448,8 @@ static int32_t alloc_ctx(int64_t n, int32_t storage_bits, int32_t device_id, int
     c->kcap = (int)kcap;
     c->dbg = getenv("RC_DEBUG_FLAGS") ? atoi(getenv("RC_DEBUG_FLAGS")) : 0;
     c->prefetch = !(getenv("RC_NO_PREFETCH") && atoi(getenv("RC_NO_PREFETCH")));
+    if (getenv("RC_BULK_KERNEL")) c->bulk_kernel = !strcmp(getenv("RC_BULK_KERNEL"), "sym") ? 1 : (!strcmp(getenv("RC_BULK_KERNEL"), "perm") ? 0 : -1);
+    if (getenv("RC_SYM_ITEM_TILES")) c->sym_item_tiles = std::max(1, atoi(getenv("RC_SYM_ITEM_TILES")));
     *out = c;
     return RC_OK;
 }
@@ -1429,6 +1657,7 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
     for (int g = 0; g < 2; ++g) {
         HIPCHK(c, hipMemsetAsync(c->keys[g], 0xFF, (size_t)(n + 2) * sizeof(u64), c->sA));
         HIPCHK(c, hipMemsetAsync(c->arrive[g], 0, 64, c->sA));
+        HIPCHK(c, hipMemsetAsync(c->work[g], 0, 64, c->sA));
     }
     View V = make_view(c);
     const size_t lds = std::max(tab_bytes(c->kcap, c->n, 1), 2 * sizeof(int) * (size_t)c->kcap);
@@ -1456,12 +1685,27 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
         else { HIPCHK(c, hipEventCreate(&ev.first)); HIPCHK(c, hipEventCreate(&ev.second)); }
         HIPCHK(c, hipEventRecord(ev.first, c->sB));
     }
-    // bulk_lds: unused dynamic LDS that caps k_bulk at bulk_blocks_per_cu workgroups per CU, which (i) spreads the
-    // grid evenly over the CUs and (ii) leaves registers/wave slots on every CU for the concurrent k_resolve
-    if (c->bits == 64)
-        k_bulk<long long><<<gb, 256, c->bulk_lds, c->sB>>>(V, c->rows_per_split, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1));
-    else
-        k_bulk<int><<<gb, 256, c->bulk_lds, c->sB>>>(V, c->rows_per_split, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1));
+    // Kernel choice.  k_bulk_sym reads half the bytes but wants the points of a cluster to be contiguous in the
+    // point order (few label runs); both kernels are exact for any labelling, so a stale run count only costs speed.
+    bool use_sym = (c->bits == 64) && (c->bulk_kernel == 1 || (c->bulk_kernel < 0 && (long long)c->hsum->runs * 32 <= (long long)c->n));
+    c->last_bulk_kernel = use_sym ? 1 : 0;
+    if (use_sym) {
+        const int ncb = (c->n + RC_SYM_TC - 1) / RC_SYM_TC;
+        int nitems = 0;
+        for (int J = 0; J < ncb; ++J) {
+            const int ntile = (std::min(RC_SYM_TC * J + RC_SYM_TC, c->n) + RC_SYM_TR - 1) / RC_SYM_TR;
+            nitems += (ntile + c->sym_item_tiles - 1) / c->sym_item_tiles;
+        }
+        const int nblocks = std::max(1, std::min(nitems, 2 * c->num_cus));
+        k_bulk_sym<<<nblocks, 256, 0, c->sB>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), c->sym_item_tiles, nitems);
+    } else {
+        // bulk_lds: unused dynamic LDS that caps k_bulk at bulk_blocks_per_cu workgroups per CU, which (i) spreads the
+        // grid evenly over the CUs and (ii) leaves registers/wave slots on every CU for the concurrent k_resolve
+        if (c->bits == 64)
+            k_bulk<long long><<<gb, 256, c->bulk_lds, c->sB>>>(V, c->rows_per_split, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1));
+        else
+            k_bulk<int><<<gb, 256, c->bulk_lds, c->sB>>>(V, c->rows_per_split, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1));
+    }
     if (timed) {
         HIPCHK(c, hipEventRecord(ev.second, c->sB));
         c->ev_pending.push_back(ev);
@@ -2244,6 +2488,7 @@ extern "C" int32_t rc_set_mode(rc_ctx *c, int32_t mode)
         for (int g = 0; g < 2; ++g) {
             HIPCHK(c, hipMemsetAsync(c->keys[g], 0xFF, (size_t)(c->n + 2) * sizeof(u64), c->sA));
             HIPCHK(c, hipMemsetAsync(c->arrive[g], 0, 64, c->sA));
+            HIPCHK(c, hipMemsetAsync(c->work[g], 0, 64, c->sA));
         }
         const int minus1 = -1;
         HIPCHK(c, hipMemcpyAsync(&c->sc->last_change_sweep, &minus1, sizeof(int), hipMemcpyHostToDevice, c->sA));
@@ -2255,5 +2500,17 @@ extern "C" int32_t rc_set_mode(rc_ctx *c, int32_t mode)
         c->t_next = 0;
         c->bulk_enq = -1;
     }
+    return RC_OK;
+}
+
+
+// Which row-reduction kernel the last enqueued sweep used (0: k_bulk, full read; 1: k_bulk_sym, upper triangle only)
+// and the bytes of matrix data it has to read per launch — what bench.py prices the roofline against.
+extern "C" int32_t rc_bulk_kernel_info(rc_ctx *c, int32_t *which, double *algorithmic_bytes)
+{
+    if (!c) return fail(c, RC_ERR_ARG, "rc_bulk_kernel_info: NULL ctx");
+    const double n = c->n, esz = c->bits / 8.0;
+    if (which) *which = c->last_bulk_kernel;
+    if (algorithmic_bytes) *algorithmic_bytes = c->last_bulk_kernel ? 2.0 * (n * (n + 1) / 2) * esz : 2.0 * n * n * esz;
     return RC_OK;
 }

@@ -1,0 +1,636 @@
+// sym_tune.hip — prototype of the symmetric row-bucket reduction: read only the upper triangle of the symmetric
+// matrices; every entry x = X[a][b] (a < b) contributes to S[slot_a][b] (register accumulation over rows, as k_bulk)
+// and to S[slot_b][a] (wave reduction over the lanes' columns per distinct slot).  Verified against the full kernel.
+//   hipcc --offload-arch=gfx950 -O3 -o sym_tune sym_tune.hip && ./sym_tune [n] [K] [shuffle_labels]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+typedef long long ll2 __attribute__((ext_vector_type(2)));
+typedef unsigned long long u64;
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1);} } while (0)
+
+struct V { int n, ld; const long long *Dq, *Lq; long long *SD, *SL; const int *slot_of; };
+
+__device__ __forceinline__ void atom(long long *p, long long v) { __hip_atomic_fetch_add((u64 *)p, (u64)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// reference: full matrix, natural row order, flush on slot change (same as k_bulk with perm = identity)
+__global__ __launch_bounds__(256) void k_full(V v, int rows)
+{
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 2;
+    const int p0 = blockIdx.y * rows, p1 = min(v.n, p0 + rows);
+    if (p0 >= p1) return;
+    long long a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+    int cur = v.slot_of[p0];
+    for (int p = p0; p < p1; ++p) {
+        const int s = v.slot_of[p];
+        const ll2 d = __builtin_nontemporal_load((const ll2 *)(v.Dq + (size_t)p * v.ld + i));
+        const ll2 l = __builtin_nontemporal_load((const ll2 *)(v.Lq + (size_t)p * v.ld + i));
+        if (s != cur) { atom(v.SD + (size_t)cur * v.ld + i, a0); atom(v.SD + (size_t)cur * v.ld + i + 1, a1); atom(v.SL + (size_t)cur * v.ld + i, b0); atom(v.SL + (size_t)cur * v.ld + i + 1, b1); a0 = a1 = b0 = b1 = 0; cur = s; }
+        a0 += d.x; a1 += d.y; b0 += l.x; b1 += l.y;
+    }
+    atom(v.SD + (size_t)cur * v.ld + i, a0); atom(v.SD + (size_t)cur * v.ld + i + 1, a1); atom(v.SL + (size_t)cur * v.ld + i, b0); atom(v.SL + (size_t)cur * v.ld + i + 1, b1);
+}
+
+__device__ __forceinline__ long long wave_sum(long long x)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+
+#define U 8
+// symmetric: upper triangle only
+template <int MODE>  // 0: T1 only (timing ablation), 1: T1 + T2
+__global__ __launch_bounds__(256) void k_sym(V v, int rows)
+{
+    const int c0 = blockIdx.x * 512;
+    const int i = c0 + threadIdx.x * 2;               // columns b = i, i+1
+    const int p0 = blockIdx.y * rows;
+    const int p1 = min(min(v.n, p0 + rows), c0 + 512); // rows a >= c0+512 have no column b >= a in this block
+    if (p0 >= p1) return;
+    const int lane = threadIdx.x & 63;
+    const int sb0 = (i < v.n) ? v.slot_of[i] : -1, sb1 = (i + 1 < v.n) ? v.slot_of[i + 1] : -1;
+    const size_t ld = v.ld;
+    long long a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+    int cur = v.slot_of[p0];
+    for (int p = p0; p < p1; p += U) {
+        ll2 d[U], l[U];
+        int s[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int a = min(p + u, p1 - 1);
+            s[u] = v.slot_of[a];
+            d[u] = __builtin_nontemporal_load((const ll2 *)(v.Dq + (size_t)a * ld + i));
+            l[u] = __builtin_nontemporal_load((const ll2 *)(v.Lq + (size_t)a * ld + i));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int a = p + u;
+            if (a >= p1) break;
+            // T1 takes b >= a (diagonal included once), T2 takes b > a
+            const long long x0 = (i >= a) ? d[u].x : 0, x1 = (i + 1 >= a) ? d[u].y : 0;
+            const long long y0 = (i >= a) ? l[u].x : 0, y1 = (i + 1 >= a) ? l[u].y : 0;
+            if (s[u] != cur) { atom(v.SD + (size_t)cur * ld + i, a0); atom(v.SD + (size_t)cur * ld + i + 1, a1); atom(v.SL + (size_t)cur * ld + i, b0); atom(v.SL + (size_t)cur * ld + i + 1, b1); a0 = a1 = b0 = b1 = 0; cur = s[u]; }
+            a0 += x0; a1 += x1; b0 += y0; b1 += y1;
+            if (MODE == 1) {
+                const long long t0 = (i > a) ? d[u].x : 0, t1 = (i + 1 > a) ? d[u].y : 0;
+                const long long w0 = (i > a) ? l[u].x : 0, w1 = (i + 1 > a) ? l[u].y : 0;
+                // per distinct slot among this wave's columns: masked wave reduction, one atomic per matrix
+                u64 rem0 = __ballot(sb0 >= 0 && i > a), rem1 = __ballot(sb1 >= 0 && i + 1 > a);
+                while (rem0 | rem1) {
+                    int sl;
+                    if (rem0) sl = __shfl(sb0, __ffsll((long long)rem0) - 1); else sl = __shfl(sb1, __ffsll((long long)rem1) - 1);
+                    // prefer the lower column: compare first set bits
+                    if (rem0 && rem1) {
+                        const int f0 = __ffsll((long long)rem0) - 1, f1 = __ffsll((long long)rem1) - 1;
+                        sl = (f1 < f0) ? __shfl(sb1, f1) : __shfl(sb0, f0);
+                    }
+                    const bool m0 = (sb0 == sl), m1 = (sb1 == sl);
+                    const long long vd = (m0 ? t0 : 0) + (m1 ? t1 : 0), vl = (m0 ? w0 : 0) + (m1 ? w1 : 0);
+                    const long long sd = wave_sum(vd), sl2 = wave_sum(vl);
+                    if (lane == 0) { atom(v.SD + (size_t)sl * ld + a, sd); atom(v.SL + (size_t)sl * ld + a, sl2); }
+                    rem0 &= ~__ballot(m0); rem1 &= ~__ballot(m1);
+                }
+            }
+        }
+    }
+    atom(v.SD + (size_t)cur * ld + i, a0); atom(v.SD + (size_t)cur * ld + i + 1, a1); atom(v.SL + (size_t)cur * ld + i, b0); atom(v.SL + (size_t)cur * ld + i + 1, b1);
+}
+
+
+// ---- variant B: second direction through an LDS transpose of each 8-row × 512-column sub-tile ----
+#define SUBR 8
+#define NBMAX 48                       // distinct slots per 512-column block handled through LDS bins
+#define PADCOL(c) ((c) + ((c) >> 4) * 2)   // 16 B of padding after every 128 B: conflict-free 16-column strips
+#define TILEW (512 + 64)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_sym_lds(V v, int rows)
+{
+    __shared__ __attribute__((aligned(16))) long long tD[SUBR][TILEW], tL[SUBR][TILEW];
+    __shared__ unsigned long long bins[SUBR][NBMAX][2];
+    __shared__ short cs[512];           // compact slot index of every column of the block (-1: padding column)
+    __shared__ int dslot[NBMAX + 1];    // compact index -> slot
+    __shared__ int nd_sh;
+    __shared__ short map[1024];         // slot -> compact index (kcap <= 1024 in this prototype)
+    const int c0 = blockIdx.x * 512;
+    const int tid = threadIdx.x;
+    const int i = c0 + tid * 2;
+    const int p0 = blockIdx.y * rows;
+    const int p1 = min(min(v.n, p0 + rows), c0 + 512);
+    if (p0 >= p1) return;
+    const size_t ld = v.ld;
+    // ---- block prologue: compact slot ids of the 512 columns
+    for (int q = tid; q < 1024; q += 256) map[q] = -1;
+    if (tid == 0) nd_sh = 0;
+    for (int q = tid; q < SUBR * NBMAX * 2; q += 256) ((unsigned long long *)bins)[q] = 0;
+    __syncthreads();
+    // two-phase: mark used slots, then a single thread enumerates them (<= 1024 slots)
+    for (int e = 0; e < 2; ++e) { const int b = c0 + tid * 2 + e; if (b < v.n) map[v.slot_of[b]] = -2; }
+    __syncthreads();
+    if (tid == 0) {
+        int nd = 0;
+        for (int s = 0; s < 1024; ++s) if (map[s] == -2) { map[s] = (short)nd; if (nd < NBMAX) dslot[nd] = s; ++nd; }
+        nd_sh = nd;
+    }
+    __syncthreads();
+    const int nd = nd_sh;
+    for (int e = 0; e < 2; ++e) { const int col = tid * 2 + e, b = c0 + col; cs[col] = (b < v.n) ? map[v.slot_of[b]] : (short)-1; }
+    __syncthreads();
+    const bool use_bins = (nd <= NBMAX);
+    const int tr = tid >> 5, tg = tid & 31;                 // second-direction role: row tr of the sub-tile, columns tg*16..+15
+    long long a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+    int cur = v.slot_of[p0];
+    for (int p = p0; p < p1; p += SUBR) {
+        ll2 d[SUBR], l[SUBR];
+        int s[SUBR];
+#pragma unroll
+        for (int u = 0; u < SUBR; ++u) {
+            const int a = min(p + u, p1 - 1);
+            s[u] = v.slot_of[a];
+            d[u] = __builtin_nontemporal_load((const ll2 *)(v.Dq + (size_t)a * ld + i));
+            l[u] = __builtin_nontemporal_load((const ll2 *)(v.Lq + (size_t)a * ld + i));
+        }
+#pragma unroll
+        for (int u = 0; u < SUBR; ++u) {
+            const int a = p + u;
+            const bool live = a < p1;
+            const long long x0 = (live && i >= a) ? d[u].x : 0, x1 = (live && i + 1 >= a) ? d[u].y : 0;
+            const long long y0 = (live && i >= a) ? l[u].x : 0, y1 = (live && i + 1 >= a) ? l[u].y : 0;
+            if (live && s[u] != cur) { atom(v.SD + (size_t)cur * ld + i, a0); atom(v.SD + (size_t)cur * ld + i + 1, a1); atom(v.SL + (size_t)cur * ld + i, b0); atom(v.SL + (size_t)cur * ld + i + 1, b1); a0 = a1 = b0 = b1 = 0; cur = s[u]; }
+            a0 += x0; a1 += x1; b0 += y0; b1 += y1;
+            if (MODE == 1) {
+                ll2 td, tl;
+                td.x = (live && i > a) ? d[u].x : 0; td.y = (live && i + 1 > a) ? d[u].y : 0;
+                tl.x = (live && i > a) ? l[u].x : 0; tl.y = (live && i + 1 > a) ? l[u].y : 0;
+                *(ll2 *)&tD[u][PADCOL(tid * 2)] = td;
+                *(ll2 *)&tL[u][PADCOL(tid * 2)] = tl;
+            }
+        }
+        if (MODE == 1) {
+            __syncthreads();
+            // thread (tr, tg): 16 consecutive columns of row tr, grouped by compact slot
+            const int a = p + tr;
+            if (a < p1) {
+                long long sd = 0, sl = 0;
+                int cc = cs[tg * 16];
+#pragma unroll
+                for (int q = 0; q < 16; q += 2) {
+                    const int col = tg * 16 + q;
+                    const ll2 xd = *(const ll2 *)&tD[tr][PADCOL(col)], xl = *(const ll2 *)&tL[tr][PADCOL(col)];
+                    const int c_0 = cs[col], c_1 = cs[col + 1];
+                    if (c_0 != cc) { if (cc >= 0 && (sd | sl)) { if (use_bins) { atomicAdd(&bins[tr][cc][0], (u64)sd); atomicAdd(&bins[tr][cc][1], (u64)sl); } } sd = sl = 0; cc = c_0; }
+                    sd += xd.x; sl += xl.x;
+                    if (c_1 != cc) { if (cc >= 0 && (sd | sl)) { if (use_bins) { atomicAdd(&bins[tr][cc][0], (u64)sd); atomicAdd(&bins[tr][cc][1], (u64)sl); } } sd = sl = 0; cc = c_1; }
+                    sd += xd.y; sl += xl.y;
+                }
+                if (cc >= 0 && (sd | sl)) { if (use_bins) { atomicAdd(&bins[tr][cc][0], (u64)sd); atomicAdd(&bins[tr][cc][1], (u64)sl); } }
+            }
+            __syncthreads();
+            // bins -> global
+            for (int q = tid; q < SUBR * nd * 2 && use_bins; q += 256) {
+                const int r = q / (nd * 2), rem = q % (nd * 2), c = rem >> 1, w = rem & 1;
+                const unsigned long long val = bins[r][c][w];
+                if (val) { bins[r][c][w] = 0; atom((w ? v.SL : v.SD) + (size_t)dslot[c] * ld + (p + r), (long long)val); }
+            }
+            __syncthreads();
+        }
+    }
+    atom(v.SD + (size_t)cur * ld + i, a0); atom(v.SD + (size_t)cur * ld + i + 1, a1); atom(v.SL + (size_t)cur * ld + i, b0); atom(v.SL + (size_t)cur * ld + i + 1, b1);
+}
+
+// ---- variant C: persistent blocks + dynamic items, precomputed compact column slots, register prefetch,
+//      second direction = LDS transpose + per-strip run sums + half-wave shuffle reduction (no LDS atomics) ----
+struct V3 { V v; const short *cs; const int *dsl; const int *nd; int *counter; int item_rows; int nitems; };
+#define NB3 8   // distinct slots per 512-column block handled by the shuffle path
+__global__ __launch_bounds__(256) void k_colprep(V v, short *cs, int *dsl, int *nd)
+{
+    // one block per 512-column block: compact ids in order of first appearance (natural column order)
+    __shared__ int seen[4096];
+    const int c0 = blockIdx.x * 512;
+    for (int q = threadIdx.x; q < 4096; q += 256) seen[q] = -1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int k = 0;
+        for (int c = 0; c < 512; ++c) {
+            const int b = c0 + c;
+            if (b >= v.n) { cs[b < v.ld ? b : v.ld - 1] = -1; continue; }
+            const int s = v.slot_of[b];
+            if (seen[s] < 0) { seen[s] = k; if (k < 64) dsl[blockIdx.x * 64 + k] = s; ++k; }
+            cs[b] = (short)seen[s];
+        }
+        nd[blockIdx.x] = k;
+    }
+}
+
+__device__ __forceinline__ long long half_sum(long long x)
+{
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+
+__global__ __launch_bounds__(256) void k_sym3(V3 a)
+{
+    __shared__ __attribute__((aligned(16))) long long tD[SUBR][TILEW], tL[SUBR][TILEW];
+    __shared__ int item_sh;
+    const V &v = a.v;
+    const int tid = threadIdx.x, tr = tid >> 5, tg = tid & 31;
+    const size_t ld = v.ld;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) item_sh = atomicAdd(a.counter, 1);
+        __syncthreads();
+        int item = item_sh;
+        if (item >= a.nitems) break;
+        // decode: column block J has ceil((512 J + 512) / item_rows) items; heavy column blocks first
+        int J = v.ld / 512 - 1;
+        for (;; --J) { const int cnt = (512 * J + 512 + a.item_rows - 1) / a.item_rows; if (item < cnt) break; item -= cnt; }
+        const int c0 = J * 512, i = c0 + tid * 2;
+        const int p0 = item * a.item_rows, p1 = min(min(v.n, p0 + a.item_rows), c0 + 512);
+        const int nd = a.nd[J];
+        // this thread's strip of 16 columns: compact slot ids (fixed for the item)
+        short c16[16];
+        {
+            const ll2 w0 = *(const ll2 *)(a.cs + c0 + tg * 16), w1 = *(const ll2 *)(a.cs + c0 + tg * 16 + 8);
+            *(ll2 *)&c16[0] = w0; *(ll2 *)&c16[8] = w1;
+        }
+        const int runA = c16[0];
+        int runB = -2, nruns = 1;
+#pragma unroll
+        for (int q = 1; q < 16; ++q) if (c16[q] != c16[q - 1]) { ++nruns; if (runB == -2) runB = c16[q]; }
+        const bool simple = (nruns <= 2) && (nd <= NB3);
+        long long a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+        int cur = v.slot_of[p0];
+        ll2 d[SUBR], l[SUBR];
+        int s[SUBR];
+#pragma unroll
+        for (int u = 0; u < SUBR; ++u) {
+            const int r = min(p0 + u, p1 - 1);
+            s[u] = v.slot_of[r];
+            d[u] = __builtin_nontemporal_load((const ll2 *)(v.Dq + (size_t)r * ld + i));
+            l[u] = __builtin_nontemporal_load((const ll2 *)(v.Lq + (size_t)r * ld + i));
+        }
+        for (int p = p0; p < p1; p += SUBR) {
+#pragma unroll
+            for (int u = 0; u < SUBR; ++u) {
+                const int r = p + u;
+                const bool live = r < p1;
+                const long long x0 = (live && i >= r) ? d[u].x : 0, x1 = (live && i + 1 >= r) ? d[u].y : 0;
+                const long long y0 = (live && i >= r) ? l[u].x : 0, y1 = (live && i + 1 >= r) ? l[u].y : 0;
+                if (live && s[u] != cur) { atom(v.SD + (size_t)cur * ld + i, a0); atom(v.SD + (size_t)cur * ld + i + 1, a1); atom(v.SL + (size_t)cur * ld + i, b0); atom(v.SL + (size_t)cur * ld + i + 1, b1); a0 = a1 = b0 = b1 = 0; cur = s[u]; }
+                a0 += x0; a1 += x1; b0 += y0; b1 += y1;
+                ll2 td, tl;
+                td.x = (live && i > r) ? d[u].x : 0; td.y = (live && i + 1 > r) ? d[u].y : 0;
+                tl.x = (live && i > r) ? l[u].x : 0; tl.y = (live && i + 1 > r) ? l[u].y : 0;
+                *(ll2 *)&tD[u][PADCOL(tid * 2)] = td;
+                *(ll2 *)&tL[u][PADCOL(tid * 2)] = tl;
+            }
+            // prefetch the next sub-tile while the second direction of this one is computed
+            if (p + SUBR < p1) {
+#pragma unroll
+                for (int u = 0; u < SUBR; ++u) {
+                    const int r = min(p + SUBR + u, p1 - 1);
+                    s[u] = v.slot_of[r];
+                    d[u] = __builtin_nontemporal_load((const ll2 *)(v.Dq + (size_t)r * ld + i));
+                    l[u] = __builtin_nontemporal_load((const ll2 *)(v.Lq + (size_t)r * ld + i));
+                }
+            }
+            __syncthreads();
+            {
+                const int r = p + tr;   // rows >= p1 hold zeros in the tile
+                long long sA_d = 0, sA_l = 0, sB_d = 0, sB_l = 0;
+                if (simple) {
+#pragma unroll
+                    for (int q = 0; q < 16; q += 2) {
+                        const ll2 xd = *(const ll2 *)&tD[tr][PADCOL(tg * 16 + q)], xl = *(const ll2 *)&tL[tr][PADCOL(tg * 16 + q)];
+                        if (c16[q] == runA) { sA_d += xd.x; sA_l += xl.x; } else { sB_d += xd.x; sB_l += xl.x; }
+                        if (c16[q + 1] == runA) { sA_d += xd.y; sA_l += xl.y; } else { sB_d += xd.y; sB_l += xl.y; }
+                    }
+                    for (int c = 0; c < nd; ++c) {
+                        const long long vd = (runA == c ? sA_d : 0) + (runB == c ? sB_d : 0);
+                        const long long vl = (runA == c ? sA_l : 0) + (runB == c ? sB_l : 0);
+                        const long long rd = half_sum(vd), rl = half_sum(vl);
+                        if (tg == 0 && r < p1) { const int sl = a.dsl[J * 64 + c]; if (rd) atom(v.SD + (size_t)sl * ld + r, rd); if (rl) atom(v.SL + (size_t)sl * ld + r, rl); }
+                    }
+                }
+                // uniform decision per block is not guaranteed (strips differ): the generic path runs per thread
+                if (!simple && r < p1) {
+                    for (int q = 0; q < 16; ++q) {
+                        const int b = c0 + tg * 16 + q;
+                        if (b >= v.n) continue;
+                        const long long xd = tD[tr][PADCOL(tg * 16 + q)], xl = tL[tr][PADCOL(tg * 16 + q)];
+                        const int sl = v.slot_of[b];
+                        if (xd) atom(v.SD + (size_t)sl * ld + r, xd);
+                        if (xl) atom(v.SL + (size_t)sl * ld + r, xl);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        atom(v.SD + (size_t)cur * ld + i, a0); atom(v.SD + (size_t)cur * ld + i + 1, a1); atom(v.SL + (size_t)cur * ld + i, b0); atom(v.SL + (size_t)cur * ld + i + 1, b1);
+    }
+}
+
+// ---- variant D: dual-orientation tiles.  A 32-row × 128-column tile of each matrix is staged in LDS (strictly upper
+//      entries only); column threads accumulate down the rows (direction 1, registers carried across tiles),
+//      row threads accumulate along the columns (direction 2).  No shuffles; every flush is a coalesced atomic. ----
+#define TR 32
+#define TC 128
+#define TP (TC + 2)     // row pitch in elements: 130*8 B -> row threads hit distinct banks
+struct V4 { V v; int *counter; int item_tiles; int nitems; };
+__global__ __launch_bounds__(256) void k_sym4(V4 a)
+{
+    __shared__ __attribute__((aligned(16))) long long tD[TR][TP], tL[TR][TP];
+    __shared__ int item_sh;
+    __shared__ int cslot[TC];   // slot of each column of the current column block
+    __shared__ int rslot[TR];   // slot of each row of the current tile
+    const V &v = a.v;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const size_t ld = v.ld;
+    const int ncb = v.ld / TC;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) item_sh = atomicAdd(a.counter, 1);
+        __syncthreads();
+        int item = item_sh;
+        if (item >= a.nitems) break;
+        int J = ncb - 1;
+        for (;; --J) { const int ntile = (TC * J + TC + TR - 1) / TR; const int cnt = (ntile + a.item_tiles - 1) / a.item_tiles; if (item < cnt) break; item -= cnt; }
+        const int c0 = J * TC;
+        const int t_begin = item * a.item_tiles, t_end = min((TC * J + TC + TR - 1) / TR, t_begin + a.item_tiles);
+        if (tid < TC) cslot[tid] = (c0 + tid < v.n) ? v.slot_of[c0 + tid] : -1;
+        // loader role: thread -> (row lr of the tile, 16-byte piece lp): 32 rows x 64 pieces = 2048 pieces per matrix, 8 per thread
+        ll2 d[8], l[8];
+        auto issue = [&](int t) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int piece = q * 256 + tid, lr = piece >> 6, lp = piece & 63;
+                const int r = min(t * TR + lr, v.n - 1);
+                d[q] = __builtin_nontemporal_load((const ll2 *)(v.Dq + (size_t)r * ld + c0 + lp * 2));
+                l[q] = __builtin_nontemporal_load((const ll2 *)(v.Lq + (size_t)r * ld + c0 + lp * 2));
+            }
+        };
+        issue(t_begin);
+        // direction-1 accumulators (waves 0,1: one column per lane; wave 0 = D, wave 1 = L ... use 128 lanes: tid<128 -> column tid, both matrices)
+        long long accD = 0, accL = 0;
+        int cur = -1;
+        for (int t = t_begin; t < t_end; ++t) {
+            const int r0 = t * TR;
+            __syncthreads();   // previous tile fully consumed
+            if (tid < TR) rslot[tid] = (r0 + tid < v.n) ? v.slot_of[r0 + tid] : -1;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int piece = q * 256 + tid, lr = piece >> 6, lp = piece & 63;
+                const int r = r0 + lr, b = c0 + lp * 2;
+                const bool live = r < v.n;
+                ll2 x = d[q], y = l[q];
+                if (!(live && b > r)) { x.x = 0; y.x = 0; }
+                if (!(live && b + 1 > r)) { x.y = 0; y.y = 0; }
+                *(ll2 *)&tD[lr][lp * 2] = x;
+                *(ll2 *)&tL[lr][lp * 2] = y;
+            }
+            if (t + 1 < t_end) issue(t + 1);
+            __syncthreads();
+            if (tid < TC) {
+                // direction 1: column b = c0 + tid accumulates rows r0..r0+31; flush when the row's slot changes
+                const int b = c0 + tid;
+                for (int r = 0; r < TR; ++r) {
+                    const int sr = rslot[r];
+                    if (sr != cur) {
+                        if (cur >= 0) { if (accD) atom(v.SD + (size_t)cur * ld + b, accD); if (accL) atom(v.SL + (size_t)cur * ld + b, accL); }
+                        accD = accL = 0; cur = sr;
+                    }
+                    accD += tD[r][tid]; accL += tL[r][tid];
+                }
+            } else {
+                // direction 2: waves 2,3 -> 128 threads = 32 rows x 2 column halves x 2 matrices
+                const int q = tid - TC, r = q & 31, half = (q >> 5) & 1, mat = q >> 6;
+                const long long (*T)[TP] = mat ? tL : tD;
+                long long *S = mat ? v.SL : v.SD;
+                const int arow = r0 + r;
+                long long acc = 0;
+                int cc = cslot[half * 64];
+                for (int c = half * 64; c < half * 64 + 64; ++c) {
+                    const int sc = cslot[c];
+                    if (sc != cc) { if (cc >= 0 && acc && arow < v.n) atom(S + (size_t)cc * ld + arow, acc); acc = 0; cc = sc; }
+                    acc += T[r][c];
+                }
+                if (cc >= 0 && acc && arow < v.n) atom(S + (size_t)cc * ld + arow, acc);
+            }
+        }
+        if (tid < TC && cur >= 0) { const int b = c0 + tid; if (accD) atom(v.SD + (size_t)cur * ld + b, accD); if (accL) atom(v.SL + (size_t)cur * ld + b, accL); }
+        // diagonal entries (S includes j = i): D[a][a] goes to S[slot_a][a]; logD's diagonal is 0
+        if (t_begin == 0 && tid < TC) { const int a_ = c0 + tid; if (a_ < v.n) { const long long x = v.Dq[(size_t)a_ * ld + a_]; if (x) atom(v.SD + (size_t)v.slot_of[a_] * ld + a_, x); } }
+    }
+}
+
+// ---- variant E: variant D with chunked, batched LDS reads (8 rows / 8 columns at a time; chunk-uniform fast path) ----
+__global__ __launch_bounds__(256) void k_sym5(V4 a)
+{
+    __shared__ __attribute__((aligned(16))) long long tt[2][TR][TP];   // [matrix][row][col]
+    __shared__ int item_sh;
+    __shared__ int cslot[TC], rslot[TR];
+    __shared__ int cchk[TC / 8], rchk[TR / 8];   // slot of an 8-wide chunk if uniform, else -2
+    const V &v = a.v;
+    const int tid = threadIdx.x;
+    const size_t ld = v.ld;
+    const int ncb = v.ld / TC;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) item_sh = atomicAdd(a.counter, 1);
+        __syncthreads();
+        int item = item_sh;
+        if (item >= a.nitems) break;
+        int J = ncb - 1;
+        for (;; --J) { const int ntile = (TC * J + TC + TR - 1) / TR; const int cnt = (ntile + a.item_tiles - 1) / a.item_tiles; if (item < cnt) break; item -= cnt; }
+        const int c0 = J * TC;
+        const int t_begin = item * a.item_tiles, t_end = min((TC * J + TC + TR - 1) / TR, t_begin + a.item_tiles);
+        if (tid < TC) cslot[tid] = (c0 + tid < v.n) ? v.slot_of[c0 + tid] : -1;
+        __syncthreads();
+        if (tid < TC / 8) { const int s0 = cslot[tid * 8]; bool u = true; for (int q = 1; q < 8; ++q) u = u && (cslot[tid * 8 + q] == s0); cchk[tid] = u ? s0 : -2; }
+        ll2 d[8], l[8];
+        auto issue = [&](int t) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int piece = q * 256 + tid, lr = piece >> 6, lp = piece & 63;
+                const int r = min(t * TR + lr, v.n - 1);
+                d[q] = __builtin_nontemporal_load((const ll2 *)(v.Dq + (size_t)r * ld + c0 + lp * 2));
+                l[q] = __builtin_nontemporal_load((const ll2 *)(v.Lq + (size_t)r * ld + c0 + lp * 2));
+            }
+        };
+        issue(t_begin);
+        long long accD = 0, accL = 0;
+        int cur = -1;
+        for (int t = t_begin; t < t_end; ++t) {
+            const int r0 = t * TR;
+            __syncthreads();
+            if (tid < TR) rslot[tid] = (r0 + tid < v.n) ? v.slot_of[r0 + tid] : -1;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int piece = q * 256 + tid, lr = piece >> 6, lp = piece & 63;
+                const int r = r0 + lr, b = c0 + lp * 2;
+                const bool live = r < v.n;
+                ll2 x = d[q], y = l[q];
+                if (!(live && b > r)) { x.x = 0; y.x = 0; }
+                if (!(live && b + 1 > r)) { x.y = 0; y.y = 0; }
+                *(ll2 *)&tt[0][lr][lp * 2] = x;
+                *(ll2 *)&tt[1][lr][lp * 2] = y;
+            }
+            if (t + 1 < t_end) issue(t + 1);
+            __syncthreads();
+            if (tid < TR / 8) { const int s0 = rslot[tid * 8]; bool u = true; for (int q = 1; q < 8; ++q) u = u && (rslot[tid * 8 + q] == s0); rchk[tid] = u ? s0 : -2; }
+            __syncthreads();
+            if (tid < TC) {
+                const int b = c0 + tid;
+#pragma unroll
+                for (int ch = 0; ch < TR / 8; ++ch) {
+                    long long xd[8], xl[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { xd[q] = tt[0][ch * 8 + q][tid]; xl[q] = tt[1][ch * 8 + q][tid]; }
+                    const int cs_ = __builtin_amdgcn_readfirstlane(rchk[ch]);
+                    if (cs_ != -2) {
+                        if (cs_ != cur) { if (cur >= 0) { if (accD) atom(v.SD + (size_t)cur * ld + b, accD); if (accL) atom(v.SL + (size_t)cur * ld + b, accL); } accD = accL = 0; cur = cs_; }
+                        accD += ((xd[0] + xd[1]) + (xd[2] + xd[3])) + ((xd[4] + xd[5]) + (xd[6] + xd[7]));
+                        accL += ((xl[0] + xl[1]) + (xl[2] + xl[3])) + ((xl[4] + xl[5]) + (xl[6] + xl[7]));
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int sr = __builtin_amdgcn_readfirstlane(rslot[ch * 8 + q]);
+                            if (sr != cur) { if (cur >= 0) { if (accD) atom(v.SD + (size_t)cur * ld + b, accD); if (accL) atom(v.SL + (size_t)cur * ld + b, accL); } accD = accL = 0; cur = sr; }
+                            accD += xd[q]; accL += xl[q];
+                        }
+                    }
+                }
+            } else {
+                // direction 2: wave 2 -> columns 0..63, wave 3 -> columns 64..127; lanes 0-31: D rows, lanes 32-63: L rows
+                const int q2 = tid - TC, half = q2 >> 6, r = q2 & 31, mat = (q2 >> 5) & 1;
+                long long *S = mat ? v.SL : v.SD;
+                const int arow = r0 + r;
+                long long acc = 0;
+                int cc = -1;
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch) {
+                    const int cb = half * 64 + ch * 8;
+                    const ll2 x0 = *(const ll2 *)&tt[mat][r][cb], x1 = *(const ll2 *)&tt[mat][r][cb + 2], x2 = *(const ll2 *)&tt[mat][r][cb + 4], x3 = *(const ll2 *)&tt[mat][r][cb + 6];
+                    const int cs_ = __builtin_amdgcn_readfirstlane(cchk[cb >> 3]);
+                    if (cs_ != -2) {
+                        if (cs_ != cc) { if (cc >= 0 && acc && arow < v.n) atom(S + (size_t)cc * ld + arow, acc); acc = 0; cc = cs_; }
+                        acc += ((x0.x + x0.y) + (x1.x + x1.y)) + ((x2.x + x2.y) + (x3.x + x3.y));
+                    } else {
+                        const long long xs[8] = {x0.x, x0.y, x1.x, x1.y, x2.x, x2.y, x3.x, x3.y};
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int sc = __builtin_amdgcn_readfirstlane(cslot[cb + q]);
+                            if (sc != cc) { if (cc >= 0 && acc && arow < v.n) atom(S + (size_t)cc * ld + arow, acc); acc = 0; cc = sc; }
+                            acc += xs[q];
+                        }
+                    }
+                }
+                if (cc >= 0 && acc && arow < v.n) atom(S + (size_t)cc * ld + arow, acc);
+            }
+        }
+        if (tid < TC && cur >= 0) { const int b = c0 + tid; if (accD) atom(v.SD + (size_t)cur * ld + b, accD); if (accL) atom(v.SL + (size_t)cur * ld + b, accL); }
+        if (t_begin == 0 && tid < TC) { const int a_ = c0 + tid; if (a_ < v.n) { const long long x = v.Dq[(size_t)a_ * ld + a_]; if (x) atom(v.SD + (size_t)v.slot_of[a_] * ld + a_, x); } }
+    }
+}
+
+int main(int argc, char **argv)
+{
+    const int n = argc > 1 ? atoi(argv[1]) : 8192, K = argc > 2 ? atoi(argv[2]) : 50, shuffle = argc > 3 ? atoi(argv[3]) : 0, kcap = 128;
+    const int ld = ((n + 1023) / 1024) * 1024;
+    std::vector<long long> hD((size_t)n * ld, 0), hL((size_t)n * ld, 0);
+    srand(1);
+    for (int a = 0; a < n; ++a)
+        for (int b = a; b < n; ++b) {
+            const long long x = ((long long)rand() << 16) ^ rand(), y = -(((long long)rand() << 14) ^ rand());
+            hD[(size_t)a * ld + b] = x; hD[(size_t)b * ld + a] = x;
+            hL[(size_t)a * ld + b] = (a == b) ? 0 : y; hL[(size_t)b * ld + a] = (a == b) ? 0 : y;
+        }
+    std::vector<int> slot(n);
+    for (int p = 0; p < n; ++p) slot[p] = (int)((long long)p * K / n);
+    if (shuffle) std::random_shuffle(slot.begin(), slot.end());
+    V v; v.n = n; v.ld = ld;
+    long long *Dq, *Lq, *SD, *SL; int *ds;
+    CHK(hipMalloc(&Dq, hD.size() * 8)); CHK(hipMalloc(&Lq, hL.size() * 8));
+    CHK(hipMalloc(&SD, (size_t)kcap * ld * 8)); CHK(hipMalloc(&SL, (size_t)kcap * ld * 8)); CHK(hipMalloc(&ds, n * 4));
+    CHK(hipMemcpy(Dq, hD.data(), hD.size() * 8, hipMemcpyHostToDevice)); CHK(hipMemcpy(Lq, hL.data(), hL.size() * 8, hipMemcpyHostToDevice));
+    CHK(hipMemcpy(ds, slot.data(), n * 4, hipMemcpyHostToDevice));
+    v.Dq = Dq; v.Lq = Lq; v.SD = SD; v.SL = SL; v.slot_of = ds;
+    hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    std::vector<long long> refD((size_t)kcap * ld), refL((size_t)kcap * ld), h((size_t)kcap * ld);
+    auto run = [&](const char *name, int which, int rows, bool check) {
+        float tot = 0, best = 1e9;
+        const int IT = 8;
+        for (int it = 0; it < IT + 2; ++it) {
+            CHK(hipMemset(SD, 0, (size_t)kcap * ld * 8)); CHK(hipMemset(SL, 0, (size_t)kcap * ld * 8));
+            dim3 g(ld / 512, (n + rows - 1) / rows);
+            CHK(hipEventRecord(e0));
+            if (which == 0) k_full<<<g, 256>>>(v, rows);
+            else if (which == 1) k_sym<0><<<g, 256>>>(v, rows);
+            else if (which == 2) k_sym<1><<<g, 256>>>(v, rows);
+            else if (which == 3) k_sym_lds<0><<<g, 256>>>(v, rows);
+            else k_sym_lds<1><<<g, 256>>>(v, rows);
+            CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+            float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+            if (it >= 2) { tot += ms; best = std::min(best, ms); }
+        }
+        const char *ok = "";
+        if (which == 0) { CHK(hipMemcpy(refD.data(), SD, refD.size() * 8, hipMemcpyDeviceToHost)); CHK(hipMemcpy(refL.data(), SL, refL.size() * 8, hipMemcpyDeviceToHost)); }
+        else if (check) {
+            CHK(hipMemcpy(h.data(), SD, h.size() * 8, hipMemcpyDeviceToHost)); bool e = (h == refD);
+            CHK(hipMemcpy(h.data(), SL, h.size() * 8, hipMemcpyDeviceToHost)); e = e && (h == refL);
+            ok = e ? "EXACT" : "MISMATCH";
+        }
+        printf("%-28s rows=%4d  avg %.1f us  best %.1f us  %s\n", name, rows, tot / 8 * 1e3, best * 1e3, ok);
+    };
+    run("full (natural order)", 0, 256, false);
+    for (int rows : {64, 128, 256}) run("sym T1 only (ablation)", 1, rows, false);
+    {   // variant C
+        short *cs; int *dsl, *nd, *counter;
+        CHK(hipMalloc(&cs, ld * 2)); CHK(hipMalloc(&dsl, (ld / 512) * 64 * 4)); CHK(hipMalloc(&nd, (ld / 512) * 4)); CHK(hipMalloc(&counter, 4));
+        k_colprep<<<ld / 512, 256>>>(v, cs, dsl, nd);
+        CHK(hipDeviceSynchronize());
+        for (int item_rows : {32}) for (int nblocks : {512}) {
+            V3 a; a.v = v; a.cs = cs; a.dsl = dsl; a.nd = nd; a.counter = counter; a.item_rows = item_rows;
+            int nitems = 0; for (int J = 0; J < ld / 512; ++J) nitems += (512 * J + 512 + item_rows - 1) / item_rows;
+            a.nitems = nitems;
+            float tot = 0, best = 1e9;
+            for (int it = 0; it < 10; ++it) {
+                CHK(hipMemset(SD, 0, (size_t)kcap * ld * 8)); CHK(hipMemset(SL, 0, (size_t)kcap * ld * 8)); CHK(hipMemset(counter, 0, 4));
+                CHK(hipEventRecord(e0));
+                k_sym3<<<nblocks, 256>>>(a);
+                CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+                float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+                if (it >= 2) { tot += ms; best = std::min(best, ms); }
+            }
+            CHK(hipMemcpy(h.data(), SD, h.size() * 8, hipMemcpyDeviceToHost)); bool e = (h == refD);
+            CHK(hipMemcpy(h.data(), SL, h.size() * 8, hipMemcpyDeviceToHost)); e = e && (h == refL);
+            printf("sym3 item_rows=%3d blocks=%3d items=%4d  avg %.1f us  best %.1f us  %s\n", item_rows, nblocks, nitems, tot / 8 * 1e3, best * 1e3, e ? "EXACT" : "MISMATCH");
+        }
+    }
+    {   // variant D
+        int *counter; CHK(hipMalloc(&counter, 4));
+        for (int variant : {4, 5}) for (int item_tiles : {2, 4, 8}) for (int nblocks : {512}) {
+            V4 a; a.v = v; a.counter = counter; a.item_tiles = item_tiles;
+            int nitems = 0; for (int J = 0; J < ld / TC; ++J) { int nt = (TC * J + TC + TR - 1) / TR; nitems += (nt + item_tiles - 1) / item_tiles; }
+            a.nitems = nitems;
+            float tot = 0, best = 1e9;
+            for (int it = 0; it < 10; ++it) {
+                CHK(hipMemset(SD, 0, (size_t)kcap * ld * 8)); CHK(hipMemset(SL, 0, (size_t)kcap * ld * 8)); CHK(hipMemset(counter, 0, 4));
+                CHK(hipEventRecord(e0));
+                if (variant == 4) k_sym4<<<nblocks, 256>>>(a); else k_sym5<<<nblocks, 256>>>(a);
+                CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+                float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+                if (it >= 2) { tot += ms; best = std::min(best, ms); }
+            }
+            CHK(hipMemcpy(h.data(), SD, h.size() * 8, hipMemcpyDeviceToHost)); bool e = (h == refD);
+            CHK(hipMemcpy(h.data(), SL, h.size() * 8, hipMemcpyDeviceToHost)); e = e && (h == refL);
+            printf("sym%d item_tiles=%2d blocks=%3d items=%4d  avg %.1f us  best %.1f us  %s\n", variant, item_tiles, nblocks, nitems, tot / 8 * 1e3, best * 1e3, e ? "EXACT" : "MISMATCH");
+        }
+    }
+    if (0) for (int rows : {64}) run("sym T1+T2 (shuffle)", 2, rows, true);
+
+    return 0;
+}
