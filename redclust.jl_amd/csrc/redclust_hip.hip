@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void k_bulk_sym(View V, int wgen, int zgen, in
             if (tid < RC_SYM_TC) {
                 // direction 1: column b = c0 + tid gathers the rows of the tile, grouped by the rows' slots
                 const int b = c0 + tid;
-#pragma unroll
+#pragma unroll 1  // keeps the kernel under 192 VGPRs so that a k_resolve block fits on the CU beside two of these
                 for (int ch = 0; ch < RC_SYM_TR / 8; ++ch) {
                     long long xd[8], xl[8];
 #pragma unroll
@@ -1171,7 +1171,8 @@ struct rc_ctx {
     int *lsnap[2] = {nullptr, nullptr}, *work[2] = {nullptr, nullptr};  // label snapshots / work counters of k_bulk_sym
     int bulk_kernel = -1;      // RC_BULK_KERNEL: -1 auto, 0 k_bulk (full read, any layout), 1 k_bulk_sym (upper triangle)
     int last_bulk_kernel = 0;  // what the last enqueue chose
-    int sym_item_tiles = 4;
+    int sym_item_tiles = 8;
+    int res_threads = RC_RES_THREADS;  // k_resolve block size (RC_RES_THREADS env: 256 or 512)
     double *A = nullptr;
     u64 *keys[2] = {nullptr, nullptr};
     unsigned *arrive[2] = {nullptr, nullptr};
@@ -1290,8 +1291,8 @@ static void free_all(rc_ctx *c)
         if (c->ev_bulk[q]) (void)hipEventDestroy(c->ev_bulk[q]);
         if (c->ev_res[q]) (void)hipEventDestroy(c->ev_res[q]);
     }
+    if (c->sB && c->sB != c->sA) (void)hipStreamDestroy(c->sB);
     if (c->sA) (void)hipStreamDestroy(c->sA);
-    if (c->sB) (void)hipStreamDestroy(c->sB);
     delete c;
 }
 
@@ -1315,7 +1316,12 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     int pr_least = 0, pr_greatest = 0;
     HIPCHK(c, hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
     HIPCHK(c, hipStreamCreateWithPriority(&c->sA, hipStreamNonBlocking, pr_greatest));
-    HIPCHK(c, hipStreamCreateWithPriority(&c->sB, hipStreamNonBlocking, pr_least));
+    if (getenv("RC_ONE_STREAM") && atoi(getenv("RC_ONE_STREAM"))) {
+        c->sB = c->sA;  // experiment: everything in order on one stream, no cross-stream events
+        c->prefetch = false;
+    } else {
+        HIPCHK(c, hipStreamCreateWithPriority(&c->sB, hipStreamNonBlocking, pr_least));
+    }
     for (int q = 0; q < 4; ++q) {
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_bulk[q], hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_res[q], hipEventDisableTiming));
@@ -1449,6 +1455,7 @@ static int32_t alloc_ctx(int64_t n, int32_t storage_bits, int32_t device_id, int
     c->dbg = getenv("RC_DEBUG_FLAGS") ? atoi(getenv("RC_DEBUG_FLAGS")) : 0;
     c->prefetch = !(getenv("RC_NO_PREFETCH") && atoi(getenv("RC_NO_PREFETCH")));
     if (getenv("RC_BULK_KERNEL")) c->bulk_kernel = !strcmp(getenv("RC_BULK_KERNEL"), "sym") ? 1 : (!strcmp(getenv("RC_BULK_KERNEL"), "perm") ? 0 : -1);
+    if (getenv("RC_RES_THREADS")) c->res_threads = (atoi(getenv("RC_RES_THREADS")) == 256) ? 256 : 512;
     if (getenv("RC_SYM_ITEM_TILES")) c->sym_item_tiles = std::max(1, atoi(getenv("RC_SYM_ITEM_TILES")));
     *out = c;
     return RC_OK;
@@ -1766,7 +1773,7 @@ extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t 
         }
         sa.own_gen = c->inc_gen;
         sa.next_gen = -1;
-        k_resolve<<<c->G, RC_RES_THREADS, lds, c->sA>>>(V, sa, c->G);
+        k_resolve<<<c->G, c->res_threads, lds, c->sA>>>(V, sa, c->G);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(c->ev_res[t & 3], c->sA));
         c->t_next = t + 1;
@@ -1779,7 +1786,7 @@ extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t 
     sa.own_gen = (int)(t % 3);
     sa.next_gen = (int)((t + 1) % 3);
     HIPCHK(c, hipStreamWaitEvent(c->sA, c->ev_bulk[t & 3], 0));
-    k_resolve<<<c->G, RC_RES_THREADS, lds, c->sA>>>(V, sa, c->G);
+    k_resolve<<<c->G, c->res_threads, lds, c->sA>>>(V, sa, c->G);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev_res[t & 3], c->sA));
     c->t_next = t + 1;
