@@ -557,6 +557,181 @@ __global__ __launch_bounds__(256) void k_bulk_sym(View V, int wgen, int zgen, in
     }
 }
 
+
+// k_bulk_sym32 — the same symmetric reduction for 32-bit storage: 32-row × 256-column int32 tiles (1 KiB row
+// segments), all 256 threads take a column in direction 1 and then a (row, matrix, 64-column quarter) in direction 2.
+#define RC_SYM32_TC 256
+#define RC_SYM32_TP (RC_SYM32_TC + 4)
+__global__ __launch_bounds__(256) void k_bulk_sym32(View V, int wgen, int zgen, int sgen, int cgen, int item_tiles, int nitems)
+{
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) int tt[2][RC_SYM_TR][RC_SYM32_TP];
+    __shared__ int item_sh, J_sh;
+    __shared__ int cslot[RC_SYM32_TC], rslot[RC_SYM_TR];
+    __shared__ int cchk[RC_SYM32_TC / 8], rchk[RC_SYM_TR / 8];
+    const int tid = threadIdx.x;
+    const size_t ld = (size_t)V.ld;
+    {
+        const int hi = V.sc->slot_hi;
+        const size_t total2 = (size_t)hi * ld / 2;
+        const size_t nthreads = (size_t)gridDim.x * 256;
+        ll2 *zd = (ll2 *)V.SD[zgen], *zl = (ll2 *)V.SL[zgen];
+        const ll2 z = {0, 0};
+        for (size_t q = (size_t)blockIdx.x * 256 + tid; q < total2; q += nthreads) { zd[q] = z; zl[q] = z; }
+        if (blockIdx.x == 0 && tid == 0) *V.work[cgen ^ 1] = 0;
+    }
+    const int *__restrict__ Dq = (const int *)V.Dq;
+    const int *__restrict__ Lq = (const int *)V.Lq;
+    const int *__restrict__ slot = V.snap[sgen];
+    long long *SD = V.SD[wgen], *SL = V.SL[wgen];
+    const int n = V.n;
+    const int ncb = (n + RC_SYM32_TC - 1) / RC_SYM32_TC;
+    int *counter = V.work[cgen];
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) {
+            int item = atomicAdd(counter, 1);
+            int J = -1;
+            if (item < nitems) {
+                for (J = ncb - 1;; --J) {
+                    const int ntile = (min(RC_SYM32_TC * J + RC_SYM32_TC, n) + RC_SYM_TR - 1) / RC_SYM_TR;
+                    const int cnt = (ntile + item_tiles - 1) / item_tiles;
+                    if (item < cnt) break;
+                    item -= cnt;
+                }
+            }
+            item_sh = item; J_sh = J;
+        }
+        __syncthreads();
+        const int J = J_sh, item = item_sh;
+        if (J < 0) break;
+        const int c0 = J * RC_SYM32_TC;
+        const int ntile = (min(c0 + RC_SYM32_TC, n) + RC_SYM_TR - 1) / RC_SYM_TR;
+        const int t_begin = item * item_tiles, t_end = min(ntile, t_begin + item_tiles);
+        cslot[tid] = (c0 + tid < n) ? slot[c0 + tid] : -1;
+        __syncthreads();
+        if (tid < RC_SYM32_TC / 8) {
+            const int s0 = cslot[tid * 8];
+            bool u = true;
+            for (int q = 1; q < 8; ++q) u = u && (cslot[tid * 8 + q] == s0);
+            cchk[tid] = u ? s0 : -2;
+        }
+        i4 d[8], l[8];
+        auto issue = [&](int t) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int piece = q * 256 + tid, lr = piece >> 6, lp = piece & 63;
+                const int r = min(t * RC_SYM_TR + lr, n - 1);
+                d[q] = __builtin_nontemporal_load((const i4 *)(Dq + (size_t)r * ld + c0 + lp * 4));
+                l[q] = __builtin_nontemporal_load((const i4 *)(Lq + (size_t)r * ld + c0 + lp * 4));
+            }
+        };
+        issue(t_begin);
+        long long accD = 0, accL = 0;
+        int cur = -1;
+        const int b = c0 + tid;
+        for (int t = t_begin; t < t_end; ++t) {
+            const int r0 = t * RC_SYM_TR;
+            __syncthreads();
+            if (tid < RC_SYM_TR) rslot[tid] = (r0 + tid < n) ? slot[r0 + tid] : -1;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int piece = q * 256 + tid, lr = piece >> 6, lp = piece & 63;
+                const int r = r0 + lr, bb = c0 + lp * 4;
+                const bool live = r < n;
+                i4 x = d[q], y = l[q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (!(live && bb + e > r)) { x[e] = 0; y[e] = 0; }
+                *(i4 *)&tt[0][lr][lp * 4] = x;
+                *(i4 *)&tt[1][lr][lp * 4] = y;
+            }
+            if (t + 1 < t_end) issue(t + 1);
+            __syncthreads();
+            if (tid < RC_SYM_TR / 8) {
+                const int s0 = rslot[tid * 8];
+                bool u = true;
+                for (int q = 1; q < 8; ++q) u = u && (rslot[tid * 8 + q] == s0);
+                rchk[tid] = u ? s0 : -2;
+            }
+            __syncthreads();
+            // direction 1: column b gathers the rows of the tile
+#pragma unroll 1
+            for (int ch = 0; ch < RC_SYM_TR / 8; ++ch) {
+                long long xd[8], xl[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { xd[q] = tt[0][ch * 8 + q][tid]; xl[q] = tt[1][ch * 8 + q][tid]; }
+                const int cs_ = __builtin_amdgcn_readfirstlane(rchk[ch]);
+                if (cs_ != -2) {
+                    if (cs_ != cur) {
+                        if (cur >= 0) {
+                            if (accD) __hip_atomic_fetch_add((u64 *)(SD + (size_t)cur * ld + b), (u64)accD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (accL) __hip_atomic_fetch_add((u64 *)(SL + (size_t)cur * ld + b), (u64)accL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        accD = accL = 0; cur = cs_;
+                    }
+                    accD += ((xd[0] + xd[1]) + (xd[2] + xd[3])) + ((xd[4] + xd[5]) + (xd[6] + xd[7]));
+                    accL += ((xl[0] + xl[1]) + (xl[2] + xl[3])) + ((xl[4] + xl[5]) + (xl[6] + xl[7]));
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int sr = __builtin_amdgcn_readfirstlane(rslot[ch * 8 + q]);
+                        if (sr != cur) {
+                            if (cur >= 0) {
+                                if (accD) __hip_atomic_fetch_add((u64 *)(SD + (size_t)cur * ld + b), (u64)accD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (accL) __hip_atomic_fetch_add((u64 *)(SL + (size_t)cur * ld + b), (u64)accL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            accD = accL = 0; cur = sr;
+                        }
+                        accD += xd[q]; accL += xl[q];
+                    }
+                }
+            }
+            // direction 2: wave w -> columns 64w..64w+63; lanes 0-31 rows of D, lanes 32-63 rows of logD
+            {
+                const int quarter = tid >> 6, r = tid & 31, mat = (tid >> 5) & 1;
+                long long *S = mat ? SL : SD;
+                const int arow = r0 + r;
+                long long acc = 0;
+                int cc = -1;
+#pragma unroll 2
+                for (int ch = 0; ch < 8; ++ch) {
+                    const int cb = quarter * 64 + ch * 8;
+                    const i4 x0 = *(const i4 *)&tt[mat][r][cb], x1 = *(const i4 *)&tt[mat][r][cb + 4];
+                    const int cs_ = __builtin_amdgcn_readfirstlane(cchk[cb >> 3]);
+                    if (cs_ != -2) {
+                        if (cs_ != cc) {
+                            if (cc >= 0 && acc && arow < n) __hip_atomic_fetch_add((u64 *)(S + (size_t)cc * ld + arow), (u64)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            acc = 0; cc = cs_;
+                        }
+                        acc += (((long long)x0[0] + x0[1]) + ((long long)x0[2] + x0[3])) + (((long long)x1[0] + x1[1]) + ((long long)x1[2] + x1[3]));
+                    } else {
+                        const int xs[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int sc = __builtin_amdgcn_readfirstlane(cslot[cb + q]);
+                            if (sc != cc) {
+                                if (cc >= 0 && acc && arow < n) __hip_atomic_fetch_add((u64 *)(S + (size_t)cc * ld + arow), (u64)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                acc = 0; cc = sc;
+                            }
+                            acc += xs[q];
+                        }
+                    }
+                }
+                if (cc >= 0 && acc && arow < n) __hip_atomic_fetch_add((u64 *)(S + (size_t)cc * ld + arow), (u64)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (cur >= 0) {
+            if (accD) __hip_atomic_fetch_add((u64 *)(SD + (size_t)cur * ld + b), (u64)accD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (accL) __hip_atomic_fetch_add((u64 *)(SL + (size_t)cur * ld + b), (u64)accL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (t_begin == 0 && b < n) {
+            const long long x = V.diagq[b];
+            if (x) __hip_atomic_fetch_add((u64 *)(SD + (size_t)slot[b] * ld + b), (u64)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Slot tables replicated in LDS by every block of k_resolve.
 // ---------------------------------------------------------------------------------------------------
@@ -1694,17 +1869,21 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
     }
     // Kernel choice.  k_bulk_sym reads half the bytes but wants the points of a cluster to be contiguous in the
     // point order (few label runs); both kernels are exact for any labelling, so a stale run count only costs speed.
-    bool use_sym = (c->bits == 64) && (c->bulk_kernel == 1 || (c->bulk_kernel < 0 && (long long)c->hsum->runs * 32 <= (long long)c->n));
+    bool use_sym = (c->bulk_kernel == 1 || (c->bulk_kernel < 0 && (long long)c->hsum->runs * 32 <= (long long)c->n));
     c->last_bulk_kernel = use_sym ? 1 : 0;
     if (use_sym) {
-        const int ncb = (c->n + RC_SYM_TC - 1) / RC_SYM_TC;
+        const int TC = (c->bits == 64) ? RC_SYM_TC : RC_SYM32_TC;
+        const int ncb = (c->n + TC - 1) / TC;
         int nitems = 0;
         for (int J = 0; J < ncb; ++J) {
-            const int ntile = (std::min(RC_SYM_TC * J + RC_SYM_TC, c->n) + RC_SYM_TR - 1) / RC_SYM_TR;
+            const int ntile = (std::min(TC * J + TC, c->n) + RC_SYM_TR - 1) / RC_SYM_TR;
             nitems += (ntile + c->sym_item_tiles - 1) / c->sym_item_tiles;
         }
         const int nblocks = std::max(1, std::min(nitems, 2 * c->num_cus));
-        k_bulk_sym<<<nblocks, 256, 0, c->sB>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), c->sym_item_tiles, nitems);
+        if (c->bits == 64)
+            k_bulk_sym<<<nblocks, 256, 0, c->sB>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), c->sym_item_tiles, nitems);
+        else
+            k_bulk_sym32<<<nblocks, 256, 0, c->sB>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), c->sym_item_tiles, nitems);
     } else {
         // bulk_lds: unused dynamic LDS that caps k_bulk at bulk_blocks_per_cu workgroups per CU, which (i) spreads the
         // grid evenly over the CUs and (ii) leaves registers/wave slots on every CU for the concurrent k_resolve
