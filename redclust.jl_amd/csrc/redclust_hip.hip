@@ -1347,7 +1347,7 @@ struct rc_ctx {
     int bulk_kernel = -1;      // RC_BULK_KERNEL: -1 auto, 0 k_bulk (full read, any layout), 1 k_bulk_sym (upper triangle)
     int last_bulk_kernel = 0;  // what the last enqueue chose
     int sym_item_tiles = 8;
-    int res_threads = RC_RES_THREADS;  // k_resolve block size (RC_RES_THREADS env: 256 or 512)
+    int res_threads = 0;       // k_resolve block size: 0 = adaptive, else forced by RC_RES_THREADS (256 or 512)
     double *A = nullptr;
     u64 *keys[2] = {nullptr, nullptr};
     unsigned *arrive[2] = {nullptr, nullptr};
@@ -1941,6 +1941,12 @@ extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t 
     sa.t = (int)t;
     sa.dbg = c->dbg;
     const size_t lds = std::max(tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64), 2 * sizeof(int) * (size_t)c->kcap);
+    // Resolver block size.  With 256 threads (one wave per SIMD, 112 VGPRs) a k_resolve block fits on a CU beside two
+    // k_bulk_sym blocks, so the resolver of sweep t really overlaps the row reduction of sweep t+1 (config 5:
+    // 1.36 -> 0.99 ms per sweep).  With many label changes per sweep the rounds dominate and 512 threads are faster.
+    int res_threads = c->res_threads;
+    if (res_threads == 0)
+        res_threads = (!c->incremental && c->prefetch && c->last_bulk_kernel == 1 && c->hsum->n_changes <= 32) ? 256 : 512;
     if (c->incremental) {
         // exact incremental mode: the row-sum table of the current labels already exists (one k_bulk after
         // rc_set_state) and every label change corrects it in place — no matrix traffic at all in this sweep
@@ -1952,7 +1958,7 @@ extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t 
         }
         sa.own_gen = c->inc_gen;
         sa.next_gen = -1;
-        k_resolve<<<c->G, c->res_threads, lds, c->sA>>>(V, sa, c->G);
+        k_resolve<<<c->G, res_threads, lds, c->sA>>>(V, sa, c->G);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(c->ev_res[t & 3], c->sA));
         c->t_next = t + 1;
@@ -1965,7 +1971,7 @@ extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t 
     sa.own_gen = (int)(t % 3);
     sa.next_gen = (int)((t + 1) % 3);
     HIPCHK(c, hipStreamWaitEvent(c->sA, c->ev_bulk[t & 3], 0));
-    k_resolve<<<c->G, c->res_threads, lds, c->sA>>>(V, sa, c->G);
+    k_resolve<<<c->G, res_threads, lds, c->sA>>>(V, sa, c->G);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev_res[t & 3], c->sA));
     c->t_next = t + 1;

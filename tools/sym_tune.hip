@@ -536,6 +536,226 @@ __global__ __launch_bounds__(256) void k_sym5(V4 a)
     }
 }
 
+#define TR16 16
+__global__ __launch_bounds__(256) void k_sym5r16(V4 a)
+{
+    __shared__ __attribute__((aligned(16))) long long tt[2][TR16][TP];   // [matrix][row][col]
+    __shared__ int item_sh;
+    __shared__ int cslot[TC], rslot[TR16];
+    __shared__ int cchk[TC / 8], rchk[TR16 / 8];   // slot of an 8-wide chunk if uniform, else -2
+    const V &v = a.v;
+    const int tid = threadIdx.x;
+    const size_t ld = v.ld;
+    const int ncb = v.ld / TC;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) item_sh = atomicAdd(a.counter, 1);
+        __syncthreads();
+        int item = item_sh;
+        if (item >= a.nitems) break;
+        int J = ncb - 1;
+        for (;; --J) { const int ntile = (TC * J + TC + TR16 - 1) / TR16; const int cnt = (ntile + a.item_tiles - 1) / a.item_tiles; if (item < cnt) break; item -= cnt; }
+        const int c0 = J * TC;
+        const int t_begin = item * a.item_tiles, t_end = min((TC * J + TC + TR16 - 1) / TR16, t_begin + a.item_tiles);
+        if (tid < TC) cslot[tid] = (c0 + tid < v.n) ? v.slot_of[c0 + tid] : -1;
+        __syncthreads();
+        if (tid < TC / 8) { const int s0 = cslot[tid * 8]; bool u = true; for (int q = 1; q < 8; ++q) u = u && (cslot[tid * 8 + q] == s0); cchk[tid] = u ? s0 : -2; }
+        ll2 d[4], l[4];
+        auto issue = [&](int t) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int piece = q * 256 + tid, lr = piece >> 6, lp = piece & 63;
+                const int r = min(t * TR16 + lr, v.n - 1);
+                d[q] = __builtin_nontemporal_load((const ll2 *)(v.Dq + (size_t)r * ld + c0 + lp * 2));
+                l[q] = __builtin_nontemporal_load((const ll2 *)(v.Lq + (size_t)r * ld + c0 + lp * 2));
+            }
+        };
+        issue(t_begin);
+        long long accD = 0, accL = 0;
+        int cur = -1;
+        for (int t = t_begin; t < t_end; ++t) {
+            const int r0 = t * TR16;
+            __syncthreads();
+            if (tid < TR16) rslot[tid] = (r0 + tid < v.n) ? v.slot_of[r0 + tid] : -1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int piece = q * 256 + tid, lr = piece >> 6, lp = piece & 63;
+                const int r = r0 + lr, b = c0 + lp * 2;
+                const bool live = r < v.n;
+                ll2 x = d[q], y = l[q];
+                if (!(live && b > r)) { x.x = 0; y.x = 0; }
+                if (!(live && b + 1 > r)) { x.y = 0; y.y = 0; }
+                *(ll2 *)&tt[0][lr][lp * 2] = x;
+                *(ll2 *)&tt[1][lr][lp * 2] = y;
+            }
+            if (t + 1 < t_end) issue(t + 1);
+            __syncthreads();
+            if (tid < TR16 / 8) { const int s0 = rslot[tid * 8]; bool u = true; for (int q = 1; q < 8; ++q) u = u && (rslot[tid * 8 + q] == s0); rchk[tid] = u ? s0 : -2; }
+            __syncthreads();
+            if (tid < TC) {
+                const int b = c0 + tid;
+#pragma unroll
+                for (int ch = 0; ch < TR16 / 8; ++ch) {
+                    long long xd[8], xl[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { xd[q] = tt[0][ch * 8 + q][tid]; xl[q] = tt[1][ch * 8 + q][tid]; }
+                    const int cs_ = __builtin_amdgcn_readfirstlane(rchk[ch]);
+                    if (cs_ != -2) {
+                        if (cs_ != cur) { if (cur >= 0) { if (accD) atom(v.SD + (size_t)cur * ld + b, accD); if (accL) atom(v.SL + (size_t)cur * ld + b, accL); } accD = accL = 0; cur = cs_; }
+                        accD += ((xd[0] + xd[1]) + (xd[2] + xd[3])) + ((xd[4] + xd[5]) + (xd[6] + xd[7]));
+                        accL += ((xl[0] + xl[1]) + (xl[2] + xl[3])) + ((xl[4] + xl[5]) + (xl[6] + xl[7]));
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int sr = __builtin_amdgcn_readfirstlane(rslot[ch * 8 + q]);
+                            if (sr != cur) { if (cur >= 0) { if (accD) atom(v.SD + (size_t)cur * ld + b, accD); if (accL) atom(v.SL + (size_t)cur * ld + b, accL); } accD = accL = 0; cur = sr; }
+                            accD += xd[q]; accL += xl[q];
+                        }
+                    }
+                }
+            } else if (tid < TC + 64) {
+                const int q2 = tid - TC, half = __builtin_amdgcn_readfirstlane(q2 >> 5), r = q2 & 15, mat = (q2 >> 4) & 1;
+                long long *S = mat ? v.SL : v.SD;
+                const int arow = r0 + r;
+                long long acc = 0;
+                int cc = -1;
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch) {
+                    const int cb = half * 64 + ch * 8;
+                    const ll2 x0 = *(const ll2 *)&tt[mat][r][cb], x1 = *(const ll2 *)&tt[mat][r][cb + 2], x2 = *(const ll2 *)&tt[mat][r][cb + 4], x3 = *(const ll2 *)&tt[mat][r][cb + 6];
+                    const int cs_ = __builtin_amdgcn_readfirstlane(cchk[cb >> 3]);
+                    if (cs_ != -2) {
+                        if (cs_ != cc) { if (cc >= 0 && acc && arow < v.n) atom(S + (size_t)cc * ld + arow, acc); acc = 0; cc = cs_; }
+                        acc += ((x0.x + x0.y) + (x1.x + x1.y)) + ((x2.x + x2.y) + (x3.x + x3.y));
+                    } else {
+                        const long long xs[8] = {x0.x, x0.y, x1.x, x1.y, x2.x, x2.y, x3.x, x3.y};
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int sc = __builtin_amdgcn_readfirstlane(cslot[cb + q]);
+                            if (sc != cc) { if (cc >= 0 && acc && arow < v.n) atom(S + (size_t)cc * ld + arow, acc); acc = 0; cc = sc; }
+                            acc += xs[q];
+                        }
+                    }
+                }
+                if (cc >= 0 && acc && arow < v.n) atom(S + (size_t)cc * ld + arow, acc);
+            }
+        }
+        if (tid < TC && cur >= 0) { const int b = c0 + tid; if (accD) atom(v.SD + (size_t)cur * ld + b, accD); if (accL) atom(v.SL + (size_t)cur * ld + b, accL); }
+        if (t_begin == 0 && tid < TC) { const int a_ = c0 + tid; if (a_ < v.n) { const long long x = v.Dq[(size_t)a_ * ld + a_]; if (x) atom(v.SD + (size_t)v.slot_of[a_] * ld + a_, x); } }
+    }
+}
+
+
+template <int ABL> __global__ __launch_bounds__(256) void k_sym5a(V4 a)
+{
+    __shared__ __attribute__((aligned(16))) long long tt[2][TR][TP];   // [matrix][row][col]
+    __shared__ int item_sh;
+    __shared__ int cslot[TC], rslot[TR];
+    __shared__ int cchk[TC / 8], rchk[TR / 8];   // slot of an 8-wide chunk if uniform, else -2
+    const V &v = a.v;
+    const int tid = threadIdx.x;
+    const size_t ld = v.ld;
+    const int ncb = v.ld / TC;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) item_sh = atomicAdd(a.counter, 1);
+        __syncthreads();
+        int item = item_sh;
+        if (item >= a.nitems) break;
+        int J = ncb - 1;
+        for (;; --J) { const int ntile = (TC * J + TC + TR - 1) / TR; const int cnt = (ntile + a.item_tiles - 1) / a.item_tiles; if (item < cnt) break; item -= cnt; }
+        const int c0 = J * TC;
+        const int t_begin = item * a.item_tiles, t_end = min((TC * J + TC + TR - 1) / TR, t_begin + a.item_tiles);
+        if (tid < TC) cslot[tid] = (c0 + tid < v.n) ? v.slot_of[c0 + tid] : -1;
+        __syncthreads();
+        if (tid < TC / 8) { const int s0 = cslot[tid * 8]; bool u = true; for (int q = 1; q < 8; ++q) u = u && (cslot[tid * 8 + q] == s0); cchk[tid] = u ? s0 : -2; }
+        ll2 d[8], l[8];
+        auto issue = [&](int t) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int piece = q * 256 + tid, lr = piece >> 6, lp = piece & 63;
+                const int r = min(t * TR + lr, v.n - 1);
+                d[q] = __builtin_nontemporal_load((const ll2 *)(v.Dq + (size_t)r * ld + c0 + lp * 2));
+                l[q] = __builtin_nontemporal_load((const ll2 *)(v.Lq + (size_t)r * ld + c0 + lp * 2));
+            }
+        };
+        issue(t_begin);
+        long long accD = 0, accL = 0;
+        int cur = -1;
+        for (int t = t_begin; t < t_end; ++t) {
+            const int r0 = t * TR;
+            __syncthreads();
+            if (tid < TR) rslot[tid] = (r0 + tid < v.n) ? v.slot_of[r0 + tid] : -1;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int piece = q * 256 + tid, lr = piece >> 6, lp = piece & 63;
+                const int r = r0 + lr, b = c0 + lp * 2;
+                const bool live = r < v.n;
+                ll2 x = d[q], y = l[q];
+                if (!(live && b > r)) { x.x = 0; y.x = 0; }
+                if (!(live && b + 1 > r)) { x.y = 0; y.y = 0; }
+                if (ABL & 4) { accD += x.x + x.y; accL += y.x + y.y; } else {
+                *(ll2 *)&tt[0][lr][lp * 2] = x;
+                *(ll2 *)&tt[1][lr][lp * 2] = y; }
+            }
+            if (t + 1 < t_end) issue(t + 1);
+            __syncthreads();
+            if (tid < TR / 8) { const int s0 = rslot[tid * 8]; bool u = true; for (int q = 1; q < 8; ++q) u = u && (rslot[tid * 8 + q] == s0); rchk[tid] = u ? s0 : -2; }
+            __syncthreads();
+            if ((ABL & 2) == 0 && tid < TC) {
+                const int b = c0 + tid;
+#pragma unroll
+                for (int ch = 0; ch < TR / 8; ++ch) {
+                    long long xd[8], xl[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { xd[q] = tt[0][ch * 8 + q][tid]; xl[q] = tt[1][ch * 8 + q][tid]; }
+                    const int cs_ = __builtin_amdgcn_readfirstlane(rchk[ch]);
+                    if (cs_ != -2) {
+                        if (cs_ != cur) { if (cur >= 0) { if (accD) atom(v.SD + (size_t)cur * ld + b, accD); if (accL) atom(v.SL + (size_t)cur * ld + b, accL); } accD = accL = 0; cur = cs_; }
+                        accD += ((xd[0] + xd[1]) + (xd[2] + xd[3])) + ((xd[4] + xd[5]) + (xd[6] + xd[7]));
+                        accL += ((xl[0] + xl[1]) + (xl[2] + xl[3])) + ((xl[4] + xl[5]) + (xl[6] + xl[7]));
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int sr = __builtin_amdgcn_readfirstlane(rslot[ch * 8 + q]);
+                            if (sr != cur) { if (cur >= 0) { if (accD) atom(v.SD + (size_t)cur * ld + b, accD); if (accL) atom(v.SL + (size_t)cur * ld + b, accL); } accD = accL = 0; cur = sr; }
+                            accD += xd[q]; accL += xl[q];
+                        }
+                    }
+                }
+            } else if ((ABL & 1) == 0 && tid >= TC) {
+                // direction 2: wave 2 -> columns 0..63, wave 3 -> columns 64..127; lanes 0-31: D rows, lanes 32-63: L rows
+                const int q2 = tid - TC, half = q2 >> 6, r = q2 & 31, mat = (q2 >> 5) & 1;
+                long long *S = mat ? v.SL : v.SD;
+                const int arow = r0 + r;
+                long long acc = 0;
+                int cc = -1;
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch) {
+                    const int cb = half * 64 + ch * 8;
+                    const ll2 x0 = *(const ll2 *)&tt[mat][r][cb], x1 = *(const ll2 *)&tt[mat][r][cb + 2], x2 = *(const ll2 *)&tt[mat][r][cb + 4], x3 = *(const ll2 *)&tt[mat][r][cb + 6];
+                    const int cs_ = __builtin_amdgcn_readfirstlane(cchk[cb >> 3]);
+                    if (cs_ != -2) {
+                        if (cs_ != cc) { if (cc >= 0 && acc && arow < v.n) atom(S + (size_t)cc * ld + arow, acc); acc = 0; cc = cs_; }
+                        acc += ((x0.x + x0.y) + (x1.x + x1.y)) + ((x2.x + x2.y) + (x3.x + x3.y));
+                    } else {
+                        const long long xs[8] = {x0.x, x0.y, x1.x, x1.y, x2.x, x2.y, x3.x, x3.y};
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int sc = __builtin_amdgcn_readfirstlane(cslot[cb + q]);
+                            if (sc != cc) { if (cc >= 0 && acc && arow < v.n) atom(S + (size_t)cc * ld + arow, acc); acc = 0; cc = sc; }
+                            acc += xs[q];
+                        }
+                    }
+                }
+                if (cc >= 0 && acc && arow < v.n) atom(S + (size_t)cc * ld + arow, acc);
+            }
+        }
+        if (tid < TC && cur >= 0) { const int b = c0 + tid; if (accD) atom(v.SD + (size_t)cur * ld + b, accD); if (accL) atom(v.SL + (size_t)cur * ld + b, accL); }
+        if (t_begin == 0 && tid < TC) { const int a_ = c0 + tid; if (a_ < v.n) { const long long x = v.Dq[(size_t)a_ * ld + a_]; if (x) atom(v.SD + (size_t)v.slot_of[a_] * ld + a_, x); } }
+    }
+}
+
 int main(int argc, char **argv)
 {
     const int n = argc > 1 ? atoi(argv[1]) : 8192, K = argc > 2 ? atoi(argv[2]) : 50, shuffle = argc > 3 ? atoi(argv[3]) : 0, kcap = 128;
@@ -612,15 +832,20 @@ int main(int argc, char **argv)
     }
     {   // variant D
         int *counter; CHK(hipMalloc(&counter, 4));
-        for (int variant : {4, 5}) for (int item_tiles : {2, 4, 8}) for (int nblocks : {512}) {
+        for (int variant : {5, 10}) for (int item_tiles : {4, 8, 16}) for (int nblocks : {512, 1024}) {
             V4 a; a.v = v; a.counter = counter; a.item_tiles = item_tiles;
-            int nitems = 0; for (int J = 0; J < ld / TC; ++J) { int nt = (TC * J + TC + TR - 1) / TR; nitems += (nt + item_tiles - 1) / item_tiles; }
+            const int trv = (variant == 10) ? 16 : TR; int nitems = 0; for (int J = 0; J < ld / TC; ++J) { int nt = (TC * J + TC + trv - 1) / trv; nitems += (nt + item_tiles - 1) / item_tiles; }
             a.nitems = nitems;
             float tot = 0, best = 1e9;
             for (int it = 0; it < 10; ++it) {
                 CHK(hipMemset(SD, 0, (size_t)kcap * ld * 8)); CHK(hipMemset(SL, 0, (size_t)kcap * ld * 8)); CHK(hipMemset(counter, 0, 4));
                 CHK(hipEventRecord(e0));
-                if (variant == 4) k_sym4<<<nblocks, 256>>>(a); else k_sym5<<<nblocks, 256>>>(a);
+                if (variant == 4) k_sym4<<<nblocks, 256>>>(a); else if (variant == 5) k_sym5<<<nblocks, 256>>>(a);
+                else if (variant == 6) k_sym5a<1><<<nblocks, 256>>>(a);   // no direction 2
+                else if (variant == 7) k_sym5a<3><<<nblocks, 256>>>(a);   // staging + barriers only
+                else if (variant == 8) k_sym5a<7><<<nblocks, 256>>>(a);   // loads only (no LDS)
+                else if (variant == 9) k_sym5a<2><<<nblocks, 256>>>(a);                     // no direction 1
+                else k_sym5r16<<<nblocks, 256>>>(a);
                 CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
                 float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
                 if (it >= 2) { tot += ms; best = std::min(best, ms); }
