@@ -51,7 +51,7 @@ typedef struct rc_params {
 /* Counters of the last rc_gibbs_sweep (diagnostics; no reference counterpart). */
 typedef struct rc_sweep_stats {
     int64_t n_changes; /* points whose label changed in the sweep */
-    int64_t n_rounds;  /* scoring passes launched (1 + n_changes in the exact speculative scheme) */
+    int64_t n_rounds;  /* resolve rounds (tentative scoring passes); between 1 and 1 + n_changes */
     int64_t K;         /* clusters after the sweep (state.K, src/mcmc.jl:254) */
 } rc_sweep_stats;
 

@@ -49,6 +49,7 @@ typedef unsigned long long u64;
 #define RC_RES_THREADS 512  // k_resolve block: 32 points x 16 candidate streams; 2 waves/SIMD so it co-resides with k_bulk
 #define RC_PTS 32           // points per chunk (lanes of a half wave)
 #define RC_MAX_KCAP 4096
+#define RC_MAXB 1024         // tentative changers validated per resolve round
 #define RC_SPIN_LIMIT (1u << 23)
 
 // error bits in DevScalars.err
@@ -90,7 +91,10 @@ struct View {
     int *snap[2];              // [n] slot of every point as it was when the generation was written (k_bulk_sym reads these)
     int *work[2];              // work-item counters of k_bulk_sym (two generations)
     const double *A;           // [n+1] size table
-    u64 *keys[2];              // [n+2] one first-change word per round (two generations)
+    u64 *keys[2];              // [n+2] one word per resolve round: first violation (batch rounds) (two generations)
+    u64 *cword[2];             // [nchunks] per 32-point chunk: (round stamp << 32) | mask of tentative changers (two generations)
+    unsigned *rec;             // [n] (own slot << 16) | (target slot + 1) of a tentative changer (0 target = new cluster)
+    int *tent;                 // [n] tentative target of every point (owner-private)
     unsigned *arrive[2];       // grid-barrier arrival counters (two generations)
     DevScalars *sc;
     HostSummary *hsum;         // device address of the host-mapped summary
@@ -746,11 +750,15 @@ struct Tab {
     double *red_v;   // [NW][32] reduction scratch (NW = waves per block)
     int *red_pos, *red_slot;
     int *misc;       // [0]=K [1]=smallest_empty [2]=scratch min [3]=b [4]=structural [5]=fail [6]=barrier ok [7]=slot_hi
-    u64 *blk_key;    // block-local first-change key
+    u64 *blk_key;    // block-local minimum (first violation)
+    // batch of tentative changers of the current round (identical in every block)
+    int *bx, *ba, *bb;        // [RC_MAXB] point, source slot, target slot, ascending in point index
+    unsigned char *affected;  // [kcap] slot is a source or target of a batch changer
+    int *ccnt;                // [nchunks + 1] scratch: changers per chunk / exclusive offsets
 };
 
 #define RC_A16(x) (((x) + 15) & ~(size_t)15)
-__host__ __device__ inline size_t tab_layout(int kcap, int n, int nw, size_t *off /*12*/)
+__host__ __device__ inline size_t tab_layout(int kcap, int n, int nw, size_t *off /*17*/)
 {
     size_t o = 0;
     off[0] = o; o = RC_A16(o + sizeof(double) * kcap);          // base_o
@@ -765,24 +773,31 @@ __host__ __device__ inline size_t tab_layout(int kcap, int n, int nw, size_t *of
     off[9] = o; o = RC_A16(o + sizeof(int) * 8);                // misc
     off[10] = o; o = RC_A16(o + sizeof(short) * kcap);          // pos
     off[11] = o; o = RC_A16(o + sizeof(short) * kcap);          // act
+    off[12] = o; o = RC_A16(o + sizeof(int) * RC_MAXB);         // bx
+    off[13] = o; o = RC_A16(o + sizeof(int) * RC_MAXB);         // ba
+    off[14] = o; o = RC_A16(o + sizeof(int) * RC_MAXB);         // bb
+    off[15] = o; o = RC_A16(o + (size_t)kcap);                  // affected
+    off[16] = o; o = RC_A16(o + sizeof(int) * ((n + RC_PTS - 1) / RC_PTS + 1));  // ccnt
     return o;
 }
 
 __device__ Tab tab_carve(char *smem, int kcap, int n, int nw)
 {
-    size_t off[12];
+    size_t off[17];
     tab_layout(kcap, n, nw, off);
     Tab T;
     T.base_o = (double *)(smem + off[0]); T.base_s = (double *)(smem + off[1]); T.red_v = (double *)(smem + off[2]);
     T.blk_key = (u64 *)(smem + off[3]); T.size = (int *)(smem + off[4]); T.label = (int *)(smem + off[5]);
     T.red_pos = (int *)(smem + off[6]); T.red_slot = (int *)(smem + off[7]); T.used = (unsigned *)(smem + off[8]);
     T.misc = (int *)(smem + off[9]); T.pos = (short *)(smem + off[10]); T.act = (short *)(smem + off[11]);
+    T.bx = (int *)(smem + off[12]); T.ba = (int *)(smem + off[13]); T.bb = (int *)(smem + off[14]);
+    T.affected = (unsigned char *)(smem + off[15]); T.ccnt = (int *)(smem + off[16]);
     return T;
 }
 
 static size_t tab_bytes(int kcap, int n, int nw)
 {
-    size_t off[12];
+    size_t off[17];
     return tab_layout(kcap, n, nw, off);
 }
 
@@ -973,34 +988,64 @@ __device__ __forceinline__ void best_merge(double &bv, int &bp, int &bs, double 
     if (s != -2 && (bs == -2 || v > bv || (v == bv && p < bp))) { bv = v; bp = p; bs = s; }
 }
 
-__device__ void score_chunk(const View &V, const SweepArgs &a, Tab &T, const long long *SD, const long long *SL,
-                            int chunk, int after_i)
+// mode 0 (tentative): decisions under the committed state; the target of every point goes to V.tent, changers to
+//   V.rec and the chunk's stamped mask word.
+// mode 1 (validate): point i is evaluated under the committed state PLUS the first nb_i batch changers that precede
+//   it (exact integer corrections of the two row sums and the sizes involved); a decision that differs from the
+//   tentative one is a violation (block-local minimum in T.blk_key).  Points outside (lo, hi] are skipped.
+__device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long long *SD, const long long *SL,
+                           int chunk, int lo, int hi, int mode, int nb, u64 *cword, unsigned stamp)
 {
     const int pt = threadIdx.x & (RC_PTS - 1), st = threadIdx.x >> 5, NS = blockDim.x >> 5;
     const int wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
     const int i = chunk * RC_PTS + pt;
-    const bool valid = (i < V.n) && (i > after_i);
+    const bool valid = (i < V.n) && (i > lo) && (i <= hi);
     const int K = T.misc[0];
     double bestv = -INFINITY;
     int bestpos = 0x7fffffff, bestslot = -2;
     int own = 0, Ki = K, single = 0;
     if (valid) {
         own = V.slot_of[i];
-        single = (T.size[own] == 1);
+        const size_t ld = (size_t)V.ld;
+        // number of batch changers before i (bx ascending)
+        int j = 0;
+        if (mode == 1) {
+            int lo_ = 0, hi_ = nb;
+            while (lo_ < hi_) { const int mid = (lo_ + hi_) >> 1; if (T.bx[mid] < i) lo_ = mid + 1; else hi_ = mid; }
+            j = lo_;
+        }
+        int so = T.size[own];
+        if (mode == 1 && T.affected[own])
+            for (int q = 0; q < j; ++q) so += (T.bb[q] == own) - (T.ba[q] == own);
+        single = (so == 1);
         const int pown = T.pos[own];
         Ki = K - single;
         const long long dg = V.diagq[i];
-        const size_t ld = (size_t)V.ld;
         for (int pos = st; pos < ((a.dbg & 1) ? 0 : K); pos += NS) {
             const int k = T.act[pos];
             const int isown = (k == own);
-            const int s = T.size[k] - isown;
+            int sz = T.size[k];
+            long long sd = SD[(size_t)k * ld + i], sl = SL[(size_t)k * ld + i];
+            bool touched = false;
+            if (mode == 1 && T.affected[k]) {
+                for (int q = 0; q < j; ++q) {
+                    const int qa = T.ba[q], qb = T.bb[q];
+                    if (qa == k || qb == k) {
+                        const size_t e = (size_t)T.bx[q] * ld + i;
+                        const long long xd = (V.bits == 64) ? ((const long long *)V.Dq)[e] : (long long)((const int *)V.Dq)[e];
+                        const long long xl = (V.bits == 64) ? ((const long long *)V.Lq)[e] : (long long)((const int *)V.Lq)[e];
+                        const int sg = (qb == k) - (qa == k);
+                        sd += sg * xd; sl += sg * xl; sz += sg;
+                        touched = true;
+                    }
+                }
+            }
+            const int s = sz - isown;
             if (s == 0) continue;  // own singleton cluster: not a candidate once i is removed (mcmc.jl:193-196)
             const int pe = pos - (single && pos > pown);
-            const long long sd = SD[(size_t)k * ld + i] - (isown ? dg : 0);  // i itself excluded (clusts[i] = -1)
-            const long long sl = SL[(size_t)k * ld + i];                      // logD diagonal is 0 (types.jl:155)
-            const double SDr = (double)sd * V.scD, SLr = (double)sl * V.scL;
-            const double base = isown ? T.base_s[k] : T.base_o[k];
+            sd -= (isown ? dg : 0);                                              // i itself excluded (clusts[i] = -1)
+            const double SDr = (double)sd * V.scD, SLr = (double)sl * V.scL;      // logD diagonal is 0 (types.jl:155)
+            const double base = touched ? tab_base(V, a, s) : (isown ? T.base_s[k] : T.base_o[k]);
             double lik = V.cL * SLr - (V.alpha + V.delta1 * (double)s) * log1p(SDr / V.beta);
             if (V.repulsion) lik += (V.zeta + V.delta2 * (double)s) * log1p(SDr / V.gamma);
             double v = base + lik;
@@ -1038,20 +1083,32 @@ __device__ void score_chunk(const View &V, const SweepArgs &a, Tab &T, const lon
         const double ov = __shfl_xor(bv, 32);
         const int op = __shfl_xor(bp, 32), os = __shfl_xor(bs, 32);
         best_merge(bv, bp, bs, ov, op, os);
+        bool changed = false;
+        int target = own;
         if (half == 0 && valid) {
-            bool changed;
             if (bs >= 0) {
                 changed = (bs != own);
+                target = bs;
             } else {
                 // new label = smallest empty label once i is removed (mcmc.jl:199)
                 const int se = T.misc[1];
                 const int newlab = single ? min(T.label[own], se) : se;
                 changed = !(single && newlab == T.label[own]);
+                target = changed ? -1 : own;
             }
-            if (changed) {
-                const u64 key = ((u64)(unsigned)i << 32) | ((u64)(unsigned)own << 16) | (u64)(unsigned)(bs + 1);
-                atomicMin(T.blk_key, key);
+        }
+        if (mode == 0) {
+            if (half == 0 && valid) {
+                V.tent[i] = target;
+                if (changed) __hip_atomic_store(V.rec + i, ((unsigned)own << 16) | (unsigned)(target + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            const u64 m = __ballot(changed) & 0xFFFFFFFFull;
+            if (m) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the records are out before the mask that announces them
+                if (threadIdx.x == 0) __hip_atomic_store(cword + chunk, ((u64)stamp << 32) | m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else if (half == 0 && valid && target != V.tent[i]) {
+            atomicMin(T.blk_key, (u64)(unsigned)i);
         }
     }
     __syncthreads();
@@ -1174,12 +1231,67 @@ __device__ bool grid_barrier(const View &V, Tab &T, unsigned *arrive, unsigned t
     return sh_ok != 0;
 }
 
+// Commit of the first `nc` batch changers (all of them plain moves between existing clusters that stay non-empty):
+// sizes, per-slot constants, slot_of, and the S corrections for every point this block owns (both generations).
+__device__ void commit_batch(const View &V, const SweepArgs &sa, Tab &T, int nc, int G, int own_gen, int next_gen)
+{
+    if (threadIdx.x == 0)
+        for (int q = 0; q < nc; ++q) { T.size[T.ba[q]] -= 1; T.size[T.bb[q]] += 1; }
+    __syncthreads();
+    tab_bases(V, sa, T);
+    const int nchunks = (V.n + RC_PTS - 1) / RC_PTS;
+    const int pt = threadIdx.x & (RC_PTS - 1), st = threadIdx.x >> 5, NS = blockDim.x >> 5;
+    long long *SDo = V.SD[own_gen], *SLo = V.SL[own_gen];
+    long long *SDn = next_gen >= 0 ? V.SD[next_gen] : nullptr, *SLn = next_gen >= 0 ? V.SL[next_gen] : nullptr;
+    for (int c = blockIdx.x; c < nchunks; c += G) {
+        const int i = c * RC_PTS + pt;
+        if (i >= V.n) continue;
+        // Own generation: plain read-modify-write (this block reads these rows again next round, through its L1), so
+        // every (slot row, point) is touched by exactly one thread — stream (slot mod NS).  Next generation: atomics,
+        // because the row reduction of the following sweep is adding to it concurrently.
+        for (int q = 0; q < nc; ++q) {
+            const int a = T.ba[q], b = T.bb[q];
+            const bool da = (a % NS) == st, db = (b % NS) == st;
+            if (!da && !db) continue;
+            const size_t e = (size_t)T.bx[q] * V.ld + i;
+            const long long xd = (V.bits == 64) ? ((const long long *)V.Dq)[e] : (long long)((const int *)V.Dq)[e];
+            const long long xl = (V.bits == 64) ? ((const long long *)V.Lq)[e] : (long long)((const int *)V.Lq)[e];
+            const size_t ia = (size_t)a * V.ld + i, ib = (size_t)b * V.ld + i;
+            if (da) {
+                SDo[ia] -= xd; SLo[ia] -= xl;
+                if (SDn) {
+                    __hip_atomic_fetch_add((u64 *)(SDn + ia), (u64)(-xd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add((u64 *)(SLn + ia), (u64)(-xl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (db) {
+                SDo[ib] += xd; SLo[ib] += xl;
+                if (SDn) {
+                    __hip_atomic_fetch_add((u64 *)(SDn + ib), (u64)xd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add((u64 *)(SLn + ib), (u64)xl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
+    for (int q = threadIdx.x; q < nc; q += blockDim.x) V.slot_of[T.bx[q]] = T.bb[q];  // same values from every block
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------------
-// k_resolve — one persistent launch per sweep: round 0 scores every point; each further round commits the
-// first change and re-draws the points after it.  G blocks (G <= #CUs; they need not start together: the
-// spin is bounded only by a generous timeout, and k_bulk never waits on this kernel).
-// Sweep t reads S generation t%3, corrects generations t%3 and (t+1)%3, uses key/barrier generation t%2
-// (and re-arms generation (t+1)%2), and leaves perm generation t%2 describing the labels after the sweep.
+// k_resolve — one persistent launch per sweep.  Each round:
+//   1. every remaining point is scored and drawn in parallel under the committed state (tentative decisions);
+//   2. barrier; every block assembles the same ordered batch of tentative changers (up to RC_MAXB, cut before the
+//      first one that would create, empty or rename a cluster);
+//   3. every point after the first changer is re-drawn under the committed state plus the batch changers that
+//      precede it; the smallest point whose decision differs from its tentative one is the first violation;
+//   4. barrier; the batch changers before the violation are committed at once.
+// By induction over the point order this is exactly the sequential sweep: a point before the first violation saw
+// precisely the changes of its predecessors.  Independent changes therefore cost two barriers per round instead of
+// one barrier each; a structural change (birth / death / rename) is committed alone as before.
+// G blocks (G <= #CUs; they need not start together: the spin is bounded only by a generous timeout, and k_bulk
+// never waits on this kernel).  Sweep t reads S generation own_gen, corrects own_gen and next_gen, uses key /
+// chunk-word / barrier generation t%2 (and re-arms generation (t+1)%2), and leaves perm / snapshot generation t%2
+// describing the labels after the sweep.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(RC_RES_THREADS) void k_resolve(View V, SweepArgs sa, int G)
 {
@@ -1188,34 +1300,113 @@ __global__ __launch_bounds__(RC_RES_THREADS) void k_resolve(View V, SweepArgs sa
     const int t = sa.t, own_gen = sa.own_gen, next_gen = sa.next_gen, kg = t & 1;
     const long long *SD = V.SD[own_gen], *SL = V.SL[own_gen];
     u64 *keys = V.keys[kg];
+    u64 *cword = V.cword[kg];
     unsigned *arrive = V.arrive[kg];
     tab_load(V, T);
     tab_bases(V, sa, T);
     const int nchunks = (V.n + RC_PTS - 1) / RC_PTS;
-    int after = -1, round = 0, changes = 0;
+    int after = -1, round = 0, changes = 0, nbar = 0;
     bool ok = true;
     for (;;) {
+        const unsigned stamp = (unsigned)round + 1u;
+        // 1. tentative decisions of the points after `after`
         for (int c = blockIdx.x; c < nchunks; c += G)
-            if (c * RC_PTS + RC_PTS - 1 > after) score_chunk(V, sa, T, SD, SL, c, after);
+            if (c * RC_PTS + RC_PTS - 1 > after) eval_chunk(V, sa, T, SD, SL, c, after, V.n, 0, 0, cword, stamp);
+        if (sa.dbg & 2) break;
+        ok = grid_barrier(V, T, arrive, (unsigned)G * (unsigned)(++nbar), RC_KEY_NONE, keys + round);
+        if (!ok) break;
+        // 2. the ordered batch of tentative changers
+        for (int c = threadIdx.x; c <= nchunks; c += blockDim.x) {
+            int cnt = 0;
+            if (c < nchunks && c * RC_PTS + RC_PTS - 1 > after) {
+                const u64 w = __hip_atomic_load(cword + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(w >> 32) == stamp) cnt = __popc((unsigned)w);
+            }
+            T.ccnt[c] = cnt;
+        }
+        for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) T.affected[k] = 0;
+        __syncthreads();
+        if (threadIdx.x == 0) {  // exclusive offsets (nchunks <= 1024 for n <= 32768)
+            int o = 0;
+            for (int c = 0; c <= nchunks; ++c) { const int x = T.ccnt[c]; T.ccnt[c] = o; o += x; }
+        }
+        __syncthreads();
+        const int total = T.ccnt[nchunks];
+        if (total == 0) break;  // no point wants to move: the sweep is complete
+        for (int c = threadIdx.x; c < nchunks; c += blockDim.x) {
+            int o = T.ccnt[c];
+            if (T.ccnt[c + 1] > o && o < RC_MAXB + 1) {
+                unsigned m = (unsigned)__hip_atomic_load(cword + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while (m && o <= RC_MAXB) {
+                    const int bit = __ffs((int)m) - 1;
+                    m &= m - 1;
+                    const int x = c * RC_PTS + bit;
+                    if (o < RC_MAXB) {
+                        const unsigned rc = __hip_atomic_load(V.rec + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        T.bx[o] = x; T.ba[o] = (int)(rc >> 16); T.bb[o] = (int)(rc & 0xFFFFu) - 1;
+                    } else {
+                        T.misc[2] = x;  // first changer that does not fit into the batch
+                    }
+                    ++o;
+                }
+            }
+        }
+        __syncthreads();
+        // cut before the first structural changer (target = new cluster, or the source cluster would become empty)
+        if (threadIdx.x == 0) {
+            const int nb0 = min(total, RC_MAXB);
+            int nb = nb0, hi = (total > RC_MAXB) ? T.misc[2] - 1 : V.n - 1;
+            for (int q = 0; q < nb0; ++q) {
+                const int a = T.ba[q], b = T.bb[q];
+                if (b < 0 || T.size[a] <= 1) { nb = q; hi = T.bx[q] - 1; break; }
+                T.size[a] -= 1; T.size[b] += 1;  // simulated; undone below
+            }
+            for (int q = 0; q < nb; ++q) { T.size[T.ba[q]] += 1; T.size[T.bb[q]] -= 1; T.affected[T.ba[q]] = 1; T.affected[T.bb[q]] = 1; }
+            T.misc[3] = nb; T.misc[4] = hi;
+            *T.blk_key = RC_KEY_NONE;
+        }
+        __syncthreads();
+        const int nb = T.misc[3], hi = T.misc[4];
+        if (nb == 0) {
+            // the first changer is structural: commit it alone (tables are rebuilt); its successors are re-drawn next round
+            const u64 key = ((u64)(unsigned)T.bx[0] << 32) | ((u64)(unsigned)T.ba[0] << 16) | (u64)(unsigned)(T.bb[0] + 1);
+            const int x0 = T.bx[0];
+            __syncthreads();
+            ok = commit_change(V, sa, T, key, G, own_gen, next_gen);
+            if (!ok) break;
+            after = x0;
+            ++round; ++changes;
+            if (round > V.n) break;
+            continue;
+        }
+        // 3. validation of the points after the first changer, each under the changers that precede it
+        const int first = T.bx[0];
+        for (int c = blockIdx.x; c < nchunks; c += G)
+            if (c * RC_PTS + RC_PTS - 1 > first && c * RC_PTS <= hi) eval_chunk(V, sa, T, SD, SL, c, first, hi, 1, nb, cword, stamp);
         __syncthreads();
         const u64 mine = *T.blk_key;
-        if (sa.dbg & 2) break;
-        ok = grid_barrier(V, T, arrive, (unsigned)G * (unsigned)(round + 1), mine, keys + round);
+        ok = grid_barrier(V, T, arrive, (unsigned)G * (unsigned)(++nbar), mine, keys + round);
         if (!ok) break;
-        const u64 key = __hip_atomic_load(keys + round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (key == RC_KEY_NONE) break;
-        if (threadIdx.x == 0) *T.blk_key = RC_KEY_NONE;
-        ok = commit_change(V, sa, T, key, G, own_gen, next_gen);
-        if (!ok) break;
-        after = (int)(key >> 32);
+        // 4. commit the changers before the first violation
+        const u64 vk = __hip_atomic_load(keys + round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int limit = (vk == RC_KEY_NONE) ? hi + 1 : (int)vk;   // points < limit are final
+        int nc = 0;
+        {
+            int lo_ = 0, hi_ = nb;
+            while (lo_ < hi_) { const int mid = (lo_ + hi_) >> 1; if (T.bx[mid] < limit) lo_ = mid + 1; else hi_ = mid; }
+            nc = lo_;
+        }
+        commit_batch(V, sa, T, nc, G, own_gen, next_gen);
+        changes += nc;
+        after = limit - 1;
         ++round;
-        ++changes;
-        if (round > V.n) break;  // cannot happen: each round finalises at least one more point
+        if (round > V.n) break;  // cannot happen: every round finalises at least the first changer
     }
     if (blockIdx.x == 0) {
         __syncthreads();
-        // re-arm the other key/barrier generation for the next sweep (its last user, sweep t-1, has finished)
+        // re-arm the other key / chunk-word / barrier generation for the next sweep (its last user, sweep t-1, is done)
         for (int q = threadIdx.x; q < V.n + 2; q += blockDim.x) V.keys[kg ^ 1][q] = RC_KEY_NONE;
+        for (int q = threadIdx.x; q < nchunks; q += blockDim.x) V.cword[kg ^ 1][q] = 0;
         if (threadIdx.x == 0) *V.arrive[kg ^ 1] = 0u;
         tab_store(V, T);
         const int last = V.sc->last_change_sweep;
@@ -1344,6 +1535,9 @@ struct rc_ctx {
     short *slot_pos = nullptr, *slot_act = nullptr;
     int *perm[2] = {nullptr, nullptr}, *pslot[2] = {nullptr, nullptr};
     int *lsnap[2] = {nullptr, nullptr}, *work[2] = {nullptr, nullptr};  // label snapshots / work counters of k_bulk_sym
+    u64 *cword[2] = {nullptr, nullptr};
+    unsigned *rec = nullptr;
+    int *tent = nullptr;
     int bulk_kernel = -1;      // RC_BULK_KERNEL: -1 auto, 0 k_bulk (full read, any layout), 1 k_bulk_sym (upper triangle)
     int last_bulk_kernel = 0;  // what the last enqueue chose
     int sym_item_tiles = 8;
@@ -1418,7 +1612,8 @@ static View make_view(const rc_ctx *c)
     V.n = c->n; V.ld = c->ld; V.kcap = c->kcap;
     V.Dq = c->Dq; V.Lq = c->Lq; V.bits = c->bits; V.diagq = c->diagq;
     for (int g = 0; g < 3; ++g) { V.SD[g] = c->SD[g]; V.SL[g] = c->SL[g]; }
-    for (int g = 0; g < 2; ++g) { V.perm[g] = c->perm[g]; V.pslot[g] = c->pslot[g]; V.keys[g] = c->keys[g]; V.arrive[g] = c->arrive[g]; V.snap[g] = c->lsnap[g]; V.work[g] = c->work[g]; }
+    for (int g = 0; g < 2; ++g) { V.perm[g] = c->perm[g]; V.pslot[g] = c->pslot[g]; V.keys[g] = c->keys[g]; V.arrive[g] = c->arrive[g]; V.snap[g] = c->lsnap[g]; V.work[g] = c->work[g]; V.cword[g] = c->cword[g]; }
+    V.rec = c->rec; V.tent = c->tent;
     V.slot_of = c->slot_of; V.slot_size = c->slot_size; V.slot_label = c->slot_label;
     V.slot_pos = c->slot_pos; V.slot_act = c->slot_act;
     V.A = c->A; V.sc = c->sc; V.hsum = c->hsum_dev;
@@ -1455,7 +1650,7 @@ static void free_all(rc_ctx *c)
     (void)hipSetDevice(c->dev);
     void *ptrs[] = {c->Dq, c->Lq, c->diagq, c->SD[0], c->SD[1], c->SD[2], c->SL[0], c->SL[1], c->SL[2], c->slot_of,
                     c->slot_size, c->slot_label, c->slot_pos, c->slot_act, c->perm[0], c->perm[1], c->pslot[0],
-                    c->pslot[1], c->lsnap[0], c->lsnap[1], c->work[0], c->work[1], c->A, c->keys[0], c->keys[1], c->arrive[0], c->arrive[1], c->sc, c->blocks,
+                    c->pslot[1], c->lsnap[0], c->lsnap[1], c->work[0], c->work[1], c->cword[0], c->cword[1], c->rec, c->tent, c->A, c->keys[0], c->keys[1], c->arrive[0], c->arrive[1], c->sc, c->blocks,
                     c->counts, c->cc_out, c->snap, c->d_moves};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1540,10 +1735,14 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
         HIPCHK2(hipMalloc(&c->lsnap[g], (size_t)n * sizeof(int)));
         HIPCHK2(hipMalloc(&c->work[g], 64));
         HIPCHK2(hipMemsetAsync(c->work[g], 0, 64, s));
+        HIPCHK2(hipMalloc(&c->cword[g], ((size_t)(n + RC_PTS - 1) / RC_PTS + 1) * sizeof(u64)));
+        HIPCHK2(hipMemsetAsync(c->cword[g], 0, ((size_t)(n + RC_PTS - 1) / RC_PTS + 1) * sizeof(u64), s));
         HIPCHK2(hipMalloc(&c->keys[g], (size_t)(n + 2) * sizeof(u64)));
         HIPCHK2(hipMalloc(&c->arrive[g], 64));
     }
     HIPCHK2(hipMalloc(&c->slot_of, (size_t)n * sizeof(int)));
+    HIPCHK2(hipMalloc(&c->rec, (size_t)n * sizeof(unsigned)));
+    HIPCHK2(hipMalloc(&c->tent, (size_t)n * sizeof(int)));
     HIPCHK2(hipMalloc(&c->slot_size, (size_t)c->kcap * sizeof(int)));
     HIPCHK2(hipMalloc(&c->slot_label, (size_t)c->kcap * sizeof(int)));
     HIPCHK2(hipMalloc(&c->slot_pos, (size_t)c->kcap * sizeof(short)));
@@ -1838,6 +2037,7 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
     }
     for (int g = 0; g < 2; ++g) {
         HIPCHK(c, hipMemsetAsync(c->keys[g], 0xFF, (size_t)(n + 2) * sizeof(u64), c->sA));
+        HIPCHK(c, hipMemsetAsync(c->cword[g], 0, ((size_t)(n + RC_PTS - 1) / RC_PTS + 1) * sizeof(u64), c->sA));
         HIPCHK(c, hipMemsetAsync(c->arrive[g], 0, 64, c->sA));
         HIPCHK(c, hipMemsetAsync(c->work[g], 0, 64, c->sA));
     }
@@ -2679,6 +2879,7 @@ extern "C" int32_t rc_set_mode(rc_ctx *c, int32_t mode)
         }
         for (int g = 0; g < 2; ++g) {
             HIPCHK(c, hipMemsetAsync(c->keys[g], 0xFF, (size_t)(c->n + 2) * sizeof(u64), c->sA));
+            HIPCHK(c, hipMemsetAsync(c->cword[g], 0, ((size_t)(c->n + RC_PTS - 1) / RC_PTS + 1) * sizeof(u64), c->sA));
             HIPCHK(c, hipMemsetAsync(c->arrive[g], 0, 64, c->sA));
             HIPCHK(c, hipMemsetAsync(c->work[g], 0, 64, c->sA));
         }

@@ -756,6 +756,101 @@ template <int ABL> __global__ __launch_bounds__(256) void k_sym5a(V4 a)
     }
 }
 
+
+// ---- variant F: direction 1 straight from the loaded registers (each thread owns 2 columns x 8 rows of the tile, rows
+//      w, w+4, ... of wave w); LDS serves direction 2 only, done by all 256 threads (32 rows x 2 matrices x 4 quarters) ----
+__global__ __launch_bounds__(256) void k_sym6(V4 a)
+{
+    __shared__ __attribute__((aligned(16))) long long tt[2][TR][TP];
+    __shared__ int item_sh;
+    __shared__ int cslot[TC];
+    __shared__ int cchk[TC / 8];
+    const V &v = a.v;
+    const int tid = threadIdx.x, w = tid >> 6, lp = tid & 63;
+    const size_t ld = v.ld;
+    const int ncb = v.ld / TC;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) item_sh = atomicAdd(a.counter, 1);
+        __syncthreads();
+        int item = item_sh;
+        if (item >= a.nitems) break;
+        int J = ncb - 1;
+        for (;; --J) { const int ntile = (TC * J + TC + TR - 1) / TR; const int cnt = (ntile + a.item_tiles - 1) / a.item_tiles; if (item < cnt) break; item -= cnt; }
+        const int c0 = J * TC;
+        const int t_begin = item * a.item_tiles, t_end = min((TC * J + TC + TR - 1) / TR, t_begin + a.item_tiles);
+        if (tid < TC) cslot[tid] = (c0 + tid < v.n) ? v.slot_of[c0 + tid] : -1;
+        __syncthreads();
+        if (tid < TC / 8) { const int s0 = cslot[tid * 8]; bool u = true; for (int q = 1; q < 8; ++q) u = u && (cslot[tid * 8 + q] == s0); cchk[tid] = u ? s0 : -2; }
+        const int b = c0 + lp * 2;          // this thread's two columns
+        ll2 d[8], l[8];
+        int sr[8];
+        auto issue = [&](int t) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = min(t * TR + q * 4 + w, v.n - 1);
+                sr[q] = v.slot_of[r];
+                d[q] = __builtin_nontemporal_load((const ll2 *)(v.Dq + (size_t)r * ld + b));
+                l[q] = __builtin_nontemporal_load((const ll2 *)(v.Lq + (size_t)r * ld + b));
+            }
+        };
+        issue(t_begin);
+        long long aD0 = 0, aD1 = 0, aL0 = 0, aL1 = 0;
+        int cur = -1;
+        for (int t = t_begin; t < t_end; ++t) {
+            const int r0 = t * TR;
+            __syncthreads();   // previous tile consumed by direction 2
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int lr = q * 4 + w, r = r0 + lr;
+                const bool live = r < v.n;
+                ll2 x = d[q], y = l[q];
+                if (!(live && b > r)) { x.x = 0; y.x = 0; }
+                if (!(live && b + 1 > r)) { x.y = 0; y.y = 0; }
+                const int s_ = __builtin_amdgcn_readfirstlane(sr[q]);
+                if (live && s_ != cur) {
+                    if (cur >= 0) { if (aD0) atom(v.SD + (size_t)cur * ld + b, aD0); if (aD1) atom(v.SD + (size_t)cur * ld + b + 1, aD1); if (aL0) atom(v.SL + (size_t)cur * ld + b, aL0); if (aL1) atom(v.SL + (size_t)cur * ld + b + 1, aL1); }
+                    aD0 = aD1 = aL0 = aL1 = 0; cur = s_;
+                }
+                aD0 += x.x; aD1 += x.y; aL0 += y.x; aL1 += y.y;
+                *(ll2 *)&tt[0][lr][lp * 2] = x;
+                *(ll2 *)&tt[1][lr][lp * 2] = y;
+            }
+            if (t + 1 < t_end) issue(t + 1);
+            __syncthreads();
+            {
+                // direction 2: wave w -> columns 32w..32w+31; lanes 0-31 rows of D, lanes 32-63 rows of logD
+                const int r = tid & 31, mat = (tid >> 5) & 1;
+                long long *S = mat ? v.SL : v.SD;
+                const int arow = r0 + r;
+                long long acc = 0;
+                int cc = -1;
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) {
+                    const int cb = w * 32 + ch * 8;
+                    const ll2 x0 = *(const ll2 *)&tt[mat][r][cb], x1 = *(const ll2 *)&tt[mat][r][cb + 2], x2 = *(const ll2 *)&tt[mat][r][cb + 4], x3 = *(const ll2 *)&tt[mat][r][cb + 6];
+                    const int cs_ = __builtin_amdgcn_readfirstlane(cchk[cb >> 3]);
+                    if (cs_ != -2) {
+                        if (cs_ != cc) { if (cc >= 0 && acc && arow < v.n) atom(S + (size_t)cc * ld + arow, acc); acc = 0; cc = cs_; }
+                        acc += ((x0.x + x0.y) + (x1.x + x1.y)) + ((x2.x + x2.y) + (x3.x + x3.y));
+                    } else {
+                        const long long xs[8] = {x0.x, x0.y, x1.x, x1.y, x2.x, x2.y, x3.x, x3.y};
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int sc = __builtin_amdgcn_readfirstlane(cslot[cb + q]);
+                            if (sc != cc) { if (cc >= 0 && acc && arow < v.n) atom(S + (size_t)cc * ld + arow, acc); acc = 0; cc = sc; }
+                            acc += xs[q];
+                        }
+                    }
+                }
+                if (cc >= 0 && acc && arow < v.n) atom(S + (size_t)cc * ld + arow, acc);
+            }
+        }
+        if (cur >= 0) { if (aD0) atom(v.SD + (size_t)cur * ld + b, aD0); if (aD1) atom(v.SD + (size_t)cur * ld + b + 1, aD1); if (aL0) atom(v.SL + (size_t)cur * ld + b, aL0); if (aL1) atom(v.SL + (size_t)cur * ld + b + 1, aL1); }
+        if (t_begin == 0 && tid < TC) { const int a_ = c0 + tid; if (a_ < v.n) { const long long x = v.Dq[(size_t)a_ * ld + a_]; if (x) atom(v.SD + (size_t)v.slot_of[a_] * ld + a_, x); } }
+    }
+}
+
 int main(int argc, char **argv)
 {
     const int n = argc > 1 ? atoi(argv[1]) : 8192, K = argc > 2 ? atoi(argv[2]) : 50, shuffle = argc > 3 ? atoi(argv[3]) : 0, kcap = 128;
@@ -832,7 +927,7 @@ int main(int argc, char **argv)
     }
     {   // variant D
         int *counter; CHK(hipMalloc(&counter, 4));
-        for (int variant : {5, 10}) for (int item_tiles : {4, 8, 16}) for (int nblocks : {512, 1024}) {
+        for (int variant : {5, 11}) for (int item_tiles : {4, 8, 16}) for (int nblocks : {512}) {
             V4 a; a.v = v; a.counter = counter; a.item_tiles = item_tiles;
             const int trv = (variant == 10) ? 16 : TR; int nitems = 0; for (int J = 0; J < ld / TC; ++J) { int nt = (TC * J + TC + trv - 1) / trv; nitems += (nt + item_tiles - 1) / item_tiles; }
             a.nitems = nitems;
@@ -845,7 +940,8 @@ int main(int argc, char **argv)
                 else if (variant == 7) k_sym5a<3><<<nblocks, 256>>>(a);   // staging + barriers only
                 else if (variant == 8) k_sym5a<7><<<nblocks, 256>>>(a);   // loads only (no LDS)
                 else if (variant == 9) k_sym5a<2><<<nblocks, 256>>>(a);                     // no direction 1
-                else k_sym5r16<<<nblocks, 256>>>(a);
+                else if (variant == 10) k_sym5r16<<<nblocks, 256>>>(a);
+                else k_sym6<<<nblocks, 256>>>(a);
                 CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
                 float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
                 if (it >= 2) { tot += ms; best = std::min(best, ms); }
