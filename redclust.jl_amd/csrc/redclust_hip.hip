@@ -1582,6 +1582,9 @@ struct rc_ctx {
     std::vector<int64_t> checkpoint;     // labels saved by rc_state_checkpoint
     int *d_moves = nullptr;
     size_t d_moves_cap = 0;
+    long long state_version = 0;         // bumped whenever labels may have changed (sweeps, moves, rc_set_state)
+    long long ll_version = -1;           // state_version the cached log-likelihood belongs to
+    double ll_cached = 0.0;
     char err[512] = {0};
 };
 
@@ -2049,6 +2052,7 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
     c->last = s;
     c->t_next = 0;
     c->bulk_enq = -1;
+    c->state_version++;
     c->have_state = true;
     return RC_OK;
 }
@@ -2162,6 +2166,7 @@ extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t 
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(c->ev_res[t & 3], c->sA));
         c->t_next = t + 1;
+        c->state_version++;
         return RC_OK;
     }
     if (c->bulk_enq < t) {
@@ -2175,6 +2180,7 @@ extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t 
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev_res[t & 3], c->sA));
     c->t_next = t + 1;
+    c->state_version++;
     if (c->prefetch) {
         // software pipeline: the row reduction of the next sweep starts now, under the labels known before
         // this sweep; k_resolve adds this sweep's label changes to it (exact integer atomics)
@@ -2555,6 +2561,7 @@ static int32_t apply_labels(rc_ctx *c, const std::vector<int64_t> &cur, const st
             moved.push_back(i);
         }
     if (moved.empty()) return RC_OK;
+    c->state_version++;
     int free_scan = 0;
     for (int i : moved) {
         const int lab = (int)next[(size_t)i];
@@ -2659,13 +2666,21 @@ struct Restricted {
     double abratio, zgratio, lg_d1, lg_d2, logp;
     const std::vector<int64_t> *U;  // sorted indices of i, j and S: every member of the two candidate clusters
     std::vector<std::vector<int64_t>> fixed_members;  // members of C[1] / C[2] when they are not candidates
+    int64_t fixed_label[2] = {-1, -1};
 
-    double member_sum(const double *M, int64_t x, const std::vector<int64_t> &clusts, int64_t lab) const
+    // Row sums of item x over the members of the two candidate clusters, in ONE pass over U (ascending index, so
+    // each cluster's sum is accumulated in ascending member order exactly as findall + matsum do, mcmc.jl:308-311,
+    // utils.jl:9-17).  out[0..1] = D sums, out[2..3] = logD sums.
+    void cand_sums(int64_t x, const std::vector<int64_t> &clusts, const int64_t cand[2], double out[4]) const
     {
-        double s = 0;  // ascending member order, as findall + matsum (mcmc.jl:308-311, utils.jl:9-17)
-        for (int64_t y : *U)
-            if (clusts[(size_t)y] == lab) s += M[(size_t)x * (size_t)n + (size_t)y];
-        return s;
+        double d0 = 0, d1 = 0, l0 = 0, l1 = 0;
+        const double *Dx = D + (size_t)x * (size_t)n, *Lx = L + (size_t)x * (size_t)n;
+        for (int64_t y : *U) {
+            const int64_t c = clusts[(size_t)y];
+            if (c == cand[0]) { d0 += Dx[y]; l0 += Lx[y]; }
+            else if (c == cand[1]) { d1 += Dx[y]; l1 += Lx[y]; }
+        }
+        out[0] = d0; out[1] = d1; out[2] = l0; out[3] = l1;
     }
     static double list_sum(const double *M, int64_t x, int64_t n, const std::vector<int64_t> &mem)
     {
@@ -2673,6 +2688,9 @@ struct Restricted {
         for (int64_t y : mem) s += M[(size_t)x * (size_t)n + (size_t)y];
         return s;
     }
+    // sums over the (static) members of C[1] / C[2] when they are not candidates: computed once per item and proposal
+    std::vector<double> fixedD[2], fixedL[2];
+    std::vector<char> fixed_have[2];
 
     // one scan (mcmc.jl:302-352); returns log_transition_prob
     double scan(std::vector<int64_t> &clusts, std::vector<int64_t> &sizes, const std::vector<int64_t> &items,
@@ -2684,22 +2702,28 @@ struct Restricted {
         int64_t firsts[2] = {0, 0};
         for (int64_t k = 0, f = 0; k < n && f < 2; ++k)
             if (sizes[(size_t)k] > 0) firsts[f++] = k + 1;
-        fixed_members.assign(2, {});
-        for (int t = 0; t < 2; ++t)
-            if (firsts[t] != 0 && firsts[t] != cand[0] && firsts[t] != cand[1])
-                for (int64_t y = 0; y < n; ++y)
-                    if (clusts[(size_t)y] == firsts[t]) fixed_members[(size_t)t].push_back(y);
+        if (fixed_label[0] != firsts[0] || fixed_label[1] != firsts[1] || fixed_members.size() != 2) {
+            fixed_members.assign(2, {});
+            for (int t = 0; t < 2; ++t) {
+                fixed_label[t] = firsts[t];
+                fixedD[t].assign((size_t)n, 0.0); fixedL[t].assign((size_t)n, 0.0); fixed_have[t].assign((size_t)n, 0);
+                if (firsts[t] != 0 && firsts[t] != cand[0] && firsts[t] != cand[1])
+                    for (int64_t y = 0; y < n; ++y)
+                        if (clusts[(size_t)y] == firsts[t]) fixed_members[(size_t)t].push_back(y);
+            }
+        }
         const int64_t m = (int64_t)items.size();
         double ltp = 0;
         for (int64_t q = 0; q < m; ++q) {
             const int64_t x = items[(size_t)q];
             sizes[(size_t)clusts[(size_t)x] - 1] -= 1;                                   // mcmc.jl:303
             clusts[(size_t)x] = -1;                                                      // mcmc.jl:304
-            double L1[2], lpr[2], L2p_c[2], logprobs[2];
+            double L1[2], lpr[2], L2p_c[2], logprobs[2], cs[4];
+            cand_sums(x, clusts, cand, cs);
             for (int k = 0; k < 2; ++k) {                                                // mcmc.jl:307-326
                 const double sz = (double)sizes[(size_t)cand[k] - 1];
-                const double sD = member_sum(D, x, clusts, cand[k]);
-                const double sL = member_sum(L, x, clusts, cand[k]);
+                const double sD = cs[k];
+                const double sL = cs[2 + k];
                 const double a_i = al + d1 * sz, b_i = be + sD, z_i = ze + d2 * sz, g_i = ga + sD;
                 L1[k] = std::lgamma(a_i) + abratio - a_i * std::log(b_i) + (d1 - 1) * sL - sz * lg_d1;
                 lpr[k] = std::log(sz + 1) + logp + std::log(sz - 1 + r) - std::log(sz);
@@ -2711,7 +2735,12 @@ struct Restricted {
                 if (firsts[t] == cand[0]) { L2p_first[t] = L2p_c[0]; continue; }
                 if (firsts[t] == cand[1]) { L2p_first[t] = L2p_c[1]; continue; }
                 const double sz = (double)sizes[(size_t)firsts[t] - 1];
-                const double sD = list_sum(D, x, n, fixed_members[(size_t)t]), sL = list_sum(L, x, n, fixed_members[(size_t)t]);
+                if (!fixed_have[t][(size_t)x]) {  // members of a non-candidate cluster do not change during the proposal
+                    fixedD[t][(size_t)x] = list_sum(D, x, n, fixed_members[(size_t)t]);
+                    fixedL[t][(size_t)x] = list_sum(L, x, n, fixed_members[(size_t)t]);
+                    fixed_have[t][(size_t)x] = 1;
+                }
+                const double sD = fixedD[t][(size_t)x], sL = fixedL[t][(size_t)x];
                 const double z_i = ze + d2 * sz, g_i = ga + sD;
                 L2p_first[t] = std::lgamma(z_i) - z_i * std::log(g_i) + zgratio + (d2 - 1) * sL - sz * lg_d2;
             }
@@ -2830,8 +2859,13 @@ extern "C" int32_t rc_splitmerge(rc_ctx *c, double r, double p, int64_t numGibbs
     (void)Klaunch;
     // likelihood ratio (mcmc.jl:462-464): both states evaluated on the device from the exact S table
     double ll_cur = 0, ll_fin = 0;
-    rc = rc_loglik(c, &ll_cur);
-    if (rc != RC_OK) return rc;
+    if (c->ll_version == c->state_version) {
+        ll_cur = c->ll_cached;  // same labels as at the last evaluation (e.g. the previous, rejected proposal)
+    } else {
+        rc = rc_loglik(c, &ll_cur);
+        if (rc != RC_OK) return rc;
+    }
+    const long long version_cur = c->state_version;
     rc = apply_labels(c, clusts, cfinal);
     if (rc != RC_OK) return rc;
     rc = rc_loglik(c, &ll_fin);
@@ -2841,9 +2875,14 @@ extern "C" int32_t rc_splitmerge(rc_ctx *c, double r, double p, int64_t numGibbs
     const double lu = std::log(rc_uniform_mh(seed, iter, mh_counter, 2));
     if (lu < lar) {                                                                      // mcmc.jl:469-472
         *accept_out = 1;  // the proposed state stays on the device (tables and perm generations already follow it)
+        c->ll_cached = ll_fin; c->ll_version = c->state_version;
         return RC_OK;
     }
-    return apply_labels(c, cfinal, clusts);                                              // rejected: revert, bit-exactly
+    rc = apply_labels(c, cfinal, clusts);                                                // rejected: revert, bit-exactly
+    if (rc != RC_OK) return rc;
+    (void)version_cur;
+    c->ll_cached = ll_cur; c->ll_version = c->state_version;                             // the reverted state is the evaluated one
+    return RC_OK;
 }
 
 
