@@ -177,7 +177,8 @@ def main():
             "coclustering_allreduce_ms": allreduce_ms, "coclustering_diag_ok": diag_ok,
             "roofline": {"kernel": kernel_name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
-                         "avg_launch_ms": bulk_avg_ms, "launches": bulk_launches, "algorithmic_bytes_per_launch": alg_bytes},
+                         "avg_launch_ms": bulk_avg_ms, "launches": bulk_launches, "algorithmic_bytes_per_launch": alg_bytes,
+                         "event_pair_overhead_ms_subtracted": ctx.event_overhead_ms()},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(D, P, truth, r, p)

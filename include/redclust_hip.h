@@ -150,12 +150,18 @@ int32_t rc_debug_rowsums(rc_ctx *ctx, int64_t label, int64_t *sumD_q /* n */, in
  * every launch, N > 1 = time every N-th launch (each timed launch costs a few microseconds of stream time),
  * negative = just read the counters. */
 int32_t rc_kernel_timing(rc_ctx *ctx, int32_t enable, double *bulk_ms_total, int64_t *bulk_launches);
+/* An event pair also measures the marker / dispatch latency around the kernel (several microseconds that a kernel
+ * trace does not include).  It is calibrated with an empty kernel when timing is enabled and subtracted from the
+ * totals above; this returns the calibrated value. */
+int32_t rc_event_overhead_ms(rc_ctx *ctx, double *out);
 
 /* Which row-reduction kernel the last enqueued sweep used — 0: k_bulk (reads every entry of D and logD, any point
  * order), 1: k_bulk_sym (reads only the upper triangle; chosen automatically when the points of a cluster are
  * contiguous in the point order, override with RC_BULK_KERNEL=perm|sym|auto) — and the matrix bytes that kernel
  * has to read per launch. */
 int32_t rc_bulk_kernel_info(rc_ctx *ctx, int32_t *which, double *algorithmic_bytes);
+/* Force the kernel: -1 automatic, 0 k_bulk, 1 k_bulk_sym (tests / measurements; results are identical). */
+int32_t rc_set_bulk_kernel(rc_ctx *ctx, int32_t which);
 
 #ifdef __cplusplus
 }

@@ -80,6 +80,8 @@ SIGNATURES = {
     "rc_state_restore": (C.c_int32, [C.c_void_p]),
     "rc_debug_rowsums": (C.c_int32, [C.c_void_p, C.c_int64, _ip, _ip, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rc_bulk_kernel_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+    "rc_set_bulk_kernel": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "rc_event_overhead_ms": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double)]),
     "rc_kernel_timing": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 
@@ -264,6 +266,14 @@ class Context:
         w, b = C.c_int32(), C.c_double()
         self._chk(self.L.rc_bulk_kernel_info(self.h, C.byref(w), C.byref(b)))
         return ("k_bulk_sym" if w.value else "k_bulk"), b.value
+
+    def set_bulk_kernel(self, which):
+        self._chk(self.L.rc_set_bulk_kernel(self.h, {"auto": -1, "perm": 0, "sym": 1}[which]))
+
+    def event_overhead_ms(self):
+        out = C.c_double()
+        self._chk(self.L.rc_event_overhead_ms(self.h, C.byref(out)))
+        return out.value
 
     def kernel_timing(self, enable=-1):
         ms = C.c_double()

@@ -381,6 +381,37 @@ def test_device_pairwise_distances():
     assert np.max(np.abs(md.D - ref)) <= 1e-12 * ref.max() and np.array_equal(md.D, md.D.T)
 
 
+@pytest.mark.parametrize("n,bits", [(333, 64), (1029, 64), (1200, 32), (2050, 32)])
+def test_symmetric_and_full_row_reduction_agree_exactly(n, bits):
+    """k_bulk_sym (reads the upper triangle only) and k_bulk (reads everything) must give the same row-sum table bit
+    for bit for sorted AND arbitrary labels, odd sizes, both storage widths — and the same sweeps."""
+    data = rc.generatemixture(n, 9, seed=n, sigma=0.2, dim=12)
+    D, truth = data["distancematrix"], data["clusts"]
+    P = rc.likelihood_hyperparams(D, truth)
+    rng = np.random.default_rng(n)
+    labelings = [truth, rng.integers(1, 10, size=n).astype(np.int64), rng.permutation(n).astype(np.int64) % 7 + 1]
+    ctxs = {}
+    for which in ("perm", "sym"):
+        c = rc.Context(D, storage_bits=bits, kcap=64)
+        c.set_params(**P); c.set_bulk_kernel(which)
+        ctxs[which] = c
+    for lab in labelings:
+        for c in ctxs.values():
+            c.set_state(lab)
+        for k in np.unique(lab):
+            a, b = ctxs["perm"].debug_rowsums(int(k)), ctxs["sym"].debug_rowsums(int(k))
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (n, bits, k)
+        assert ctxs["perm"].bulk_kernel_info()[0] == "k_bulk" and ctxs["sym"].bulk_kernel_info()[0] == "k_bulk_sym"
+        for t in range(3):
+            for c in ctxs.values():
+                c.gibbs_sweep(1.0, 0.5, 5, t)
+            sa, sb = ctxs["perm"].get_state(), ctxs["sym"].get_state()
+            assert np.array_equal(sa[0], sb[0]) and sa[2] == sb[2]
+        assert ctxs["perm"].loglik() == ctxs["sym"].loglik()
+    for c in ctxs.values():
+        c.close()
+
+
 def test_incremental_mode_is_bit_identical():
     """RC_MODE_INCREMENTAL (row-sum table maintained by exact corrections only) vs RC_MODE_FULL (recomputed every
     sweep) vs the oracle: same labels every sweep, identical loglik bits, identical row sums; switching modes
