@@ -38,6 +38,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/redclust_hip.h"
@@ -1588,6 +1589,9 @@ struct rc_ctx {
     long long state_version = 0;         // bumped whenever labels may have changed (sweeps, moves, rc_set_state)
     long long ll_version = -1;           // state_version the cached log-likelihood belongs to
     double ll_cached = 0.0;
+    // lgammal(alpha + delta1*pairs) - lgammal(alpha) and the zeta analogue, memoised by the integer pair count: between
+    // consecutive rc_loglik calls cluster sizes rarely change, so nearly all of the K + K(K-1)/2 evaluations hit
+    std::unordered_map<long long, long double> lg_memo1, lg_memo2;
     char err[512] = {0};
 };
 
@@ -1947,6 +1951,8 @@ extern "C" int32_t rc_set_params(rc_ctx *c, const rc_params *P)
     HIPCHK(c, hipStreamSynchronize(c->sA));
     HIPCHK(c, hipStreamSynchronize(c->sB));
     c->P = *P;
+    c->lg_memo1.clear();
+    c->lg_memo2.clear();
     // size table (see DESIGN.md "Score arithmetic"): long double on the host, once per parameter set
     std::vector<double> A((size_t)c->n + 1);
     const long double d1 = P->delta1, d2 = P->delta2, al = P->alpha, be = P->beta, ze = P->zeta, ga = P->gamma;
@@ -2286,8 +2292,13 @@ extern "C" int32_t rc_loglik(rc_ctx *c, double *out)
         const long double pairs = sz * (sz - 1) / 2;  // binomial(sz_k, 2)
         const long double a = al + d1 * pairs;
         const long double bd = blk(k, k, 0) / 2, bl = blk(k, k, 1) / 2;
-        L1 += (d1 - 1) * bl - pairs * lgd1 + (lgammal(a) - lga) - d1 * pairs * lb - a * log1pl(bd / be);
+        const long long pk = (long long)pairs;
+        auto it = c->lg_memo1.find(pk);
+        if (it == c->lg_memo1.end()) it = c->lg_memo1.emplace(pk, lgammal(a) - lga).first;
+        L1 += (d1 - 1) * bl - pairs * lgd1 + it->second - d1 * pairs * lb - a * log1pl(bd / be);
     }
+    if (c->lg_memo1.size() > (1u << 20)) c->lg_memo1.clear();
+    if (c->lg_memo2.size() > (1u << 20)) c->lg_memo2.clear();
     if (P.repulsion)
         for (size_t x = 0; x < act.size(); ++x)
             for (size_t y = x + 1; y < act.size(); ++y) {
@@ -2295,7 +2306,10 @@ extern "C" int32_t rc_loglik(rc_ctx *c, double *out)
                 const long double pairs = (long double)ssize[(size_t)k] * (long double)ssize[(size_t)t];
                 const long double z = ze + d2 * pairs;
                 const long double bd = blk(k, t, 0), bl = blk(k, t, 1);
-                L2 += (d2 - 1) * bl - pairs * lgd2 + (lgammal(z) - lgz) - d2 * pairs * lg - z * log1pl(bd / ga);
+                const long long pk = (long long)pairs;
+                auto it = c->lg_memo2.find(pk);
+                if (it == c->lg_memo2.end()) it = c->lg_memo2.emplace(pk, lgammal(z) - lgz).first;
+                L2 += (d2 - 1) * bl - pairs * lgd2 + it->second - d2 * pairs * lg - z * log1pl(bd / ga);
             }
     *out = (double)(L1 + L2);
     return RC_OK;

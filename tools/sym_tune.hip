@@ -694,7 +694,7 @@ template <int ABL> __global__ __launch_bounds__(256) void k_sym5a(V4 a)
                 ll2 x = d[q], y = l[q];
                 if (!(live && b > r)) { x.x = 0; y.x = 0; }
                 if (!(live && b + 1 > r)) { x.y = 0; y.y = 0; }
-                if (ABL & 4) { accD += x.x + x.y; accL += y.x + y.y; } else {
+                if (ABL & 4) { asm volatile("" :: "v"(x.x), "v"(x.y), "v"(y.x), "v"(y.y)); } else {
                 *(ll2 *)&tt[0][lr][lp * 2] = x;
                 *(ll2 *)&tt[1][lr][lp * 2] = y; }
             }
@@ -851,6 +851,121 @@ __global__ __launch_bounds__(256) void k_sym6(V4 a)
     }
 }
 
+
+// ---- variant G: 16-row x 256-column tiles (2 KiB row segments); all 256 threads do direction 1 (one column each),
+//      then direction 2 (16 rows x 2 matrices x 8 column groups of 32) ----
+#define GR 16
+#define GC 256
+#define GP (GC + 2)
+__global__ __launch_bounds__(256) void k_sym7(V4 a)
+{
+    __shared__ __attribute__((aligned(16))) long long tt[2][GR][GP];
+    __shared__ int item_sh;
+    __shared__ int cslot[GC], rslot[GR];
+    __shared__ int cchk[GC / 8], rchk[GR / 8];
+    const V &v = a.v;
+    const int tid = threadIdx.x;
+    const size_t ld = v.ld;
+    const int ncb = v.ld / GC;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) item_sh = atomicAdd(a.counter, 1);
+        __syncthreads();
+        int item = item_sh;
+        if (item >= a.nitems) break;
+        int J = ncb - 1;
+        for (;; --J) { const int ntile = (GC * J + GC + GR - 1) / GR; const int cnt = (ntile + a.item_tiles - 1) / a.item_tiles; if (item < cnt) break; item -= cnt; }
+        const int c0 = J * GC;
+        const int t_begin = item * a.item_tiles, t_end = min((GC * J + GC + GR - 1) / GR, t_begin + a.item_tiles);
+        cslot[tid] = (c0 + tid < v.n) ? v.slot_of[c0 + tid] : -1;
+        __syncthreads();
+        if (tid < GC / 8) { const int s0 = cslot[tid * 8]; bool u = true; for (int q = 1; q < 8; ++q) u = u && (cslot[tid * 8 + q] == s0); cchk[tid] = u ? s0 : -2; }
+        // loader: 16 rows x 128 sixteen-byte pieces per matrix = 2048 pieces = 8 per thread
+        ll2 d[8], l[8];
+        auto issue = [&](int t) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int piece = q * 256 + tid, lr = piece >> 7, lp = piece & 127;
+                const int r = min(t * GR + lr, v.n - 1);
+                d[q] = __builtin_nontemporal_load((const ll2 *)(v.Dq + (size_t)r * ld + c0 + lp * 2));
+                l[q] = __builtin_nontemporal_load((const ll2 *)(v.Lq + (size_t)r * ld + c0 + lp * 2));
+            }
+        };
+        issue(t_begin);
+        long long accD = 0, accL = 0;
+        int cur = -1;
+        const int b = c0 + tid;
+        for (int t = t_begin; t < t_end; ++t) {
+            const int r0 = t * GR;
+            __syncthreads();
+            if (tid < GR) rslot[tid] = (r0 + tid < v.n) ? v.slot_of[r0 + tid] : -1;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int piece = q * 256 + tid, lr = piece >> 7, lp = piece & 127;
+                const int r = r0 + lr, bb = c0 + lp * 2;
+                const bool live = r < v.n;
+                ll2 x = d[q], y = l[q];
+                if (!(live && bb > r)) { x.x = 0; y.x = 0; }
+                if (!(live && bb + 1 > r)) { x.y = 0; y.y = 0; }
+                *(ll2 *)&tt[0][lr][lp * 2] = x;
+                *(ll2 *)&tt[1][lr][lp * 2] = y;
+            }
+            if (t + 1 < t_end) issue(t + 1);
+            __syncthreads();
+            if (tid < GR / 8) { const int s0 = rslot[tid * 8]; bool u = true; for (int q = 1; q < 8; ++q) u = u && (rslot[tid * 8 + q] == s0); rchk[tid] = u ? s0 : -2; }
+            __syncthreads();
+#pragma unroll 1
+            for (int ch = 0; ch < GR / 8; ++ch) {
+                long long xd[8], xl[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { xd[q] = tt[0][ch * 8 + q][tid]; xl[q] = tt[1][ch * 8 + q][tid]; }
+                const int cs_ = __builtin_amdgcn_readfirstlane(rchk[ch]);
+                if (cs_ != -2) {
+                    if (cs_ != cur) { if (cur >= 0) { if (accD) atom(v.SD + (size_t)cur * ld + b, accD); if (accL) atom(v.SL + (size_t)cur * ld + b, accL); } accD = accL = 0; cur = cs_; }
+                    accD += ((xd[0] + xd[1]) + (xd[2] + xd[3])) + ((xd[4] + xd[5]) + (xd[6] + xd[7]));
+                    accL += ((xl[0] + xl[1]) + (xl[2] + xl[3])) + ((xl[4] + xl[5]) + (xl[6] + xl[7]));
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int sr = __builtin_amdgcn_readfirstlane(rslot[ch * 8 + q]);
+                        if (sr != cur) { if (cur >= 0) { if (accD) atom(v.SD + (size_t)cur * ld + b, accD); if (accL) atom(v.SL + (size_t)cur * ld + b, accL); } accD = accL = 0; cur = sr; }
+                        accD += xd[q]; accL += xl[q];
+                    }
+                }
+            }
+            {
+                // direction 2: thread -> (row r = tid & 15, matrix (tid >> 4) & 1, column group g = tid >> 5 of 32 columns)
+                const int r = tid & 15, mat = (tid >> 4) & 1, g = tid >> 5;
+                long long *S = mat ? v.SL : v.SD;
+                const int arow = r0 + r;
+                long long acc = 0;
+                int cc = -1;
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) {
+                    const int cb = g * 32 + ch * 8;
+                    const ll2 x0 = *(const ll2 *)&tt[mat][r][cb], x1 = *(const ll2 *)&tt[mat][r][cb + 2], x2 = *(const ll2 *)&tt[mat][r][cb + 4], x3 = *(const ll2 *)&tt[mat][r][cb + 6];
+                    const int cs_ = cchk[cb >> 3];   // two column groups per wave: not wave-uniform
+                    if (cs_ != -2) {
+                        if (cs_ != cc) { if (cc >= 0 && acc && arow < v.n) atom(S + (size_t)cc * ld + arow, acc); acc = 0; cc = cs_; }
+                        acc += ((x0.x + x0.y) + (x1.x + x1.y)) + ((x2.x + x2.y) + (x3.x + x3.y));
+                    } else {
+                        const long long xs[8] = {x0.x, x0.y, x1.x, x1.y, x2.x, x2.y, x3.x, x3.y};
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int sc = cslot[cb + q];
+                            if (sc != cc) { if (cc >= 0 && acc && arow < v.n) atom(S + (size_t)cc * ld + arow, acc); acc = 0; cc = sc; }
+                            acc += xs[q];
+                        }
+                    }
+                }
+                if (cc >= 0 && acc && arow < v.n) atom(S + (size_t)cc * ld + arow, acc);
+            }
+        }
+        if (cur >= 0) { if (accD) atom(v.SD + (size_t)cur * ld + b, accD); if (accL) atom(v.SL + (size_t)cur * ld + b, accL); }
+        if (t_begin == 0 && b < v.n) { const long long x = v.Dq[(size_t)b * ld + b]; if (x) atom(v.SD + (size_t)v.slot_of[b] * ld + b, x); }
+    }
+}
+
 int main(int argc, char **argv)
 {
     const int n = argc > 1 ? atoi(argv[1]) : 8192, K = argc > 2 ? atoi(argv[2]) : 50, shuffle = argc > 3 ? atoi(argv[3]) : 0, kcap = 128;
@@ -927,9 +1042,9 @@ int main(int argc, char **argv)
     }
     {   // variant D
         int *counter; CHK(hipMalloc(&counter, 4));
-        for (int variant : {5, 11}) for (int item_tiles : {4, 8, 16}) for (int nblocks : {512}) {
+        for (int variant : {5, 12}) for (int item_tiles : {4, 8, 16}) for (int nblocks : {512}) {
             V4 a; a.v = v; a.counter = counter; a.item_tiles = item_tiles;
-            const int trv = (variant == 10) ? 16 : TR; int nitems = 0; for (int J = 0; J < ld / TC; ++J) { int nt = (TC * J + TC + trv - 1) / trv; nitems += (nt + item_tiles - 1) / item_tiles; }
+            const int trv = (variant == 10 || variant == 12) ? 16 : TR; const int tcv = (variant == 12) ? GC : TC; int nitems = 0; for (int J = 0; J < ld / tcv; ++J) { int nt = (tcv * J + tcv + trv - 1) / trv; nitems += (nt + item_tiles - 1) / item_tiles; }
             a.nitems = nitems;
             float tot = 0, best = 1e9;
             for (int it = 0; it < 10; ++it) {
@@ -941,7 +1056,8 @@ int main(int argc, char **argv)
                 else if (variant == 8) k_sym5a<7><<<nblocks, 256>>>(a);   // loads only (no LDS)
                 else if (variant == 9) k_sym5a<2><<<nblocks, 256>>>(a);                     // no direction 1
                 else if (variant == 10) k_sym5r16<<<nblocks, 256>>>(a);
-                else k_sym6<<<nblocks, 256>>>(a);
+                else if (variant == 11) k_sym6<<<nblocks, 256>>>(a);
+                else k_sym7<<<nblocks, 256>>>(a);
                 CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
                 float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
                 if (it >= 2) { tot += ms; best = std::min(best, ms); }
