@@ -56,7 +56,13 @@ def cpu_baseline(D, P, labels, r, p, max_seconds=20.0):
     orc.sweep_literal_range(r, p, 1, 0, 1, 0, want)
     dt = time.perf_counter() - t0
     sweeps_per_s = 1.0 / (dt * n / want)
+    # the same restatement with each row bucketed once ("single-pass"): what a tidy single-threaded CPU code would do
+    orc.set_state(labels)
+    t0 = time.perf_counter()
+    orc.sweep_literal_range(r, p, 1, 0, 0, 0, n)
+    dt_sp = time.perf_counter() - t0
     return {"value": sweeps_per_s, "unit": "sweeps/s", "cores": 1, "kind": "port",
+            "single_pass_variant_sweeps_per_s": 1.0 / dt_sp,
             "sample": f"first {want} of {n} points of one sweep (faithful-cost literal C restatement of "
                       f"mcmc.jl:158-256, single thread, {dt:.1f} s), scaled to a full sweep; host has {os.cpu_count()} cores"}
 

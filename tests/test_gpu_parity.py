@@ -412,6 +412,37 @@ def test_symmetric_and_full_row_reduction_agree_exactly(n, bits):
         c.close()
 
 
+@pytest.mark.parametrize("variant", ["plain", "maxK", "norep", "bits32"])
+def test_long_trajectory_with_continual_movement(variant):
+    """150 sweeps on overlapping clusters (σ large: labels keep moving every sweep — batches, violations, births and
+    deaths in the resolver) against the oracle, state compared after every sweep."""
+    n, K = 311, 6
+    data = rc.generatemixture(n, K, seed=21, sigma=0.55, dim=8)
+    D, truth = data["distancematrix"], data["clusts"]
+    P = rc.likelihood_hyperparams(D, truth)
+    bits = 64
+    if variant == "maxK":
+        P = dict(P, maxK=9)
+    elif variant == "norep":
+        P = dict(P, repulsion=False)
+    elif variant == "bits32":
+        bits = 32
+    init = np.random.default_rng(3).integers(1, K + 1, size=n).astype(np.int64)
+    orc, ctx = make_pair(D, P, init, kcap=320, bits=bits)
+    moved = 0
+    for t in range(150):
+        r, p = rp_schedule(t)
+        ctx.gibbs_sweep(r, p, 2024, t, blocking=(t % 3 != 0))
+        orc.sweep_stable(r, p, 2024, t)
+        assert_state_equal(ctx, orc, f"({variant}, sweep {t})")
+        st = ctx.sweep_stats()
+        assert st["n_changes"] == orc.last_changes
+        moved += st["n_changes"]
+    assert moved > 150  # the chain really keeps moving
+    assert abs(ctx.loglik() - orc.loglik_stable()) <= LL_RTOL * max(1.0, abs(orc.loglik_stable()))
+    ctx.close()
+
+
 def test_incremental_mode_is_bit_identical():
     """RC_MODE_INCREMENTAL (row-sum table maintained by exact corrections only) vs RC_MODE_FULL (recomputed every
     sweep) vs the oracle: same labels every sweep, identical loglik bits, identical row sums; switching modes
