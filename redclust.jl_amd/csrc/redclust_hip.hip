@@ -79,11 +79,12 @@ struct HostSummary {
 // Everything a kernel needs, passed by value.
 struct View {
     int n, ld, kcap;
-    const void *Dq, *Lq;       // [n][ld] fixed point: int64 (bits = 64) or int32 (bits = 32)
+    const void *Dq, *Lq;       // [n][ld] fixed point: int64 (bits = 64) or int32 (bits = 32); rows/columns in INTERNAL order
     int bits;
     const long long *diagq;    // [n] Dq[i][i]
     long long *SD[3], *SL[3];  // three generations of the [kcap][ld] row-sum table (software pipelining)
-    int *slot_of;              // [n]
+    int *slot_of;              // [n] slot of every point, INTERNAL point order
+    const int *pi;             // [n] original point index -> internal index (cluster-contiguous layout chosen at rc_set_state)
     int *slot_size;            // [kcap]
     int *slot_label;           // [kcap] 1-based label, 0 = free slot
     short *slot_pos;           // [kcap] rank of the slot's label among active labels
@@ -227,6 +228,21 @@ __global__ __launch_bounds__(256) void k_pairwise(const double *__restrict__ pts
                 if (ti != tj) D[(size_t)j * n + i] = d;
             }
         }
+}
+
+// Internal layout: out[w][x] = src[ipi[w]][ipi[x]] (points of a cluster contiguous).  One block row per internal row w.
+template <typename T>
+__global__ __launch_bounds__(256) void k_relayout(const T *__restrict__ src, const int *__restrict__ ipi, int n, int ld, T *__restrict__ out)
+{
+    const int w = blockIdx.y;
+    const T *row = src + (size_t)ipi[w] * ld;
+    for (int x = blockIdx.x * 256 + threadIdx.x; x < n; x += gridDim.x * 256) out[(size_t)w * ld + x] = row[ipi[x]];
+}
+
+__global__ void k_gather_ll(const long long *__restrict__ src, const int *__restrict__ ipi, int n, long long *__restrict__ out)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < n) out[w] = src[ipi[w]];
 }
 
 // fixed-point matrix back to doubles (value = q·2^-e), for checks
@@ -753,13 +769,14 @@ struct Tab {
     int *misc;       // [0]=K [1]=smallest_empty [2]=scratch min [3]=b [4]=structural [5]=fail [6]=barrier ok [7]=slot_hi
     u64 *blk_key;    // block-local minimum (first violation)
     // batch of tentative changers of the current round (identical in every block)
-    int *bx, *ba, *bb;        // [RC_MAXB] point, source slot, target slot, ascending in point index
+    int *bx, *ba, *bb;        // [RC_MAXB] point (original index), source slot, target slot, ascending in point index
+    int *bu;                  // [RC_MAXB] internal index of the point
     unsigned char *affected;  // [kcap] slot is a source or target of a batch changer
     int *ccnt;                // [nchunks + 1] scratch: changers per chunk / exclusive offsets
 };
 
 #define RC_A16(x) (((x) + 15) & ~(size_t)15)
-__host__ __device__ inline size_t tab_layout(int kcap, int n, int nw, size_t *off /*17*/)
+__host__ __device__ inline size_t tab_layout(int kcap, int n, int nw, size_t *off /*18*/)
 {
     size_t o = 0;
     off[0] = o; o = RC_A16(o + sizeof(double) * kcap);          // base_o
@@ -779,12 +796,13 @@ __host__ __device__ inline size_t tab_layout(int kcap, int n, int nw, size_t *of
     off[14] = o; o = RC_A16(o + sizeof(int) * RC_MAXB);         // bb
     off[15] = o; o = RC_A16(o + (size_t)kcap);                  // affected
     off[16] = o; o = RC_A16(o + sizeof(int) * ((n + RC_PTS - 1) / RC_PTS + 1));  // ccnt
+    off[17] = o; o = RC_A16(o + sizeof(int) * RC_MAXB);         // bu
     return o;
 }
 
 __device__ Tab tab_carve(char *smem, int kcap, int n, int nw)
 {
-    size_t off[17];
+    size_t off[18];
     tab_layout(kcap, n, nw, off);
     Tab T;
     T.base_o = (double *)(smem + off[0]); T.base_s = (double *)(smem + off[1]); T.red_v = (double *)(smem + off[2]);
@@ -792,13 +810,13 @@ __device__ Tab tab_carve(char *smem, int kcap, int n, int nw)
     T.red_pos = (int *)(smem + off[6]); T.red_slot = (int *)(smem + off[7]); T.used = (unsigned *)(smem + off[8]);
     T.misc = (int *)(smem + off[9]); T.pos = (short *)(smem + off[10]); T.act = (short *)(smem + off[11]);
     T.bx = (int *)(smem + off[12]); T.ba = (int *)(smem + off[13]); T.bb = (int *)(smem + off[14]);
-    T.affected = (unsigned char *)(smem + off[15]); T.ccnt = (int *)(smem + off[16]);
+    T.affected = (unsigned char *)(smem + off[15]); T.ccnt = (int *)(smem + off[16]); T.bu = (int *)(smem + off[17]);
     return T;
 }
 
 static size_t tab_bytes(int kcap, int n, int nw)
 {
-    size_t off[17];
+    size_t off[18];
     return tab_layout(kcap, n, nw, off);
 }
 
@@ -1006,7 +1024,8 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
     int bestpos = 0x7fffffff, bestslot = -2;
     int own = 0, Ki = K, single = 0;
     if (valid) {
-        own = V.slot_of[i];
+        const int u = V.pi[i];  // matrices, S and slot_of are stored in the internal (cluster-contiguous) point order
+        own = V.slot_of[u];
         const size_t ld = (size_t)V.ld;
         // number of batch changers before i (bx ascending)
         int j = 0;
@@ -1021,18 +1040,18 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
         single = (so == 1);
         const int pown = T.pos[own];
         Ki = K - single;
-        const long long dg = V.diagq[i];
+        const long long dg = V.diagq[u];
         for (int pos = st; pos < ((a.dbg & 1) ? 0 : K); pos += NS) {
             const int k = T.act[pos];
             const int isown = (k == own);
             int sz = T.size[k];
-            long long sd = SD[(size_t)k * ld + i], sl = SL[(size_t)k * ld + i];
+            long long sd = SD[(size_t)k * ld + u], sl = SL[(size_t)k * ld + u];
             bool touched = false;
             if (mode == 1 && T.affected[k]) {
                 for (int q = 0; q < j; ++q) {
                     const int qa = T.ba[q], qb = T.bb[q];
                     if (qa == k || qb == k) {
-                        const size_t e = (size_t)T.bx[q] * ld + i;
+                        const size_t e = (size_t)T.bu[q] * ld + u;
                         const long long xd = (V.bits == 64) ? ((const long long *)V.Dq)[e] : (long long)((const int *)V.Dq)[e];
                         const long long xl = (V.bits == 64) ? ((const long long *)V.Lq)[e] : (long long)((const int *)V.Lq)[e];
                         const int sg = (qb == k) - (qa == k);
@@ -1190,10 +1209,12 @@ __device__ bool commit_change(const View &V, const SweepArgs &sa, Tab &T, u64 ke
             long long *So = (job < 2) ? V.SD[own_gen] : V.SL[own_gen];
             long long *Sn = (job < 2) ? V.SD[next_gen < 0 ? own_gen : next_gen] : V.SL[next_gen < 0 ? own_gen : next_gen];
             const int slot = (job & 1) ? b : a;
+            const int ustar = V.pi[istar];
             for (int c = blockIdx.x; c < nchunks; c += G) {
-                const int i = c * RC_PTS + pt;
-                if (i < V.n) {
-                    const size_t e = (size_t)istar * V.ld + i;
+                const int io = c * RC_PTS + pt;
+                if (io < V.n) {
+                    const int i = V.pi[io];
+                    const size_t e = (size_t)ustar * V.ld + i;
                     const long long x = (V.bits == 64) ? ((const long long *)M)[e] : (long long)((const int *)M)[e];
                     const long long dx = (job & 1) ? x : -x;
                     So[(size_t)slot * V.ld + i] += dx;
@@ -1203,7 +1224,7 @@ __device__ bool commit_change(const View &V, const SweepArgs &sa, Tab &T, u64 ke
             }
         }
     }
-    if (threadIdx.x == 0) V.slot_of[istar] = b;  // same value from every block
+    if (threadIdx.x == 0) V.slot_of[V.pi[istar]] = b;  // same value from every block
     __syncthreads();
     return true;
 }
@@ -1245,8 +1266,9 @@ __device__ void commit_batch(const View &V, const SweepArgs &sa, Tab &T, int nc,
     long long *SDo = V.SD[own_gen], *SLo = V.SL[own_gen];
     long long *SDn = next_gen >= 0 ? V.SD[next_gen] : nullptr, *SLn = next_gen >= 0 ? V.SL[next_gen] : nullptr;
     for (int c = blockIdx.x; c < nchunks; c += G) {
-        const int i = c * RC_PTS + pt;
-        if (i >= V.n) continue;
+        const int io = c * RC_PTS + pt;
+        if (io >= V.n) continue;
+        const int i = V.pi[io];
         // Own generation: plain read-modify-write (this block reads these rows again next round, through its L1), so
         // every (slot row, point) is touched by exactly one thread — stream (slot mod NS).  Next generation: atomics,
         // because the row reduction of the following sweep is adding to it concurrently.
@@ -1254,7 +1276,7 @@ __device__ void commit_batch(const View &V, const SweepArgs &sa, Tab &T, int nc,
             const int a = T.ba[q], b = T.bb[q];
             const bool da = (a % NS) == st, db = (b % NS) == st;
             if (!da && !db) continue;
-            const size_t e = (size_t)T.bx[q] * V.ld + i;
+            const size_t e = (size_t)T.bu[q] * V.ld + i;
             const long long xd = (V.bits == 64) ? ((const long long *)V.Dq)[e] : (long long)((const int *)V.Dq)[e];
             const long long xl = (V.bits == 64) ? ((const long long *)V.Lq)[e] : (long long)((const int *)V.Lq)[e];
             const size_t ia = (size_t)a * V.ld + i, ib = (size_t)b * V.ld + i;
@@ -1274,7 +1296,7 @@ __device__ void commit_batch(const View &V, const SweepArgs &sa, Tab &T, int nc,
             }
         }
     }
-    for (int q = threadIdx.x; q < nc; q += blockDim.x) V.slot_of[T.bx[q]] = T.bb[q];  // same values from every block
+    for (int q = threadIdx.x; q < nc; q += blockDim.x) V.slot_of[T.bu[q]] = T.bb[q];  // same values from every block
     __syncthreads();
 }
 
@@ -1344,7 +1366,7 @@ __global__ __launch_bounds__(RC_RES_THREADS) void k_resolve(View V, SweepArgs sa
                     const int x = c * RC_PTS + bit;
                     if (o < RC_MAXB) {
                         const unsigned rc = __hip_atomic_load(V.rec + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        T.bx[o] = x; T.ba[o] = (int)(rc >> 16); T.bb[o] = (int)(rc & 0xFFFFu) - 1;
+                        T.bx[o] = x; T.bu[o] = V.pi[x]; T.ba[o] = (int)(rc >> 16); T.bb[o] = (int)(rc & 0xFFFFu) - 1;
                     } else {
                         T.misc[2] = x;  // first changer that does not fit into the batch
                     }
@@ -1468,10 +1490,11 @@ __global__ __launch_bounds__(256) void k_blocksums(View V, int gen, int hi, long
 // ---------------------------------------------------------------------------------------------------
 #define RC_CC_BATCH 32
 #define RC_CC_ROWS 16
-__global__ __launch_bounds__(256) void k_snapshot(const int *__restrict__ slot_of, int n, int ldn, unsigned short *__restrict__ snap)
+__global__ __launch_bounds__(256) void k_snapshot(const int *__restrict__ slot_of, const int *__restrict__ pi, int n, int ldn,
+                                                 unsigned short *__restrict__ snap)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < ldn) snap[i] = (i < n) ? (unsigned short)slot_of[i] : (unsigned short)0xFFFE;
+    const int i = blockIdx.x * 256 + threadIdx.x;  // original point order: the count matrix is the caller's
+    if (i < ldn) snap[i] = (i < n) ? (unsigned short)slot_of[pi[i]] : (unsigned short)0xFFFE;
 }
 
 __global__ __launch_bounds__(256) void k_cocluster_batch(const unsigned short *__restrict__ snap, int cnt, int n, int ldn,
@@ -1530,8 +1553,12 @@ struct rc_ctx {
     int eD = 0, eL = 0;
     hipStream_t sA = nullptr;  // resolve + observables (high priority)
     hipStream_t sB = nullptr;  // row-bucket reduction (k_bulk)
-    void *Dq = nullptr, *Lq = nullptr;  // int64 or int32 fixed point
-    long long *diagq = nullptr;
+    void *Dq = nullptr, *Lq = nullptr;  // int64 or int32 fixed point, INTERNAL point order (what the kernels read)
+    void *Dq_src = nullptr, *Lq_src = nullptr;  // the same matrices in the caller's point order (source of every re-layout)
+    long long *diagq = nullptr, *diag_src = nullptr;
+    int *pi = nullptr, *ipi = nullptr;  // device: original -> internal, internal -> original
+    std::vector<int> h_pi, h_ipi;       // host copies
+    bool relayout = true;               // RC_NO_RELAYOUT=1 keeps the caller's point order
     int bits = 64;
     long long *SD[3] = {nullptr, nullptr, nullptr}, *SL[3] = {nullptr, nullptr, nullptr};
     int *slot_of = nullptr, *slot_size = nullptr, *slot_label = nullptr;
@@ -1620,7 +1647,7 @@ static View make_view(const rc_ctx *c)
 {
     View V{};
     V.n = c->n; V.ld = c->ld; V.kcap = c->kcap;
-    V.Dq = c->Dq; V.Lq = c->Lq; V.bits = c->bits; V.diagq = c->diagq;
+    V.Dq = c->Dq; V.Lq = c->Lq; V.bits = c->bits; V.diagq = c->diagq; V.pi = c->pi;
     for (int g = 0; g < 3; ++g) { V.SD[g] = c->SD[g]; V.SL[g] = c->SL[g]; }
     for (int g = 0; g < 2; ++g) { V.perm[g] = c->perm[g]; V.pslot[g] = c->pslot[g]; V.keys[g] = c->keys[g]; V.arrive[g] = c->arrive[g]; V.snap[g] = c->lsnap[g]; V.work[g] = c->work[g]; V.cword[g] = c->cword[g]; }
     V.rec = c->rec; V.tent = c->tent;
@@ -1658,7 +1685,7 @@ static void free_all(rc_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->dev);
-    void *ptrs[] = {c->Dq, c->Lq, c->diagq, c->SD[0], c->SD[1], c->SD[2], c->SL[0], c->SL[1], c->SL[2], c->slot_of,
+    void *ptrs[] = {c->Dq, c->Lq, c->Dq_src, c->Lq_src, c->diag_src, c->pi, c->ipi, c->diagq, c->SD[0], c->SD[1], c->SD[2], c->SL[0], c->SL[1], c->SL[2], c->slot_of,
                     c->slot_size, c->slot_label, c->slot_pos, c->slot_act, c->perm[0], c->perm[1], c->pslot[0],
                     c->pslot[1], c->lsnap[0], c->lsnap[1], c->work[0], c->work[1], c->cword[0], c->cword[1], c->rec, c->tent, c->A, c->keys[0], c->keys[1], c->arrive[0], c->arrive[1], c->sc, c->blocks,
                     c->counts, c->cc_out, c->snap, c->d_moves};
@@ -1734,7 +1761,12 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     const size_t esz = (size_t)c->bits / 8;
     HIPCHK2(hipMalloc(&c->Dq, (size_t)n * ld * esz));
     HIPCHK2(hipMalloc(&c->Lq, (size_t)n * ld * esz));
+    HIPCHK2(hipMalloc(&c->Dq_src, (size_t)n * ld * esz));
+    HIPCHK2(hipMalloc(&c->Lq_src, (size_t)n * ld * esz));
     HIPCHK2(hipMalloc(&c->diagq, (size_t)n * sizeof(long long)));
+    HIPCHK2(hipMalloc(&c->diag_src, (size_t)n * sizeof(long long)));
+    HIPCHK2(hipMalloc(&c->pi, (size_t)n * sizeof(int)));
+    HIPCHK2(hipMalloc(&c->ipi, (size_t)n * sizeof(int)));
     for (int g = 0; g < 3; ++g) {
         HIPCHK2(hipMalloc(&c->SD[g], (size_t)c->kcap * ld * sizeof(long long)));
         HIPCHK2(hipMalloc(&c->SL[g], (size_t)c->kcap * ld * sizeof(long long)));
@@ -1765,6 +1797,8 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     HIPCHK2(hipMalloc(&c->blocks, (size_t)c->kcap * c->kcap * 4 * sizeof(long long)));
     HIPCHK2(hipMemsetAsync(c->Dq, 0, (size_t)n * ld * esz, s));
     HIPCHK2(hipMemsetAsync(c->Lq, 0, (size_t)n * ld * esz, s));
+    HIPCHK2(hipMemsetAsync(c->Dq_src, 0, (size_t)n * ld * esz, s));
+    HIPCHK2(hipMemsetAsync(c->Lq_src, 0, (size_t)n * ld * esz, s));
     HIPCHK2(hipMemsetAsync(c->slot_size, 0, (size_t)c->kcap * sizeof(int), s));
     HIPCHK2(hipMemsetAsync(c->slot_label, 0, (size_t)c->kcap * sizeof(int), s));
     HIPCHK2(hipMemsetAsync(c->sc, 0, sizeof(DevScalars), s));
@@ -1805,12 +1839,20 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     c->eD = quant_exponent(n, maxD, c->bits);
     c->eL = quant_exponent(n, maxL, c->bits);
     if (c->bits == 64) {
-        k_quantize<long long><<<gb, 256, 0, s>>>(tmpD, (int)n, c->ld, c->eD, (long long *)c->Dq, c->diagq);
-        k_quantize<long long><<<gb, 256, 0, s>>>(tmpL, (int)n, c->ld, c->eL, (long long *)c->Lq, nullptr);
+        k_quantize<long long><<<gb, 256, 0, s>>>(tmpD, (int)n, c->ld, c->eD, (long long *)c->Dq_src, c->diag_src);
+        k_quantize<long long><<<gb, 256, 0, s>>>(tmpL, (int)n, c->ld, c->eL, (long long *)c->Lq_src, nullptr);
     } else {
-        k_quantize<int><<<gb, 256, 0, s>>>(tmpD, (int)n, c->ld, c->eD, (int *)c->Dq, c->diagq);
-        k_quantize<int><<<gb, 256, 0, s>>>(tmpL, (int)n, c->ld, c->eL, (int *)c->Lq, nullptr);
+        k_quantize<int><<<gb, 256, 0, s>>>(tmpD, (int)n, c->ld, c->eD, (int *)c->Dq_src, c->diag_src);
+        k_quantize<int><<<gb, 256, 0, s>>>(tmpL, (int)n, c->ld, c->eL, (int *)c->Lq_src, nullptr);
     }
+    // until rc_set_state chooses a cluster-contiguous layout the internal order is the caller's
+    c->h_pi.resize((size_t)n); c->h_ipi.resize((size_t)n);
+    for (int64_t q = 0; q < n; ++q) { c->h_pi[(size_t)q] = (int)q; c->h_ipi[(size_t)q] = (int)q; }
+    HIPCHK2(hipMemcpyAsync(c->pi, c->h_pi.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK2(hipMemcpyAsync(c->ipi, c->h_ipi.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK2(hipMemcpyAsync(c->Dq, c->Dq_src, (size_t)n * ld * esz, hipMemcpyDeviceToDevice, s));
+    HIPCHK2(hipMemcpyAsync(c->Lq, c->Lq_src, (size_t)n * ld * esz, hipMemcpyDeviceToDevice, s));
+    HIPCHK2(hipMemcpyAsync(c->diagq, c->diag_src, (size_t)n * sizeof(long long), hipMemcpyDeviceToDevice, s));
     HIPCHK2(hipStreamSynchronize(s));
     HIPCHK2(hipGetLastError());
     cleanup();
@@ -1838,6 +1880,7 @@ static int32_t alloc_ctx(int64_t n, int32_t storage_bits, int32_t device_id, int
     c->kcap = (int)kcap;
     c->dbg = getenv("RC_DEBUG_FLAGS") ? atoi(getenv("RC_DEBUG_FLAGS")) : 0;
     c->prefetch = !(getenv("RC_NO_PREFETCH") && atoi(getenv("RC_NO_PREFETCH")));
+    c->relayout = !(getenv("RC_NO_RELAYOUT") && atoi(getenv("RC_NO_RELAYOUT")));
     if (getenv("RC_BULK_KERNEL")) c->bulk_kernel = !strcmp(getenv("RC_BULK_KERNEL"), "sym") ? 1 : (!strcmp(getenv("RC_BULK_KERNEL"), "perm") ? 0 : -1);
     if (getenv("RC_RES_THREADS")) c->res_threads = (atoi(getenv("RC_RES_THREADS")) == 256) ? 256 : 512;
     if (getenv("RC_SYM_ITEM_TILES")) c->sym_item_tiles = std::max(1, atoi(getenv("RC_SYM_ITEM_TILES")));
@@ -1930,7 +1973,7 @@ extern "C" int32_t rc_get_matrix(rc_ctx *c, int32_t which, double *out_n_by_n)
     double *tmp = nullptr;
     HIPCHK(c, hipMalloc(&tmp, nn * sizeof(double)));
     const int gb = (int)std::min<size_t>((nn + 255) / 256, 8192);
-    const void *Q = which ? c->Lq : c->Dq;
+    const void *Q = which ? c->Lq_src : c->Dq_src;  // the caller's point order
     const double scale = std::ldexp(1.0, -(which ? c->eL : c->eD));
     if (c->bits == 64) k_dequantize<long long><<<gb, 256, 0, c->sA>>>((const long long *)Q, c->n, c->ld, scale, tmp);
     else k_dequantize<int><<<gb, 256, 0, c->sA>>>((const int *)Q, c->n, c->ld, scale, tmp);
@@ -2032,8 +2075,32 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
             slabel[(size_t)K] = lab;
             ++K;
         }
+    // Internal point order: points of a cluster contiguous (stable sort by label), so that the symmetric row reduction
+    // meets few label runs whatever order the caller's points are in.  The sweep itself still visits the points in the
+    // caller's order (k_resolve maps i -> pi[i]).
+    std::vector<int> ipi((size_t)n), pi((size_t)n);
+    for (int i = 0; i < n; ++i) ipi[(size_t)i] = i;
+    if (c->relayout)
+        std::stable_sort(ipi.begin(), ipi.end(), [&](int a, int b) { return clusts[a] < clusts[b]; });
+    for (int w = 0; w < n; ++w) pi[(size_t)ipi[(size_t)w]] = w;
+    if (pi != c->h_pi) {
+        c->h_pi = pi; c->h_ipi = ipi;
+        HIPCHK(c, hipMemcpy(c->pi, pi.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->ipi, ipi.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+        dim3 g((unsigned)std::min(64, (n + 255) / 256), (unsigned)n);
+        if (c->bits == 64) {
+            k_relayout<long long><<<g, 256, 0, c->sA>>>((const long long *)c->Dq_src, c->ipi, n, c->ld, (long long *)c->Dq);
+            k_relayout<long long><<<g, 256, 0, c->sA>>>((const long long *)c->Lq_src, c->ipi, n, c->ld, (long long *)c->Lq);
+        } else {
+            k_relayout<int><<<g, 256, 0, c->sA>>>((const int *)c->Dq_src, c->ipi, n, c->ld, (int *)c->Dq);
+            k_relayout<int><<<g, 256, 0, c->sA>>>((const int *)c->Lq_src, c->ipi, n, c->ld, (int *)c->Lq);
+        }
+        k_gather_ll<<<(n + 255) / 256, 256, 0, c->sA>>>(c->diag_src, c->ipi, n, c->diagq);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->sA));
+    }
     std::vector<int> so((size_t)n);
-    for (int i = 0; i < n; ++i) so[(size_t)i] = slot_of_label[(size_t)clusts[i]];
+    for (int w = 0; w < n; ++w) so[(size_t)w] = slot_of_label[(size_t)clusts[ipi[(size_t)w]]];
     DevScalars s{};
     s.K = K;
     s.slot_hi = K;
@@ -2245,7 +2312,7 @@ extern "C" int32_t rc_get_state(rc_ctx *c, int64_t *clusts, int64_t *clustsizes,
     int32_t rc = pull_state(c, so, ssize, slabel, clusts != nullptr);
     if (rc != RC_OK) return rc;
     if (clusts)
-        for (int i = 0; i < c->n; ++i) clusts[i] = slabel[(size_t)so[(size_t)i]];
+        for (int i = 0; i < c->n; ++i) clusts[i] = slabel[(size_t)so[(size_t)c->h_pi[(size_t)i]]];
     if (clustsizes) {
         std::memset(clustsizes, 0, (size_t)c->n * sizeof(int64_t));
         for (int k = 0; k < c->kcap; ++k)
@@ -2371,7 +2438,7 @@ extern "C" int32_t rc_record_sample(rc_ctx *c, int64_t *canonical_out)
     HIPCHK(c, hipSetDevice(c->dev));
     int32_t rc = ensure_counts(c);
     if (rc != RC_OK) return rc;
-    k_snapshot<<<(c->ldc + 255) / 256, 256, 0, c->sA>>>(c->slot_of, c->n, c->ldc, c->snap + (size_t)c->snap_cnt * c->ldc);
+    k_snapshot<<<(c->ldc + 255) / 256, 256, 0, c->sA>>>(c->slot_of, c->pi, c->n, c->ldc, c->snap + (size_t)c->snap_cnt * c->ldc);
     HIPCHK(c, hipGetLastError());
     if (++c->snap_cnt == RC_CC_BATCH) {
         rc = flush_counts(c);
@@ -2386,7 +2453,7 @@ extern "C" int32_t rc_record_sample(rc_ctx *c, int64_t *canonical_out)
         std::vector<int> map((size_t)c->kcap, 0);
         int next = 0;
         for (int i = 0; i < c->n; ++i) {
-            int &m = map[(size_t)so[(size_t)i]];
+            int &m = map[(size_t)so[(size_t)c->h_pi[(size_t)i]]];
             if (m == 0) m = ++next;
             canonical_out[i] = m;
         }
@@ -2475,8 +2542,15 @@ extern "C" int32_t rc_debug_rowsums(rc_ctx *c, int64_t label, int64_t *sumD_q, i
         if (sumL_q) std::memset(sumL_q, 0, (size_t)c->n * 8);
         return RC_OK;
     }
-    if (sumD_q) HIPCHK(c, hipMemcpy(sumD_q, c->SD[gen] + (size_t)slot * c->ld, (size_t)c->n * 8, hipMemcpyDeviceToHost));
-    if (sumL_q) HIPCHK(c, hipMemcpy(sumL_q, c->SL[gen] + (size_t)slot * c->ld, (size_t)c->n * 8, hipMemcpyDeviceToHost));
+    std::vector<int64_t> tmp((size_t)c->n);
+    if (sumD_q) {
+        HIPCHK(c, hipMemcpy(tmp.data(), c->SD[gen] + (size_t)slot * c->ld, (size_t)c->n * 8, hipMemcpyDeviceToHost));
+        for (int i = 0; i < c->n; ++i) sumD_q[i] = tmp[(size_t)c->h_pi[(size_t)i]];  // back to the caller's point order
+    }
+    if (sumL_q) {
+        HIPCHK(c, hipMemcpy(tmp.data(), c->SL[gen] + (size_t)slot * c->ld, (size_t)c->n * 8, hipMemcpyDeviceToHost));
+        for (int i = 0; i < c->n; ++i) sumL_q[i] = tmp[(size_t)c->h_pi[(size_t)i]];
+    }
     return RC_OK;
 }
 
@@ -2566,7 +2640,7 @@ static int32_t pull_labels(rc_ctx *c, std::vector<int64_t> &labels, std::vector<
     if (rc != RC_OK) return rc;
     labels.resize((size_t)c->n);
     sizes.assign((size_t)c->n, 0);
-    for (int i = 0; i < c->n; ++i) labels[(size_t)i] = slabel[(size_t)so[(size_t)i]];
+    for (int i = 0; i < c->n; ++i) labels[(size_t)i] = slabel[(size_t)so[(size_t)c->h_pi[(size_t)i]]];
     K = 0;
     for (int k = 0; k < c->kcap; ++k)
         if (slabel[(size_t)k] > 0) { sizes[(size_t)slabel[(size_t)k] - 1] = ssize[(size_t)k]; ++K; }
@@ -2616,7 +2690,7 @@ static int32_t apply_labels(rc_ctx *c, const std::vector<int64_t> &cur, const st
         const int a = slot_of_label[(size_t)cur[(size_t)i]], b = slot_of_label[(size_t)next[(size_t)i]];
         ssize[(size_t)a] -= 1;
         ssize[(size_t)b] += 1;
-        mv.push_back(i); mv.push_back(a); mv.push_back(b);
+        mv.push_back(c->h_pi[(size_t)i]); mv.push_back(a); mv.push_back(b);  // device arrays are in internal order
     }
     int K = 0, hi = c->last.slot_hi;
     for (int k = 0; k < c->kcap; ++k) {
@@ -2652,7 +2726,7 @@ static int32_t apply_labels(rc_ctx *c, const std::vector<int64_t> &cur, const st
     std::vector<int> so((size_t)n);
     HIPCHK(c, hipMemcpyAsync(so.data(), c->slot_of, so.size() * sizeof(int), hipMemcpyDeviceToHost, c->sA));
     HIPCHK(c, hipStreamSynchronize(c->sA));
-    for (size_t q = 0; q < moved.size(); ++q) so[(size_t)moved[q]] = mv[3 * q + 2];
+    for (size_t q = 0; q < moved.size(); ++q) so[(size_t)mv[3 * q]] = mv[3 * q + 2];
     // only K / slot_hi (and, when the change persists and both perm generations are rebuilt, last_change_sweep) are
     // touched: the other device scalars belong to the sweep pipeline
     const int kv[2] = {K, hi}, minus1 = -1;
@@ -2728,6 +2802,10 @@ struct Restricted {
     // sums over the (static) members of C[1] / C[2] when they are not candidates: computed once per item and proposal
     std::vector<double> fixedD[2], fixedL[2];
     std::vector<char> fixed_have[2];
+    // lgamma(α + δ1·sz) and lgamma(ζ + δ2·sz) depend on the integer size only: memoised (same values, fewer calls)
+    std::vector<double> lgA, lgZ;
+    double lg_alpha_i(double sz) { const size_t k = (size_t)sz; if (lgA.size() <= k) lgA.resize(k + 64, NAN); if (lgA[k] != lgA[k]) lgA[k] = std::lgamma(c->P.alpha + c->P.delta1 * sz); return lgA[k]; }
+    double lg_zeta_i(double sz) { const size_t k = (size_t)sz; if (lgZ.size() <= k) lgZ.resize(k + 64, NAN); if (lgZ[k] != lgZ[k]) lgZ[k] = std::lgamma(c->P.zeta + c->P.delta2 * sz); return lgZ[k]; }
 
     // one scan (mcmc.jl:302-352); returns log_transition_prob
     double scan(std::vector<int64_t> &clusts, std::vector<int64_t> &sizes, const std::vector<int64_t> &items,
@@ -2762,9 +2840,9 @@ struct Restricted {
                 const double sD = cs[k];
                 const double sL = cs[2 + k];
                 const double a_i = al + d1 * sz, b_i = be + sD, z_i = ze + d2 * sz, g_i = ga + sD;
-                L1[k] = std::lgamma(a_i) + abratio - a_i * std::log(b_i) + (d1 - 1) * sL - sz * lg_d1;
+                L1[k] = lg_alpha_i(sz) + abratio - a_i * std::log(b_i) + (d1 - 1) * sL - sz * lg_d1;
                 lpr[k] = std::log(sz + 1) + logp + std::log(sz - 1 + r) - std::log(sz);
-                L2p_c[k] = std::lgamma(z_i) - z_i * std::log(g_i) + zgratio + (d2 - 1) * sL - sz * lg_d2;
+                L2p_c[k] = lg_zeta_i(sz) - z_i * std::log(g_i) + zgratio + (d2 - 1) * sL - sz * lg_d2;
             }
             double L2p_first[2];
             for (int t = 0; t < 2; ++t) {                                                // mcmc.jl:327-331
@@ -2779,7 +2857,7 @@ struct Restricted {
                 }
                 const double sD = fixedD[t][(size_t)x], sL = fixedL[t][(size_t)x];
                 const double z_i = ze + d2 * sz, g_i = ga + sD;
-                L2p_first[t] = std::lgamma(z_i) - z_i * std::log(g_i) + zgratio + (d2 - 1) * sL - sz * lg_d2;
+                L2p_first[t] = lg_zeta_i(sz) - z_i * std::log(g_i) + zgratio + (d2 - 1) * sL - sz * lg_d2;
             }
             const double L2_i = L2p_first[0] + L2p_first[1];                             // Q3
             for (int k = 0; k < 2; ++k)
