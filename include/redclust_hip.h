@@ -162,6 +162,13 @@ int32_t rc_event_overhead_ms(rc_ctx *ctx, double *out);
 int32_t rc_bulk_kernel_info(rc_ctx *ctx, int32_t *which, double *algorithmic_bytes);
 /* Force the kernel: -1 automatic, 0 k_bulk, 1 k_bulk_sym (tests / measurements; results are identical). */
 int32_t rc_set_bulk_kernel(rc_ctx *ctx, int32_t which);
+/* Internal point layout.  rc_set_state stores D and logD with the points of a cluster contiguous (a stable sort of
+ * the caller's points by label), so that k_bulk_sym applies whatever order the caller's points come in; the sweep
+ * still visits the points in the caller's order and every output is in the caller's order.  Label movement
+ * fragments the layout; in automatic kernel mode the library re-lays the points out when the number of label runs
+ * in internal order exceeds n/32 (at most once per 32 sweeps; the chain is bit-identical either way).  Returns the
+ * number of layouts built so far and the current run count.  RC_NO_RELAYOUT=1 keeps the caller's order throughout. */
+int32_t rc_layout_info(rc_ctx *ctx, int32_t *n_relayouts, int32_t *label_runs);
 
 #ifdef __cplusplus
 }

@@ -81,6 +81,7 @@ SIGNATURES = {
     "rc_debug_rowsums": (C.c_int32, [C.c_void_p, C.c_int64, _ip, _ip, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rc_bulk_kernel_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "rc_set_bulk_kernel": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "rc_layout_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rc_event_overhead_ms": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double)]),
     "rc_kernel_timing": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
@@ -269,6 +270,12 @@ class Context:
 
     def set_bulk_kernel(self, which):
         self._chk(self.L.rc_set_bulk_kernel(self.h, {"auto": -1, "perm": 0, "sym": 1}[which]))
+
+    def layout_info(self):
+        """(layouts built so far, label runs in the internal point order)"""
+        a, b = C.c_int32(), C.c_int32()
+        self._chk(self.L.rc_layout_info(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def event_overhead_ms(self):
         out = C.c_double()

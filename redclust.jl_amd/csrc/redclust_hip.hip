@@ -1559,6 +1559,7 @@ struct rc_ctx {
     int *pi = nullptr, *ipi = nullptr;  // device: original -> internal, internal -> original
     std::vector<int> h_pi, h_ipi;       // host copies
     bool relayout = true;               // RC_NO_RELAYOUT=1 keeps the caller's point order
+    int n_relayouts = 0;                // re-layouts done so far (rc_set_state + automatic ones)
     int bits = 64;
     long long *SD[3] = {nullptr, nullptr, nullptr}, *SL[3] = {nullptr, nullptr, nullptr};
     int *slot_of = nullptr, *slot_size = nullptr, *slot_label = nullptr;
@@ -2085,6 +2086,7 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
     for (int w = 0; w < n; ++w) pi[(size_t)ipi[(size_t)w]] = w;
     if (pi != c->h_pi) {
         c->h_pi = pi; c->h_ipi = ipi;
+        c->n_relayouts++;
         HIPCHK(c, hipMemcpy(c->pi, pi.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(c->ipi, ipi.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
         dim3 g((unsigned)std::min(64, (n + 255) / 256), (unsigned)n);
@@ -2202,15 +2204,30 @@ static int32_t ensure_S(rc_ctx *c, int *gen)
     return RC_OK;
 }
 
+static int32_t pull_labels(rc_ctx *c, std::vector<int64_t> &labels, std::vector<int64_t> &sizes, int64_t &K);
+
 extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t seed, uint64_t sweep_index)
 {
     if (!c) return fail(c, RC_ERR_ARG, "rc_gibbs_sweep: NULL ctx");
     if (!c->have_params || !c->have_state) return fail(c, RC_ERR_STATE, "rc_gibbs_sweep: rc_set_params and rc_set_state must be called first");
     if (!(r > 0.0) || !(p > 0.0 && p < 1.0)) return fail(c, RC_ERR_ARG, "rc_gibbs_sweep: need r > 0 and 0 < p < 1 (got r=%g p=%g)", r, p);
     HIPCHK(c, hipSetDevice(c->dev));
+    int32_t rc;
+    // Label movement fragments the internal layout (every move can add two label runs).  Once the symmetric row
+    // reduction would be given up for that reason, and a fresh layout would bring it back, re-lay the points out:
+    // drain the pipeline and set the same labels again.  Slot numbers change, the partition and its labels do not, and
+    // all sums are exact integers, so the chain is bit-identical with or without this step.
+    if (!c->incremental && c->relayout && c->bulk_kernel < 0 && c->t_next >= 32 &&
+        (long long)c->hsum->runs * 32 > (long long)c->n && (long long)c->hsum->K * 64 <= (long long)c->n) {
+        std::vector<int64_t> labels, sizes;
+        int64_t K = 0;
+        rc = pull_labels(c, labels, sizes, K);
+        if (rc != RC_OK) return rc;
+        rc = rc_set_state(c, labels.data());
+        if (rc != RC_OK) return rc;
+    }
     View V = make_view(c);
     const long long t = c->t_next;
-    int32_t rc;
     if (t >= 0x7ffffff0ll) return fail(c, RC_ERR_STATE, "rc_gibbs_sweep: internal sweep counter exhausted; call rc_set_state");
     SweepArgs sa;
     sa.r = r;
@@ -3062,6 +3079,17 @@ extern "C" int32_t rc_bulk_kernel_info(rc_ctx *c, int32_t *which, double *algori
     return RC_OK;
 }
 
+
+extern "C" int32_t rc_layout_info(rc_ctx *c, int32_t *n_relayouts, int32_t *label_runs)
+{
+    if (!c) return fail(c, RC_ERR_ARG, "rc_layout_info: NULL ctx");
+    HIPCHK(c, hipSetDevice(c->dev));
+    int32_t rc = sync_and_check(c);
+    if (rc != RC_OK) return rc;
+    if (n_relayouts) *n_relayouts = c->n_relayouts;
+    if (label_runs) *label_runs = c->hsum->runs;
+    return RC_OK;
+}
 
 // Selects the row-reduction kernel: -1 automatic (by label-run count), 0 k_bulk (full read), 1 k_bulk_sym (upper
 // triangle).  Both are exact for every labelling; this only exists for tests and measurements.

@@ -412,6 +412,75 @@ def test_symmetric_and_full_row_reduction_agree_exactly(n, bits):
         c.close()
 
 
+def test_internal_layout_shuffled_points():
+    """Points arrive in random order: the library lays them out cluster-contiguously inside (so the symmetric row
+    reduction is chosen), yet sweeps, row sums, matrices and the co-clustering matrix all come back in the caller's
+    order and match the oracle / a context with the layout disabled."""
+    n, K = 1500, 7
+    data = rc.generatemixture(n, K, seed=77, sigma=0.3, dim=10)
+    rng = np.random.default_rng(3)
+    sh = rng.permutation(n)
+    D = np.ascontiguousarray(data["distancematrix"][np.ix_(sh, sh)])
+    truth = data["clusts"][sh]
+    assert np.count_nonzero(np.diff(truth)) > n // 2          # thoroughly unsorted
+    P = rc.likelihood_hyperparams(D, truth)
+    orc = O.Oracle(D, P)
+    ctx = rc.Context(D, kcap=64, logD=orc.logD)
+    ctx.set_params(**P)
+    ctx.set_state(truth)
+    assert np.allclose(ctx.get_matrix(0), D, rtol=0, atol=np.ldexp(1.0, -40) * D.max())
+    orc.set_state(truth)
+    for k in (1, 4, 7):
+        sd, sl = ctx.debug_rowsums(k)[:2]
+        m = truth == k
+        assert np.array_equal(sd, orc.Dq[:, m].sum(axis=1)) and np.array_equal(sl, orc.Lq[:, m].sum(axis=1))
+    ctx.cocluster_reset()
+    acc = np.zeros((n, n))
+    for t in range(6):
+        ctx.gibbs_sweep(1.1, 0.45, 9, t)
+        orc.sweep_stable(1.1, 0.45, 9, t)
+        lab, sizes, Kc = ctx.get_state()
+        assert np.array_equal(lab, orc.clusts) and np.array_equal(sizes, orc.sizes) and Kc == orc.K
+        ctx.record_sample(False)
+        acc += lab[:, None] == lab[None, :]
+        if t == 0:   # fresh layout: K label runs, so the symmetric kernel was chosen
+            assert ctx.bulk_kernel_info()[0] == "k_bulk_sym"
+    assert np.array_equal(ctx.cocluster(6), acc / 6)
+    assert abs(ctx.loglik() - orc.loglik_stable()) <= 1e-9 * abs(orc.loglik_stable())
+    ctx.close()
+
+
+def test_automatic_relayout_is_invisible():
+    """Overlapping clusters in shuffled order: label movement fragments the internal layout, the library re-lays the
+    points out on its own, and the chain is bit-identical to one that keeps the caller's order (RC_NO_RELAYOUT=1)."""
+    n, K = 2048, 4
+    data = rc.generatemixture(n, K, seed=5, sigma=0.6, dim=6)
+    sh = np.random.default_rng(8).permutation(n)
+    D = np.ascontiguousarray(data["distancematrix"][np.ix_(sh, sh)])
+    truth = data["clusts"][sh]
+    P = dict(rc.likelihood_hyperparams(D, truth), maxK=12)
+    ctx = rc.Context(D, kcap=64)
+    ctx.set_params(**P)
+    ctx.set_state(truth)
+    ref = rc.Context(D, kcap=64)
+    ref.set_params(**P)
+    ref.set_bulk_kernel("perm")            # forced kernel: never re-lays out after rc_set_state
+    ref.set_state(truth)
+    l0 = ctx.layout_info()[0]
+    moved = 0
+    for t in range(120):
+        ctx.gibbs_sweep(1.0, 0.5, 3, t, blocking=False)
+        ref.gibbs_sweep(1.0, 0.5, 3, t, blocking=False)
+        if t % 10 == 9:
+            a, b = ctx.get_state(), ref.get_state()
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2], t
+            moved += ctx.sweep_stats()["n_changes"]
+    assert moved > 0
+    assert ctx.loglik() == ref.loglik()
+    assert ctx.layout_info()[0] > l0, "expected at least one automatic re-layout (runs=%d)" % ctx.layout_info()[1]
+    ctx.close(); ref.close()
+
+
 @pytest.mark.parametrize("variant", ["plain", "maxK", "norep", "bits32"])
 def test_long_trajectory_with_continual_movement(variant):
     """150 sweeps on overlapping clusters (σ large: labels keep moving every sweep — batches, violations, births and
