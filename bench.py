@@ -184,6 +184,12 @@ def main():
             "roofline": {"kernel": kernel_name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
                          "avg_launch_ms": bulk_avg_ms, "launches": bulk_launches, "algorithmic_bytes_per_launch": alg_bytes,
+                         # SURVEY §8(d) prices a sweep at 2·n²·sizeof (every entry of D and logD read once, as the
+                         # reference does).  k_bulk_sym needs only the upper triangle, so `achieved`/`frac` above are
+                         # the conservative physical figures (bytes this kernel must read); these two use §8(d)'s
+                         "survey_8d_bytes_per_launch": full_bytes,
+                         "achieved_at_survey_8d_bytes": (full_bytes / (bulk_avg_ms * 1e-3) / 1e9) if bulk_launches else None,
+                         "frac_at_survey_8d_bytes": (full_bytes / (bulk_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if bulk_launches else None,
                          "event_pair_overhead_ms_subtracted": ctx.event_overhead_ms()},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -170,6 +170,35 @@ int32_t rc_set_bulk_kernel(rc_ctx *ctx, int32_t which);
  * number of layouts built so far and the current run count.  RC_NO_RELAYOUT=1 keeps the caller's order throughout. */
 int32_t rc_layout_info(rc_ctx *ctx, int32_t *n_relayouts, int32_t *label_runs);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Point estimation — the step after the sampler.  Stand-alone entry points (no rc_ctx): they
+ * take host label vectors as MCMCResult.clusts holds them; errors are read with rc_last_error(NULL).
+ * ------------------------------------------------------------------------------------------------------------- */
+
+/* loss specifiers of getpointestimate(method = "MPEL") (src/pointestimate.jl:38-47) */
+#define RC_LOSS_BINDER 0 /* "binder": randindex(x, y)[3] */
+#define RC_LOSS_OMARI 1  /* "omARI":  1 - randindex(x, y)[1] */
+#define RC_LOSS_VI 2     /* "VI":     varinfo(x, y) */
+#define RC_LOSS_ID 3     /* "ID":     infodist(x, y; normalised = false) */
+
+/* The MPEL search of getpointestimate (src/pointestimate.jl:49-58): lossmatrix[i][j] = loss(clusts[i], clusts[j])
+ * for every pair of the m samples (computed for i < j and mirrored, zero diagonal), its column sums and the index
+ * (0-based) of the first minimal one.  samples: m×n row-major (sample s = samples[s*n ..]), labels in 1..n.
+ * lossmatrix (m×m), colsum (m), argmin and kernel_ms (device time of the pair kernel) may each be NULL. */
+int32_t rc_loss_matrix(int32_t device, const int64_t *samples, int64_t m, int64_t n, int32_t loss,
+                       double *lossmatrix, double *colsum, int64_t *argmin, double *kernel_ms);
+
+/* Everything evaluateclustering (src/summaries.jl:12-23), binderloss and infodist (src/pointestimate.jl:68-99)
+ * derive from a pair of labelings: Clustering.jl's randindex 4-tuple, mutualinfo (normed = false / true), varinfo,
+ * the two entropies and the information distance (plain / normalised by max entropy as infodist does). */
+typedef struct rc_pair_measures_t {
+    double ari, ri, mirkin, hubert;
+    double mi, nmi, vi;
+    double ha, hb;
+    double id, nid;
+} rc_pair_measures_t;
+int32_t rc_pair_measures(int32_t device, const int64_t *a, const int64_t *b, int64_t n, rc_pair_measures_t *out);
+
 #ifdef __cplusplus
 }
 #endif

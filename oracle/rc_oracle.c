@@ -888,3 +888,110 @@ void orc_pairwise_euclidean(int64_t n, int64_t dim, const double *pts, double *D
     }
     free(sa2);
 }
+
+
+/* ================================================================================================
+ * Point estimation (src/pointestimate.jl) and clustering comparison (src/summaries.jl:12-23).
+ *
+ * The pairwise measures come from Clustering.jl (third party, Project.toml:22 pins 0.13.5 / 0.14 / 0.15; not under
+ * the reference checkout).  Restated from their published definitions on the contingency table n_ij of the two
+ * labelings, row sums a_i, column sums b_j, N points:
+ *   randindex (Hubert & Arabie 1985):  t1 = C(N,2), t2 = Σ n_ij², t3 = (Σ a_i² + Σ b_j²)/2,
+ *       nc = (N(N²+1) − (N+1)Σa_i² − (N+1)Σb_j² + 2 Σa_i² Σb_j² / N) / (2(N−1)),
+ *       A = t1 + t2 − t3, D = t3 − t2;  ARI = (A − nc)/(t1 − nc) (0 if t1 == nc), RI = A/t1, Mirkin = D/t1,
+ *       Hubert = (A − D)/t1
+ *   mutualinfo(normed=false): I = Σ (n_ij/N) log(N n_ij / (a_i b_j));   normed: 2I/(H(a) + H(b))
+ *   varinfo (Meilă 2007):     VI = H(a) + H(b) − 2I
+ *   entropy(counts/N):        H(a) = −Σ (a_i/N) log(a_i/N)
+ * Every quantity is evaluated from the four sums  Σ n_ij log n_ij, Σ a_i log a_i, Σ b_j log b_j, Σ n_ij²  so that
+ * the GPU path (same sums, different summation order) agrees to rounding.
+ * ============================================================================================== */
+
+typedef struct {
+    double ari, ri, mirkin, hubert; /* randindex(a, b) */
+    double mi, nmi, vi;             /* mutualinfo(normed=false), mutualinfo(normed=true), varinfo */
+    double ha, hb;                  /* entropy(counts(a)/N), entropy(counts(b)/N) */
+    double id, nid;                 /* infodist(normalised=false / true), pointestimate.jl:89-99 */
+} orc_pair_measures;
+
+static int cmp_i64(const void *x, const void *y)
+{
+    int64_t u = *(const int64_t *)x, v = *(const int64_t *)y;
+    return (u > v) - (u < v);
+}
+
+/* labels: any positive integers ≤ n (as in the reference: 1..n) */
+void orc_pair_measures_eval(int64_t n, const int64_t *a, const int64_t *b, orc_pair_measures *out)
+{
+    int64_t *ca = calloc((size_t)n + 1, sizeof(int64_t)), *cb = calloc((size_t)n + 1, sizeof(int64_t));
+    /* contingency table through a sort of the (a, b) key: no K×K storage */
+    int64_t *key = malloc((size_t)n * sizeof(int64_t));
+    for (int64_t i = 0; i < n; ++i) { ca[a[i]]++; cb[b[i]]++; key[i] = a[i] * (n + 1) + b[i]; }
+    qsort(key, (size_t)n, sizeof(int64_t), cmp_i64);
+    double e_ab = 0, e_a = 0, e_b = 0, t2 = 0, nis = 0, njs = 0;
+    for (int64_t i = 0; i < n;) {
+        int64_t j = i;
+        while (j < n && key[j] == key[i]) ++j;
+        double c = (double)(j - i);
+        e_ab += c * log(c);
+        t2 += c * c;
+        i = j;
+    }
+    for (int64_t l = 1; l <= n; ++l) {
+        if (ca[l]) { e_a += (double)ca[l] * log((double)ca[l]); nis += (double)ca[l] * (double)ca[l]; }
+        if (cb[l]) { e_b += (double)cb[l] * log((double)cb[l]); njs += (double)cb[l] * (double)cb[l]; }
+    }
+    const double N = (double)n, logN = log(N);
+    const double t1 = N * (N - 1) / 2, t3 = 0.5 * (nis + njs);
+    const double nc = (N * (N * N + 1) - (N + 1) * nis - (N + 1) * njs + 2 * (nis * njs) / N) / (2 * (N - 1));
+    const double A = t1 + t2 - t3, Dd = -t2 + t3;
+    out->ari = (t1 == nc) ? 0.0 : (A - nc) / (t1 - nc);
+    out->ri = A / t1;
+    out->mirkin = Dd / t1;
+    out->hubert = (A - Dd) / t1;
+    out->ha = logN - e_a / N;
+    out->hb = logN - e_b / N;
+    out->mi = (e_ab - e_a - e_b) / N + logN;
+    out->nmi = 2 * out->mi / (out->ha + out->hb);
+    out->vi = out->ha + out->hb - 2 * out->mi;
+    const double hmax = out->ha > out->hb ? out->ha : out->hb;
+    out->id = hmax - out->mi;
+    out->nid = 1 - out->mi / hmax;
+    free(ca); free(cb); free(key);
+}
+
+/* loss kinds of getpointestimate(method="MPEL") (pointestimate.jl:38-47): 0 binder = randindex[3], 1 omARI = 1 − ARI,
+ * 2 VI = varinfo, 3 ID = infodist(normalised=false) */
+static double pick_loss(const orc_pair_measures *m, int kind)
+{
+    switch (kind) {
+    case 0: return m->mirkin;
+    case 1: return 1 - m->ari;
+    case 2: return m->vi;
+    default: return m->id;
+    }
+}
+
+/* The MPEL search (pointestimate.jl:49-58): upper-triangle losses, symmetrised, column sums, first argmin.
+ * samples: m×n row-major.  lossmatrix (m×m, may be NULL), colsum (m).  Returns the 0-based argmin. */
+int64_t orc_mpel(int64_t m, int64_t n, const int64_t *samples, int kind, double *lossmatrix, double *colsum)
+{
+    double *L = lossmatrix ? lossmatrix : calloc((size_t)(m * m), sizeof(double));
+    for (int64_t i = 0; i < m * m; ++i) L[i] = 0;
+    orc_pair_measures pm;
+    for (int64_t i = 0; i < m; ++i)
+        for (int64_t j = i + 1; j < m; ++j) {
+            orc_pair_measures_eval(n, samples + i * n, samples + j * n, &pm);
+            L[i * m + j] = pick_loss(&pm, kind);
+            L[j * m + i] = L[i * m + j];
+        }
+    int64_t best = 0;
+    for (int64_t j = 0; j < m; ++j) {
+        double s = 0;
+        for (int64_t i = 0; i < m; ++i) s += L[i * m + j];
+        colsum[j] = s;
+        if (s < colsum[best]) best = j;
+    }
+    if (!lossmatrix) free(L);
+    return best;
+}

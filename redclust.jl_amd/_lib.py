@@ -31,13 +31,17 @@ class RcParams(C.Structure):
                                                         ("pad_", C.c_uint8 * 7)]
 
 
+class RcPairMeasures(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("ari", "ri", "mirkin", "hubert", "mi", "nmi", "vi", "ha", "hb", "id", "nid")]
+
+
 class RcSweepStats(C.Structure):
     _fields_ = [("n_changes", C.c_int64), ("n_rounds", C.c_int64), ("K", C.c_int64)]
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, "redclust_hip.hip"), HEADER]
+    srcs = [os.path.join(CSRC, "redclust_hip.hip"), os.path.join(CSRC, "pointestimate.inc.hip"), HEADER]
     if not force and os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(s) for s in srcs):
         return SO
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", SO, srcs[0]]
@@ -81,6 +85,9 @@ SIGNATURES = {
     "rc_debug_rowsums": (C.c_int32, [C.c_void_p, C.c_int64, _ip, _ip, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rc_bulk_kernel_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "rc_set_bulk_kernel": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "rc_loss_matrix": (C.c_int32, [C.c_int32, _ip, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                   C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "rc_pair_measures": (C.c_int32, [C.c_int32, _ip, _ip, C.c_int64, C.POINTER(RcPairMeasures)]),
     "rc_layout_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rc_event_overhead_ms": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double)]),
     "rc_kernel_timing": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -287,3 +294,32 @@ class Context:
         cnt = C.c_int64()
         self._chk(self.L.rc_kernel_timing(self.h, int(enable), C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+
+def loss_matrix(samples, loss: int, device: int = 0, want_matrix: bool = True):
+    """rc_loss_matrix: (lossmatrix or None, column sums, 0-based argmin, kernel ms) for an m×n int64 label matrix."""
+    L = lib()
+    S = np.ascontiguousarray(samples, dtype=np.int64)
+    if S.ndim != 2:
+        raise ValueError("samples must be an m×n matrix of labels")
+    m, n = S.shape
+    M = np.zeros((m, m)) if want_matrix else None
+    cs = np.zeros(m)
+    am, ms = C.c_int64(), C.c_double()
+    rc = L.rc_loss_matrix(device, S.reshape(-1), m, n, int(loss), None if M is None else M.ctypes.data_as(C.c_void_p),
+                          cs.ctypes.data_as(C.c_void_p), C.byref(am), C.byref(ms))
+    if rc != RC_OK:
+        raise RedClustHIPError(rc, L.rc_last_error(None).decode())
+    return M, cs, int(am.value), float(ms.value)
+
+
+def pair_measures(a, b, device: int = 0) -> dict:
+    """rc_pair_measures as a dict."""
+    L = lib()
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    b = np.ascontiguousarray(b, dtype=np.int64)
+    out = RcPairMeasures()
+    rc = L.rc_pair_measures(device, a, b, len(a), C.byref(out))
+    if rc != RC_OK:
+        raise RedClustHIPError(rc, L.rc_last_error(None).decode())
+    return {k: getattr(out, k) for k, _ in RcPairMeasures._fields_}

@@ -3110,3 +3110,5 @@ extern "C" int32_t rc_event_overhead_ms(rc_ctx *c, double *out)
     *out = c->ev_overhead_ms;
     return RC_OK;
 }
+
+#include "pointestimate.inc.hip"

@@ -101,6 +101,7 @@ def main():
                                     T.uniform(2**40 + 7, 2**33 + 1, 8191, 50)])
     np.savez_compressed(os.path.join(HERE, "golden_sweeps.npz"), **gold)
     make_golden_mh(data)
+    make_golden_pointestimate(data)
     print("wrote", HERE)
 
 
@@ -136,6 +137,31 @@ def make_golden_mh(data):
         print(tag, "accepted", int(np.sum(acc)), "splits proposed", int(np.sum(spl)), "K", Ks[0], "->", Ks[-1])
     gold["cases"] = np.array(cases)
     np.savez_compressed(os.path.join(HERE, "golden_mh.npz"), **gold)
+
+
+def make_golden_pointestimate(data):
+    """MPEL loss matrices (pointestimate.jl:49-58) and evaluateclustering (summaries.jl:12-23) of the transcription on
+    30 samples of a teacher-forced chain on paper dataset 1 (random init, so early samples differ a lot)."""
+    D, truth = data["D1"], data["labels1"]
+    P = T.likelihood_hyperparams(D, truth)
+    logD = T.make_logD(D)
+    rng = np.random.default_rng(2024)
+    cl = rng.integers(1, 11, size=100).astype(np.int64)
+    sz, K = T.state_from_labels(cl)
+    samples = []
+    for t in range(30):
+        T.sweep(D, logD, cl, sz, P, 1.0, 0.5, 77, t)
+        samples.append(cl.copy())
+    gold = {"samples": np.array(samples), "truth": truth}
+    for loss in ("binder", "omARI", "VI", "ID"):
+        i, L, cs = T.getpointestimate_mpel(samples, loss)
+        gold[f"lossmatrix_{loss}"] = L
+        gold[f"colsum_{loss}"] = cs
+        gold[f"argmin_{loss}"] = np.array(i)
+        print("pointestimate", loss, "argmin", i, "min expected loss", cs[i] / len(samples))
+    for k, v in T.evaluateclustering(samples[-1], truth).items():
+        gold[f"eval_{k}"] = np.array(v)
+    np.savez_compressed(os.path.join(HERE, "golden_pointestimate.npz"), **gold)
 
 
 if __name__ == "__main__":

@@ -345,3 +345,90 @@ def sample_labels(D, logD, clusts, sizes, K, P, r, p, numMH, numGibbs, seed, it)
             state = final                                   # rebinding: the caller's arrays are not touched
     Knew = sweep(D, logD, state[0], state[1], P, r, p, seed, it)
     return accept, split, (Knew if state[0] is clusts else K)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Point estimation / clustering comparison (src/pointestimate.jl, src/summaries.jl:12-23).  Clustering.jl's
+# randindex / varinfo / mutualinfo are third party (not under the reference checkout): written here from their
+# textbook definitions on the contingency table, deliberately NOT through the four-sums route the C oracle takes.
+# ---------------------------------------------------------------------------------------------------------------
+def contingency(a, b):
+    ua, ia = np.unique(a, return_inverse=True)
+    ub, ib = np.unique(b, return_inverse=True)
+    C = np.zeros((len(ua), len(ub)), dtype=np.int64)
+    np.add.at(C, (ia, ib), 1)
+    return C
+
+
+def randindex(a, b):
+    """(ARI, RI, Mirkin, Hubert) — Hubert & Arabie (1985) as Clustering.jl's randindex returns them."""
+    C = contingency(a, b).astype(np.float64)
+    n = C.sum()
+    nis = (C.sum(axis=1) ** 2).sum()
+    njs = (C.sum(axis=0) ** 2).sum()
+    t1 = n * (n - 1) / 2
+    t2 = (C ** 2).sum()
+    t3 = 0.5 * (nis + njs)
+    nc = (n * (n ** 2 + 1) - (n + 1) * nis - (n + 1) * njs + 2 * (nis * njs) / n) / (2 * (n - 1))
+    A = t1 + t2 - t3
+    Dd = -t2 + t3
+    ari = 0.0 if t1 == nc else (A - nc) / (t1 - nc)
+    return ari, A / t1, Dd / t1, (A - Dd) / t1
+
+
+def entropy_of_labels(a):
+    p = np.unique(a, return_counts=True)[1] / len(a)
+    return float(-(p * np.log(p)).sum())
+
+
+def mutualinfo(a, b, normed=True):
+    C = contingency(a, b)
+    n = C.sum()
+    P = C / n
+    pa, pb = P.sum(axis=1, keepdims=True), P.sum(axis=0, keepdims=True)
+    nz = P > 0
+    mi = float((P[nz] * np.log(P[nz] / (pa @ pb)[nz])).sum())
+    if normed:
+        return 2 * mi / (entropy_of_labels(a) + entropy_of_labels(b))
+    return mi
+
+
+def varinfo(a, b):
+    return entropy_of_labels(a) + entropy_of_labels(b) - 2 * mutualinfo(a, b, normed=False)
+
+
+def binderloss(a, b, normalised=True):
+    """pointestimate.jl:68-76"""
+    n = len(a)
+    return randindex(a, b)[2] * (1 if normalised else n * (n - 1) // 2)
+
+
+def infodist(a, b, normalised=True):
+    """pointestimate.jl:89-99"""
+    hu, hv = entropy_of_labels(a), entropy_of_labels(b)
+    mi = mutualinfo(a, b, normed=False)
+    return 1 - mi / max(hu, hv) if normalised else max(hu, hv) - mi
+
+
+def evaluateclustering(clusts, truth):
+    """summaries.jl:12-23"""
+    n = len(clusts)
+    ari, _, nbloss, _ = randindex(clusts, truth)
+    vi = varinfo(clusts, truth)
+    idd = infodist(clusts, truth, normalised=False)
+    return dict(nbloss=nbloss, ari=ari, vi=vi, nvi=vi / np.log(n), id=idd, nid=idd / np.log(n),
+                nmi=mutualinfo(clusts, truth))
+
+
+def getpointestimate_mpel(samples, loss):
+    """pointestimate.jl:36-58: upper-triangle loss matrix, symmetrised, column sums, first argmin (0-based)."""
+    fn = {"binder": lambda x, y: randindex(x, y)[2], "omARI": lambda x, y: 1 - randindex(x, y)[0],
+          "VI": varinfo, "ID": lambda x, y: infodist(x, y, normalised=False)}[loss]
+    m = len(samples)
+    L = np.zeros((m, m))
+    for i in range(m):
+        for j in range(i + 1, m):
+            L[i, j] = fn(samples[i], samples[j])
+    L = L + L.T
+    cs = L.sum(axis=0)
+    return int(np.argmin(cs)), L, cs

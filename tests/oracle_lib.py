@@ -82,8 +82,34 @@ def lib():
                                   i64, u64, u64, u64, i32, C.POINTER(OrcMHInfo)]
     L.orc_sample_labels.argtypes = [i64, _dp, _dp, C.c_void_p, C.c_void_p, i32, i32, C.c_void_p, _ip, _ip,
                                     C.POINTER(i64), PP, f64, f64, i64, i64, u64, u64, i32, _bp, _bp]
+    L.orc_pair_measures_eval.restype = None
+    L.orc_pair_measures_eval.argtypes = [i64, _ip, _ip, C.POINTER(OrcPairMeasures)]
+    L.orc_mpel.restype = i64
+    L.orc_mpel.argtypes = [i64, i64, _ip, i32, C.c_void_p, _dp]
     _lib = L
     return L
+
+
+class OrcPairMeasures(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("ari", "ri", "mirkin", "hubert", "mi", "nmi", "vi", "ha", "hb", "id", "nid")]
+
+
+def pair_measures(a, b) -> dict:
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    b = np.ascontiguousarray(b, dtype=np.int64)
+    out = OrcPairMeasures()
+    lib().orc_pair_measures_eval(len(a), a, b, C.byref(out))
+    return {k: getattr(out, k) for k, _ in OrcPairMeasures._fields_}
+
+
+def mpel(samples, kind):
+    """(0-based argmin, loss matrix, column sums) of orc_mpel"""
+    S = np.ascontiguousarray(samples, dtype=np.int64)
+    m, n = S.shape
+    Lm = np.zeros((m, m))
+    cs = np.zeros(m)
+    i = lib().orc_mpel(m, n, S.reshape(-1), int(kind), Lm.ctypes.data_as(C.c_void_p), cs)
+    return int(i), Lm, cs
 
 
 def params(P: dict) -> OrcParams:
