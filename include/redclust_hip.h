@@ -171,6 +171,52 @@ int32_t rc_set_bulk_kernel(rc_ctx *ctx, int32_t which);
 int32_t rc_layout_info(rc_ctx *ctx, int32_t *n_relayouts, int32_t *label_runs);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * The iteration loop of runsampler (src/mcmc.jl:533-556) as native host code: per iteration sample_r!, sample_p!
+ * (src/mcmc.jl:80-155, on the build's counter-based scalar stream — DESIGN.md), sample_labels! (numMH split–merge
+ * proposals, then the Gibbs sweep; src/mcmc.jl:356-479) and the recording rule (src/mcmc.jl:546-553).  Recorded
+ * samples also enter the device co-clustering counts (read them with rc_cocluster afterwards).
+ * ------------------------------------------------------------------------------------------------------------- */
+#define RC_SM_AS_WRITTEN 0 /* split–merge exactly as the reference executes it (an accepted
+                            * proposal is discarded together with that iteration's Gibbs scan) */
+#define RC_SM_INTENDED 1   /* accepted proposals are kept and swept */
+
+typedef struct rc_chain_options {
+    int64_t numiters, burnin, thin; /* MCMCOptionsList (src/types.jl:3-43) */
+    int64_t numGibbs, numMH;
+    int32_t splitmerge_mode;        /* RC_SM_* */
+    int32_t pad_;
+    uint64_t seed;                  /* keys the label, split–merge and scalar streams */
+    uint64_t first_iter;            /* stream index of the first iteration (0 for a fresh chain; continue with numiters) */
+    double r0, p0;                  /* MCMCState.r / .p at the start */
+    double proposalsd_r;            /* PriorHyperparamsList.proposalsd_r (src/types.jl:102) */
+    const double *r_trace, *p_trace;/* both NULL: free-running; else numiters forced values (parity tests) */
+    int64_t max_samples;            /* capacity of the per-sample output arrays */
+} rc_chain_options;
+
+typedef struct rc_chain_outputs {
+    /* per recorded sample (capacity max_samples; each pointer may be NULL) — MCMCResult fields, src/types.jl:193-248 */
+    int64_t *clusts;                /* max_samples × n, sortlabels'd (src/mcmc.jl:547) */
+    int64_t *K;
+    double *r, *p, *loglik, *logposterior;
+    /* per iteration (may be NULL) */
+    uint8_t *r_acceptances;         /* numiters */
+    uint8_t *splitmerge_acceptances, *splitmerge_splits; /* numiters × numMH */
+    double *r_all, *p_all;          /* numiters: the r and p every iteration used */
+    /* scalars written on return */
+    int64_t num_samples;
+    double runtime_s;               /* wall time of the loop (MCMCResult.runtime, src/mcmc.jl:586) */
+    double r_final, p_final;
+} rc_chain_outputs;
+
+int32_t rc_run_chain(rc_ctx *ctx, const rc_chain_options *opt, rc_chain_outputs *out);
+
+/* One sample_r + sample_p pair exactly as rc_run_chain draws them (tests; host only, no GPU needed).  sizes: the K
+ * non-empty cluster sizes in ascending label order. */
+int32_t rc_scalar_updates(uint64_t seed, uint64_t iter, double r, double p, const int64_t *sizes, int64_t K, int64_t n,
+                          double eta, double sigma, double proposalsd_r, double u, double v, double *r_out,
+                          double *p_out, uint8_t *accept_out);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Point estimation — the step after the sampler.  Stand-alone entry points (no rc_ctx): they
  * take host label vectors as MCMCResult.clusts holds them; errors are read with rc_last_error(NULL).
  * ------------------------------------------------------------------------------------------------------------- */

@@ -995,3 +995,94 @@ int64_t orc_mpel(int64_t m, int64_t n, const int64_t *samples, int kind, double 
     if (!lossmatrix) free(L);
     return best;
 }
+
+
+/* ================================================================================================
+ * Scalar updates of the chain: sample_r (src/mcmc.jl:94-136) and sample_p (src/mcmc.jl:147-155).
+ *
+ * The reference draws through Distributions.jl (truncated Normal, Beta) on Julia's global RNG; neither the
+ * stream nor Distributions' internal algorithms can be reproduced, so the build defines its own exact samplers
+ * on its counter-based uniform stream (DESIGN.md "scalar stream"):
+ *   uniform  u(iter, kind, d) = Philox4x32-10, key (seed_lo, seed_hi ^ 0x52505F5F), counter (d, kind, iter_lo,
+ *            iter_hi), u = (top 52 bits + 0.5)·2^-52;  kind 0 = r update, 1 = p update;  d counts the draws
+ *   normal   Box–Muller: z = sqrt(-2 log u_d) · cos(2π u_{d+1})  (two draws each)
+ *   truncated(Normal(mu, sd), 0, Inf): redraw until mu + sd·z >= 0
+ *   Gamma(a, 1), a >= 1: Marsaglia & Tsang (2000): d = a − 1/3, c = 1/sqrt(9d); z normal, v = (1 + cz)³,
+ *            accept if v > 0 and log u < z²/2 + d − dv + d log v;  a < 1: Gamma(a+1)·u^(1/a)
+ *   Beta(a, b) = X/(X+Y), X ~ Gamma(a), Y ~ Gamma(b)
+ * The log-densities are the reference's expressions literally.
+ * ============================================================================================== */
+typedef struct { uint64_t seed, iter; uint32_t kind; uint64_t draw; } orc_scalar_stream;
+
+static double ss_uniform(orc_scalar_stream *s)
+{
+    uint32_t c[4] = {(uint32_t)s->draw, s->kind, (uint32_t)s->iter, (uint32_t)(s->iter >> 32)};
+    s->draw++;
+    philox4x32_10(c, (uint32_t)s->seed, (uint32_t)(s->seed >> 32) ^ 0x52505F5Fu);
+    uint64_t bits = (((uint64_t)c[0] << 32) | c[1]) >> 12;
+    return ((double)bits + 0.5) * 0x1p-52;
+}
+
+static double ss_normal(orc_scalar_stream *s)
+{
+    const double u1 = ss_uniform(s), u2 = ss_uniform(s);
+    return sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2);
+}
+
+static double ss_gamma(orc_scalar_stream *s, double a)
+{
+    double boost = 1.0;
+    if (a < 1.0) { boost = pow(ss_uniform(s), 1.0 / a); a += 1.0; }
+    const double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    for (;;) {
+        const double z = ss_normal(s);
+        const double t = 1.0 + c * z;
+        const double u = ss_uniform(s);
+        if (t <= 0) continue;
+        const double v = t * t * t;
+        if (log(u) < 0.5 * z * z + d - d * v + d * log(v)) return d * v * boost;
+    }
+}
+
+double orc_scalar_uniform(uint64_t seed, uint64_t iter, uint32_t kind, uint64_t draw)
+{
+    orc_scalar_stream s = {seed, iter, kind, draw};
+    return ss_uniform(&s);
+}
+
+/* logpdf(truncated(Normal(mu, sd), lower = 0, upper = Inf), x), x >= 0 */
+static double logpdf_truncnorm0(double x, double mu, double sd)
+{
+    const double z = (x - mu) / sd;
+    return -0.5 * z * z - log(sd) - 0.91893853320467274178 - log(0.5 * erfc(-(mu / sd) * 0.70710678118654752440));
+}
+
+/* sample_r (mcmc.jl:94-136).  C: sizes of the K non-empty clusters (ascending label order).  Returns the new r,
+ * *accept = 0/1. */
+double orc_sample_r(uint64_t seed, uint64_t iter, double r, double p, const int64_t *C, int64_t K, double eta,
+                    double sigma, double proposalsd_r, int *accept)
+{
+    orc_scalar_stream s = {seed, iter, 0, 0};
+    double rc;
+    do rc = r + proposalsd_r * ss_normal(&s); while (rc < 0);                                        /* :105-110 */
+    double lpc = (eta - 1) * log(rc) + (double)K * (rc * log(1 - p) - lgamma(rc)) - rc * sigma;      /* :118 */
+    double lpo = (eta - 1) * log(r) + (double)K * (r * log(1 - p) - lgamma(r)) - r * sigma;          /* :119 */
+    for (int64_t k = 0; k < K; ++k) {                                                                /* :120-123 */
+        lpc = lpc + lgamma((double)(C[k] - 1) + rc);
+        lpo = lpo + lgamma((double)(C[k] - 1) + r);
+    }
+    const double lpr = logpdf_truncnorm0(rc, r, proposalsd_r) - logpdf_truncnorm0(r, rc, proposalsd_r); /* :125-126 */
+    double bound = lpc - lpo - lpr;
+    if (bound > 0) bound = 0;                                                                        /* minimum([0, …]) */
+    *accept = log(ss_uniform(&s)) < bound;                                                           /* :131-135 */
+    return *accept ? rc : r;
+}
+
+/* sample_p (mcmc.jl:147-155): rand(Beta(n − K + u, r K + v)) */
+double orc_sample_p(uint64_t seed, uint64_t iter, int64_t K, int64_t n, double r, double u, double v)
+{
+    orc_scalar_stream s = {seed, iter, 1, 0};
+    const double x = ss_gamma(&s, (double)(n - K) + u);
+    const double y = ss_gamma(&s, r * (double)K + v);
+    return x / (x + y);
+}

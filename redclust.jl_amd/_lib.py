@@ -35,13 +35,28 @@ class RcPairMeasures(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("ari", "ri", "mirkin", "hubert", "mi", "nmi", "vi", "ha", "hb", "id", "nid")]
 
 
+class RcChainOptions(C.Structure):
+    _fields_ = [("numiters", C.c_int64), ("burnin", C.c_int64), ("thin", C.c_int64), ("numGibbs", C.c_int64),
+                ("numMH", C.c_int64), ("splitmerge_mode", C.c_int32), ("pad_", C.c_int32), ("seed", C.c_uint64),
+                ("first_iter", C.c_uint64), ("r0", C.c_double), ("p0", C.c_double), ("proposalsd_r", C.c_double),
+                ("r_trace", C.c_void_p), ("p_trace", C.c_void_p), ("max_samples", C.c_int64)]
+
+
+class RcChainOutputs(C.Structure):
+    _fields_ = [("clusts", C.c_void_p), ("K", C.c_void_p), ("r", C.c_void_p), ("p", C.c_void_p), ("loglik", C.c_void_p),
+                ("logposterior", C.c_void_p), ("r_acceptances", C.c_void_p), ("splitmerge_acceptances", C.c_void_p),
+                ("splitmerge_splits", C.c_void_p), ("r_all", C.c_void_p), ("p_all", C.c_void_p),
+                ("num_samples", C.c_int64), ("runtime_s", C.c_double), ("r_final", C.c_double), ("p_final", C.c_double)]
+
+
 class RcSweepStats(C.Structure):
     _fields_ = [("n_changes", C.c_int64), ("n_rounds", C.c_int64), ("K", C.c_int64)]
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, "redclust_hip.hip"), os.path.join(CSRC, "pointestimate.inc.hip"), HEADER]
+    srcs = [os.path.join(CSRC, "redclust_hip.hip"), os.path.join(CSRC, "pointestimate.inc.hip"),
+            os.path.join(CSRC, "chain.inc.hip"), HEADER]
     if not force and os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(s) for s in srcs):
         return SO
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", SO, srcs[0]]
@@ -85,6 +100,10 @@ SIGNATURES = {
     "rc_debug_rowsums": (C.c_int32, [C.c_void_p, C.c_int64, _ip, _ip, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rc_bulk_kernel_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "rc_set_bulk_kernel": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "rc_run_chain": (C.c_int32, [C.c_void_p, C.POINTER(RcChainOptions), C.POINTER(RcChainOutputs)]),
+    "rc_scalar_updates": (C.c_int32, [C.c_uint64, C.c_uint64, C.c_double, C.c_double, _ip, C.c_int64, C.c_int64, C.c_double,
+                                      C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),
+                                      C.POINTER(C.c_double), C.POINTER(C.c_uint8)]),
     "rc_loss_matrix": (C.c_int32, [C.c_int32, _ip, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                    C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "rc_pair_measures": (C.c_int32, [C.c_int32, _ip, _ip, C.c_int64, C.POINTER(RcPairMeasures)]),
@@ -277,6 +296,36 @@ class Context:
 
     def set_bulk_kernel(self, which):
         self._chk(self.L.rc_set_bulk_kernel(self.h, {"auto": -1, "perm": 0, "sym": 1}[which]))
+
+    def run_chain(self, numiters, burnin, thin, numGibbs, numMH, seed, r0, p0, proposalsd_r, splitmerge="as_written",
+                  rp_trace=None, first_iter=0):
+        """rc_run_chain: the whole iteration loop natively.  Returns a dict of numpy arrays (MCMCResult fields)."""
+        ns = max((numiters - burnin) // thin, 0) if thin > 0 else 0   # thin <= 0 is rejected by the library
+        n = self.n
+        res = dict(clusts=np.zeros((ns, n), np.int64), K=np.zeros(ns, np.int64), r=np.zeros(ns), p=np.zeros(ns),
+                   loglik=np.zeros(ns), logposterior=np.zeros(ns), r_acceptances=np.zeros(numiters, np.uint8),
+                   splitmerge_acceptances=np.zeros(numiters * numMH, np.uint8),
+                   splitmerge_splits=np.zeros(numiters * numMH, np.uint8), r_all=np.zeros(numiters), p_all=np.zeros(numiters))
+        o = RcChainOptions(numiters, burnin, thin, numGibbs, numMH, {"as_written": 0, "intended": 1}[splitmerge], 0,
+                           int(seed), int(first_iter), float(r0), float(p0), float(proposalsd_r), None, None, ns)
+        keep = []
+        if rp_trace is not None:
+            rt = np.ascontiguousarray(rp_trace[0], dtype=np.float64)
+            pt = np.ascontiguousarray(rp_trace[1], dtype=np.float64)
+            assert len(rt) >= numiters and len(pt) >= numiters
+            keep = [rt, pt]
+            o.r_trace, o.p_trace = rt.ctypes.data, pt.ctypes.data
+        out = RcChainOutputs()
+        for k in ("clusts", "K", "r", "p", "loglik", "logposterior", "r_acceptances", "splitmerge_acceptances",
+                  "splitmerge_splits", "r_all", "p_all"):
+            setattr(out, k, res[k].ctypes.data if res[k].size else None)
+        self._chk(self.L.rc_run_chain(self.h, C.byref(o), C.byref(out)))
+        del keep
+        res["num_samples"], res["runtime_s"] = int(out.num_samples), float(out.runtime_s)
+        res["r_final"], res["p_final"] = float(out.r_final), float(out.p_final)
+        for k in ("r_acceptances", "splitmerge_acceptances", "splitmerge_splits"):
+            res[k] = res[k].astype(bool)
+        return res
 
     def layout_info(self):
         """(layouts built so far, label runs in the internal point order)"""

@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>
@@ -3112,3 +3113,4 @@ extern "C" int32_t rc_event_overhead_ms(rc_ctx *c, double *out)
 }
 
 #include "pointestimate.inc.hip"
+#include "chain.inc.hip"

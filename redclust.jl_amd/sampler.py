@@ -77,11 +77,17 @@ def _mean_and_var(x):
 def runsampler(data: MCMCData, options: MCMCOptionsList | None = None, params: PriorHyperparamsList | None = None,
                init: MCMCState | None = None, *, verbose: bool = True, seed: int = 0, rng=None, device: int = 0,
                kcap: int = 0, ctx: Context | None = None, rp_trace=None, splitmerge: str = "as_written",
-               host_logD=None) -> MCMCResult:
+               host_logD=None, engine: str | None = None) -> MCMCResult:
     """runsampler(data, options, params, init; verbose) — src/mcmc.jl:501-590.
 
-    seed keys the counter-based uniform stream of the label draws; rng (numpy Generator) drives
-    the host-side r / p updates.  rp_trace=(r_seq, p_seq) teacher-forces r and p instead (parity tests)."""
+    seed keys the counter-based streams of the label draws, the split–merge proposals and the scalar r / p updates
+    (DESIGN.md).  engine="native" (default) runs the whole iteration loop inside the library (rc_run_chain);
+    engine="python" keeps the loop in this function and draws r / p from `rng` (a numpy Generator; giving `rng`
+    selects it).  rp_trace=(r_seq, p_seq) teacher-forces r and p instead (parity tests)."""
+    if engine is None:
+        engine = "python" if rng is not None else "native"
+    if engine not in ("native", "python"):
+        raise ValueError("engine must be 'native' or 'python'")
     options = options or MCMCOptionsList()
     if params is None:
         raise NotImplementedError("fitprior is outside this build's scope (SURVEY.md §8): pass params explicitly")
@@ -110,7 +116,21 @@ def runsampler(data: MCMCData, options: MCMCOptionsList | None = None, params: P
         out(f"Setup: {numiters} iterations, {numsamples} samples, {n} observations.")
         j = 0
         t0 = time.perf_counter()
-        for i in range(1, numiters + 1):
+        if engine == "native":
+            ch = ctx.run_chain(numiters, burnin, thin, options.numGibbs, numMH, seed, state.r, state.p,
+                               params.proposalsd_r, splitmerge=splitmerge, rp_trace=rp_trace)
+            for j in range(ch["num_samples"]):
+                result.clusts[j][:] = ch["clusts"][j]
+            for k in ("K", "r", "p", "loglik", "logposterior"):
+                getattr(result, k)[:] = ch[k]
+            result.r_acceptances[:] = ch["r_acceptances"]
+            result.splitmerge_acceptances[:] = ch["splitmerge_acceptances"]
+            result.splitmerge_splits[:] = ch["splitmerge_splits"]
+            state.r, state.p = ch["r_final"], ch["p_final"]
+            numiters_py = 0
+        else:
+            numiters_py = numiters
+        for i in range(1, numiters_py + 1):
             if rp_trace is None:
                 C = state.clustsizes[state.clustsizes > 0]
                 state.r, acc = sample_r(rng, state.r, state.p, C, state.K, params.eta, params.sigma, params.proposalsd_r)

@@ -102,6 +102,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "golden_sweeps.npz"), **gold)
     make_golden_mh(data)
     make_golden_pointestimate(data)
+    make_golden_chain(data)
     print("wrote", HERE)
 
 
@@ -162,6 +163,31 @@ def make_golden_pointestimate(data):
     for k, v in T.evaluateclustering(samples[-1], truth).items():
         gold[f"eval_{k}"] = np.array(v)
     np.savez_compressed(os.path.join(HERE, "golden_pointestimate.npz"), **gold)
+
+
+def make_golden_chain(data):
+    """Free-running chains of the transcription's runsampler loop (mcmc.jl:533-556; scalar updates on the build's
+    scalar stream): paper dataset 1 with numMH = 0 and dataset 1 (three merged pairs of true clusters as init) with
+    numMH = 2, numGibbs = 5 (seed chosen so that proposals of both kinds are accepted)."""
+    gold = {}
+    for tag, d, numMH, iters, seed in (("d1_gibbs", 1, 0, 40, 100), ("d1_mh", 1, 2, 25, 103)):
+        D, truth = data[f"D{d}"], data[f"labels{d}"]
+        P = T.likelihood_hyperparams(D, truth)
+        init = truth.copy()
+        if numMH:
+            init[init == 2] = 1; init[init == 4] = 3; init[init == 9] = 8
+        else:
+            init = np.random.default_rng(9).integers(1, 11, size=100).astype(np.int64)
+        rec = T.run_chain(D, init, P, 1.0, 0.5, iters, 5, 2, 5, numMH, seed, eta=P["eta"], sigma=P["sigma"],
+                          proposalsd_r=0.7, u=P["u"], v=P["v"])
+        gold[f"{tag}_init"] = init
+        gold[f"{tag}_seed"] = np.array(seed)
+        gold[f"{tag}_numMH"] = np.array(numMH)
+        gold[f"{tag}_iters"] = np.array(iters)
+        for k, v in rec.items():
+            gold[f"{tag}_{k}"] = np.array(v)
+        print(tag, "K", rec["K"], "r accepted", int(np.sum(rec["r_acc"])), "sm accepted", int(np.sum(rec["sm_acc"])) if numMH else "-")
+    np.savez_compressed(os.path.join(HERE, "golden_chain.npz"), **gold)
 
 
 if __name__ == "__main__":

@@ -18,6 +18,8 @@ cannot be reproduced outside Julia).
 """
 from __future__ import annotations
 
+import math
+
 import numpy as np
 from scipy.special import gammaln
 
@@ -432,3 +434,98 @@ def getpointestimate_mpel(samples, loss):
     L = L + L.T
     cs = L.sum(axis=0)
     return int(np.argmin(cs)), L, cs
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Scalar updates: sample_r (mcmc.jl:94-136), sample_p (mcmc.jl:147-155) on the build's scalar stream
+# (Philox key (seed_lo, seed_hi ^ 0x52505F5F), counter (draw, kind, iter_lo, iter_hi); Box–Muller normals,
+# Marsaglia–Tsang gammas) and the host loop of runsampler (mcmc.jl:533-556).
+# ---------------------------------------------------------------------------------------------------------------
+class ScalarStream:
+    def __init__(self, seed, it, kind):
+        self.seed, self.it, self.kind, self.draw = seed, it, kind, 0
+
+    def uniform(self):
+        out = philox4x32_10([self.draw & 0xFFFFFFFF, self.kind, self.it & 0xFFFFFFFF, (self.it >> 32) & 0xFFFFFFFF],
+                            [self.seed & 0xFFFFFFFF, ((self.seed >> 32) & 0xFFFFFFFF) ^ 0x52505F5F])
+        self.draw += 1
+        bits = ((int(out[0]) << 32) | int(out[1])) >> 12
+        return (bits + 0.5) * 2.0 ** -52
+
+    def normal(self):
+        u1, u2 = self.uniform(), self.uniform()
+        return math.sqrt(-2.0 * math.log(u1)) * math.cos(2 * math.pi * u2)
+
+    def gamma(self, a):
+        boost = 1.0
+        if a < 1.0:
+            boost = self.uniform() ** (1.0 / a)
+            a += 1.0
+        d = a - 1.0 / 3.0
+        c = 1.0 / math.sqrt(9.0 * d)
+        while True:
+            z = self.normal()
+            t = 1.0 + c * z
+            u = self.uniform()
+            if t <= 0:
+                continue
+            v = t * t * t
+            if math.log(u) < 0.5 * z * z + d - d * v + d * math.log(v):
+                return d * v * boost
+
+
+def _logpdf_truncnorm0(x, mu, sd):
+    from scipy.special import log_ndtr
+    z = (x - mu) / sd
+    return -0.5 * z * z - math.log(sd) - 0.5 * math.log(2 * math.pi) - float(log_ndtr(mu / sd))
+
+
+def sample_r(seed, it, r, p, C, K, eta, sigma, proposalsd_r):
+    s = ScalarStream(seed, it, 0)
+    while True:
+        rc = r + proposalsd_r * s.normal()
+        if rc >= 0:
+            break
+    C = np.asarray(C, dtype=np.float64)
+    lpc = (eta - 1) * math.log(rc) + K * (rc * math.log(1 - p) - float(gammaln(rc))) - rc * sigma
+    lpo = (eta - 1) * math.log(r) + K * (r * math.log(1 - p) - float(gammaln(r))) - r * sigma
+    for nk in C:
+        lpc += float(gammaln(nk - 1 + rc))
+        lpo += float(gammaln(nk - 1 + r))
+    lpr = _logpdf_truncnorm0(rc, r, proposalsd_r) - _logpdf_truncnorm0(r, rc, proposalsd_r)
+    if math.log(s.uniform()) < min(0.0, lpc - lpo - lpr):
+        return rc, True
+    return r, False
+
+
+def sample_p(seed, it, K, n, r, u, v):
+    s = ScalarStream(seed, it, 1)
+    x = s.gamma(n - K + u)
+    y = s.gamma(r * K + v)
+    return x / (x + y)
+
+
+def run_chain(D, clusts, P, r, p, numiters, burnin, thin, numGibbs, numMH, seed, eta=1.0, sigma=1.0, proposalsd_r=1.0,
+              u=1.0, v=1.0):
+    """runsampler's loop (mcmc.jl:533-556) as written: sample_r!, sample_p!, sample_labels!, record."""
+    n = D.shape[0]
+    logD = make_logD(D)
+    clusts = clusts.copy()
+    sizes, K = state_from_labels(clusts)
+    rec = dict(r=[], p=[], K=[], loglik=[], logposterior=[], clusts=[], r_acc=[], sm_acc=[], sm_split=[], r_all=[], p_all=[])
+    for i in range(1, numiters + 1):
+        C = sizes[sizes > 0]
+        r, acc = sample_r(seed, i - 1, r, p, C, K, eta, sigma, proposalsd_r)
+        rec["r_acc"].append(acc)
+        p = sample_p(seed, i - 1, K, n, r, u, v)
+        rec["r_all"].append(r); rec["p_all"].append(p)
+        if numMH > 0:
+            a, s, K = sample_labels(D, logD, clusts, sizes, K, P, r, p, numMH, numGibbs, seed, i - 1)
+            rec["sm_acc"] += list(np.atleast_1d(a)); rec["sm_split"] += list(np.atleast_1d(s))
+        else:
+            K = sweep(D, logD, clusts, sizes, P, r, p, seed, i - 1)
+        if i > burnin and (i - burnin) % thin == 0:
+            ll = loglik(D, logD, clusts, sizes, P)
+            rec["clusts"].append(sortlabels(clusts)); rec["K"].append(K); rec["r"].append(r); rec["p"].append(p)
+            rec["loglik"].append(ll); rec["logposterior"].append(ll + logprior(sizes, r, p, dict(P, eta=eta, sigma=sigma, u=u, v=v)))
+    return rec

@@ -82,6 +82,12 @@ def lib():
                                   i64, u64, u64, u64, i32, C.POINTER(OrcMHInfo)]
     L.orc_sample_labels.argtypes = [i64, _dp, _dp, C.c_void_p, C.c_void_p, i32, i32, C.c_void_p, _ip, _ip,
                                     C.POINTER(i64), PP, f64, f64, i64, i64, u64, u64, i32, _bp, _bp]
+    L.orc_sample_r.restype = f64
+    L.orc_sample_r.argtypes = [u64, u64, f64, f64, _ip, i64, f64, f64, f64, C.POINTER(C.c_int)]
+    L.orc_sample_p.restype = f64
+    L.orc_sample_p.argtypes = [u64, u64, i64, i64, f64, f64, f64]
+    L.orc_scalar_uniform.restype = f64
+    L.orc_scalar_uniform.argtypes = [u64, u64, C.c_uint32, u64]
     L.orc_pair_measures_eval.restype = None
     L.orc_pair_measures_eval.argtypes = [i64, _ip, _ip, C.POINTER(OrcPairMeasures)]
     L.orc_mpel.restype = i64
@@ -92,6 +98,49 @@ def lib():
 
 class OrcPairMeasures(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("ari", "ri", "mirkin", "hubert", "mi", "nmi", "vi", "ha", "hb", "id", "nid")]
+
+
+def sample_r(seed, it, r, p, sizes, eta, sigma, proposalsd_r):
+    """orc_sample_r: (new r, accepted).  sizes: non-empty cluster sizes in ascending label order."""
+    Cs = np.ascontiguousarray(sizes, dtype=np.int64)
+    acc = C.c_int()
+    out = lib().orc_sample_r(seed, it, r, p, Cs, len(Cs), eta, sigma, proposalsd_r, C.byref(acc))
+    return out, bool(acc.value)
+
+
+def sample_p(seed, it, K, n, r, u, v):
+    return lib().orc_sample_p(seed, it, K, n, r, u, v)
+
+
+def run_chain(orc, init, r, p, numiters, burnin, thin, numGibbs, numMH, seed, proposalsd_r=1.0, rp_trace=None,
+              stable=True, intended=False):
+    """runsampler's loop (mcmc.jl:533-556) on an Oracle: sample_r!, sample_p!, sample_labels!, recording rule."""
+    orc.set_state(init)
+    P = orc.P
+    rec = dict(r=[], p=[], K=[], loglik=[], logposterior=[], clusts=[], r_acc=[], sm_acc=[], sm_split=[], r_all=[], p_all=[])
+    for i in range(1, numiters + 1):
+        if rp_trace is None:
+            sizes = orc.sizes[orc.sizes > 0]
+            r, acc = sample_r(seed, i - 1, r, p, sizes, P.eta, P.sigma, proposalsd_r)
+            p = sample_p(seed, i - 1, len(sizes), orc.n, r, P.u, P.v)
+            rec["r_acc"].append(acc)
+        else:
+            r, p = float(rp_trace[0][i - 1]), float(rp_trace[1][i - 1])
+        rec["r_all"].append(r); rec["p_all"].append(p)
+        if numMH > 0 and not intended:
+            _, a, s = orc.sample_labels(r, p, numMH, numGibbs, seed, i - 1, mode=1 if stable else 0)
+            rec["sm_acc"] += list(a); rec["sm_split"] += list(s)
+        else:
+            if numMH > 0:
+                for mh in range(numMH):
+                    info = orc.mh_proposal(r, p, numGibbs, seed, i - 1, mh, mode=1 if stable else 0)
+                    rec["sm_acc"].append(bool(info.accept)); rec["sm_split"].append(bool(info.split))
+            (orc.sweep_stable if stable else orc.sweep_literal)(r, p, seed, i - 1)
+        if i > burnin and (i - burnin) % thin == 0:
+            ll = orc.loglik_stable() if stable else orc.loglik_literal()
+            rec["clusts"].append(orc.sortlabels()); rec["K"].append(orc.K); rec["r"].append(r); rec["p"].append(p)
+            rec["loglik"].append(ll); rec["logposterior"].append(ll + orc.logprior(r, p))
+    return {k: np.array(v) for k, v in rec.items()}
 
 
 def pair_measures(a, b) -> dict:

@@ -1,0 +1,124 @@
+"""GPU parity of the native iteration loop rc_run_chain (csrc/chain.inc.hip; runsampler's loop, mcmc.jl:533-556)
+against the oracle's loop and the golden chains, free-running (the scalar r / p updates included) and teacher-forced."""
+import os
+
+import numpy as np
+import pytest
+
+import np_transcription as T
+import oracle_lib as O
+import redclust_amd as rc
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+LL_RTOL = 1e-9
+
+
+def paper(d=1):
+    z = np.load(os.path.join(HERE, "golden", "paper_datasets.npz"))
+    return z[f"D{d}"], z[f"labels{d}"]
+
+
+def make(D, P, init):
+    orc = O.Oracle(D, P)
+    ctx = rc.Context(D, logD=orc.logD)
+    ctx.set_params(**P)
+    ctx.set_state(init)
+    ctx.cocluster_reset()
+    return orc, ctx
+
+
+@pytest.mark.parametrize("tag", ["d1_gibbs", "d1_mh"])
+def test_free_running_chain_vs_oracle_and_golden(tag):
+    g = np.load(os.path.join(HERE, "golden", "golden_chain.npz"))
+    D, truth = paper(1)
+    P = T.likelihood_hyperparams(D, truth)
+    init = g[f"{tag}_init"]
+    numMH, iters, seed = int(g[f"{tag}_numMH"]), int(g[f"{tag}_iters"]), int(g[f"{tag}_seed"])
+    orc, ctx = make(D, P, init)
+    if numMH:
+        ctx.attach_host_matrices(D, orc.logD)
+    ch = ctx.run_chain(iters, 5, 2, 5, numMH, seed, 1.0, 0.5, 0.7)
+    ref = O.run_chain(orc, init, 1.0, 0.5, iters, 5, 2, 5, numMH, seed, proposalsd_r=0.7, stable=True)
+    ns = len(ref["K"])
+    assert ch["num_samples"] == ns == (iters - 5) // 2
+    # scalar draws, labels and split–merge decisions: exact, against the oracle and the golden vectors
+    for got, want in ((ch["r_all"], ref["r_all"]), (ch["p_all"], ref["p_all"]), (ch["r"], ref["r"]), (ch["p"], ref["p"]),
+                      (ch["clusts"], ref["clusts"]), (ch["K"], ref["K"]), (ch["r_acceptances"], ref["r_acc"]),
+                      (ch["r_all"], g[f"{tag}_r_all"]), (ch["p_all"], g[f"{tag}_p_all"]), (ch["clusts"], g[f"{tag}_clusts"]),
+                      (ch["K"], g[f"{tag}_K"])):
+        assert np.array_equal(got, want)
+    if numMH:
+        assert np.array_equal(ch["splitmerge_acceptances"], ref["sm_acc"]) and np.array_equal(ch["splitmerge_splits"], ref["sm_split"])
+        assert np.array_equal(ch["splitmerge_acceptances"], g[f"{tag}_sm_acc"]) and ch["splitmerge_acceptances"].sum() >= 1
+    assert np.allclose(ch["loglik"], ref["loglik"], rtol=LL_RTOL, atol=0)
+    assert np.allclose(ch["logposterior"], ref["logposterior"], rtol=1e-6, atol=0)      # north_star tolerance
+    assert np.allclose(ch["loglik"], g[f"{tag}_loglik"], rtol=1e-7)                     # literal arithmetic there
+    # co-clustering of the recorded samples
+    acc = sum((c[:, None] == c[None, :]).astype(np.float64) for c in ref["clusts"])
+    assert np.array_equal(ctx.cocluster(ns), acc / ns)
+    # the final device state is the oracle's
+    lab, sizes, K = ctx.get_state()
+    assert np.array_equal(lab, orc.clusts) and K == orc.K
+    ctx.close()
+
+
+def test_teacher_forced_and_intended_mode():
+    D, truth = paper(1)
+    P = T.likelihood_hyperparams(D, truth)
+    init = truth.copy(); init[init == 2] = 1; init[init == 4] = 3; init[init == 9] = 8
+    rs = np.full(30, 1.0); ps = np.full(30, 0.5)
+    orc, ctx = make(D, P, init)
+    ctx.attach_host_matrices(D, orc.logD)
+    ch = ctx.run_chain(30, 0, 3, 5, 2, 4322, 1.0, 0.5, 1.0, splitmerge="intended", rp_trace=(rs, ps))
+    ref = O.run_chain(orc, init, 1.0, 0.5, 30, 0, 3, 5, 2, 4322, rp_trace=(rs, ps), stable=True, intended=True)
+    assert np.array_equal(ch["clusts"], ref["clusts"]) and np.array_equal(ch["splitmerge_acceptances"], ref["sm_acc"])
+    assert np.array_equal(ch["splitmerge_splits"], ref["sm_split"]) and np.array_equal(ch["r"], ref["r"])
+    assert ch["splitmerge_acceptances"].sum() >= 1
+    assert np.allclose(ch["loglik"], ref["loglik"], rtol=LL_RTOL, atol=0)
+    ctx.close()
+
+
+def test_continuation_and_bad_arguments():
+    """first_iter continues the streams: 10 + 15 iterations = 25 iterations."""
+    D, truth = paper(2)
+    P = T.likelihood_hyperparams(D, truth)
+    init = np.random.default_rng(1).integers(1, 11, 100).astype(np.int64)
+    _, a = make(D, P, init)
+    _, b = make(D, P, init)
+    full = a.run_chain(25, 0, 1, 5, 0, 5, 1.0, 0.5, 1.0)
+    h1 = b.run_chain(10, 0, 1, 5, 0, 5, 1.0, 0.5, 1.0)
+    h2 = b.run_chain(15, 0, 1, 5, 0, 5, h1["r_final"], h1["p_final"], 1.0, first_iter=10)
+    assert np.array_equal(full["clusts"], np.vstack([h1["clusts"], h2["clusts"]]))
+    assert np.array_equal(full["r"], np.concatenate([h1["r"], h2["r"]]))
+    assert np.array_equal(full["loglik"], np.concatenate([h1["loglik"], h2["loglik"]]))
+    with pytest.raises(rc.RedClustHIPError):
+        b.run_chain(5, 0, 0, 5, 0, 5, 1.0, 0.5, 1.0)          # thin = 0
+    with pytest.raises(rc.RedClustHIPError):
+        b.run_chain(5, 0, 1, 5, 1, 5, 1.0, 0.5, 1.0)          # numMH > 0 without host matrices
+    with pytest.raises(rc.RedClustHIPError):
+        b.run_chain(5, 0, 1, 5, 0, 5, -1.0, 0.5, 1.0)
+    a.close(); b.close()
+
+
+def test_runsampler_engines_agree():
+    """runsampler(engine="native") and the Python loop produce the same MCMCResult under teacher-forced r / p, and the
+    native engine fills every field free-running (the reference's @test_nothrow runs, test/test_sampler.jl)."""
+    D, truth = paper(1)
+    P = rc.likelihood_hyperparams(D, truth)
+    params = rc.PriorHyperparamsList(**{k: P[k] for k in ("delta1", "delta2", "alpha", "beta", "zeta", "gamma")})
+    init = np.random.default_rng(2).integers(1, 11, 100).astype(np.int64)
+    rs = 0.8 + 0.02 * np.arange(40); ps = 0.3 + 0.005 * np.arange(40)
+    res = {}
+    for eng in ("native", "python"):
+        res[eng] = rc.runsampler(rc.MCMCData(D), rc.MCMCOptionsList(numiters=40, burnin=8, thin=4, numMH=1), params,
+                                 rc.MCMCState(init, 1.0, 0.5), verbose=False, seed=31, rp_trace=(rs, ps), engine=eng)
+    a, b = res["native"], res["python"]
+    assert all(np.array_equal(x, y) for x, y in zip(a.clusts, b.clusts))
+    for f in ("K", "r", "p", "loglik", "logposterior", "posterior_coclustering", "splitmerge_acceptances", "splitmerge_splits"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    free = rc.runsampler(rc.MCMCData(D), rc.MCMCOptionsList(numiters=200, burnin=50, thin=5), params,
+                         rc.MCMCState(init, 1.0, 0.5), verbose=False, seed=4)
+    assert len(free.clusts) == 30 and np.all(free.K > 0) and np.all(np.isfinite(free.logposterior))
+    assert 0 < free.r_acceptance_rate < 1 and np.all((free.p > 0) & (free.p < 1)) and free.mean_iter_time > 0
+    assert np.all(np.diag(free.posterior_coclustering) == 1.0)
