@@ -102,6 +102,75 @@ static void sizes_by_label(rc_ctx *c, std::vector<int64_t> &C)
     for (auto &e : bl) C.push_back(e.second);
 }
 
+// ---- asynchronous recorder -------------------------------------------------------------------------------------
+// A recorded sample (mcmc.jl:546-553) needs the labels, the block sums for loglik and the cluster sizes of the state
+// an iteration ends in.  Instead of stalling the loop on them, the device part (label snapshot into the co-clustering
+// queue + copy to pinned memory, k_blocksums + copy) is enqueued on stream A in front of the next sweep, and the host
+// part (sortlabels, the scalar part of loglik, logprior) runs after that sweep has been launched, i.e. under it.
+struct Pending {
+    bool active = false;
+    int64_t j = 0;
+    double r = 0, p = 0;
+    int hi = 0, K = 0;
+    std::vector<int> ssize, slabel;
+};
+constexpr int REC_SLOT = RC_REC_SLOTS - 1;  // slot 0 belongs to rc_loglik (split–merge proposals call it)
+
+// the state to record must be complete and its summary visible to the host (sync_and_check done)
+static int32_t record_enqueue(rc_ctx *c, Pending &R, bool want_labels)
+{
+    int32_t rc = ensure_counts(c);
+    if (rc != RC_OK) return rc;
+    R.hi = std::max(1, std::min(c->kcap, c->hsum->slot_hi));
+    R.K = c->hsum->K;
+    rc = ensure_pinned(c, R.hi);
+    if (rc != RC_OK) return rc;
+    R.ssize.resize((size_t)c->kcap); R.slabel.resize((size_t)c->kcap);
+    for (int k = 0; k < c->kcap; ++k) {
+        R.ssize[(size_t)k] = c->hsum->size_label[2 * k];
+        R.slabel[(size_t)k] = c->hsum->size_label[2 * k + 1];
+    }
+    unsigned short *row = c->snap + (size_t)c->snap_cnt * c->ldc;
+    k_snapshot<<<(c->ldc + 255) / 256, 256, 0, c->sA>>>(c->slot_of, c->pi, c->n, c->ldc, row);
+    HIPCHK(c, hipGetLastError());
+    if (want_labels) HIPCHK(c, hipMemcpyAsync(c->pinLab[REC_SLOT], row, (size_t)c->n * sizeof(unsigned short), hipMemcpyDeviceToHost, c->sA));
+    if (++c->snap_cnt == RC_CC_BATCH) {
+        rc = flush_counts(c);
+        if (rc != RC_OK) return rc;
+    }
+    rc = loglik_enqueue(c, R.hi, c->pinB[REC_SLOT]);
+    if (rc != RC_OK) return rc;
+    HIPCHK(c, hipEventRecord(c->pinEv[REC_SLOT], c->sA));
+    return RC_OK;
+}
+
+static int32_t record_finish(rc_ctx *c, Pending &R, rc_chain_outputs *out)
+{
+    HIPCHK(c, hipEventSynchronize(c->pinEv[REC_SLOT]));
+    const int64_t j = R.j;
+    if (out->clusts) {
+        // sortlabels (utils.jl:69-74): relabel by order of first appearance; the snapshot is in the caller's point order
+        int64_t *dst = out->clusts + (size_t)j * c->n;
+        std::vector<int> map((size_t)c->kcap, 0);
+        int next = 0;
+        const unsigned short *lab = c->pinLab[REC_SLOT];
+        for (int i = 0; i < c->n; ++i) {
+            int &m = map[(size_t)lab[i]];
+            if (m == 0) m = ++next;
+            dst[i] = m;
+        }
+    }
+    const double ll = loglik_host(c, R.hi, R.ssize.data(), c->pinB[REC_SLOT]);                    // mcmc.jl:551
+    const double lp = logprior_host(c, R.ssize.data(), R.slabel.data(), R.r, R.p);
+    if (out->K) out->K[j] = R.K;
+    if (out->r) out->r[j] = R.r;
+    if (out->p) out->p[j] = R.p;
+    if (out->loglik) out->loglik[j] = ll;
+    if (out->logposterior) out->logposterior[j] = ll + lp;                                        // mcmc.jl:552
+    R.active = false;
+    return RC_OK;
+}
+
 }  // namespace chain
 
 extern "C" int32_t rc_scalar_updates(uint64_t seed, uint64_t iter, double r, double p, const int64_t *sizes, int64_t K,
@@ -136,16 +205,30 @@ extern "C" int32_t rc_run_chain(rc_ctx *c, const rc_chain_options *o, rc_chain_o
     double r = o->r0, p = o->p0;
     std::vector<int64_t> C;
     int64_t j = 0;
+    chain::Pending pend;
+    bool pend_enqueued = false;
     const auto t0 = std::chrono::steady_clock::now();
     for (int64_t i = 1; i <= o->numiters; ++i) {
         const uint64_t it = o->first_iter + (uint64_t)(i - 1);
+        if (!o->r_trace || pend.active) {
+            // K and the sizes of the current state: host-mapped summary of the last sweep (or of rc_set_state)
+            rc = sync_and_check(c);
+            if (rc != RC_OK) return rc;
+        }
+        if (pend.active) {                      // the previous iteration ended in a state to record: device part now
+            rc = chain::record_enqueue(c, pend, out->clusts != nullptr);
+            if (rc != RC_OK) return rc;
+            pend_enqueued = true;
+            if (o->numMH > 0) {                 // proposals run their own loglik through the same staging: finish first
+                rc = chain::record_finish(c, pend, out);
+                if (rc != RC_OK) return rc;
+                pend_enqueued = false;
+            }
+        }
         if (o->r_trace) {
             r = o->r_trace[i - 1]; p = o->p_trace[i - 1];
             if (!(r > 0.0) || !(p > 0.0 && p < 1.0)) return fail(c, RC_ERR_ARG, "rc_run_chain: r_trace/p_trace entry %lld out of range", (long long)i);
         } else {
-            // K and the sizes of the current state: host-mapped summary of the last sweep (or of rc_set_state)
-            rc = sync_and_check(c);
-            if (rc != RC_OK) return rc;
             chain::sizes_by_label(c, C);
             bool acc = false;
             r = chain::sample_r(o->seed, it, r, p, C, P.eta, P.sigma, o->proposalsd_r, &acc);      // mcmc.jl:538
@@ -178,25 +261,28 @@ extern "C" int32_t rc_run_chain(rc_ctx *c, const rc_chain_options *o, rc_chain_o
             rc = rc_gibbs_sweep_async(c, r, p, o->seed, it);                                      // mcmc.jl:477
             if (rc != RC_OK) return rc;
         }
+        if (pend_enqueued) {                    // host part of the previous sample, under the sweep just launched
+            rc = chain::record_finish(c, pend, out);
+            if (rc != RC_OK) return rc;
+            pend_enqueued = false;
+        }
         if (i > o->burnin && (i - o->burnin) % o->thin == 0) {                                    // mcmc.jl:546
             if (j >= o->max_samples) return fail(c, RC_ERR_ARG, "rc_run_chain: more samples than max_samples=%lld", (long long)o->max_samples);
-            rc = rc_record_sample(c, out->clusts ? out->clusts + (size_t)j * n : nullptr);        // sortlabels + counts
-            if (rc != RC_OK) return rc;
-            double ll = 0, lp = 0;
-            rc = rc_loglik(c, &ll);                                                               // mcmc.jl:551
-            if (rc != RC_OK) return rc;
-            rc = rc_logprior(c, r, p, &lp);
-            if (rc != RC_OK) return rc;
-            if (out->K) out->K[j] = c->hsum->K;
-            if (out->r) out->r[j] = r;
-            if (out->p) out->p[j] = p;
-            if (out->loglik) out->loglik[j] = ll;
-            if (out->logposterior) out->logposterior[j] = ll + lp;                                // mcmc.jl:552
-            ++j;
+            pend.active = true;
+            pend.j = j++;
+            pend.r = r; pend.p = p;
         }
     }
     rc = sync_and_check(c);
     if (rc != RC_OK) return rc;
+    if (pend.active) {
+        rc = chain::record_enqueue(c, pend, out->clusts != nullptr);
+        if (rc != RC_OK) return rc;
+        rc = chain::record_finish(c, pend, out);
+        if (rc != RC_OK) return rc;
+        rc = sync_and_check(c);
+        if (rc != RC_OK) return rc;
+    }
     out->num_samples = j;
     out->runtime_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     out->r_final = r;

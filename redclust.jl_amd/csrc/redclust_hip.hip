@@ -72,6 +72,8 @@ struct DevScalars {
 // Per-sweep summary written by block 0 of k_resolve straight into host-mapped pinned memory: the host needs K and
 // the cluster sizes after every sweep for the scalar r / p updates (src/mcmc.jl:84-89,139-144) —
 // one stream synchronisation and no copy call.
+constexpr int RC_REC_SLOTS = 2;  // sample slots of the asynchronous recorder (rc_run_chain)
+
 struct HostSummary {
     int K, n_changes, n_rounds, err, slot_hi, seq, runs, pad1;
     int size_label[2 * RC_MAX_KCAP];  // [2k] = size of slot k, [2k+1] = its 1-based label (0 = free)
@@ -1618,9 +1620,20 @@ struct rc_ctx {
     long long state_version = 0;         // bumped whenever labels may have changed (sweeps, moves, rc_set_state)
     long long ll_version = -1;           // state_version the cached log-likelihood belongs to
     double ll_cached = 0.0;
+    std::vector<long long> B_cur;        // block sums, slot sizes and labels of the state ll_cached belongs to
+    std::vector<int> B_ssize, B_slabel;
+    int B_hi = 0;
+    long long B_version = -2;
     // lgammal(alpha + delta1*pairs) - lgammal(alpha) and the zeta analogue, memoised by the integer pair count: between
     // consecutive rc_loglik calls cluster sizes rarely change, so nearly all of the K + K(K-1)/2 evaluations hit
     std::unordered_map<long long, long double> lg_memo1, lg_memo2;
+    struct LLTerm { long long e[4] = {0, 0, 0, 0}; int sk = -1, st = -1; long double term = 0; };
+    std::vector<LLTerm> ll_cache;        // loglik terms per slot pair ([t][k], ll_dim × ll_dim), see loglik_host
+    int ll_dim = 0;
+    long long *pinB[RC_REC_SLOTS] = {};  // pinned staging: block sums / label snapshot / completion event per sample slot
+    unsigned short *pinLab[RC_REC_SLOTS] = {};
+    hipEvent_t pinEv[RC_REC_SLOTS] = {};
+    int pin_hi = 0;
     char err[512] = {0};
 };
 
@@ -1694,6 +1707,11 @@ static void free_all(rc_ctx *c)
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->hsum) (void)hipHostFree(c->hsum);
+    for (int q = 0; q < RC_REC_SLOTS; ++q) {
+        if (c->pinB[q]) (void)hipHostFree(c->pinB[q]);
+        if (c->pinLab[q]) (void)hipHostFree(c->pinLab[q]);
+        if (c->pinEv[q]) (void)hipEventDestroy(c->pinEv[q]);
+    }
     for (auto &e : c->ev_pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &e : c->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (int q = 0; q < 4; ++q) {
@@ -1705,8 +1723,29 @@ static void free_all(rc_ctx *c)
     delete c;
 }
 
+// RC_SM_PROFILE=1: wall time per phase of rc_splitmerge, printed by rc_destroy
+struct SmProfile {
+    double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long calls = 0;
+    bool on = getenv("RC_SM_PROFILE") && atoi(getenv("RC_SM_PROFILE"));
+    std::chrono::steady_clock::time_point last;
+    void start() { if (on) { last = std::chrono::steady_clock::now(); ++calls; } }
+    void lap(int k) { if (on) { auto now = std::chrono::steady_clock::now(); t[k] += std::chrono::duration<double>(now - last).count(); last = now; } }
+    void report() const
+    {
+        if (!on || !calls) return;
+        static const char *names[8] = {"pull_labels", "launch_state", "scans", "loglik_current", "apply", "loglik_proposed", "revert", "-"};
+        fprintf(stderr, "[rc_splitmerge profile] %lld proposals:", calls);
+        for (int k = 0; k < 7; ++k) fprintf(stderr, " %s %.1f us", names[k], t[k] / (double)calls * 1e6);
+        fprintf(stderr, "\n");
+    }
+};
+static SmProfile g_smprof;
+static void smprof_report() { g_smprof.report(); }
+
 extern "C" int32_t rc_destroy(rc_ctx *ctx)
 {
+    smprof_report();
     if (!ctx) return RC_OK;
     (void)hipSetDevice(ctx->dev);
     if (ctx->sA) (void)hipStreamSynchronize(ctx->sA);
@@ -1998,6 +2037,8 @@ extern "C" int32_t rc_set_params(rc_ctx *c, const rc_params *P)
     c->P = *P;
     c->lg_memo1.clear();
     c->lg_memo2.clear();
+    c->ll_cache.clear();
+    c->ll_dim = 0;
     // size table (see DESIGN.md "Score arithmetic"): long double on the host, once per parameter set
     std::vector<double> A((size_t)c->n + 1);
     const long double d1 = P->delta1, d2 = P->delta2, al = P->alpha, be = P->beta, ze = P->zeta, ga = P->gamma;
@@ -2340,47 +2381,45 @@ extern "C" int32_t rc_get_state(rc_ctx *c, int64_t *clusts, int64_t *clustsizes,
     return RC_OK;
 }
 
-extern "C" int32_t rc_loglik(rc_ctx *c, double *out)
+// Scalar part of loglik (mcmc.jl:26-54) in long double, regrouped as in the oracle's "stable" mode, from the exact
+// fixed-point block sums B[t][k] (hi × hi × 4: D hi/lo, logD hi/lo) and the slot sizes.  A term depends only on its
+// two cluster sizes and its block sums, and most of them do not change from one recorded sample to the next, so the
+// terms are cached per slot pair and re-evaluated only when their (integer) inputs differ: the value — and the order
+// of the summation — is exactly that of evaluating every term afresh.
+static double loglik_host(rc_ctx *c, int hi, const int *ssize, const long long *B)
 {
-    if (!c || !out) return fail(c, RC_ERR_ARG, "rc_loglik: NULL argument");
-    if (!c->have_params || !c->have_state) return fail(c, RC_ERR_STATE, "rc_loglik: params and state must be set");
-    HIPCHK(c, hipSetDevice(c->dev));
-    int gen = 0;
-    int32_t rc = ensure_S(c, &gen);
-    if (rc != RC_OK) return rc;
-    std::vector<int> so, ssize, slabel;
-    rc = pull_state(c, so, ssize, slabel, false);  // also refreshes c->last (slot_hi)
-    if (rc != RC_OK) return rc;
-    const int hi = std::max(1, std::min(c->kcap, c->last.slot_hi));
-    View V = make_view(c);
-    k_blocksums<<<hi, 256, (size_t)hi * 4 * sizeof(u64), c->sA>>>(V, gen, hi, c->blocks);
-    HIPCHK(c, hipGetLastError());
-    std::vector<long long> B((size_t)hi * hi * 4);
-    HIPCHK(c, hipMemcpyAsync(B.data(), c->blocks, B.size() * sizeof(long long), hipMemcpyDeviceToHost, c->sA));
-    HIPCHK(c, hipStreamSynchronize(c->sA));
-    // scalar part of loglik (mcmc.jl:26-54) in long double, regrouped as in oracle "stable" mode
-    std::vector<int> act;
-    for (int k = 0; k < c->kcap; ++k)
-        if (ssize[(size_t)k] > 0) act.push_back(k);
     const rc_params &P = c->P;
     const long double d1 = P.delta1, d2 = P.delta2, al = P.alpha, be = P.beta, ze = P.zeta, ga = P.gamma;
     const long double lga = lgammal(al), lgz = lgammal(ze), lgd1 = lgammal(d1), lgd2 = lgammal(d2);
     const long double lb = logl(be), lg = logl(ga);
     const long double scD = ldexpl(1.0L, -c->eD), scL = ldexpl(1.0L, -c->eL);
-    auto blk = [&](int k, int t, int which) -> long double {
-        const long long *e = &B[((size_t)t * hi + k) * 4 + (which ? 2 : 0)];
-        return ((long double)e[0] * (long double)(1ll << RC_LO_BITS) + (long double)e[1]) * (which ? scL : scD);
+    if (hi > c->ll_dim) {
+        c->ll_dim = std::max(hi, std::min(c->kcap, 2 * hi));
+        c->ll_cache.assign((size_t)c->ll_dim * c->ll_dim, rc_ctx::LLTerm{});
+    }
+    auto blk = [&](const long long *e, int which) -> long double {
+        return ((long double)e[which ? 2 : 0] * (long double)(1ll << RC_LO_BITS) + (long double)e[which ? 3 : 1]) * (which ? scL : scD);
     };
+    std::vector<int> act;
+    for (int k = 0; k < hi; ++k)
+        if (ssize[k] > 0) act.push_back(k);
     long double L1 = 0, L2 = 0;
     for (int k : act) {
-        const long double sz = ssize[(size_t)k];
-        const long double pairs = sz * (sz - 1) / 2;  // binomial(sz_k, 2)
-        const long double a = al + d1 * pairs;
-        const long double bd = blk(k, k, 0) / 2, bl = blk(k, k, 1) / 2;
-        const long long pk = (long long)pairs;
-        auto it = c->lg_memo1.find(pk);
-        if (it == c->lg_memo1.end()) it = c->lg_memo1.emplace(pk, lgammal(a) - lga).first;
-        L1 += (d1 - 1) * bl - pairs * lgd1 + it->second - d1 * pairs * lb - a * log1pl(bd / be);
+        const long long *e = &B[((size_t)k * hi + k) * 4];
+        rc_ctx::LLTerm &T = c->ll_cache[(size_t)k * c->ll_dim + k];
+        if (!(T.sk == ssize[k] && T.e[0] == e[0] && T.e[1] == e[1] && T.e[2] == e[2] && T.e[3] == e[3])) {
+            const long double sz = ssize[k];
+            const long double pairs = sz * (sz - 1) / 2;  // binomial(sz_k, 2)
+            const long double a = al + d1 * pairs;
+            const long double bd = blk(e, 0) / 2, bl = blk(e, 1) / 2;
+            const long long pk = (long long)pairs;
+            auto it = c->lg_memo1.find(pk);
+            if (it == c->lg_memo1.end()) it = c->lg_memo1.emplace(pk, lgammal(a) - lga).first;
+            T.term = (d1 - 1) * bl - pairs * lgd1 + it->second - d1 * pairs * lb - a * log1pl(bd / be);
+            T.sk = ssize[k]; T.st = ssize[k];
+            std::memcpy(T.e, e, sizeof(T.e));
+        }
+        L1 += T.term;
     }
     if (c->lg_memo1.size() > (1u << 20)) c->lg_memo1.clear();
     if (c->lg_memo2.size() > (1u << 20)) c->lg_memo2.clear();
@@ -2388,16 +2427,99 @@ extern "C" int32_t rc_loglik(rc_ctx *c, double *out)
         for (size_t x = 0; x < act.size(); ++x)
             for (size_t y = x + 1; y < act.size(); ++y) {
                 const int k = act[x], t = act[y];
-                const long double pairs = (long double)ssize[(size_t)k] * (long double)ssize[(size_t)t];
-                const long double z = ze + d2 * pairs;
-                const long double bd = blk(k, t, 0), bl = blk(k, t, 1);
-                const long long pk = (long long)pairs;
-                auto it = c->lg_memo2.find(pk);
-                if (it == c->lg_memo2.end()) it = c->lg_memo2.emplace(pk, lgammal(z) - lgz).first;
-                L2 += (d2 - 1) * bl - pairs * lgd2 + it->second - d2 * pairs * lg - z * log1pl(bd / ga);
+                const long long *e = &B[((size_t)t * hi + k) * 4];
+                rc_ctx::LLTerm &T = c->ll_cache[(size_t)t * c->ll_dim + k];
+                if (!(T.sk == ssize[k] && T.st == ssize[t] && T.e[0] == e[0] && T.e[1] == e[1] && T.e[2] == e[2] && T.e[3] == e[3])) {
+                    const long double pairs = (long double)ssize[k] * (long double)ssize[t];
+                    const long double z = ze + d2 * pairs;
+                    const long double bd = blk(e, 0), bl = blk(e, 1);
+                    const long long pk = (long long)pairs;
+                    auto it = c->lg_memo2.find(pk);
+                    if (it == c->lg_memo2.end()) it = c->lg_memo2.emplace(pk, lgammal(z) - lgz).first;
+                    T.term = (d2 - 1) * bl - pairs * lgd2 + it->second - d2 * pairs * lg - z * log1pl(bd / ga);
+                    T.sk = ssize[k]; T.st = ssize[t];
+                    std::memcpy(T.e, e, sizeof(T.e));
+                }
+                L2 += T.term;
             }
-    *out = (double)(L1 + L2);
+    return (double)(L1 + L2);
+}
+
+// enqueues the block sums of the current state on stream A and their copy into the pinned buffer `dst`
+// (hi·hi·4 int64); the caller synchronises (stream or event) before reading
+static int32_t loglik_enqueue(rc_ctx *c, int hi, long long *dst)
+{
+    int gen = 0;
+    int32_t rc = ensure_S(c, &gen);
+    if (rc != RC_OK) return rc;
+    View V = make_view(c);
+    k_blocksums<<<hi, 256, (size_t)hi * 4 * sizeof(u64), c->sA>>>(V, gen, hi, c->blocks);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(dst, c->blocks, (size_t)hi * hi * 4 * sizeof(long long), hipMemcpyDeviceToHost, c->sA));
     return RC_OK;
+}
+
+// pinned staging for block sums / label snapshots of sample slot q (0..RC_REC_SLOTS-1), sized for `hi` slots.
+// Grows by reallocation: call only while no asynchronous copy into the buffers is outstanding.
+static int32_t ensure_pinned(rc_ctx *c, int hi)
+{
+    if (c->pinB[0] && hi <= c->pin_hi) return RC_OK;
+    const int cap = std::min(c->kcap, std::max(64, 2 * hi));
+    HIPCHK(c, hipStreamSynchronize(c->sA));
+    for (int q = 0; q < RC_REC_SLOTS; ++q) {
+        if (c->pinB[q]) (void)hipHostFree(c->pinB[q]);
+        c->pinB[q] = nullptr;
+        HIPCHK(c, hipHostMalloc((void **)&c->pinB[q], (size_t)cap * cap * 4 * sizeof(long long), hipHostMallocDefault));
+        if (!c->pinLab[q]) {
+            HIPCHK(c, hipHostMalloc((void **)&c->pinLab[q], (size_t)(c->n + 8) * sizeof(unsigned short), hipHostMallocDefault));
+            HIPCHK(c, hipEventCreateWithFlags(&c->pinEv[q], hipEventDisableTiming));
+        }
+    }
+    c->pin_hi = cap;
+    return RC_OK;
+}
+
+extern "C" int32_t rc_loglik(rc_ctx *c, double *out)
+{
+    if (!c || !out) return fail(c, RC_ERR_ARG, "rc_loglik: NULL argument");
+    if (!c->have_params || !c->have_state) return fail(c, RC_ERR_STATE, "rc_loglik: params and state must be set");
+    HIPCHK(c, hipSetDevice(c->dev));
+    std::vector<int> so, ssize, slabel;
+    int32_t rc = pull_state(c, so, ssize, slabel, false);  // also refreshes c->last (slot_hi)
+    if (rc != RC_OK) return rc;
+    const int hi = std::max(1, std::min(c->kcap, c->last.slot_hi));
+    rc = ensure_pinned(c, hi);
+    if (rc != RC_OK) return rc;
+    rc = loglik_enqueue(c, hi, c->pinB[0]);
+    if (rc != RC_OK) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->sA));
+    *out = loglik_host(c, hi, ssize.data(), c->pinB[0]);
+    // keep the block sums: a merge proposal's log-likelihood follows from them without touching the device
+    c->B_cur.assign(c->pinB[0], c->pinB[0] + (size_t)hi * hi * 4);
+    c->B_ssize = ssize; c->B_slabel = slabel;
+    c->B_hi = hi;
+    c->B_version = c->state_version;
+    return RC_OK;
+}
+
+// logprior (mcmc.jl:58-78) from slot sizes / labels
+static double logprior_host(rc_ctx *c, const int *ssize, const int *slabel, double r, double p)
+{
+    const rc_params &P = c->P;
+    const double n = c->n;
+    double K = 0;
+    for (int k = 0; k < c->kcap; ++k) K += ssize[k] > 0;
+    // logpdf(Gamma(η, 1/σ), r) + logpdf(Beta(u, v), p)   (mcmc.jl:73)
+    const double lgam = P.eta * std::log(P.sigma) - std::lgamma(P.eta) + (P.eta - 1) * std::log(r) - P.sigma * r;
+    const double lbet = std::lgamma(P.u + P.v) - std::lgamma(P.u) - std::lgamma(P.v) + (P.u - 1) * std::log(p) + (P.v - 1) * std::log(1 - p);
+    double L = std::lgamma(K + 1) + (n - K) * std::log(p) + (r * K) * std::log(1 - p) - K * std::lgamma(r) + lgam + lbet;
+    // Σ_j log n_j + lgΓ(n_j + r − 1) over non-empty clusters in ascending label order (mcmc.jl:74-76)
+    std::vector<std::pair<int, int>> bylabel;
+    for (int k = 0; k < c->kcap; ++k)
+        if (ssize[k] > 0) bylabel.push_back({slabel[k], ssize[k]});
+    std::sort(bylabel.begin(), bylabel.end());
+    for (auto &e : bylabel) L += std::log((double)e.second) + std::lgamma((double)e.second + r - 1);
+    return L;
 }
 
 extern "C" int32_t rc_logprior(rc_ctx *c, double r, double p, double *out)
@@ -2409,21 +2531,7 @@ extern "C" int32_t rc_logprior(rc_ctx *c, double r, double p, double *out)
     std::vector<int> so, ssize, slabel;
     int32_t rc = pull_state(c, so, ssize, slabel, false);
     if (rc != RC_OK) return rc;
-    const rc_params &P = c->P;
-    const double n = c->n;
-    double K = 0;
-    for (int k = 0; k < c->kcap; ++k) K += ssize[(size_t)k] > 0;
-    // logpdf(Gamma(η, 1/σ), r) + logpdf(Beta(u, v), p)   (mcmc.jl:73)
-    const double lgam = P.eta * std::log(P.sigma) - std::lgamma(P.eta) + (P.eta - 1) * std::log(r) - P.sigma * r;
-    const double lbet = std::lgamma(P.u + P.v) - std::lgamma(P.u) - std::lgamma(P.v) + (P.u - 1) * std::log(p) + (P.v - 1) * std::log(1 - p);
-    double L = std::lgamma(K + 1) + (n - K) * std::log(p) + (r * K) * std::log(1 - p) - K * std::lgamma(r) + lgam + lbet;
-    // Σ_j log n_j + lgΓ(n_j + r − 1) over non-empty clusters in ascending label order (mcmc.jl:74-76)
-    std::vector<std::pair<int, int>> bylabel;
-    for (int k = 0; k < c->kcap; ++k)
-        if (ssize[(size_t)k] > 0) bylabel.push_back({slabel[(size_t)k], ssize[(size_t)k]});
-    std::sort(bylabel.begin(), bylabel.end());
-    for (auto &e : bylabel) L += std::log((double)e.second) + std::lgamma((double)e.second + r - 1);
-    *out = L;
+    *out = logprior_host(c, ssize.data(), slabel.data(), r, p);
     return RC_OK;
 }
 
@@ -2800,15 +2908,23 @@ struct Restricted {
     // Row sums of item x over the members of the two candidate clusters, in ONE pass over U (ascending index, so
     // each cluster's sum is accumulated in ascending member order exactly as findall + matsum do, mcmc.jl:308-311,
     // utils.jl:9-17).  out[0..1] = D sums, out[2..3] = logD sums.
-    void cand_sums(int64_t x, const std::vector<int64_t> &clusts, const int64_t cand[2], double out[4]) const
+    // The members are kept as two sorted index lists (rebuilt from U at the start of a scan, updated as items move), so
+    // the four sums are four independent add chains without a label test per element.
+    std::vector<int64_t> mem[2];
+    void cand_sums(int64_t x, double out[4]) const
     {
         double d0 = 0, d1 = 0, l0 = 0, l1 = 0;
         const double *Dx = D + (size_t)x * (size_t)n, *Lx = L + (size_t)x * (size_t)n;
-        for (int64_t y : *U) {
-            const int64_t c = clusts[(size_t)y];
-            if (c == cand[0]) { d0 += Dx[y]; l0 += Lx[y]; }
-            else if (c == cand[1]) { d1 += Dx[y]; l1 += Lx[y]; }
+        const std::vector<int64_t> &A = mem[0], &B = mem[1];
+        const size_t na = A.size(), nb = B.size(), both = na < nb ? na : nb;
+        size_t q = 0;
+        for (; q < both; ++q) {
+            const int64_t ya = A[q], yb = B[q];
+            d0 += Dx[ya]; l0 += Lx[ya];
+            d1 += Dx[yb]; l1 += Lx[yb];
         }
+        for (size_t t = q; t < na; ++t) { d0 += Dx[A[t]]; l0 += Lx[A[t]]; }
+        for (size_t t = q; t < nb; ++t) { d1 += Dx[B[t]]; l1 += Lx[B[t]]; }
         out[0] = d0; out[1] = d1; out[2] = l0; out[3] = l1;
     }
     static double list_sum(const double *M, int64_t x, int64_t n, const std::vector<int64_t> &mem)
@@ -2824,6 +2940,17 @@ struct Restricted {
     std::vector<double> lgA, lgZ;
     double lg_alpha_i(double sz) { const size_t k = (size_t)sz; if (lgA.size() <= k) lgA.resize(k + 64, NAN); if (lgA[k] != lgA[k]) lgA[k] = std::lgamma(c->P.alpha + c->P.delta1 * sz); return lgA[k]; }
     double lg_zeta_i(double sz) { const size_t k = (size_t)sz; if (lgZ.size() <= k) lgZ.resize(k + 64, NAN); if (lgZ[k] != lgZ[k]) lgZ[k] = std::lgamma(c->P.zeta + c->P.delta2 * sz); return lgZ[k]; }
+    // the prior-ratio term log(sz+1) + log p + log(sz−1+r) − log(sz) (mcmc.jl:312-313) also depends on the size only
+    std::vector<double> lprM;
+    double lpr_i(double sz)
+    {
+        const size_t k = (size_t)sz;
+        if (lprM.size() <= k) lprM.resize(k + 64, NAN);
+        if (lprM[k] != lprM[k] && sz > 0) lprM[k] = std::log(sz + 1) + logp + std::log(sz - 1 + r) - std::log(sz);
+        return sz > 0 ? lprM[k] : std::log(sz + 1) + logp + std::log(sz - 1 + r) - std::log(sz);
+    }
+    // the L2 term of a non-candidate first cluster is the same in every scan of the proposal
+    std::vector<double> fixedTerm[2];
 
     // one scan (mcmc.jl:302-352); returns log_transition_prob
     double scan(std::vector<int64_t> &clusts, std::vector<int64_t> &sizes, const std::vector<int64_t> &items,
@@ -2840,6 +2967,7 @@ struct Restricted {
             for (int t = 0; t < 2; ++t) {
                 fixed_label[t] = firsts[t];
                 fixedD[t].assign((size_t)n, 0.0); fixedL[t].assign((size_t)n, 0.0); fixed_have[t].assign((size_t)n, 0);
+                fixedTerm[t].assign((size_t)n, 0.0);
                 if (firsts[t] != 0 && firsts[t] != cand[0] && firsts[t] != cand[1])
                     for (int64_t y = 0; y < n; ++y)
                         if (clusts[(size_t)y] == firsts[t]) fixed_members[(size_t)t].push_back(y);
@@ -2847,19 +2975,28 @@ struct Restricted {
         }
         const int64_t m = (int64_t)items.size();
         double ltp = 0;
+        mem[0].clear(); mem[1].clear();
+        for (int64_t y : *U) {
+            if (clusts[(size_t)y] == cand[0]) mem[0].push_back(y);
+            else if (clusts[(size_t)y] == cand[1]) mem[1].push_back(y);
+        }
         for (int64_t q = 0; q < m; ++q) {
             const int64_t x = items[(size_t)q];
+            {
+                std::vector<int64_t> &from = mem[clusts[(size_t)x] == cand[0] ? 0 : 1];
+                from.erase(std::lower_bound(from.begin(), from.end(), x));
+            }
             sizes[(size_t)clusts[(size_t)x] - 1] -= 1;                                   // mcmc.jl:303
             clusts[(size_t)x] = -1;                                                      // mcmc.jl:304
             double L1[2], lpr[2], L2p_c[2], logprobs[2], cs[4];
-            cand_sums(x, clusts, cand, cs);
+            cand_sums(x, cs);
             for (int k = 0; k < 2; ++k) {                                                // mcmc.jl:307-326
                 const double sz = (double)sizes[(size_t)cand[k] - 1];
                 const double sD = cs[k];
                 const double sL = cs[2 + k];
                 const double a_i = al + d1 * sz, b_i = be + sD, z_i = ze + d2 * sz, g_i = ga + sD;
                 L1[k] = lg_alpha_i(sz) + abratio - a_i * std::log(b_i) + (d1 - 1) * sL - sz * lg_d1;
-                lpr[k] = std::log(sz + 1) + logp + std::log(sz - 1 + r) - std::log(sz);
+                lpr[k] = lpr_i(sz);
                 L2p_c[k] = lg_zeta_i(sz) - z_i * std::log(g_i) + zgratio + (d2 - 1) * sL - sz * lg_d2;
             }
             double L2p_first[2];
@@ -2872,10 +3009,11 @@ struct Restricted {
                     fixedD[t][(size_t)x] = list_sum(D, x, n, fixed_members[(size_t)t]);
                     fixedL[t][(size_t)x] = list_sum(L, x, n, fixed_members[(size_t)t]);
                     fixed_have[t][(size_t)x] = 1;
+                    const double sD = fixedD[t][(size_t)x], sL = fixedL[t][(size_t)x];
+                    const double z_i = ze + d2 * sz, g_i = ga + sD;
+                    fixedTerm[t][(size_t)x] = lg_zeta_i(sz) - z_i * std::log(g_i) + zgratio + (d2 - 1) * sL - sz * lg_d2;
                 }
-                const double sD = fixedD[t][(size_t)x], sL = fixedL[t][(size_t)x];
-                const double z_i = ze + d2 * sz, g_i = ga + sD;
-                L2p_first[t] = lg_zeta_i(sz) - z_i * std::log(g_i) + zgratio + (d2 - 1) * sL - sz * lg_d2;
+                L2p_first[t] = fixedTerm[t][(size_t)x];
             }
             const double L2_i = L2p_first[0] + L2p_first[1];                             // Q3
             for (int k = 0; k < 2; ++k)
@@ -2893,6 +3031,7 @@ struct Restricted {
             }
             clusts[(size_t)x] = cand[k];                                                 // mcmc.jl:344-345
             sizes[(size_t)cand[k] - 1] += 1;
+            mem[k].insert(std::lower_bound(mem[k].begin(), mem[k].end(), x), x);
             double mn = logprobs[0] < logprobs[1] ? logprobs[0] : logprobs[1];           // mcmc.jl:348 (Q2)
             if (logprobs[0] != logprobs[0] || logprobs[1] != logprobs[1]) mn = NAN;      // minimum() propagates NaN
             const double p0 = std::exp(logprobs[0] + mn), p1 = std::exp(logprobs[1] + mn);
@@ -2919,8 +3058,10 @@ extern "C" int32_t rc_splitmerge(rc_ctx *c, double r, double p, int64_t numGibbs
     const int64_t n = c->n;
     std::vector<int64_t> clusts, sizes;
     int64_t K;
+    g_smprof.start();
     int32_t rc = pull_labels(c, clusts, sizes, K);
     if (rc != RC_OK) return rc;
+    g_smprof.lap(0);
     // chaperones (mcmc.jl:379)
     int64_t i = (int64_t)std::floor(rc_uniform_mh(seed, iter, mh_counter, 0) * (double)n);
     int64_t j = (int64_t)std::floor(rc_uniform_mh(seed, iter, mh_counter, 1) * (double)(n - 1));
@@ -2962,6 +3103,7 @@ extern "C" int32_t rc_splitmerge(rc_ctx *c, double r, double p, int64_t numGibbs
     R.zgratio = P.zeta * std::log(P.gamma) - std::lgamma(P.zeta);
     R.lg_d1 = std::lgamma(P.delta1); R.lg_d2 = std::lgamma(P.delta2); R.logp = std::log(p);
     R.U = &U;
+    g_smprof.lap(1);
     for (int64_t s = 0; s < numGibbs; ++s) R.scan(claunch, szlaunch, S, cand, nullptr, s);  // mcmc.jl:411-414
     std::vector<int64_t> cfinal, szfinal;
     double log_prior_ratio, log_proposal_ratio;
@@ -2990,29 +3132,66 @@ extern "C" int32_t rc_splitmerge(rc_ctx *c, double r, double p, int64_t numGibbs
         log_proposal_ratio = -ltp;
     }
     (void)Klaunch;
+    g_smprof.lap(2);
     // likelihood ratio (mcmc.jl:462-464): both states evaluated on the device from the exact S table
     double ll_cur = 0, ll_fin = 0;
-    if (c->ll_version == c->state_version) {
+    if (c->ll_version == c->state_version && c->B_version == c->state_version) {
         ll_cur = c->ll_cached;  // same labels as at the last evaluation (e.g. the previous, rejected proposal)
     } else {
         rc = rc_loglik(c, &ll_cur);
         if (rc != RC_OK) return rc;
     }
     const long long version_cur = c->state_version;
-    rc = apply_labels(c, clusts, cfinal);
-    if (rc != RC_OK) return rc;
-    rc = rc_loglik(c, &ll_fin);
-    if (rc != RC_OK) return rc;
+    g_smprof.lap(3);
+    bool applied = false;
+    if (ci != cj) {
+        // Merge: block sums are additive — B'(m, l) = B(ci, l) + B(cj, l), B'(m, m) = B(ci,ci) + B(cj,cj) + 2 B(ci,cj) —
+        // so the merged state's log-likelihood is evaluated on the host from the current state's exact integer block
+        // sums: the same integers k_blocksums would produce after applying the merge, hence the same value, with no
+        // device work and nothing to revert when the proposal is rejected (the common case).
+        const int hi = c->B_hi;
+        int si = -1, sj = -1;
+        for (int k = 0; k < hi; ++k) {
+            if (c->B_ssize[(size_t)k] > 0 && c->B_slabel[(size_t)k] == ci) si = k;
+            if (c->B_ssize[(size_t)k] > 0 && c->B_slabel[(size_t)k] == cj) sj = k;
+        }
+        if (si < 0 || sj < 0) return fail(c, RC_ERR_STATE, "rc_splitmerge: internal: slots of the merged clusters not found");
+        std::vector<long long> Bm = c->B_cur;
+        std::vector<int> szm(c->B_ssize.begin(), c->B_ssize.begin() + hi);
+        for (int k = 0; k < hi; ++k)
+            for (int w = 0; w < 4; ++w) Bm[((size_t)sj * hi + k) * 4 + w] += Bm[((size_t)si * hi + k) * 4 + w];
+        for (int t = 0; t < hi; ++t)
+            for (int w = 0; w < 4; ++w) Bm[((size_t)t * hi + sj) * 4 + w] += Bm[((size_t)t * hi + si) * 4 + w];
+        szm[(size_t)sj] += szm[(size_t)si];
+        szm[(size_t)si] = 0;
+        ll_fin = loglik_host(c, hi, szm.data(), Bm.data());
+        g_smprof.lap(5);
+    } else {
+        rc = apply_labels(c, clusts, cfinal);
+        if (rc != RC_OK) return rc;
+        applied = true;
+        g_smprof.lap(4);
+        rc = rc_loglik(c, &ll_fin);
+        if (rc != RC_OK) return rc;
+        g_smprof.lap(5);
+    }
     const double x = log_prior_ratio + (ll_fin - ll_cur) - log_proposal_ratio;
     const double lar = (x != x) ? NAN : (x < 0 ? x : 0.0);                                // minimum([0, x]) propagates NaN
     const double lu = std::log(rc_uniform_mh(seed, iter, mh_counter, 2));
     if (lu < lar) {                                                                      // mcmc.jl:469-472
-        *accept_out = 1;  // the proposed state stays on the device (tables and perm generations already follow it)
+        *accept_out = 1;  // the proposed state stays on the device (tables and perm generations follow it)
+        if (!applied) {
+            rc = apply_labels(c, clusts, cfinal);
+            if (rc != RC_OK) return rc;
+            g_smprof.lap(4);
+        }
         c->ll_cached = ll_fin; c->ll_version = c->state_version;
         return RC_OK;
     }
+    if (!applied) return RC_OK;                                                          // nothing was touched
     rc = apply_labels(c, cfinal, clusts);                                                // rejected: revert, bit-exactly
     if (rc != RC_OK) return rc;
+    g_smprof.lap(6);
     (void)version_cur;
     c->ll_cached = ll_cur; c->ll_version = c->state_version;                             // the reverted state is the evaluated one
     return RC_OK;
