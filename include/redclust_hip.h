@@ -170,6 +170,16 @@ int32_t rc_set_bulk_kernel(rc_ctx *ctx, int32_t which);
  * number of layouts built so far and the current run count.  RC_NO_RELAYOUT=1 keeps the caller's order throughout. */
 int32_t rc_layout_info(rc_ctx *ctx, int32_t *n_relayouts, int32_t *label_runs);
 
+/* The within- / between-cluster split of the pairwise dissimilarities under the CURRENT labels, as fitprior forms it
+ * for its Gamma fits (src/prior.jl:73-75: A = upper-triangle entries of pairs in one cluster, B = the rest;
+ * src/prior.jl:96-110 consume |A|, sum(A), sum(log A) and the same of B).  From the K×K block sums of the row-sum
+ * table: no pass over the n×n matrices. */
+typedef struct rc_wb_stats {
+    int64_t count_within, count_between;
+    double sum_within, sumlog_within, sum_between, sumlog_between;
+} rc_wb_stats;
+int32_t rc_within_between(rc_ctx *ctx, rc_wb_stats *out);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * The iteration loop of runsampler (src/mcmc.jl:533-556) as native host code: per iteration sample_r!, sample_p!
  * (src/mcmc.jl:80-155, on the build's counter-based scalar stream — DESIGN.md), sample_labels! (numMH split–merge

@@ -35,6 +35,11 @@ class RcPairMeasures(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("ari", "ri", "mirkin", "hubert", "mi", "nmi", "vi", "ha", "hb", "id", "nid")]
 
 
+class RcWbStats(C.Structure):
+    _fields_ = [("count_within", C.c_int64), ("count_between", C.c_int64), ("sum_within", C.c_double),
+                ("sumlog_within", C.c_double), ("sum_between", C.c_double), ("sumlog_between", C.c_double)]
+
+
 class RcChainOptions(C.Structure):
     _fields_ = [("numiters", C.c_int64), ("burnin", C.c_int64), ("thin", C.c_int64), ("numGibbs", C.c_int64),
                 ("numMH", C.c_int64), ("splitmerge_mode", C.c_int32), ("pad_", C.c_int32), ("seed", C.c_uint64),
@@ -100,6 +105,7 @@ SIGNATURES = {
     "rc_debug_rowsums": (C.c_int32, [C.c_void_p, C.c_int64, _ip, _ip, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rc_bulk_kernel_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "rc_set_bulk_kernel": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "rc_within_between": (C.c_int32, [C.c_void_p, C.POINTER(RcWbStats)]),
     "rc_run_chain": (C.c_int32, [C.c_void_p, C.POINTER(RcChainOptions), C.POINTER(RcChainOutputs)]),
     "rc_scalar_updates": (C.c_int32, [C.c_uint64, C.c_uint64, C.c_double, C.c_double, _ip, C.c_int64, C.c_int64, C.c_double,
                                       C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),
@@ -326,6 +332,12 @@ class Context:
         for k in ("r_acceptances", "splitmerge_acceptances", "splitmerge_splits"):
             res[k] = res[k].astype(bool)
         return res
+
+    def within_between(self) -> dict:
+        """rc_within_between: |A|, ΣA, Σlog A and |B|, ΣB, Σlog B of fitprior's split under the current labels."""
+        o = RcWbStats()
+        self._chk(self.L.rc_within_between(self.h, C.byref(o)))
+        return {k: getattr(o, k) for k, _ in RcWbStats._fields_}
 
     def layout_info(self):
         """(layouts built so far, label runs in the internal point order)"""

@@ -2502,6 +2502,56 @@ extern "C" int32_t rc_loglik(rc_ctx *c, double *out)
     return RC_OK;
 }
 
+// The within- / between-cluster split of the upper triangle that fitprior feeds to its Gamma fits
+// (src/prior.jl:73-75: A = distances of pairs in the same cluster, B = the others; :96-110 use |A|, ΣA, Σlog A and the
+// same for B) for the CURRENT labels, from the block sums: Σ_A = ½ Σ_k B(k,k), Σ_B = Σ_{k<t} B(k,t).  Exact integer
+// accumulation; the only rounding is the fixed-point quantisation of the entries.
+extern "C" int32_t rc_within_between(rc_ctx *c, rc_wb_stats *out)
+{
+    if (!c || !out) return fail(c, RC_ERR_ARG, "rc_within_between: NULL argument");
+    if (!c->have_state) return fail(c, RC_ERR_STATE, "rc_within_between: no state set");
+    HIPCHK(c, hipSetDevice(c->dev));
+    std::vector<int> so, ssize, slabel;
+    int32_t rc = pull_state(c, so, ssize, slabel, false);
+    if (rc != RC_OK) return rc;
+    const int hi = std::max(1, std::min(c->kcap, c->last.slot_hi));
+    rc = ensure_pinned(c, hi);
+    if (rc != RC_OK) return rc;
+    rc = loglik_enqueue(c, hi, c->pinB[0]);
+    if (rc != RC_OK) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->sA));
+    const long long *B = c->pinB[0];
+    __int128 wD = 0, wL = 0, bD = 0, bL = 0;
+    long long cntA = 0, cntB = 0;
+    auto val = [&](int t, int k, int which) -> __int128 {
+        const long long *e = &B[((size_t)t * hi + k) * 4 + (which ? 2 : 0)];
+        return (__int128)e[0] * ((__int128)1 << RC_LO_BITS) + (__int128)e[1];
+    };
+    for (int k = 0; k < hi; ++k) {
+        if (ssize[(size_t)k] <= 0) continue;
+        const long long sk = ssize[(size_t)k];
+        cntA += sk * (sk - 1) / 2;
+        wD += val(k, k, 0); wL += val(k, k, 1);          // every within pair twice, the (zero) diagonal once
+        for (int t = k + 1; t < hi; ++t) {
+            if (ssize[(size_t)t] <= 0) continue;
+            cntB += sk * (long long)ssize[(size_t)t];
+            bD += val(t, k, 0); bL += val(t, k, 1);
+        }
+    }
+    // the diagonal of D is kept as stored (types.jl:155 zeroes only logD's): remove it from the within sum
+    std::vector<long long> dg((size_t)c->n);
+    HIPCHK(c, hipMemcpy(dg.data(), c->diagq, (size_t)c->n * sizeof(long long), hipMemcpyDeviceToHost));
+    __int128 dsum = 0;
+    for (long long v : dg) dsum += v;
+    const long double scD = ldexpl(1.0L, -c->eD), scL = ldexpl(1.0L, -c->eL);
+    out->count_within = cntA; out->count_between = cntB;
+    out->sum_within = (double)((long double)(wD - dsum) * scD / 2);
+    out->sumlog_within = (double)((long double)wL * scL / 2);
+    out->sum_between = (double)((long double)bD * scD);
+    out->sumlog_between = (double)((long double)bL * scL);
+    return RC_OK;
+}
+
 // logprior (mcmc.jl:58-78) from slot sizes / labels
 static double logprior_host(rc_ctx *c, const int *ssize, const int *slabel, double r, double p)
 {

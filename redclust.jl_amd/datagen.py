@@ -84,3 +84,15 @@ def likelihood_hyperparams(D: np.ndarray, labels: np.ndarray, block: int = 2048)
     d2 = _gamma_shape_mle(sumB / cntB, slogB / cntB)
     return dict(delta1=d1, delta2=d2, alpha=cntA * d1, beta=sumA, zeta=cntB * d2, gamma=sumB,
                 eta=1.0, sigma=1.0, u=1.0, v=1.0, repulsion=True, maxK=0)
+
+
+def likelihood_hyperparams_device(ctx, labels) -> dict:
+    """likelihood_hyperparams with the within / between sums taken from the device's block sums (rc_within_between):
+    no host pass over the n×n matrix.  ctx: a Context holding D; its state is set to `labels`."""
+    ctx.set_state(np.asarray(labels, dtype=np.int64))
+    w = ctx.within_between()
+    cntA, cntB = w["count_within"], w["count_between"]
+    d1 = _gamma_shape_mle(w["sum_within"] / cntA, w["sumlog_within"] / cntA)
+    d2 = _gamma_shape_mle(w["sum_between"] / cntB, w["sumlog_between"] / cntB)
+    return dict(delta1=d1, delta2=d2, alpha=cntA * d1, beta=w["sum_within"], zeta=cntB * d2, gamma=w["sum_between"],
+                eta=1.0, sigma=1.0, u=1.0, v=1.0, repulsion=True, maxK=0)

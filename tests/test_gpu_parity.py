@@ -634,3 +634,23 @@ def test_config5_properties():
     c3, s3, K3 = ctx.get_state()
     assert s3.sum() == n and K3 == np.sum(s3 > 0) and ctx.sweep_stats()["n_changes"] > 0
     ctx.close()
+
+
+def test_within_between_split_from_block_sums():
+    """fitprior's A / B split (prior.jl:73-75) under given labels from the device block sums == a host pass over D."""
+    data = rc.generatemixture(700, 6, seed=12, sigma=0.3, dim=8)
+    sh = np.random.default_rng(0).permutation(700)
+    D = np.ascontiguousarray(data["distancematrix"][np.ix_(sh, sh)]); lab = data["clusts"][sh]
+    ctx = rc.Context(D)
+    P_dev = rc.likelihood_hyperparams_device(ctx, lab)
+    P_host = rc.likelihood_hyperparams(D, lab)
+    w = ctx.within_between()
+    iu = np.triu_indices(700, 1)
+    same = (lab[:, None] == lab[None, :])[iu]
+    assert w["count_within"] == int(same.sum()) and w["count_between"] == int((~same).sum())
+    assert np.isclose(w["sum_within"], D[iu][same].sum(), rtol=1e-12) and np.isclose(w["sum_between"], D[iu][~same].sum(), rtol=1e-12)
+    assert np.isclose(w["sumlog_within"], np.log(D[iu][same]).sum(), rtol=1e-10)
+    assert np.isclose(w["sumlog_between"], np.log(D[iu][~same]).sum(), rtol=1e-10)
+    for k in ("delta1", "delta2", "alpha", "beta", "zeta", "gamma"):
+        assert np.isclose(P_dev[k], P_host[k], rtol=1e-9), k
+    ctx.close()
