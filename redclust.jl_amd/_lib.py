@@ -11,7 +11,7 @@ import numpy as np
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
-SO = os.path.join(CSRC, "libredclust_hip.so")
+SO = os.environ.get("RC_LIB_PATH") or os.path.join(CSRC, "libredclust_hip.so")   # RC_LIB_PATH: experiment builds
 HEADER = os.path.join(ROOT, "include", "redclust_hip.h")
 
 RC_OK = 0

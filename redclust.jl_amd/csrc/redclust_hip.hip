@@ -85,6 +85,10 @@ struct View {
     const void *Dq, *Lq;       // [n][ld] fixed point: int64 (bits = 64) or int32 (bits = 32); rows/columns in INTERNAL order
     int bits;
     const long long *diagq;    // [n] Dq[i][i]
+    int derived;               // 1: logD is not stored; Lq(i,j) = rc_qlog(Dq(i,j)) for i != j, 0 on the diagonal
+    double qsD, qsL;           // 2^-eD, 2^eL
+    const double2 *ltab;       // [128] table of rc_qlog (see there)
+    int qeD;                   // eD
     long long *SD[3], *SL[3];  // three generations of the [kcap][ld] row-sum table (software pipelining)
     int *slot_of;              // [n] slot of every point, INTERNAL point order
     const int *pi;             // [n] original point index -> internal index (cluster-contiguous layout chosen at rc_set_state)
@@ -234,6 +238,76 @@ __global__ __launch_bounds__(256) void k_pairwise(const double *__restrict__ pts
 }
 
 // Internal layout: out[w][x] = src[ipi[w]][ipi[x]] (points of a cluster contiguous).  One block row per internal row w.
+// ---------------------------------------------------------------------------------------------------
+// Derived logD.  When the caller gives only D (MCMCData computes logD = log.(D − Diagonal(D) + I) itself,
+// types.jl:155), the fixed-point logD need not be stored at all: Lq(i,j) = rint(log(Dq(i,j)·2^-eD)·2^eL) is a pure
+// function of Dq(i,j), evaluated by every consumer with this one routine, so the row reduction reads HALF the bytes.
+// log(x), x = 2^k·m, m ∈ [1,2): j = top 7 fraction bits of m, c_j = 1 + (j+½)/128, r = m/c_j − 1 ∈ [−1/257, 1/257],
+// log x = k·ln2 + log c_j + log1p(r) with the degree-6 Taylor polynomial of log1p (|error| < 3·10^-18) — ≈25 VALU
+// instructions and one 16-byte table read, against ≈100 for the libm log (tools/log_tune.hip: 268 MB of D streamed
+// with two of these per 16 B in 44.6 µs; with the libm log 119 µs; sum only 40.4 µs).  |result − libm log| ≤ 5·10^-16,
+// far below the quantum 2^-eL; what matters for exactness is only that every consumer uses this same function.
+// ltab[j] = (1/c_j, log c_j).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long rc_qlog(long long dq, int eD, double sL, const double2 *__restrict__ tab)
+{
+    // integer front end (no int64 -> double conversion): normalise, split off exponent, table index and mantissa
+    const int lz = __clzll(dq);
+    const unsigned long long mant = (unsigned long long)dq << lz;           // leading one at bit 63
+    const int k = 63 - lz - eD;                                             // x = dq·2^-eD = m·2^k
+    const int j = (int)(mant >> 56) & 127;
+    const double m = __longlong_as_double((long long)((mant >> 11) & 0x000fffffffffffffull) | 0x3ff0000000000000ll);
+    const double2 t = tab[j];                                               // (1/c_j, log c_j)
+    const double r = fma(m, t.x, -1.0);
+    double p = fma(r, -1.0 / 6, 1.0 / 5);
+    p = fma(r, p, -1.0 / 4);
+    p = fma(r, p, 1.0 / 3);
+    p = fma(r, p, -1.0 / 2);
+    p = fma(r * r, p, r);
+    const double L = fma((double)k, 0.69314718055994530942, t.y + p);
+    // rint(L·2^eL) as an integer by the magic-number trick (|L·2^eL| < 2^51 by the choice of eL)
+    const double v = fma(L, sL, 0x1.8p52);
+    const long long q = __double_as_longlong(v) - __double_as_longlong(0x1.8p52);
+    return dq > 0 ? q : 0ll;   // padding and masked entries carry dq = 0
+}
+
+// logD entry (row, col) in internal order, stored or derived; xd = Dq(row, col) when the caller has it already
+__device__ __forceinline__ long long rc_load_L(const View &V, int row, int col, long long xd)
+{
+    if (V.derived) return row == col ? 0ll : rc_qlog(xd, V.qeD, V.qsL, V.ltab);
+    const size_t e = (size_t)row * V.ld + col;
+    return (V.bits == 64) ? ((const long long *)V.Lq)[e] : (long long)((const int *)V.Lq)[e];
+}
+
+// one-off scan for the derived mode: smallest off-diagonal Dq (must be > 0) and largest |log| (fixes eL)
+__global__ void k_derived_scan(const long long *__restrict__ Dq, int n, int ld, int eD, const double2 *__restrict__ tab,
+                               long long *min_dq, u64 *maxabs_bits)
+{
+    long long mn = 0x7fffffffffffffffll;
+    double mx = 0.0;
+    const size_t total = (size_t)n * n;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = t / n, j = t % n;
+        if (i == j) continue;
+        const long long dq = Dq[i * ld + j];
+        mn = min(mn, dq);
+        if (dq > 0) mx = fmax(mx, fabs((double)rc_qlog(dq, eD, 0x1p40, tab) * 0x1p-40));
+    }
+    atomicMin((long long *)min_dq, mn);
+    atomicMax((unsigned long long *)maxabs_bits, (unsigned long long)__double_as_longlong(mx));
+}
+
+// dequantised logD for rc_get_matrix in the derived mode (caller's order: Dq_src)
+__global__ void k_derived_matrix(const long long *__restrict__ Dq, int n, int ld, int eD, double sL, double scale,
+                                 const double2 *__restrict__ tab, double *__restrict__ out)
+{
+    const size_t total = (size_t)n * n;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = t / n, j = t % n;
+        out[t] = (i == j) ? 0.0 : (double)rc_qlog(Dq[i * ld + j], eD, sL, tab) * scale;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_relayout(const T *__restrict__ src, const int *__restrict__ ipi, int n, int ld, T *__restrict__ out)
 {
@@ -324,12 +398,23 @@ template <typename T> struct Seg;
 template <> struct Seg<long long> { typedef ll2 vec; static constexpr int C = 2; };
 template <> struct Seg<int> { typedef int vec __attribute__((ext_vector_type(4))); static constexpr int C = 4; };
 
-template <typename T>
+template <typename T, bool DERIVED = false>
 __global__ __launch_bounds__(256) void k_bulk(View V, int rows_per_split, int wgen, int zgen, int pgen)
 {
     typedef typename Seg<T>::vec vec;
     constexpr int C = Seg<T>::C;
     const size_t ld = (size_t)V.ld;
+    __shared__ double2 ltab_sh[DERIVED ? 128 : 1];
+    if (DERIVED) { if (threadIdx.x < 128) ltab_sh[threadIdx.x] = V.ltab[threadIdx.x]; __syncthreads(); }
+    const int qeD = V.qeD;
+    const double qsL = V.qsL;
+    // derived logD of the C entries of row j at this thread's columns (diagonal and padding -> 0)
+    auto derive = [&](const vec &d, int j, int col0) {
+        vec l;
+#pragma unroll
+        for (int q = 0; q < C; ++q) l[q] = (j == col0 + q) ? 0 : (T)rc_qlog((long long)d[q], qeD, qsL, ltab_sh);
+        return l;
+    };
     {   // clear generation zgen, rows < slot_hi (rows above are zero by invariant)
         const int hi = V.sc->slot_hi;
         const size_t total2 = (size_t)hi * ld / 2;
@@ -368,7 +453,11 @@ __global__ __launch_bounds__(256) void k_bulk(View V, int rows_per_split, int wg
 #pragma unroll
         for (int u = 0; u < RC_BULK_U; ++u) {
             d[u] = __builtin_nontemporal_load((const vec *)(Dq + (size_t)j[u] * ld));  // streamed once per sweep
-            l[u] = __builtin_nontemporal_load((const vec *)(Lq + (size_t)j[u] * ld));
+            if (!DERIVED) l[u] = __builtin_nontemporal_load((const vec *)(Lq + (size_t)j[u] * ld));
+        }
+        if (DERIVED) {
+#pragma unroll
+            for (int u = 0; u < RC_BULK_U; ++u) l[u] = derive(d[u], j[u], i);
         }
 #pragma unroll
         for (int u = 0; u < RC_BULK_U; ++u) {
@@ -380,7 +469,7 @@ __global__ __launch_bounds__(256) void k_bulk(View V, int rows_per_split, int wg
     for (; p < p1; ++p) {
         const int j = perm[p], sl = pslot[p];
         const vec d = __builtin_nontemporal_load((const vec *)(Dq + (size_t)j * ld));
-        const vec l = __builtin_nontemporal_load((const vec *)(Lq + (size_t)j * ld));
+        const vec l = DERIVED ? derive(d, j, i) : __builtin_nontemporal_load((const vec *)(Lq + (size_t)j * ld));
         if (sl != cur) { flush(cur); cur = sl; }
 #pragma unroll
         for (int q = 0; q < C; ++q) { aD[q] += (long long)d[q]; aL[q] += (long long)l[q]; }
@@ -405,9 +494,14 @@ __global__ __launch_bounds__(256) void k_bulk(View V, int rows_per_split, int wg
 #define RC_SYM_TR 32
 #define RC_SYM_TC 128
 #define RC_SYM_TP (RC_SYM_TC + 2)  // row pitch in elements: row threads hit distinct LDS banks
+template <bool DERIVED>
 __global__ __launch_bounds__(256) void k_bulk_sym(View V, int wgen, int zgen, int sgen, int cgen, int item_tiles, int nitems)
 {
     __shared__ __attribute__((aligned(16))) long long tt[2][RC_SYM_TR][RC_SYM_TP];  // [matrix][row][col]
+    __shared__ double2 ltab_sh[DERIVED ? 128 : 1];
+    if (DERIVED && threadIdx.x < 128) ltab_sh[threadIdx.x] = V.ltab[threadIdx.x];   // visible after the first barrier of the work loop
+    const int qeD = V.qeD;
+    const double qsL = V.qsL;
     __shared__ int item_sh, J_sh;
     __shared__ int cslot[RC_SYM_TC], rslot[RC_SYM_TR];
     __shared__ int cchk[RC_SYM_TC / 8], rchk[RC_SYM_TR / 8];  // slot of an 8-wide chunk if uniform, else -2
@@ -466,28 +560,69 @@ __global__ __launch_bounds__(256) void k_bulk_sym(View V, int wgen, int zgen, in
                 const int piece = q * 256 + tid, lr = piece >> 6, lp = piece & 63;
                 const int r = min(t * RC_SYM_TR + lr, n - 1);
                 d[q] = __builtin_nontemporal_load((const ll2 *)(Dq + (size_t)r * ld + c0 + lp * 2));
-                l[q] = __builtin_nontemporal_load((const ll2 *)(Lq + (size_t)r * ld + c0 + lp * 2));
+                if (!DERIVED) l[q] = __builtin_nontemporal_load((const ll2 *)(Lq + (size_t)r * ld + c0 + lp * 2));
             }
         };
-        issue(t_begin);
+        // derived logD: only D is loaded, so the registers of the logD pieces hold a second D tile — two tiles in flight
+        auto issue_buf = [&](ll2 (&buf)[8], int t) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int piece = q * 256 + tid, lr = piece >> 6, lp = piece & 63;
+                const int r = min(t * RC_SYM_TR + lr, n - 1);
+                buf[q] = __builtin_nontemporal_load((const ll2 *)(Dq + (size_t)r * ld + c0 + lp * 2));
+            }
+        };
+        if (DERIVED) {
+            issue_buf(d, t_begin);
+            if (t_begin + 1 < t_end) issue_buf(l, t_begin + 1);
+        } else {
+            issue(t_begin);
+        }
         long long accD = 0, accL = 0;
         int cur = -1;
         for (int t = t_begin; t < t_end; ++t) {
             const int r0 = t * RC_SYM_TR;
             __syncthreads();  // the previous tile has been consumed
             if (tid < RC_SYM_TR) rslot[tid] = (r0 + tid < n) ? slot[r0 + tid] : -1;
+            if (!DERIVED) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int piece = q * 256 + tid, lr = piece >> 6, lp = piece & 63;
-                const int r = r0 + lr, b = c0 + lp * 2;
-                const bool live = r < n;
-                ll2 x = d[q], y = l[q];
-                if (!(live && b > r)) { x.x = 0; y.x = 0; }
-                if (!(live && b + 1 > r)) { x.y = 0; y.y = 0; }
-                *(ll2 *)&tt[0][lr][lp * 2] = x;
-                *(ll2 *)&tt[1][lr][lp * 2] = y;
+                for (int q = 0; q < 8; ++q) {
+                    const int piece = q * 256 + tid, lr = piece >> 6, lp = piece & 63;
+                    const int r = r0 + lr, b = c0 + lp * 2;
+                    const bool live = r < n;
+                    ll2 x = d[q], y = l[q];
+                    if (!(live && b > r)) { x.x = 0; y.x = 0; }
+                    if (!(live && b + 1 > r)) { x.y = 0; y.y = 0; }
+                    *(ll2 *)&tt[0][lr][lp * 2] = x;
+                    *(ll2 *)&tt[1][lr][lp * 2] = y;
+                }
+            } else {
+                // derived logD: free the load registers first, so that the loads of tile t+2 fly under the logs
+                auto stage = [&](ll2 (&buf)[8]) {
+                    ll2 x[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int piece = q * 256 + tid, lr = piece >> 6, lp = piece & 63;
+                        const int r = r0 + lr, b = c0 + lp * 2;
+                        const bool live = r < n;
+                        x[q] = buf[q];
+                        if (!(live && b > r)) x[q].x = 0;      // masked entries and the zero padding beyond column n give 0
+                        if (!(live && b + 1 > r)) x[q].y = 0;
+                    }
+                    if (t + 2 < t_end) issue_buf(buf, t + 2);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int piece = q * 256 + tid, lr = piece >> 6, lp = piece & 63;
+                        ll2 y;
+                        y.x = rc_qlog(x[q].x, qeD, qsL, ltab_sh);
+                        y.y = rc_qlog(x[q].y, qeD, qsL, ltab_sh);
+                        *(ll2 *)&tt[0][lr][lp * 2] = x[q];
+                        *(ll2 *)&tt[1][lr][lp * 2] = y;
+                    }
+                };
+                if ((t - t_begin) & 1) stage(l); else stage(d);
             }
-            if (t + 1 < t_end) issue(t + 1);  // in flight while this tile is reduced
+            if (!DERIVED && t + 1 < t_end) issue(t + 1);  // in flight while this tile is reduced
             __syncthreads();
             if (tid < RC_SYM_TR / 8) {
                 const int s0 = rslot[tid * 8];
@@ -577,6 +712,424 @@ __global__ __launch_bounds__(256) void k_bulk_sym(View V, int wgen, int zgen, in
                 const long long x = V.diagq[a_];
                 if (x) __hip_atomic_fetch_add((u64 *)(SD + (size_t)slot[a_] * ld + a_), (u64)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// k_bulk_symw — wave-autonomous symmetric row-bucket reduction (64-bit storage).  Same contract as k_bulk_sym (upper
+// triangle only, exact integer result for any labelling), different machine mapping: no LDS tiles and no block
+// barriers.  A work item is 64 rows × 128 columns of the upper triangle and belongs to ONE wave:
+//   * lane ℓ owns columns c0+2ℓ, c0+2ℓ+1 and streams the rows with 16-byte non-temporal loads, several rows in flight;
+//   * direction 1 (S[slot_row][col] += x): register accumulators per lane, flushed when the row's slot changes — as k_bulk;
+//   * direction 2 (S[slot_col][row] += x): the 128 columns of a row belong to one or two clusters, so per row and
+//     distinct column slot the wave reduces its lanes' values with DPP adds (no LDS traffic) and lane (row − a0) keeps
+//     the total; after the 64 rows one coalesced 64-bit atomic per matrix and slot writes them out.
+//   Waves never wait for each other, so loads, the logs of the derived mode and the reductions of different waves
+//   overlap freely, and occupancy is bounded by registers only.
+// ---------------------------------------------------------------------------------------------------
+#define RC_SW_ROWS 64
+#define RC_SW_COLS 128
+#define RC_SW_U 8
+
+// Sums of TWO 64-bit values over the 64 lanes of a wave, results uniform.  DPP butterfly with the permuted operand
+// fused into v_add_co / v_addc_co (the compiler's own lowering of the same reduction needs 38 VALU instructions per
+// value — zero-fills, v_mov_dpp, 64-bit add — against 12 here).  The two reductions are interleaved, so an
+// instruction reads a register written four instructions earlier: the 2 wait states a DPP read needs after a VALU
+// write are covered without s_nop.  Steps: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror (every lane of
+// a 16-lane row holds the row total), row_bcast15 -> rows 1, 3, row_bcast31 -> rows 2, 3: lane 63 holds the total.
+__device__ __forceinline__ void wave_sum2_dpp(long long &a, long long &b)
+{
+    unsigned alo = (unsigned)(u64)a, ahi = (unsigned)((u64)a >> 32), blo = (unsigned)(u64)b, bhi = (unsigned)((u64)b >> 32);
+#define RC_DPP_STEP(ctrl)                                            \
+    "v_add_co_u32_dpp %0, vcc, %0, %0 " ctrl "\n\t"                  \
+    "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc " ctrl "\n\t"            \
+    "v_add_co_u32_dpp %2, vcc, %2, %2 " ctrl "\n\t"                  \
+    "v_addc_co_u32_dpp %3, vcc, %3, %3, vcc " ctrl "\n\t"
+    asm volatile("s_nop 1\n\t"
+                 RC_DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 RC_DPP_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 RC_DPP_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 RC_DPP_STEP("row_mirror row_mask:0xf bank_mask:0xf")
+                 RC_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 RC_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 0"
+                 : "+v"(alo), "+v"(ahi), "+v"(blo), "+v"(bhi)
+                 :
+                 : "vcc");
+#undef RC_DPP_STEP
+    const unsigned ral = (unsigned)__builtin_amdgcn_readlane((int)alo, 63), rah = (unsigned)__builtin_amdgcn_readlane((int)ahi, 63);
+    const unsigned rbl = (unsigned)__builtin_amdgcn_readlane((int)blo, 63), rbh = (unsigned)__builtin_amdgcn_readlane((int)bhi, 63);
+    a = (long long)(((u64)rah << 32) | ral);
+    b = (long long)(((u64)rbh << 32) | rbl);
+}
+
+template <bool DERIVED>
+__global__ __launch_bounds__(256) void k_bulk_symw(View V, int wgen, int zgen, int sgen, int cgen, int nitems)
+{
+    __shared__ double2 ltab_sh[DERIVED ? 128 : 1];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const size_t ld = (size_t)V.ld;
+    if (DERIVED && tid < 128) ltab_sh[tid] = V.ltab[tid];
+    {   // clear generation zgen, rows < slot_hi (rows above are zero by invariant); re-arm the other work counter
+        const int hi = V.sc->slot_hi;
+        const size_t total2 = (size_t)hi * ld / 2;
+        const size_t nthreads = (size_t)gridDim.x * 256;
+        ll2 *zd = (ll2 *)V.SD[zgen], *zl = (ll2 *)V.SL[zgen];
+        const ll2 z = {0, 0};
+        for (size_t q = (size_t)blockIdx.x * 256 + tid; q < total2; q += nthreads) { zd[q] = z; zl[q] = z; }
+        if (blockIdx.x == 0 && tid == 0) *V.work[cgen ^ 1] = 0;
+    }
+    __syncthreads();  // the table is visible; from here on the waves are on their own
+    const long long *__restrict__ Dq = (const long long *)V.Dq;
+    const long long *__restrict__ Lq = (const long long *)V.Lq;
+    const int *__restrict__ slot = V.snap[sgen];
+    long long *SD = V.SD[wgen], *SL = V.SL[wgen];
+    const int n = V.n;
+    const int ncb = (n + RC_SW_COLS - 1) / RC_SW_COLS;
+    const int qeD = V.qeD;
+    const double qsL = V.qsL;
+    int *counter = V.work[cgen];
+    auto add64 = [](long long *p, long long v) { __hip_atomic_fetch_add((u64 *)p, (u64)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    // the first item of a wave is its own index (thousands of waves hitting one counter at launch serialise in L2);
+    // further items come from the shared counter
+    const int nwaves = (int)gridDim.x * 4;
+    bool first = true;
+    for (;;) {
+        int item = 0;
+        if (first) {
+            item = (int)blockIdx.x * 4 + (tid >> 6);
+            first = false;
+        } else {
+            if (lane == 0) item = nwaves + atomicAdd(counter, 1);
+            item = __builtin_amdgcn_readfirstlane(item);
+        }
+        if (item >= nitems) break;
+        int J = ncb - 1;
+        for (;; --J) {   // heavy column blocks first
+            const int cnt = (min(RC_SW_COLS * J + RC_SW_COLS, n) + RC_SW_ROWS - 1) / RC_SW_ROWS;
+            if (item < cnt) break;
+            item -= cnt;
+        }
+        const int c0 = J * RC_SW_COLS, a0 = item * RC_SW_ROWS;
+        const int a1 = min(a0 + RC_SW_ROWS, min(c0 + RC_SW_COLS, n));   // rows a >= c0+128 have no column b > a here
+        const int col0 = c0 + 2 * lane, col1 = col0 + 1;
+        const int cs0 = col0 < n ? slot[col0] : -1, cs1 = col1 < n ? slot[col1] : -1;
+        const int rowslots = (a0 + lane < n) ? slot[a0 + lane] : -1;   // slot of row a0 + lane (read back with readlane)
+        // distinct column slots of this item (cluster-contiguous layout: one or two); beyond four: slow path
+        int ds0 = -1, ds1 = -1, ds2 = -1, ds3 = -1, M = 0;
+        bool rem0 = cs0 >= 0, rem1 = cs1 >= 0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const u64 b0 = __ballot(rem0), b1 = __ballot(rem1);
+            if (!(b0 | b1)) break;
+            const int s_ = b0 ? __builtin_amdgcn_readlane(cs0, __ffsll((long long)b0) - 1) : __builtin_amdgcn_readlane(cs1, __ffsll((long long)b1) - 1);
+            if (m == 0) ds0 = s_; else if (m == 1) ds1 = s_; else if (m == 2) ds2 = s_; else ds3 = s_;
+            M = m + 1;
+            rem0 = rem0 && cs0 != s_;
+            rem1 = rem1 && cs1 != s_;
+        }
+        const bool overflow = (__ballot(rem0) | __ballot(rem1)) != 0;   // uniform
+        const bool uni = (M == 1) && !overflow && __ballot(cs0 == ds0 && cs1 == ds0) == ~0ull;   // all 128 columns in one cluster
+        long long aD0 = 0, aD1 = 0, aL0 = 0, aL1 = 0;       // direction 1, slot `cur`
+        long long rD0 = 0, rD1 = 0, rD2 = 0, rD3 = 0, rL0 = 0, rL1 = 0, rL2 = 0, rL3 = 0;   // direction 2, row a0 + lane
+        int cur = -1;
+        auto flush1 = [&]() {
+            if (cur >= 0) {
+                if (aD0) add64(SD + (size_t)cur * ld + col0, aD0);
+                if (aD1) add64(SD + (size_t)cur * ld + col1, aD1);
+                if (aL0) add64(SL + (size_t)cur * ld + col0, aL0);
+                if (aL1) add64(SL + (size_t)cur * ld + col1, aL1);
+            }
+            aD0 = aD1 = aL0 = aL1 = 0;
+        };
+        for (int a = a0; a < a1; a += RC_SW_U) {
+            ll2 d[RC_SW_U], l[RC_SW_U];
+#pragma unroll
+            for (int u = 0; u < RC_SW_U; ++u) {
+                const int r = min(a + u, n - 1);
+                d[u] = __builtin_nontemporal_load((const ll2 *)(Dq + (size_t)r * ld + col0));
+                if (!DERIVED) l[u] = __builtin_nontemporal_load((const ll2 *)(Lq + (size_t)r * ld + col0));
+            }
+#pragma unroll
+            for (int u = 0; u < RC_SW_U; ++u) {
+                const int row = a + u;
+                if (row >= a1) break;                                   // uniform
+                ll2 x = d[u], y;
+                if (!DERIVED) y = l[u];
+                if (!(col0 > row)) { x.x = 0; y.x = 0; }               // strictly upper triangle only
+                if (!(col1 > row)) { x.y = 0; y.y = 0; }
+                if (DERIVED) { y.x = rc_qlog(x.x, qeD, qsL, ltab_sh); y.y = rc_qlog(x.y, qeD, qsL, ltab_sh); }
+                // direction 1
+                const int sr = __builtin_amdgcn_readlane(rowslots, row - a0);
+                if (sr != cur) { flush1(); cur = sr; }
+                aD0 += x.x; aD1 += x.y; aL0 += y.x; aL1 += y.y;
+                // direction 2
+                const bool mine = lane == row - a0;
+                if (uni) {
+                    long long tD = x.x + x.y, tL = y.x + y.y;
+                    wave_sum2_dpp(tD, tL);
+                    if (mine) { rD0 += tD; rL0 += tL; }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        if (m >= M) break;                              // uniform
+                        const int s_ = m == 0 ? ds0 : m == 1 ? ds1 : m == 2 ? ds2 : ds3;
+                        long long tD = (cs0 == s_ ? x.x : 0) + (cs1 == s_ ? x.y : 0);
+                        long long tL = (cs0 == s_ ? y.x : 0) + (cs1 == s_ ? y.y : 0);
+                        wave_sum2_dpp(tD, tL);
+                        if (mine) {
+                            if (m == 0) { rD0 += tD; rL0 += tL; } else if (m == 1) { rD1 += tD; rL1 += tL; }
+                            else if (m == 2) { rD2 += tD; rL2 += tL; } else { rD3 += tD; rL3 += tL; }
+                        }
+                    }
+                    if (overflow) {   // columns of a fifth, sixth ... cluster: element-wise atomics (rare)
+                        if (rem0) { if (x.x) add64(SD + (size_t)cs0 * ld + row, x.x); if (y.x) add64(SL + (size_t)cs0 * ld + row, y.x); }
+                        if (rem1) { if (x.y) add64(SD + (size_t)cs1 * ld + row, x.y); if (y.y) add64(SL + (size_t)cs1 * ld + row, y.y); }
+                    }
+                }
+            }
+        }
+        flush1();
+        {   // direction 2 write-out: lane r holds the totals of row a0 + r
+            const int row = a0 + lane;
+            if (row < a1) {
+                if (M > 0) { if (rD0) add64(SD + (size_t)ds0 * ld + row, rD0); if (rL0) add64(SL + (size_t)ds0 * ld + row, rL0); }
+                if (M > 1) { if (rD1) add64(SD + (size_t)ds1 * ld + row, rD1); if (rL1) add64(SL + (size_t)ds1 * ld + row, rL1); }
+                if (M > 2) { if (rD2) add64(SD + (size_t)ds2 * ld + row, rD2); if (rL2) add64(SL + (size_t)ds2 * ld + row, rL2); }
+                if (M > 3) { if (rD3) add64(SD + (size_t)ds3 * ld + row, rD3); if (rL3) add64(SL + (size_t)ds3 * ld + row, rL3); }
+            }
+        }
+        // diagonal (S includes j = i): D[a][a] -> S[slot_a][a]; logD's diagonal is 0 (types.jl:155)
+        if (item == 0) {
+            if (col0 < n) { const long long x = V.diagq[col0]; if (x) add64(SD + (size_t)cs0 * ld + col0, x); }
+            if (col1 < n) { const long long x = V.diagq[col1]; if (x) add64(SD + (size_t)cs1 * ld + col1, x); }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// k_bulk_syml — wave-autonomous symmetric reduction with a wave-PRIVATE LDS transposition (64-bit storage).
+// Like k_bulk_symw a wave owns a 64-row × 128-column item and never meets a block barrier; direction 2 is done the
+// cheap way: four rows at a time the wave writes its tile (4 × 128 values per matrix) to its own 8 KiB of LDS and reads
+// it back transposed — lane = (row r = lane >> 4, column octet q = lane & 15) sums 8 values per matrix — followed by a
+// 4-step DPP reduction inside the 16-lane DPP row.  LDS operations of one wave execute in order, so no
+// synchronisation is needed.  The 16 lanes of DPP row r then all hold the totals of tile row r; lane 16r + k keeps
+// them for tile k of the item, i.e. lane ℓ accumulates row a0 + 4(ℓ & 15) + (ℓ >> 4).
+// ---------------------------------------------------------------------------------------------------
+#define RC_SL_R 4
+// LDS row of a tile: 16 column octets of 8 values, each padded to 10 (80 B): the transposed b128 reads of a quarter wave
+// (16 lanes, one octet each) then fall on 16 different 16-byte bank groups instead of 4
+#define RC_SL_O 10
+#define RC_SL_P (16 * RC_SL_O)
+
+// sums of four 64-bit values over each 16-lane DPP row (all lanes of the row receive the totals)
+__device__ __forceinline__ void row16_sum4_dpp(long long &a, long long &b, long long &c, long long &d)
+{
+    unsigned r0 = (unsigned)(u64)a, r1 = (unsigned)((u64)a >> 32), r2 = (unsigned)(u64)b, r3 = (unsigned)((u64)b >> 32);
+    unsigned r4 = (unsigned)(u64)c, r5 = (unsigned)((u64)c >> 32), r6 = (unsigned)(u64)d, r7 = (unsigned)((u64)d >> 32);
+#define RC_DPP_STEP(ctrl)                                            \
+    "v_add_co_u32_dpp %0, vcc, %0, %0 " ctrl "\n\t"                  \
+    "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc " ctrl "\n\t"            \
+    "v_add_co_u32_dpp %2, vcc, %2, %2 " ctrl "\n\t"                  \
+    "v_addc_co_u32_dpp %3, vcc, %3, %3, vcc " ctrl "\n\t"            \
+    "v_add_co_u32_dpp %4, vcc, %4, %4 " ctrl "\n\t"                  \
+    "v_addc_co_u32_dpp %5, vcc, %5, %5, vcc " ctrl "\n\t"            \
+    "v_add_co_u32_dpp %6, vcc, %6, %6 " ctrl "\n\t"                  \
+    "v_addc_co_u32_dpp %7, vcc, %7, %7, vcc " ctrl "\n\t"
+    asm volatile("s_nop 1\n\t"
+                 RC_DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 RC_DPP_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 RC_DPP_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 RC_DPP_STEP("row_mirror row_mask:0xf bank_mask:0xf")
+                 "s_nop 0"
+                 : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)
+                 :
+                 : "vcc");
+#undef RC_DPP_STEP
+    a = (long long)(((u64)r1 << 32) | r0); b = (long long)(((u64)r3 << 32) | r2);
+    c = (long long)(((u64)r5 << 32) | r4); d = (long long)(((u64)r7 << 32) | r6);
+}
+
+template <bool DERIVED>
+__global__ __launch_bounds__(256) void k_bulk_syml(View V, int wgen, int zgen, int sgen, int cgen, int nitems)
+{
+    __shared__ __attribute__((aligned(16))) long long tl[4][2][RC_SL_R][RC_SL_P];   // [wave][matrix][row][octet-padded col]: 10 KiB per wave
+    __shared__ double2 ltab_sh[DERIVED ? 128 : 1];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t ld = (size_t)V.ld;
+    if (DERIVED && tid < 128) ltab_sh[tid] = V.ltab[tid];
+    {   // clear generation zgen, rows < slot_hi (rows above are zero by invariant); re-arm the other work counter
+        const int hi = V.sc->slot_hi;
+        const size_t total2 = (size_t)hi * ld / 2;
+        const size_t nthreads = (size_t)gridDim.x * 256;
+        ll2 *zd = (ll2 *)V.SD[zgen], *zl = (ll2 *)V.SL[zgen];
+        const ll2 z = {0, 0};
+        for (size_t q = (size_t)blockIdx.x * 256 + tid; q < total2; q += nthreads) { zd[q] = z; zl[q] = z; }
+        if (blockIdx.x == 0 && tid == 0) *V.work[cgen ^ 1] = 0;
+    }
+    __syncthreads();  // the table is visible; from here on the waves are on their own
+    long long (*tt)[RC_SL_R][RC_SL_P] = tl[wv];
+    const long long *__restrict__ Dq = (const long long *)V.Dq;
+    const long long *__restrict__ Lq = (const long long *)V.Lq;
+    const int *__restrict__ slot = V.snap[sgen];
+    long long *SD = V.SD[wgen], *SL = V.SL[wgen];
+    const int n = V.n;
+    const int ncb = (n + RC_SW_COLS - 1) / RC_SW_COLS;
+    const int qeD = V.qeD;
+    const double qsL = V.qsL;
+    int *counter = V.work[cgen];
+    const int tr = lane >> 4, tq = lane & 15;   // transposed role: tile row, column octet
+    auto add64 = [](long long *p, long long v) { __hip_atomic_fetch_add((u64 *)p, (u64)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    // the first item of a wave is its own index (thousands of waves hitting one counter at launch serialise in L2);
+    // further items come from the shared counter
+    const int nwaves = (int)gridDim.x * 4;
+    bool first = true;
+    for (;;) {
+        int item = 0;
+        if (first) {
+            item = (int)blockIdx.x * 4 + (tid >> 6);
+            first = false;
+        } else {
+            if (lane == 0) item = nwaves + atomicAdd(counter, 1);
+            item = __builtin_amdgcn_readfirstlane(item);
+        }
+        if (item >= nitems) break;
+        int J = ncb - 1;
+        for (;; --J) {   // heavy column blocks first
+            const int cnt = (min(RC_SW_COLS * J + RC_SW_COLS, n) + RC_SW_ROWS - 1) / RC_SW_ROWS;
+            if (item < cnt) break;
+            item -= cnt;
+        }
+        const int c0 = J * RC_SW_COLS, a0 = item * RC_SW_ROWS;
+        const int a1 = min(a0 + RC_SW_ROWS, min(c0 + RC_SW_COLS, n));   // rows a >= c0+128 have no column b > a here
+        const int col0 = c0 + 2 * lane, col1 = col0 + 1;
+        const int cs0 = col0 < n ? slot[col0] : -1, cs1 = col1 < n ? slot[col1] : -1;
+        const int rowslots = (a0 + lane < n) ? slot[a0 + lane] : -1;   // slot of row a0 + lane (read back with readlane)
+        // the (at most two) clusters that own the 128 columns; a third, fourth ... cluster goes the slow way
+        const int dsA = __builtin_amdgcn_readfirstlane(cs0);            // column c0 always exists
+        const u64 notA0 = __ballot(cs0 >= 0 && cs0 != dsA), notA1 = __ballot(cs1 >= 0 && cs1 != dsA);
+        int dsB = -1;
+        if (notA0 | notA1) {
+            const int l0 = notA0 ? __ffsll((long long)notA0) - 1 : 64, l1 = notA1 ? __ffsll((long long)notA1) - 1 : 64;
+            dsB = (l0 <= l1) ? __builtin_amdgcn_readlane(cs0, l0 & 63) : __builtin_amdgcn_readlane(cs1, l1 & 63);
+        }
+        const bool rem0 = cs0 >= 0 && cs0 != dsA && cs0 != dsB, rem1 = cs1 >= 0 && cs1 != dsA && cs1 != dsB;
+        const bool overflow = (__ballot(rem0) | __ballot(rem1)) != 0;   // uniform, rare
+        // classes of my eight transposed columns c0 + 8 tq + j: bit j of mB = belongs to cluster B; of mO = to neither
+        unsigned mB = 0, mO = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int cj = c0 + 8 * tq + j;
+            const int sj = cj < n ? slot[cj] : -1;
+            if (sj == dsB && dsB >= 0) mB |= 1u << j;
+            else if (sj != dsA) mO |= 1u << j;                          // other clusters and padding: not summed here
+        }
+        long long aD0 = 0, aD1 = 0, aL0 = 0, aL1 = 0;                   // direction 1, slot `cur`
+        long long rDA = 0, rLA = 0, rDB = 0, rLB = 0;                   // direction 2: row a0 + 4 (lane & 15) + (lane >> 4)
+        int cur = -1;
+        auto flush1 = [&]() {
+            if (cur >= 0) {
+                if (aD0) add64(SD + (size_t)cur * ld + col0, aD0);
+                if (aD1) add64(SD + (size_t)cur * ld + col1, aD1);
+                if (aL0) add64(SL + (size_t)cur * ld + col0, aL0);
+                if (aL1) add64(SL + (size_t)cur * ld + col1, aL1);
+            }
+            aD0 = aD1 = aL0 = aL1 = 0;
+        };
+        ll2 d[RC_SL_R], l[RC_SL_R];
+        auto issue = [&](int a) {
+#pragma unroll
+            for (int u = 0; u < RC_SL_R; ++u) {
+                const int r = min(a + u, n - 1);
+                d[u] = __builtin_nontemporal_load((const ll2 *)(Dq + (size_t)r * ld + col0));
+                if (!DERIVED) l[u] = __builtin_nontemporal_load((const ll2 *)(Lq + (size_t)r * ld + col0));
+            }
+        };
+        issue(a0);
+        for (int a = a0; a < a1; a += RC_SL_R) {
+            ll2 x[RC_SL_R], y[RC_SL_R];
+#pragma unroll
+            for (int u = 0; u < RC_SL_R; ++u) {
+                const int row = a + u;
+                x[u] = d[u];
+                if (!DERIVED) y[u] = l[u];
+                const bool live = row < a1;
+                if (!(live && col0 > row)) { x[u].x = 0; y[u].x = 0; }  // strictly upper triangle, rows of this item only
+                if (!(live && col1 > row)) { x[u].y = 0; y[u].y = 0; }
+            }
+            if (a + RC_SL_R < a1) issue(a + RC_SL_R);                   // next tile in flight under this one's work
+#pragma unroll
+            for (int u = 0; u < RC_SL_R; ++u) {
+                if (DERIVED) { y[u].x = rc_qlog(x[u].x, qeD, qsL, ltab_sh); y[u].y = rc_qlog(x[u].y, qeD, qsL, ltab_sh); }
+                *(ll2 *)&tt[0][u][(lane >> 2) * RC_SL_O + (lane & 3) * 2] = x[u];
+                *(ll2 *)&tt[1][u][(lane >> 2) * RC_SL_O + (lane & 3) * 2] = y[u];
+            }
+            // direction 1
+#pragma unroll
+            for (int u = 0; u < RC_SL_R; ++u) {
+                const int row = a + u;
+                if (row < a1) {                                         // uniform
+                    const int sr = __builtin_amdgcn_readlane(rowslots, row - a0);
+                    if (sr != cur) { flush1(); cur = sr; }
+                    aD0 += x[u].x; aD1 += x[u].y; aL0 += y[u].x; aL1 += y[u].y;
+                }
+            }
+            // direction 2: transposed read of the wave's own tile (same-wave LDS operations execute in order)
+            __builtin_amdgcn_wave_barrier();
+            long long sDA = 0, sLA = 0, sDB = 0, sLB = 0;
+            {
+                long long vD[8], vL[8];
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    const ll2 pd = *(const ll2 *)&tt[0][tr][RC_SL_O * tq + j], pl = *(const ll2 *)&tt[1][tr][RC_SL_O * tq + j];
+                    vD[j] = pd.x; vD[j + 1] = pd.y; vL[j] = pl.x; vL[j + 1] = pl.y;
+                }
+                if ((mB | mO) == 0) {                                   // all eight columns in cluster A (the usual case)
+                    sDA = ((vD[0] + vD[1]) + (vD[2] + vD[3])) + ((vD[4] + vD[5]) + (vD[6] + vD[7]));
+                    sLA = ((vL[0] + vL[1]) + (vL[2] + vL[3])) + ((vL[4] + vL[5]) + (vL[6] + vL[7]));
+                } else if (mB == 0xffu) {
+                    sDB = ((vD[0] + vD[1]) + (vD[2] + vD[3])) + ((vD[4] + vD[5]) + (vD[6] + vD[7]));
+                    sLB = ((vL[0] + vL[1]) + (vL[2] + vL[3])) + ((vL[4] + vL[5]) + (vL[6] + vL[7]));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const bool isB = (mB >> j) & 1, isO = (mO >> j) & 1;
+                        if (isB) { sDB += vD[j]; sLB += vL[j]; } else if (!isO) { sDA += vD[j]; sLA += vL[j]; }
+                    }
+                }
+                if (overflow && mO) {   // columns of a third cluster: element-wise atomics (rare)
+                    const int row = a + tr;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int cj = c0 + 8 * tq + j;
+                        if (((mO >> j) & 1) && cj < n && row < a1) {
+                            const int sj = slot[cj];
+                            if (vD[j]) add64(SD + (size_t)sj * ld + row, vD[j]);
+                            if (vL[j]) add64(SL + (size_t)sj * ld + row, vL[j]);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            row16_sum4_dpp(sDA, sLA, sDB, sLB);
+            if (tq == ((a - a0) >> 2)) { rDA += sDA; rLA += sLA; rDB += sDB; rLB += sLB; }
+        }
+        flush1();
+        {   // direction 2 write-out: lane ℓ holds the totals of row a0 + 4 (ℓ & 15) + (ℓ >> 4)
+            const int row = a0 + 4 * tq + tr;
+            if (row < a1) {
+                if (rDA) add64(SD + (size_t)dsA * ld + row, rDA);
+                if (rLA) add64(SL + (size_t)dsA * ld + row, rLA);
+                if (dsB >= 0) { if (rDB) add64(SD + (size_t)dsB * ld + row, rDB); if (rLB) add64(SL + (size_t)dsB * ld + row, rLB); }
+            }
+        }
+        // diagonal (S includes j = i): D[a][a] -> S[slot_a][a]; logD's diagonal is 0 (types.jl:155)
+        if (item == 0) {
+            if (col0 < n) { const long long x = V.diagq[col0]; if (x) add64(SD + (size_t)cs0 * ld + col0, x); }
+            if (col1 < n) { const long long x = V.diagq[col1]; if (x) add64(SD + (size_t)cs1 * ld + col1, x); }
         }
     }
 }
@@ -959,7 +1512,11 @@ __global__ __launch_bounds__(256) void k_apply_moves(View V, MoveList ML)
         if (a == b) continue;
         const size_t e = (size_t)x * V.ld + i;
         long long d0, d1, l0, l1;
-        if (V.bits == 64) {
+        if (V.derived) {
+            const ll2 d = *(const ll2 *)((const long long *)V.Dq + e);
+            d0 = d.x; d1 = d.y;
+            l0 = rc_load_L(V, x, i, d0); l1 = rc_load_L(V, x, i + 1, d1);
+        } else if (V.bits == 64) {
             const ll2 d = *(const ll2 *)((const long long *)V.Dq + e), l = *(const ll2 *)((const long long *)V.Lq + e);
             d0 = d.x; d1 = d.y; l0 = l.x; l1 = l.y;
         } else {
@@ -1056,7 +1613,7 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
                     if (qa == k || qb == k) {
                         const size_t e = (size_t)T.bu[q] * ld + u;
                         const long long xd = (V.bits == 64) ? ((const long long *)V.Dq)[e] : (long long)((const int *)V.Dq)[e];
-                        const long long xl = (V.bits == 64) ? ((const long long *)V.Lq)[e] : (long long)((const int *)V.Lq)[e];
+                        const long long xl = rc_load_L(V, T.bu[q], u, xd);
                         const int sg = (qb == k) - (qa == k);
                         sd += sg * xd; sl += sg * xl; sz += sg;
                         touched = true;
@@ -1218,7 +1775,9 @@ __device__ bool commit_change(const View &V, const SweepArgs &sa, Tab &T, u64 ke
                 if (io < V.n) {
                     const int i = V.pi[io];
                     const size_t e = (size_t)ustar * V.ld + i;
-                    const long long x = (V.bits == 64) ? ((const long long *)M)[e] : (long long)((const int *)M)[e];
+                    long long x;
+                    if (job >= 2 && V.derived) x = rc_load_L(V, ustar, i, ((const long long *)V.Dq)[e]);
+                    else x = (V.bits == 64) ? ((const long long *)M)[e] : (long long)((const int *)M)[e];
                     const long long dx = (job & 1) ? x : -x;
                     So[(size_t)slot * V.ld + i] += dx;
                     if (next_gen >= 0)
@@ -1281,7 +1840,7 @@ __device__ void commit_batch(const View &V, const SweepArgs &sa, Tab &T, int nc,
             if (!da && !db) continue;
             const size_t e = (size_t)T.bu[q] * V.ld + i;
             const long long xd = (V.bits == 64) ? ((const long long *)V.Dq)[e] : (long long)((const int *)V.Dq)[e];
-            const long long xl = (V.bits == 64) ? ((const long long *)V.Lq)[e] : (long long)((const int *)V.Lq)[e];
+            const long long xl = rc_load_L(V, T.bu[q], i, xd);
             const size_t ia = (size_t)a * V.ld + i, ib = (size_t)b * V.ld + i;
             if (da) {
                 SDo[ia] -= xd; SLo[ia] -= xl;
@@ -1562,6 +2121,11 @@ struct rc_ctx {
     int *pi = nullptr, *ipi = nullptr;  // device: original -> internal, internal -> original
     std::vector<int> h_pi, h_ipi;       // host copies
     bool relayout = true;               // RC_NO_RELAYOUT=1 keeps the caller's point order
+    int sym_variant = -1;               // RC_SYM_VARIANT: 2 k_bulk_syml (wave-private LDS transposition), 1 k_bulk_symw (DPP only), 0 block-tiled
+                                        // k_bulk_sym; -1 (default): k_bulk_syml when logD is derived, k_bulk_sym when it is stored (measured best)
+    int symw_per_cu = 6;                // RC_SYMW_PER_CU: persistent blocks of k_bulk_symw per CU
+    bool derived = false;               // logD derived from Dq on the fly (rc_qlog), not stored
+    double2 *ltab = nullptr;            // device table of rc_qlog
     int n_relayouts = 0;                // re-layouts done so far (rc_set_state + automatic ones)
     int bits = 64;
     long long *SD[3] = {nullptr, nullptr, nullptr}, *SL[3] = {nullptr, nullptr, nullptr};
@@ -1663,6 +2227,7 @@ static View make_view(const rc_ctx *c)
     View V{};
     V.n = c->n; V.ld = c->ld; V.kcap = c->kcap;
     V.Dq = c->Dq; V.Lq = c->Lq; V.bits = c->bits; V.diagq = c->diagq; V.pi = c->pi;
+    V.derived = c->derived ? 1 : 0; V.qsD = std::ldexp(1.0, -c->eD); V.qsL = std::ldexp(1.0, c->eL); V.ltab = c->ltab; V.qeD = c->eD;
     for (int g = 0; g < 3; ++g) { V.SD[g] = c->SD[g]; V.SL[g] = c->SL[g]; }
     for (int g = 0; g < 2; ++g) { V.perm[g] = c->perm[g]; V.pslot[g] = c->pslot[g]; V.keys[g] = c->keys[g]; V.arrive[g] = c->arrive[g]; V.snap[g] = c->lsnap[g]; V.work[g] = c->work[g]; V.cword[g] = c->cword[g]; }
     V.rec = c->rec; V.tent = c->tent;
@@ -1700,7 +2265,7 @@ static void free_all(rc_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->dev);
-    void *ptrs[] = {c->Dq, c->Lq, c->Dq_src, c->Lq_src, c->diag_src, c->pi, c->ipi, c->diagq, c->SD[0], c->SD[1], c->SD[2], c->SL[0], c->SL[1], c->SL[2], c->slot_of,
+    void *ptrs[] = {c->ltab, c->Dq, c->Lq, c->Dq_src, c->Lq_src, c->diag_src, c->pi, c->ipi, c->diagq, c->SD[0], c->SD[1], c->SD[2], c->SL[0], c->SL[1], c->SL[2], c->slot_of,
                     c->slot_size, c->slot_label, c->slot_pos, c->slot_act, c->perm[0], c->perm[1], c->pslot[0],
                     c->pslot[1], c->lsnap[0], c->lsnap[1], c->work[0], c->work[1], c->cword[0], c->cword[1], c->rec, c->tent, c->A, c->keys[0], c->keys[1], c->arrive[0], c->arrive[1], c->sc, c->blocks,
                     c->counts, c->cc_out, c->snap, c->d_moves};
@@ -1800,14 +2365,24 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     HIPCHK2(hipMalloc(&flags, 2 * sizeof(unsigned)));
     HIPCHK2(hipMalloc(&mx, 2 * sizeof(u64)));
     const size_t esz = (size_t)c->bits / 8;
+    // logD not given: derive it from Dq on the fly instead of storing it (rc_qlog; halves the bytes of every sweep)
+    bool derived = !logD && c->bits == 64 && !(getenv("RC_STORED_LOG") && atoi(getenv("RC_STORED_LOG")));
     HIPCHK2(hipMalloc(&c->Dq, (size_t)n * ld * esz));
-    HIPCHK2(hipMalloc(&c->Lq, (size_t)n * ld * esz));
     HIPCHK2(hipMalloc(&c->Dq_src, (size_t)n * ld * esz));
-    HIPCHK2(hipMalloc(&c->Lq_src, (size_t)n * ld * esz));
     HIPCHK2(hipMalloc(&c->diagq, (size_t)n * sizeof(long long)));
     HIPCHK2(hipMalloc(&c->diag_src, (size_t)n * sizeof(long long)));
     HIPCHK2(hipMalloc(&c->pi, (size_t)n * sizeof(int)));
     HIPCHK2(hipMalloc(&c->ipi, (size_t)n * sizeof(int)));
+    HIPCHK2(hipMalloc(&c->ltab, 128 * sizeof(double2)));
+    {
+        double tab[256];
+        for (int j = 0; j < 128; ++j) {
+            const double cj = 1.0 + ((double)j + 0.5) * (1.0 / 128);
+            tab[2 * j] = 1.0 / cj;
+            tab[2 * j + 1] = std::log(cj);
+        }
+        HIPCHK2(hipMemcpy(c->ltab, tab, sizeof(tab), hipMemcpyHostToDevice));
+    }
     for (int g = 0; g < 3; ++g) {
         HIPCHK2(hipMalloc(&c->SD[g], (size_t)c->kcap * ld * sizeof(long long)));
         HIPCHK2(hipMalloc(&c->SL[g], (size_t)c->kcap * ld * sizeof(long long)));
@@ -1837,9 +2412,7 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     HIPCHK2(hipHostGetDevicePointer((void **)&c->hsum_dev, c->hsum, 0));
     HIPCHK2(hipMalloc(&c->blocks, (size_t)c->kcap * c->kcap * 4 * sizeof(long long)));
     HIPCHK2(hipMemsetAsync(c->Dq, 0, (size_t)n * ld * esz, s));
-    HIPCHK2(hipMemsetAsync(c->Lq, 0, (size_t)n * ld * esz, s));
     HIPCHK2(hipMemsetAsync(c->Dq_src, 0, (size_t)n * ld * esz, s));
-    HIPCHK2(hipMemsetAsync(c->Lq_src, 0, (size_t)n * ld * esz, s));
     HIPCHK2(hipMemsetAsync(c->slot_size, 0, (size_t)c->kcap * sizeof(int), s));
     HIPCHK2(hipMemsetAsync(c->slot_label, 0, (size_t)c->kcap * sizeof(int), s));
     HIPCHK2(hipMemsetAsync(c->sc, 0, sizeof(DevScalars), s));
@@ -1855,14 +2428,20 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
         HIPCHK2(hipMemcpyAsync(tmpD, D, nn * sizeof(double), hipMemcpyHostToDevice, s));
     }
     k_check<<<gb, 256, 0, s>>>(tmpD, (int)n, flags, mx);
-    if (logD) {
-        HIPCHK2(hipMemcpyAsync(tmpL, logD, nn * sizeof(double), hipMemcpyHostToDevice, s));
-    } else {
-        k_make_log<<<gb, 256, 0, s>>>(tmpD, tmpL, (int)n);
-    }
-    k_maxabs<<<gb, 256, 0, s>>>(tmpL, nn, flags + 1, mx + 1);
-    unsigned hflags[2];
-    u64 hmx[2];
+    unsigned hflags[2] = {0, 0};
+    u64 hmx[2] = {0, 0};
+    auto stage_log = [&]() -> hipError_t {   // tmpL = logD (given or computed), its max and finiteness flag
+        if (logD) {
+            hipError_t e = hipMemcpyAsync(tmpL, logD, nn * sizeof(double), hipMemcpyHostToDevice, s);
+            if (e != hipSuccess) return e;
+        } else {
+            k_make_log<<<gb, 256, 0, s>>>(tmpD, tmpL, (int)n);
+        }
+        k_maxabs<<<gb, 256, 0, s>>>(tmpL, nn, flags + 1, mx + 1);
+        return hipSuccess;
+    };
+    const bool log_staged = !derived;
+    if (!derived) HIPCHK2(stage_log());
     HIPCHK2(hipMemcpyAsync(hflags, flags, sizeof(hflags), hipMemcpyDeviceToHost, s));
     HIPCHK2(hipMemcpyAsync(hmx, mx, sizeof(hmx), hipMemcpyDeviceToHost, s));
     HIPCHK2(hipStreamSynchronize(s));
@@ -1873,18 +2452,50 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
         cleanup();
         return fail(c, RC_ERR_DOMAIN, "off-diagonal entries of D must be positive (log D = -Inf / NaN otherwise).");
     }
-    if (hflags[1] & 2u) { cleanup(); return fail(c, RC_ERR_DOMAIN, "logD must be finite."); }
-    double maxD, maxL;
+    double maxD, maxL = 0;
     std::memcpy(&maxD, &hmx[0], 8);
-    std::memcpy(&maxL, &hmx[1], 8);
     c->eD = quant_exponent(n, maxD, c->bits);
+    if (c->bits == 64) k_quantize<long long><<<gb, 256, 0, s>>>(tmpD, (int)n, c->ld, c->eD, (long long *)c->Dq_src, c->diag_src);
+    else k_quantize<int><<<gb, 256, 0, s>>>(tmpD, (int)n, c->ld, c->eD, (int *)c->Dq_src, c->diag_src);
+    if (derived) {
+        long long *mn = nullptr;
+        HIPCHK2(hipMalloc(&mn, sizeof(long long)));
+        const long long big = 0x7fffffffffffffffll;
+        HIPCHK2(hipMemcpyAsync(mn, &big, sizeof(big), hipMemcpyHostToDevice, s));
+        k_derived_scan<<<gb, 256, 0, s>>>((const long long *)c->Dq_src, (int)n, c->ld, c->eD, c->ltab, mn, mx + 1);
+        long long hmn = 0;
+        hipError_t e1 = hipMemcpyAsync(&hmn, mn, sizeof(hmn), hipMemcpyDeviceToHost, s);
+        hipError_t e2 = hipMemcpyAsync(&hmx[1], mx + 1, sizeof(u64), hipMemcpyDeviceToHost, s);
+        hipError_t e3 = hipStreamSynchronize(s);
+        (void)hipFree(mn);
+        HIPCHK2(e1); HIPCHK2(e2); HIPCHK2(e3);
+        if (n > 1 && hmn <= 0) derived = false;   // an off-diagonal entry quantises to zero: keep logD of the exact doubles
+    }
+    if (!derived && !log_staged) {
+        // (stored mode reached through the fallback above: stage logD now)
+        HIPCHK2(hipMemsetAsync(mx + 1, 0, sizeof(u64), s));
+        HIPCHK2(stage_log());
+        HIPCHK2(hipMemcpyAsync(hflags, flags, sizeof(hflags), hipMemcpyDeviceToHost, s));
+        HIPCHK2(hipMemcpyAsync(hmx, mx, sizeof(hmx), hipMemcpyDeviceToHost, s));
+        HIPCHK2(hipStreamSynchronize(s));
+    }
+    if (hflags[1] & 2u) { cleanup(); return fail(c, RC_ERR_DOMAIN, "logD must be finite."); }
+    std::memcpy(&maxL, &hmx[1], 8);
     c->eL = quant_exponent(n, maxL, c->bits);
-    if (c->bits == 64) {
-        k_quantize<long long><<<gb, 256, 0, s>>>(tmpD, (int)n, c->ld, c->eD, (long long *)c->Dq_src, c->diag_src);
-        k_quantize<long long><<<gb, 256, 0, s>>>(tmpL, (int)n, c->ld, c->eL, (long long *)c->Lq_src, nullptr);
-    } else {
-        k_quantize<int><<<gb, 256, 0, s>>>(tmpD, (int)n, c->ld, c->eD, (int *)c->Dq_src, c->diag_src);
-        k_quantize<int><<<gb, 256, 0, s>>>(tmpL, (int)n, c->ld, c->eL, (int *)c->Lq_src, nullptr);
+    if (derived && maxL > 0.0) {
+        // rc_qlog rounds with the magic-number trick, which needs |logD·2^eL| < 2^51 (binding only for n < 2048)
+        int ex;
+        std::frexp(maxL, &ex);
+        c->eL = std::min(c->eL, 50 - ex);
+    }
+    c->derived = derived;
+    if (!derived) {
+        HIPCHK2(hipMalloc(&c->Lq, (size_t)n * ld * esz));
+        HIPCHK2(hipMalloc(&c->Lq_src, (size_t)n * ld * esz));
+        HIPCHK2(hipMemsetAsync(c->Lq, 0, (size_t)n * ld * esz, s));
+        HIPCHK2(hipMemsetAsync(c->Lq_src, 0, (size_t)n * ld * esz, s));
+        if (c->bits == 64) k_quantize<long long><<<gb, 256, 0, s>>>(tmpL, (int)n, c->ld, c->eL, (long long *)c->Lq_src, nullptr);
+        else k_quantize<int><<<gb, 256, 0, s>>>(tmpL, (int)n, c->ld, c->eL, (int *)c->Lq_src, nullptr);
     }
     // until rc_set_state chooses a cluster-contiguous layout the internal order is the caller's
     c->h_pi.resize((size_t)n); c->h_ipi.resize((size_t)n);
@@ -1892,7 +2503,7 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     HIPCHK2(hipMemcpyAsync(c->pi, c->h_pi.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
     HIPCHK2(hipMemcpyAsync(c->ipi, c->h_ipi.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
     HIPCHK2(hipMemcpyAsync(c->Dq, c->Dq_src, (size_t)n * ld * esz, hipMemcpyDeviceToDevice, s));
-    HIPCHK2(hipMemcpyAsync(c->Lq, c->Lq_src, (size_t)n * ld * esz, hipMemcpyDeviceToDevice, s));
+    if (!derived) HIPCHK2(hipMemcpyAsync(c->Lq, c->Lq_src, (size_t)n * ld * esz, hipMemcpyDeviceToDevice, s));
     HIPCHK2(hipMemcpyAsync(c->diagq, c->diag_src, (size_t)n * sizeof(long long), hipMemcpyDeviceToDevice, s));
     HIPCHK2(hipStreamSynchronize(s));
     HIPCHK2(hipGetLastError());
@@ -1922,6 +2533,8 @@ static int32_t alloc_ctx(int64_t n, int32_t storage_bits, int32_t device_id, int
     c->dbg = getenv("RC_DEBUG_FLAGS") ? atoi(getenv("RC_DEBUG_FLAGS")) : 0;
     c->prefetch = !(getenv("RC_NO_PREFETCH") && atoi(getenv("RC_NO_PREFETCH")));
     c->relayout = !(getenv("RC_NO_RELAYOUT") && atoi(getenv("RC_NO_RELAYOUT")));
+    if (getenv("RC_SYM_VARIANT")) c->sym_variant = atoi(getenv("RC_SYM_VARIANT"));
+    if (getenv("RC_SYMW_PER_CU")) c->symw_per_cu = std::max(1, atoi(getenv("RC_SYMW_PER_CU")));
     if (getenv("RC_BULK_KERNEL")) c->bulk_kernel = !strcmp(getenv("RC_BULK_KERNEL"), "sym") ? 1 : (!strcmp(getenv("RC_BULK_KERNEL"), "perm") ? 0 : -1);
     if (getenv("RC_RES_THREADS")) c->res_threads = (atoi(getenv("RC_RES_THREADS")) == 256) ? 256 : 512;
     if (getenv("RC_SYM_ITEM_TILES")) c->sym_item_tiles = std::max(1, atoi(getenv("RC_SYM_ITEM_TILES")));
@@ -1943,9 +2556,11 @@ static int32_t finish_create(rc_ctx *c)
         if (getenv("RC_BULK_ROWS")) c->rows_per_split = std::max(1, atoi(getenv("RC_BULK_ROWS")));
         const int per_cu = getenv("RC_BULK_PER_CU") ? atoi(getenv("RC_BULK_PER_CU")) : 2;
         c->bulk_lds = per_cu > 0 ? (size_t)((150 * 1024 / per_cu) & ~1023) : 0;
-        if (c->bulk_lds > 64 * 1024)
+        if (c->bulk_lds > 64 * 1024) {
             (void)hipFuncSetAttribute(c->bits == 64 ? (const void *)k_bulk<long long> : (const void *)k_bulk<int>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->bulk_lds);
+            (void)hipFuncSetAttribute((const void *)k_bulk<long long, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->bulk_lds);
+        }
     }
     // kernels whose dynamic LDS can exceed the 64 KiB default (large kcap)
     const size_t lds_r = std::max(tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64), 2 * sizeof(int) * (size_t)c->kcap);
@@ -2016,7 +2631,9 @@ extern "C" int32_t rc_get_matrix(rc_ctx *c, int32_t which, double *out_n_by_n)
     const int gb = (int)std::min<size_t>((nn + 255) / 256, 8192);
     const void *Q = which ? c->Lq_src : c->Dq_src;  // the caller's point order
     const double scale = std::ldexp(1.0, -(which ? c->eL : c->eD));
-    if (c->bits == 64) k_dequantize<long long><<<gb, 256, 0, c->sA>>>((const long long *)Q, c->n, c->ld, scale, tmp);
+    if (which && c->derived)
+        k_derived_matrix<<<gb, 256, 0, c->sA>>>((const long long *)c->Dq_src, c->n, c->ld, c->eD, std::ldexp(1.0, c->eL), scale, c->ltab, tmp);
+    else if (c->bits == 64) k_dequantize<long long><<<gb, 256, 0, c->sA>>>((const long long *)Q, c->n, c->ld, scale, tmp);
     else k_dequantize<int><<<gb, 256, 0, c->sA>>>((const int *)Q, c->n, c->ld, scale, tmp);
     hipError_t e = hipMemcpyAsync(out_n_by_n, tmp, nn * sizeof(double), hipMemcpyDeviceToHost, c->sA);
     if (e == hipSuccess) e = hipStreamSynchronize(c->sA);
@@ -2134,7 +2751,7 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
         dim3 g((unsigned)std::min(64, (n + 255) / 256), (unsigned)n);
         if (c->bits == 64) {
             k_relayout<long long><<<g, 256, 0, c->sA>>>((const long long *)c->Dq_src, c->ipi, n, c->ld, (long long *)c->Dq);
-            k_relayout<long long><<<g, 256, 0, c->sA>>>((const long long *)c->Lq_src, c->ipi, n, c->ld, (long long *)c->Lq);
+            if (!c->derived) k_relayout<long long><<<g, 256, 0, c->sA>>>((const long long *)c->Lq_src, c->ipi, n, c->ld, (long long *)c->Lq);
         } else {
             k_relayout<int><<<g, 256, 0, c->sA>>>((const int *)c->Dq_src, c->ipi, n, c->ld, (int *)c->Dq);
             k_relayout<int><<<g, 256, 0, c->sA>>>((const int *)c->Lq_src, c->ipi, n, c->ld, (int *)c->Lq);
@@ -2195,7 +2812,21 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
     // point order (few label runs); both kernels are exact for any labelling, so a stale run count only costs speed.
     bool use_sym = (c->bulk_kernel == 1 || (c->bulk_kernel < 0 && (long long)c->hsum->runs * 32 <= (long long)c->n));
     c->last_bulk_kernel = use_sym ? 1 : 0;
-    if (use_sym) {
+    const int sym_variant = c->sym_variant >= 0 ? c->sym_variant : (c->derived ? 2 : 0);
+    if (use_sym && c->bits == 64 && sym_variant >= 1) {
+        const int ncb = (c->n + RC_SW_COLS - 1) / RC_SW_COLS;
+        int nitems = 0;
+        for (int J = 0; J < ncb; ++J) nitems += (std::min(RC_SW_COLS * J + RC_SW_COLS, c->n) + RC_SW_ROWS - 1) / RC_SW_ROWS;
+        const int nblocks = std::max(1, std::min((nitems + 3) / 4, c->symw_per_cu * c->num_cus));
+        if (sym_variant == 2 && c->derived)
+            k_bulk_syml<true><<<nblocks, 256, 0, c->sB>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems);
+        else if (sym_variant == 2)
+            k_bulk_syml<false><<<nblocks, 256, 0, c->sB>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems);
+        else if (c->derived)
+            k_bulk_symw<true><<<nblocks, 256, 0, c->sB>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems);
+        else
+            k_bulk_symw<false><<<nblocks, 256, 0, c->sB>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems);
+    } else if (use_sym) {
         const int TC = (c->bits == 64) ? RC_SYM_TC : RC_SYM32_TC;
         const int ncb = (c->n + TC - 1) / TC;
         int nitems = 0;
@@ -2204,14 +2835,18 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
             nitems += (ntile + c->sym_item_tiles - 1) / c->sym_item_tiles;
         }
         const int nblocks = std::max(1, std::min(nitems, 2 * c->num_cus));
-        if (c->bits == 64)
-            k_bulk_sym<<<nblocks, 256, 0, c->sB>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), c->sym_item_tiles, nitems);
+        if (c->bits == 64 && c->derived)
+            k_bulk_sym<true><<<nblocks, 256, 0, c->sB>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), c->sym_item_tiles, nitems);
+        else if (c->bits == 64)
+            k_bulk_sym<false><<<nblocks, 256, 0, c->sB>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), c->sym_item_tiles, nitems);
         else
             k_bulk_sym32<<<nblocks, 256, 0, c->sB>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), c->sym_item_tiles, nitems);
     } else {
         // bulk_lds: unused dynamic LDS that caps k_bulk at bulk_blocks_per_cu workgroups per CU, which (i) spreads the
         // grid evenly over the CUs and (ii) leaves registers/wave slots on every CU for the concurrent k_resolve
-        if (c->bits == 64)
+        if (c->bits == 64 && c->derived)
+            k_bulk<long long, true><<<gb, 256, c->bulk_lds, c->sB>>>(V, c->rows_per_split, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1));
+        else if (c->bits == 64)
             k_bulk<long long><<<gb, 256, c->bulk_lds, c->sB>>>(V, c->rows_per_split, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1));
         else
             k_bulk<int><<<gb, 256, c->bulk_lds, c->sB>>>(V, c->rows_per_split, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1));
@@ -3305,7 +3940,9 @@ extern "C" int32_t rc_bulk_kernel_info(rc_ctx *c, int32_t *which, double *algori
     if (!c) return fail(c, RC_ERR_ARG, "rc_bulk_kernel_info: NULL ctx");
     const double n = c->n, esz = c->bits / 8.0;
     if (which) *which = c->last_bulk_kernel;
-    if (algorithmic_bytes) *algorithmic_bytes = c->last_bulk_kernel ? 2.0 * (n * (n + 1) / 2) * esz : 2.0 * n * n * esz;
+    // matrices the kernel reads: D and logD, or D alone when logD is derived on the fly
+    const double nmat = c->derived ? 1.0 : 2.0;
+    if (algorithmic_bytes) *algorithmic_bytes = c->last_bulk_kernel ? nmat * (n * (n + 1) / 2) * esz : nmat * n * n * esz;
     return RC_OK;
 }
 

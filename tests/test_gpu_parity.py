@@ -56,9 +56,11 @@ def test_device_logD_matches_host_within_one_quantum():
     SL = orc.Lq @ onehot
     for lab in np.unique(init):
         sd, sl, eD, eL = ctx.debug_rowsums(int(lab))
-        assert eL == orc.eL
-        # ≤ 1 quantum per summed entry
-        assert np.max(np.abs(sl - SL[:, lab - 1])) <= np.sum(init == lab)
+        # the derived-logD mode caps its exponent, so compare in real units: ≤ 1 quantum (of the coarser
+        # of the two grids) per summed entry, plus the 5e-16 by which the library's table log may differ from libm's
+        quantum = np.ldexp(1.0, -min(eL, orc.eL))
+        err = np.abs(sl * np.ldexp(1.0, -eL) - SL[:, lab - 1] * np.ldexp(1.0, -orc.eL))
+        assert np.max(err) <= np.sum(init == lab) * (quantum + 1e-15)
     ctx.close()
 
 
