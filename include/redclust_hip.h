@@ -160,6 +160,9 @@ int32_t rc_event_overhead_ms(rc_ctx *ctx, double *out);
  * contiguous in the point order, override with RC_BULK_KERNEL=perm|sym|auto) — and the matrix bytes that kernel
  * has to read per launch. */
 int32_t rc_bulk_kernel_info(rc_ctx *ctx, int32_t *which, double *algorithmic_bytes);
+/* The kernel's name as a profiler shows it (k_bulk<long long, false>, k_bulk_sym<false>, k_bulk_syml<true> ...: the
+ * template flag says whether logD is derived on the fly). */
+const char *rc_bulk_kernel_name(rc_ctx *ctx);
 /* Force the kernel: -1 automatic, 0 k_bulk, 1 k_bulk_sym (tests / measurements; results are identical). */
 int32_t rc_set_bulk_kernel(rc_ctx *ctx, int32_t which);
 /* Internal point layout.  rc_set_state stores D and logD with the points of a cluster contiguous (a stable sort of

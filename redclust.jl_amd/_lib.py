@@ -105,6 +105,7 @@ SIGNATURES = {
     "rc_debug_rowsums": (C.c_int32, [C.c_void_p, C.c_int64, _ip, _ip, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rc_bulk_kernel_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "rc_set_bulk_kernel": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "rc_bulk_kernel_name": (C.c_char_p, [C.c_void_p]),
     "rc_within_between": (C.c_int32, [C.c_void_p, C.POINTER(RcWbStats)]),
     "rc_run_chain": (C.c_int32, [C.c_void_p, C.POINTER(RcChainOptions), C.POINTER(RcChainOutputs)]),
     "rc_scalar_updates": (C.c_int32, [C.c_uint64, C.c_uint64, C.c_double, C.c_double, _ip, C.c_int64, C.c_int64, C.c_double,
@@ -299,6 +300,9 @@ class Context:
         w, b = C.c_int32(), C.c_double()
         self._chk(self.L.rc_bulk_kernel_info(self.h, C.byref(w), C.byref(b)))
         return ("k_bulk_sym" if w.value else "k_bulk"), b.value
+
+    def bulk_kernel_name(self) -> str:
+        return self.L.rc_bulk_kernel_name(self.h).decode()
 
     def set_bulk_kernel(self, which):
         self._chk(self.L.rc_set_bulk_kernel(self.h, {"auto": -1, "perm": 0, "sym": 1}[which]))

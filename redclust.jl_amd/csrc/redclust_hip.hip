@@ -3947,6 +3947,18 @@ extern "C" int32_t rc_bulk_kernel_info(rc_ctx *c, int32_t *which, double *algori
 }
 
 
+// name of the row-reduction kernel the last enqueued sweep used, as a profiler shows it
+extern "C" const char *rc_bulk_kernel_name(rc_ctx *c)
+{
+    if (!c) return "";
+    if (!c->last_bulk_kernel) return c->derived ? "k_bulk<long long, true>" : (c->bits == 64 ? "k_bulk<long long, false>" : "k_bulk<int, false>");
+    if (c->bits != 64) return "k_bulk_sym32";
+    const int v = c->sym_variant >= 0 ? c->sym_variant : (c->derived ? 2 : 0);
+    if (v == 2) return c->derived ? "k_bulk_syml<true>" : "k_bulk_syml<false>";
+    if (v == 1) return c->derived ? "k_bulk_symw<true>" : "k_bulk_symw<false>";
+    return c->derived ? "k_bulk_sym<true>" : "k_bulk_sym<false>";
+}
+
 extern "C" int32_t rc_layout_info(rc_ctx *c, int32_t *n_relayouts, int32_t *label_runs)
 {
     if (!c) return fail(c, RC_ERR_ARG, "rc_layout_info: NULL ctx");
