@@ -118,6 +118,7 @@ struct SweepArgs {
     unsigned k0, k1, sw_lo, sw_hi;
     int t;    // internal sweep index since rc_set_state: selects key / perm generations
     int own_gen, next_gen;  // S generation read (and corrected in place); generation being filled for the next sweep (-1: none)
+    int zero_gen;           // S generation this launch clears for the row reduction two sweeps ahead (-1: none)
     int dbg;  // timing ablations only (RC_DEBUG_FLAGS): 1 = skip candidate loop, 2 = skip grid barrier, 4 = skip gumbel
 };
 
@@ -415,16 +416,7 @@ __global__ __launch_bounds__(256) void k_bulk(View V, int rows_per_split, int wg
         for (int q = 0; q < C; ++q) l[q] = (j == col0 + q) ? 0 : (T)rc_qlog((long long)d[q], qeD, qsL, ltab_sh);
         return l;
     };
-    {   // clear generation zgen, rows < slot_hi (rows above are zero by invariant)
-        const int hi = V.sc->slot_hi;
-        const size_t total2 = (size_t)hi * ld / 2;
-        const size_t nthreads = (size_t)gridDim.x * gridDim.y * 256;
-        const size_t me = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
-        ll2 *zd = (ll2 *)V.SD[zgen], *zl = (ll2 *)V.SL[zgen];
-        const ll2 z = {0, 0};
-        for (size_t q = me; q < total2; q += nthreads) { zd[q] = z; zl[q] = z; }
-        if (me == 0) { *V.work[0] = 0; *V.work[1] = 0; }  // keep k_bulk_sym's work counters armed if the kernels alternate
-    }
+    (void)zgen;  // the generation for the next sweep is cleared by k_resolve (SweepArgs.zero_gen)
     const int i = (blockIdx.x * 256 + threadIdx.x) * C;
     const int p0 = blockIdx.y * rows_per_split;
     const int p1 = min(V.n, p0 + rows_per_split);
@@ -507,15 +499,7 @@ __global__ __launch_bounds__(256) void k_bulk_sym(View V, int wgen, int zgen, in
     __shared__ int cchk[RC_SYM_TC / 8], rchk[RC_SYM_TR / 8];  // slot of an 8-wide chunk if uniform, else -2
     const int tid = threadIdx.x;
     const size_t ld = (size_t)V.ld;
-    {   // clear generation zgen, rows < slot_hi (rows above are zero by invariant); re-arm the other work counter
-        const int hi = V.sc->slot_hi;
-        const size_t total2 = (size_t)hi * ld / 2;
-        const size_t nthreads = (size_t)gridDim.x * 256;
-        ll2 *zd = (ll2 *)V.SD[zgen], *zl = (ll2 *)V.SL[zgen];
-        const ll2 z = {0, 0};
-        for (size_t q = (size_t)blockIdx.x * 256 + tid; q < total2; q += nthreads) { zd[q] = z; zl[q] = z; }
-        if (blockIdx.x == 0 && tid == 0) *V.work[cgen ^ 1] = 0;
-    }
+    (void)zgen;  // generations are cleared and work counters re-armed by k_resolve (SweepArgs.zero_gen)
     const long long *__restrict__ Dq = (const long long *)V.Dq;
     const long long *__restrict__ Lq = (const long long *)V.Lq;
     const int *__restrict__ slot = V.snap[sgen];
@@ -772,15 +756,7 @@ __global__ __launch_bounds__(256) void k_bulk_symw(View V, int wgen, int zgen, i
     const int tid = threadIdx.x, lane = tid & 63;
     const size_t ld = (size_t)V.ld;
     if (DERIVED && tid < 128) ltab_sh[tid] = V.ltab[tid];
-    {   // clear generation zgen, rows < slot_hi (rows above are zero by invariant); re-arm the other work counter
-        const int hi = V.sc->slot_hi;
-        const size_t total2 = (size_t)hi * ld / 2;
-        const size_t nthreads = (size_t)gridDim.x * 256;
-        ll2 *zd = (ll2 *)V.SD[zgen], *zl = (ll2 *)V.SL[zgen];
-        const ll2 z = {0, 0};
-        for (size_t q = (size_t)blockIdx.x * 256 + tid; q < total2; q += nthreads) { zd[q] = z; zl[q] = z; }
-        if (blockIdx.x == 0 && tid == 0) *V.work[cgen ^ 1] = 0;
-    }
+    (void)zgen;  // generations are cleared and work counters re-armed by k_resolve (SweepArgs.zero_gen)
     __syncthreads();  // the table is visible; from here on the waves are on their own
     const long long *__restrict__ Dq = (const long long *)V.Dq;
     const long long *__restrict__ Lq = (const long long *)V.Lq;
@@ -961,15 +937,7 @@ __global__ __launch_bounds__(256) void k_bulk_syml(View V, int wgen, int zgen, i
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t ld = (size_t)V.ld;
     if (DERIVED && tid < 128) ltab_sh[tid] = V.ltab[tid];
-    {   // clear generation zgen, rows < slot_hi (rows above are zero by invariant); re-arm the other work counter
-        const int hi = V.sc->slot_hi;
-        const size_t total2 = (size_t)hi * ld / 2;
-        const size_t nthreads = (size_t)gridDim.x * 256;
-        ll2 *zd = (ll2 *)V.SD[zgen], *zl = (ll2 *)V.SL[zgen];
-        const ll2 z = {0, 0};
-        for (size_t q = (size_t)blockIdx.x * 256 + tid; q < total2; q += nthreads) { zd[q] = z; zl[q] = z; }
-        if (blockIdx.x == 0 && tid == 0) *V.work[cgen ^ 1] = 0;
-    }
+    (void)zgen;  // generations are cleared and work counters re-armed by k_resolve (SweepArgs.zero_gen)
     __syncthreads();  // the table is visible; from here on the waves are on their own
     long long (*tt)[RC_SL_R][RC_SL_P] = tl[wv];
     const long long *__restrict__ Dq = (const long long *)V.Dq;
@@ -1148,15 +1116,7 @@ __global__ __launch_bounds__(256) void k_bulk_sym32(View V, int wgen, int zgen, 
     __shared__ int cchk[RC_SYM32_TC / 8], rchk[RC_SYM_TR / 8];
     const int tid = threadIdx.x;
     const size_t ld = (size_t)V.ld;
-    {
-        const int hi = V.sc->slot_hi;
-        const size_t total2 = (size_t)hi * ld / 2;
-        const size_t nthreads = (size_t)gridDim.x * 256;
-        ll2 *zd = (ll2 *)V.SD[zgen], *zl = (ll2 *)V.SL[zgen];
-        const ll2 z = {0, 0};
-        for (size_t q = (size_t)blockIdx.x * 256 + tid; q < total2; q += nthreads) { zd[q] = z; zl[q] = z; }
-        if (blockIdx.x == 0 && tid == 0) *V.work[cgen ^ 1] = 0;
-    }
+    (void)zgen;  // generations are cleared and work counters re-armed by k_resolve (SweepArgs.zero_gen)
     const int *__restrict__ Dq = (const int *)V.Dq;
     const int *__restrict__ Lq = (const int *)V.Lq;
     const int *__restrict__ slot = V.snap[sgen];
@@ -1987,8 +1947,21 @@ __global__ __launch_bounds__(RC_RES_THREADS) void k_resolve(View V, SweepArgs sa
         ++round;
         if (round > V.n) break;  // cannot happen: every round finalises at least the first changer
     }
+    if (sa.zero_gen >= 0 && (blockIdx.x > 0 || G == 1)) {
+        // The blocks that have no epilogue work clear the S generation that held the sums of the labels before this
+        // sweep: nobody reads it any more, the row reduction of sweep t+2 fills it and k_resolve(t+1) adds its
+        // corrections to it (both ordered after this launch).  Rows >= slot_hi are zero by invariant.
+        const size_t total2 = (size_t)T.misc[7] * (size_t)V.ld / 2;
+        const size_t nthreads = (size_t)(G > 1 ? G - 1 : 1) * blockDim.x;
+        const size_t me = (size_t)(G > 1 ? blockIdx.x - 1 : 0) * blockDim.x + threadIdx.x;
+        ll2 *zd = (ll2 *)V.SD[sa.zero_gen], *zl = (ll2 *)V.SL[sa.zero_gen];
+        const ll2 z = {0, 0};
+        for (size_t q = me; q < total2; q += nthreads) { zd[q] = z; zl[q] = z; }
+    }
     if (blockIdx.x == 0) {
         __syncthreads();
+        // the row reduction of this sweep is complete (stream order): re-arm its work counter for sweep t+2
+        if (threadIdx.x == 0) *V.work[kg] = 0;
         // re-arm the other key / chunk-word / barrier generation for the next sweep (its last user, sweep t-1, is done)
         for (int q = threadIdx.x; q < V.n + 2; q += blockDim.x) V.keys[kg ^ 1][q] = RC_KEY_NONE;
         for (int q = threadIdx.x; q < nchunks; q += blockDim.x) V.cword[kg ^ 1][q] = 0;
@@ -2114,7 +2087,10 @@ struct rc_ctx {
     int n = 0, ld = 0, kcap = 0;
     int eD = 0, eL = 0;
     hipStream_t sA = nullptr;  // resolve + observables (high priority)
-    hipStream_t sB = nullptr;  // row-bucket reduction (k_bulk)
+    hipStream_t sB = nullptr;  // row-bucket reduction (k_bulk) of even sweeps
+    hipStream_t sB2 = nullptr; // ... of odd sweeps: consecutive row reductions do not depend on each other (the S generation a
+                               // reduction fills is cleared by k_resolve two sweeps earlier), so they may overlap and no launch gap
+                               // separates them
     void *Dq = nullptr, *Lq = nullptr;  // int64 or int32 fixed point, INTERNAL point order (what the kernels read)
     void *Dq_src = nullptr, *Lq_src = nullptr;  // the same matrices in the caller's point order (source of every re-layout)
     long long *diagq = nullptr, *diag_src = nullptr;
@@ -2284,6 +2260,7 @@ static void free_all(rc_ctx *c)
         if (c->ev_res[q]) (void)hipEventDestroy(c->ev_res[q]);
     }
     if (c->sB && c->sB != c->sA) (void)hipStreamDestroy(c->sB);
+    if (c->sB2 && c->sB2 != c->sA && c->sB2 != c->sB) (void)hipStreamDestroy(c->sB2);
     if (c->sA) (void)hipStreamDestroy(c->sA);
     delete c;
 }
@@ -2315,6 +2292,7 @@ extern "C" int32_t rc_destroy(rc_ctx *ctx)
     (void)hipSetDevice(ctx->dev);
     if (ctx->sA) (void)hipStreamSynchronize(ctx->sA);
     if (ctx->sB) (void)hipStreamSynchronize(ctx->sB);
+    if (ctx->sB2) (void)hipStreamSynchronize(ctx->sB2);
     free_all(ctx);
     return RC_OK;
 }
@@ -2331,9 +2309,12 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     HIPCHK(c, hipStreamCreateWithPriority(&c->sA, hipStreamNonBlocking, pr_greatest));
     if (getenv("RC_ONE_STREAM") && atoi(getenv("RC_ONE_STREAM"))) {
         c->sB = c->sA;  // experiment: everything in order on one stream, no cross-stream events
+        c->sB2 = c->sA;
         c->prefetch = false;
     } else {
         HIPCHK(c, hipStreamCreateWithPriority(&c->sB, hipStreamNonBlocking, pr_least));
+        if (getenv("RC_ONE_BULK_STREAM") && atoi(getenv("RC_ONE_BULK_STREAM"))) c->sB2 = c->sB;
+        else HIPCHK(c, hipStreamCreateWithPriority(&c->sB2, hipStreamNonBlocking, pr_least));
     }
     for (int q = 0; q < 4; ++q) {
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_bulk[q], hipEventDisableTiming));
@@ -2651,6 +2632,7 @@ extern "C" int32_t rc_set_params(rc_ctx *c, const rc_params *P)
     HIPCHK(c, hipSetDevice(c->dev));
     HIPCHK(c, hipStreamSynchronize(c->sA));
     HIPCHK(c, hipStreamSynchronize(c->sB));
+    HIPCHK(c, hipStreamSynchronize(c->sB2));
     c->P = *P;
     c->lg_memo1.clear();
     c->lg_memo2.clear();
@@ -2693,6 +2675,7 @@ static int32_t sync_and_check(rc_ctx *c, bool both = false)
     HIPCHK(c, hipStreamSynchronize(c->sA));
     if (both) {
         HIPCHK(c, hipStreamSynchronize(c->sB));
+        HIPCHK(c, hipStreamSynchronize(c->sB2));
         int32_t rc = drain_events(c);
         if (rc != RC_OK) return rc;
     }
@@ -2718,6 +2701,7 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
     HIPCHK(c, hipSetDevice(c->dev));
     HIPCHK(c, hipStreamSynchronize(c->sA));
     HIPCHK(c, hipStreamSynchronize(c->sB));
+    HIPCHK(c, hipStreamSynchronize(c->sB2));
     const int n = c->n;
     // clustsizes = counts(clusts, 1:n), K = sum(clustsizes .> 0)  (types.jl:135-136); slots in label order
     std::vector<int> size_by_label((size_t)n + 1, 0);
@@ -2798,7 +2782,8 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
 // clears generation (t+1)%3.  Needs k_resolve(t-2) (perm, and the last reader of the generation being cleared).
 static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
 {
-    if (t >= 2) HIPCHK(c, hipStreamWaitEvent(c->sB, c->ev_res[(t - 2) & 3], 0));
+    const hipStream_t sb = (t & 1) ? c->sB2 : c->sB;
+    if (t >= 2) HIPCHK(c, hipStreamWaitEvent(sb, c->ev_res[(t - 2) & 3], 0));
     const int splits = (c->n + c->rows_per_split - 1) / c->rows_per_split;
     dim3 gb((unsigned)(c->ld / (c->bits == 64 ? 512 : 1024)), (unsigned)splits);
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
@@ -2806,7 +2791,7 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
     if (timed) {
         if (!c->ev_free.empty()) { ev = c->ev_free.back(); c->ev_free.pop_back(); }
         else { HIPCHK(c, hipEventCreate(&ev.first)); HIPCHK(c, hipEventCreate(&ev.second)); }
-        HIPCHK(c, hipEventRecord(ev.first, c->sB));
+        HIPCHK(c, hipEventRecord(ev.first, sb));
     }
     // Kernel choice.  k_bulk_sym reads half the bytes but wants the points of a cluster to be contiguous in the
     // point order (few label runs); both kernels are exact for any labelling, so a stale run count only costs speed.
@@ -2819,13 +2804,13 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
         for (int J = 0; J < ncb; ++J) nitems += (std::min(RC_SW_COLS * J + RC_SW_COLS, c->n) + RC_SW_ROWS - 1) / RC_SW_ROWS;
         const int nblocks = std::max(1, std::min((nitems + 3) / 4, c->symw_per_cu * c->num_cus));
         if (sym_variant == 2 && c->derived)
-            k_bulk_syml<true><<<nblocks, 256, 0, c->sB>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems);
+            k_bulk_syml<true><<<nblocks, 256, 0, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems);
         else if (sym_variant == 2)
-            k_bulk_syml<false><<<nblocks, 256, 0, c->sB>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems);
+            k_bulk_syml<false><<<nblocks, 256, 0, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems);
         else if (c->derived)
-            k_bulk_symw<true><<<nblocks, 256, 0, c->sB>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems);
+            k_bulk_symw<true><<<nblocks, 256, 0, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems);
         else
-            k_bulk_symw<false><<<nblocks, 256, 0, c->sB>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems);
+            k_bulk_symw<false><<<nblocks, 256, 0, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems);
     } else if (use_sym) {
         const int TC = (c->bits == 64) ? RC_SYM_TC : RC_SYM32_TC;
         const int ncb = (c->n + TC - 1) / TC;
@@ -2836,26 +2821,26 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
         }
         const int nblocks = std::max(1, std::min(nitems, 2 * c->num_cus));
         if (c->bits == 64 && c->derived)
-            k_bulk_sym<true><<<nblocks, 256, 0, c->sB>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), c->sym_item_tiles, nitems);
+            k_bulk_sym<true><<<nblocks, 256, 0, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), c->sym_item_tiles, nitems);
         else if (c->bits == 64)
-            k_bulk_sym<false><<<nblocks, 256, 0, c->sB>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), c->sym_item_tiles, nitems);
+            k_bulk_sym<false><<<nblocks, 256, 0, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), c->sym_item_tiles, nitems);
         else
-            k_bulk_sym32<<<nblocks, 256, 0, c->sB>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), c->sym_item_tiles, nitems);
+            k_bulk_sym32<<<nblocks, 256, 0, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), c->sym_item_tiles, nitems);
     } else {
         // bulk_lds: unused dynamic LDS that caps k_bulk at bulk_blocks_per_cu workgroups per CU, which (i) spreads the
         // grid evenly over the CUs and (ii) leaves registers/wave slots on every CU for the concurrent k_resolve
         if (c->bits == 64 && c->derived)
-            k_bulk<long long, true><<<gb, 256, c->bulk_lds, c->sB>>>(V, c->rows_per_split, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1));
+            k_bulk<long long, true><<<gb, 256, c->bulk_lds, sb>>>(V, c->rows_per_split, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1));
         else if (c->bits == 64)
-            k_bulk<long long><<<gb, 256, c->bulk_lds, c->sB>>>(V, c->rows_per_split, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1));
+            k_bulk<long long><<<gb, 256, c->bulk_lds, sb>>>(V, c->rows_per_split, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1));
         else
-            k_bulk<int><<<gb, 256, c->bulk_lds, c->sB>>>(V, c->rows_per_split, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1));
+            k_bulk<int><<<gb, 256, c->bulk_lds, sb>>>(V, c->rows_per_split, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1));
     }
     if (timed) {
-        HIPCHK(c, hipEventRecord(ev.second, c->sB));
+        HIPCHK(c, hipEventRecord(ev.second, sb));
         c->ev_pending.push_back(ev);
     }
-    HIPCHK(c, hipEventRecord(c->ev_bulk[t & 3], c->sB));
+    HIPCHK(c, hipEventRecord(c->ev_bulk[t & 3], sb));
     c->bulk_enq = t;
     return RC_OK;
 }
@@ -2932,6 +2917,7 @@ extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t 
         }
         sa.own_gen = c->inc_gen;
         sa.next_gen = -1;
+        sa.zero_gen = -1;
         k_resolve<<<c->G, res_threads, lds, c->sA>>>(V, sa, c->G);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(c->ev_res[t & 3], c->sA));
@@ -2945,6 +2931,7 @@ extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t 
     }
     sa.own_gen = (int)(t % 3);
     sa.next_gen = (int)((t + 1) % 3);
+    sa.zero_gen = (int)((t + 2) % 3);
     HIPCHK(c, hipStreamWaitEvent(c->sA, c->ev_bulk[t & 3], 0));
     k_resolve<<<c->G, res_threads, lds, c->sA>>>(V, sa, c->G);
     HIPCHK(c, hipGetLastError());
@@ -3468,6 +3455,7 @@ static int32_t apply_labels(rc_ctx *c, const std::vector<int64_t> &cur, const st
     const int n = c->n;
     HIPCHK(c, hipStreamSynchronize(c->sA));
     HIPCHK(c, hipStreamSynchronize(c->sB));
+    HIPCHK(c, hipStreamSynchronize(c->sB2));
     int32_t rc = drain_events(c);
     if (rc != RC_OK) return rc;
     std::vector<int> ssize((size_t)c->kcap), slabel((size_t)c->kcap);
