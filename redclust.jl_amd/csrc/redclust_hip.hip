@@ -272,6 +272,33 @@ __device__ __forceinline__ long long rc_qlog(long long dq, int eD, double sL, co
     return dq > 0 ? q : 0ll;   // padding and masked entries carry dq = 0
 }
 
+// The same function in two halves, so that a caller with several values can issue all table reads before the first
+// use (rc_qlog waits for its table entry before it can continue).
+struct QlogPrep { int k, j; double m; };
+__device__ __forceinline__ QlogPrep rc_qlog_prep(long long dq, int eD)
+{
+    const int lz = __clzll(dq);
+    const unsigned long long mant = (unsigned long long)dq << lz;
+    QlogPrep P;
+    P.k = 63 - lz - eD;
+    P.j = (int)(mant >> 56) & 127;
+    P.m = __longlong_as_double((long long)((mant >> 11) & 0x000fffffffffffffull) | 0x3ff0000000000000ll);
+    return P;
+}
+__device__ __forceinline__ long long rc_qlog_finish(long long dq, const QlogPrep &P, double2 t, double sL)
+{
+    const double r = fma(P.m, t.x, -1.0);
+    double p = fma(r, -1.0 / 6, 1.0 / 5);
+    p = fma(r, p, -1.0 / 4);
+    p = fma(r, p, 1.0 / 3);
+    p = fma(r, p, -1.0 / 2);
+    p = fma(r * r, p, r);
+    const double L = fma((double)P.k, 0.69314718055994530942, t.y + p);
+    const double v = fma(L, sL, 0x1.8p52);
+    const long long q = __double_as_longlong(v) - __double_as_longlong(0x1.8p52);
+    return dq > 0 ? q : 0ll;
+}
+
 // logD entry (row, col) in internal order, stored or derived; xd = Dq(row, col) when the caller has it already
 __device__ __forceinline__ long long rc_load_L(const View &V, int row, int col, long long xd)
 {
@@ -714,6 +741,7 @@ __global__ __launch_bounds__(256) void k_bulk_sym(View V, int wgen, int zgen, in
 //   overlap freely, and occupancy is bounded by registers only.
 // ---------------------------------------------------------------------------------------------------
 #define RC_SW_ROWS 64
+#define RC_SW_FINE 8    // rows per unit in the light column blocks handed out last (k_bulk_syml)
 #define RC_SW_COLS 128
 #define RC_SW_U 8
 
@@ -768,20 +796,13 @@ __global__ __launch_bounds__(256) void k_bulk_symw(View V, int wgen, int zgen, i
     const double qsL = V.qsL;
     int *counter = V.work[cgen];
     auto add64 = [](long long *p, long long v) { __hip_atomic_fetch_add((u64 *)p, (u64)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    // the first item of a wave is its own index (thousands of waves hitting one counter at launch serialise in L2);
-    // further items come from the shared counter
+    // Units are dealt round-robin to the waves: a shared work counter would be hit by thousands of waves at once
+    // (a returning atomic on one address costs ~25 ns each in L2: 100 µs for 4096 waves) and all units of one
+    // granularity cost the same anyway.
     const int nwaves = (int)gridDim.x * 4;
-    bool first = true;
-    for (;;) {
-        int item = 0;
-        if (first) {
-            item = (int)blockIdx.x * 4 + (tid >> 6);
-            first = false;
-        } else {
-            if (lane == 0) item = nwaves + atomicAdd(counter, 1);
-            item = __builtin_amdgcn_readfirstlane(item);
-        }
-        if (item >= nitems) break;
+    (void)counter;
+    for (int unit = (int)blockIdx.x * 4 + (tid >> 6); unit < nitems; unit += nwaves) {
+        int item = unit;
         int J = ncb - 1;
         for (;; --J) {   // heavy column blocks first
             const int cnt = (min(RC_SW_COLS * J + RC_SW_COLS, n) + RC_SW_ROWS - 1) / RC_SW_ROWS;
@@ -930,13 +951,21 @@ __device__ __forceinline__ void row16_sum4_dpp(long long &a, long long &b, long 
 }
 
 template <bool DERIVED>
-__global__ __launch_bounds__(256) void k_bulk_syml(View V, int wgen, int zgen, int sgen, int cgen, int nitems)
+__global__ __launch_bounds__(256) void k_bulk_syml(View V, int wgen, int zgen, int sgen, int cgen, int nitems, int jsplit)
 {
-    __shared__ __attribute__((aligned(16))) long long tl[4][2][RC_SL_R][RC_SL_P];   // [wave][matrix][row][octet-padded col]: 10 KiB per wave
-    __shared__ double2 ltab_sh[DERIVED ? 128 : 1];
+    // [wave][matrix][row][octet-padded col]: 10 KiB per wave, 40 KiB per block = four blocks (16 waves) per CU exactly.
+    // The log table of the derived mode (128 × 16 B) lives in the padding: entry j of a wave's private copy sits in
+    // the two spare elements of octet (j & 15) of tile row (j >> 4) [matrix = j >> 6, row = (j >> 4) & 3].
+    __shared__ __attribute__((aligned(16))) long long tl[4][2][RC_SL_R][RC_SL_P];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t ld = (size_t)V.ld;
-    if (DERIVED && tid < 128) ltab_sh[tid] = V.ltab[tid];
+    if (DERIVED) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j = lane + 64 * h;
+            *(double2 *)&tl[wv][j >> 6][(j >> 4) & 3][(j & 15) * RC_SL_O + 8] = V.ltab[j];
+        }
+    }
     (void)zgen;  // generations are cleared and work counters re-armed by k_resolve (SweepArgs.zero_gen)
     __syncthreads();  // the table is visible; from here on the waves are on their own
     long long (*tt)[RC_SL_R][RC_SL_P] = tl[wv];
@@ -951,28 +980,26 @@ __global__ __launch_bounds__(256) void k_bulk_syml(View V, int wgen, int zgen, i
     int *counter = V.work[cgen];
     const int tr = lane >> 4, tq = lane & 15;   // transposed role: tile row, column octet
     auto add64 = [](long long *p, long long v) { __hip_atomic_fetch_add((u64 *)p, (u64)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    // the first item of a wave is its own index (thousands of waves hitting one counter at launch serialise in L2);
-    // further items come from the shared counter
+    // Units are dealt round-robin to the waves: a shared work counter would be hit by thousands of waves at once
+    // (a returning atomic on one address costs ~25 ns each in L2: 100 µs for 4096 waves) and all units of one
+    // granularity cost the same anyway.
     const int nwaves = (int)gridDim.x * 4;
-    bool first = true;
-    for (;;) {
-        int item = 0;
-        if (first) {
-            item = (int)blockIdx.x * 4 + (tid >> 6);
-            first = false;
-        } else {
-            if (lane == 0) item = nwaves + atomicAdd(counter, 1);
-            item = __builtin_amdgcn_readfirstlane(item);
-        }
-        if (item >= nitems) break;
-        int J = ncb - 1;
-        for (;; --J) {   // heavy column blocks first
-            const int cnt = (min(RC_SW_COLS * J + RC_SW_COLS, n) + RC_SW_ROWS - 1) / RC_SW_ROWS;
+    (void)counter;
+    for (int unit = (int)blockIdx.x * 4 + (tid >> 6); unit < nitems; unit += nwaves) {
+        int item = unit;
+        // Work units: column block J (heavy blocks first) × a range of rows.  Blocks J >= jsplit are cut into 64-row
+        // units — at most one per resident wave — and the light blocks below jsplit, which are handed out last, into
+        // 8-row units, so that the tail of the launch is two tiles long instead of a whole 64-row unit (and a small
+        // problem still spreads over the chip).
+        int J = ncb - 1, g = RC_SW_ROWS;
+        for (;; --J) {
+            g = (J >= jsplit) ? RC_SW_ROWS : RC_SW_FINE;
+            const int cnt = (min(RC_SW_COLS * J + RC_SW_COLS, n) + g - 1) / g;
             if (item < cnt) break;
             item -= cnt;
         }
-        const int c0 = J * RC_SW_COLS, a0 = item * RC_SW_ROWS;
-        const int a1 = min(a0 + RC_SW_ROWS, min(c0 + RC_SW_COLS, n));   // rows a >= c0+128 have no column b > a here
+        const int c0 = J * RC_SW_COLS, a0 = item * g;
+        const int a1 = min(a0 + g, min(c0 + RC_SW_COLS, n));            // rows a >= c0+128 have no column b > a here
         const int col0 = c0 + 2 * lane, col1 = col0 + 1;
         const int cs0 = col0 < n ? slot[col0] : -1, cs1 = col1 < n ? slot[col1] : -1;
         const int rowslots = (a0 + lane < n) ? slot[a0 + lane] : -1;   // slot of row a0 + lane (read back with readlane)
@@ -1029,9 +1056,24 @@ __global__ __launch_bounds__(256) void k_bulk_syml(View V, int wgen, int zgen, i
                 if (!(live && col1 > row)) { x[u].y = 0; y[u].y = 0; }
             }
             if (a + RC_SL_R < a1) issue(a + RC_SL_R);                   // next tile in flight under this one's work
+            if (DERIVED) {   // the eight logs of this tile, four at a time: table reads first, then the arithmetic
+#pragma unroll
+                for (int h = 0; h < RC_SL_R; h += 2) {
+                    QlogPrep pp[4];
+                    double2 tv[4];
+                    pp[0] = rc_qlog_prep(x[h].x, qeD); pp[1] = rc_qlog_prep(x[h].y, qeD);
+                    pp[2] = rc_qlog_prep(x[h + 1].x, qeD); pp[3] = rc_qlog_prep(x[h + 1].y, qeD);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = pp[u].j;
+                        tv[u] = *(const double2 *)&tt[j >> 6][(j >> 4) & 3][(j & 15) * RC_SL_O + 8];
+                    }
+                    y[h].x = rc_qlog_finish(x[h].x, pp[0], tv[0], qsL); y[h].y = rc_qlog_finish(x[h].y, pp[1], tv[1], qsL);
+                    y[h + 1].x = rc_qlog_finish(x[h + 1].x, pp[2], tv[2], qsL); y[h + 1].y = rc_qlog_finish(x[h + 1].y, pp[3], tv[3], qsL);
+                }
+            }
 #pragma unroll
             for (int u = 0; u < RC_SL_R; ++u) {
-                if (DERIVED) { y[u].x = rc_qlog(x[u].x, qeD, qsL, ltab_sh); y[u].y = rc_qlog(x[u].y, qeD, qsL, ltab_sh); }
                 *(ll2 *)&tt[0][u][(lane >> 2) * RC_SL_O + (lane & 3) * 2] = x[u];
                 *(ll2 *)&tt[1][u][(lane >> 2) * RC_SL_O + (lane & 3) * 2] = y[u];
             }
@@ -1753,9 +1795,15 @@ __device__ bool commit_change(const View &V, const SweepArgs &sa, Tab &T, u64 ke
 
 // Grid barrier: monotonic arrival counter; lane 0 of each block arrives after its (returning) atomicMin
 // on the round's key word, so every block's candidate is in the word before anyone leaves.  Bounded spin.
+// The arrival must also publish what this block announced to the others this round — the V.rec records and the chunk
+// word, written with agent-scope atomic stores by several waves.  __syncthreads() only waits for LDS traffic
+// (s_waitcnt lgkmcnt(0); global accesses of one CU are kept in order by its L1, which is all a workgroup barrier needs),
+// so every wave first waits for its own outstanding global stores: without this another block could see the arrival
+// before a record and assemble a different batch (observed as diverging chains once the timing changed).
 __device__ bool grid_barrier(const View &V, Tab &T, unsigned *arrive, unsigned target, u64 my_key, u64 *key_word)
 {
     int &sh_ok = T.misc[6];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         if (my_key != RC_KEY_NONE) {
@@ -2099,7 +2147,7 @@ struct rc_ctx {
     bool relayout = true;               // RC_NO_RELAYOUT=1 keeps the caller's point order
     int sym_variant = -1;               // RC_SYM_VARIANT: 2 k_bulk_syml (wave-private LDS transposition), 1 k_bulk_symw (DPP only), 0 block-tiled
                                         // k_bulk_sym; -1 (default): k_bulk_syml when logD is derived, k_bulk_sym when it is stored (measured best)
-    int symw_per_cu = 6;                // RC_SYMW_PER_CU: persistent blocks of k_bulk_symw per CU
+    int symw_per_cu = 4;                // RC_SYMW_PER_CU: resident blocks of k_bulk_syml / k_bulk_symw per CU (LDS: 40 KiB per block)
     bool derived = false;               // logD derived from Dq on the fly (rc_qlog), not stored
     double2 *ltab = nullptr;            // device table of rc_qlog
     int n_relayouts = 0;                // re-layouts done so far (rc_set_state + automatic ones)
@@ -2800,17 +2848,29 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
     const int sym_variant = c->sym_variant >= 0 ? c->sym_variant : (c->derived ? 2 : 0);
     if (use_sym && c->bits == 64 && sym_variant >= 1) {
         const int ncb = (c->n + RC_SW_COLS - 1) / RC_SW_COLS;
-        int nitems = 0;
-        for (int J = 0; J < ncb; ++J) nitems += (std::min(RC_SW_COLS * J + RC_SW_COLS, c->n) + RC_SW_ROWS - 1) / RC_SW_ROWS;
-        const int nblocks = std::max(1, std::min((nitems + 3) / 4, c->symw_per_cu * c->num_cus));
-        if (sym_variant == 2 && c->derived)
-            k_bulk_syml<true><<<nblocks, 256, 0, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems);
-        else if (sym_variant == 2)
-            k_bulk_syml<false><<<nblocks, 256, 0, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems);
-        else if (c->derived)
-            k_bulk_symw<true><<<nblocks, 256, 0, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems);
-        else
-            k_bulk_symw<false><<<nblocks, 256, 0, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems);
+        const int cap_blocks = c->symw_per_cu * c->num_cus;          // resident 4-wave blocks
+        auto rows_of = [&](int J) { return std::min(RC_SW_COLS * J + RC_SW_COLS, c->n); };
+        if (sym_variant == 2) {
+            // 64-row units for the heavy column blocks, as many as there are resident waves; 8-row units below
+            int jsplit = ncb, coarse = 0;
+            while (jsplit > 0) {
+                const int cnt = (rows_of(jsplit - 1) + RC_SW_ROWS - 1) / RC_SW_ROWS;
+                if (coarse + cnt > 4 * cap_blocks) break;
+                coarse += cnt; --jsplit;
+            }
+            if (coarse < 2 * cap_blocks) { jsplit = ncb; coarse = 0; }   // small problem: fine units everywhere
+            int nitems = coarse;
+            for (int J = 0; J < jsplit; ++J) nitems += (rows_of(J) + RC_SW_FINE - 1) / RC_SW_FINE;
+            const int nblocks = std::max(1, std::min((nitems + 3) / 4, cap_blocks));
+            if (c->derived) k_bulk_syml<true><<<nblocks, 256, 0, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems, jsplit);
+            else k_bulk_syml<false><<<nblocks, 256, 0, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems, jsplit);
+        } else {
+            int nitems = 0;
+            for (int J = 0; J < ncb; ++J) nitems += (rows_of(J) + RC_SW_ROWS - 1) / RC_SW_ROWS;
+            const int nblocks = std::max(1, std::min((nitems + 3) / 4, cap_blocks));
+            if (c->derived) k_bulk_symw<true><<<nblocks, 256, 0, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems);
+            else k_bulk_symw<false><<<nblocks, 256, 0, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems);
+        }
     } else if (use_sym) {
         const int TC = (c->bits == 64) ? RC_SYM_TC : RC_SYM32_TC;
         const int ncb = (c->n + TC - 1) / TC;

@@ -475,7 +475,12 @@ def test_automatic_relayout_is_invisible():
         ref.gibbs_sweep(1.0, 0.5, 3, t, blocking=False)
         if t % 10 == 9:
             a, b = ctx.get_state(), ref.get_state()
-            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2], t
+            cnt = np.bincount(a[0], minlength=n + 1)[1:]
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2], (
+                t, "labels equal" if np.array_equal(a[0], b[0]) else "labels differ",
+                "ctx sizes consistent with its labels" if np.array_equal(a[1], cnt) else ("ctx sizes INCONSISTENT", np.flatnonzero(a[1] != cnt), a[1][a[1] != cnt], cnt[a[1] != cnt]),
+                "ref sizes consistent with its labels" if np.array_equal(b[1], np.bincount(b[0], minlength=n + 1)[1:]) else "ref sizes INCONSISTENT",
+                ctx.layout_info(), ctx.sweep_stats(), ref.sweep_stats(), a[2], b[2])
             moved += ctx.sweep_stats()["n_changes"]
     assert moved > 0
     assert ctx.loglik() == ref.loglik()
