@@ -951,7 +951,7 @@ __device__ __forceinline__ void row16_sum4_dpp(long long &a, long long &b, long 
 }
 
 template <bool DERIVED>
-__global__ __launch_bounds__(256) void k_bulk_syml(View V, int wgen, int zgen, int sgen, int cgen, int nitems, int jsplit)
+__global__ __launch_bounds__(256) void k_bulk_syml(View V, int wgen, int zgen, int sgen, int cgen, int nitems, int jsplit, int gfine)
 {
     // [wave][matrix][row][octet-padded col]: 10 KiB per wave, 40 KiB per block = four blocks (16 waves) per CU exactly.
     // The log table of the derived mode (128 × 16 B) lives in the padding: entry j of a wave's private copy sits in
@@ -989,11 +989,11 @@ __global__ __launch_bounds__(256) void k_bulk_syml(View V, int wgen, int zgen, i
         int item = unit;
         // Work units: column block J (heavy blocks first) × a range of rows.  Blocks J >= jsplit are cut into 64-row
         // units — at most one per resident wave — and the light blocks below jsplit, which are handed out last, into
-        // 8-row units, so that the tail of the launch is two tiles long instead of a whole 64-row unit (and a small
-        // problem still spreads over the chip).
+        // units of gfine (8..32) rows, so that the tail of the launch is a few tiles long instead of a whole 64-row unit
+        // (and a small problem still spreads over the chip).
         int J = ncb - 1, g = RC_SW_ROWS;
         for (;; --J) {
-            g = (J >= jsplit) ? RC_SW_ROWS : RC_SW_FINE;
+            g = (J >= jsplit) ? RC_SW_ROWS : gfine;
             const int cnt = (min(RC_SW_COLS * J + RC_SW_COLS, n) + g - 1) / g;
             if (item < cnt) break;
             item -= cnt;
@@ -2858,12 +2858,20 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
                 if (coarse + cnt > 4 * cap_blocks) break;
                 coarse += cnt; --jsplit;
             }
-            if (coarse < 2 * cap_blocks) { jsplit = ncb; coarse = 0; }   // small problem: fine units everywhere
+            int gfine = RC_SW_FINE;
+            if (coarse < 2 * cap_blocks) {   // small problem: fine units everywhere, as large as still fills the resident waves
+                jsplit = ncb; coarse = 0;
+                for (int g = 32; g > RC_SW_FINE; g >>= 1) {
+                    int cnt = 0;
+                    for (int J = 0; J < ncb; ++J) cnt += (rows_of(J) + g - 1) / g;
+                    if (cnt >= 4 * cap_blocks) { gfine = g; break; }
+                }
+            }
             int nitems = coarse;
-            for (int J = 0; J < jsplit; ++J) nitems += (rows_of(J) + RC_SW_FINE - 1) / RC_SW_FINE;
+            for (int J = 0; J < jsplit; ++J) nitems += (rows_of(J) + gfine - 1) / gfine;
             const int nblocks = std::max(1, std::min((nitems + 3) / 4, cap_blocks));
-            if (c->derived) k_bulk_syml<true><<<nblocks, 256, 0, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems, jsplit);
-            else k_bulk_syml<false><<<nblocks, 256, 0, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems, jsplit);
+            if (c->derived) k_bulk_syml<true><<<nblocks, 256, 0, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems, jsplit, gfine);
+            else k_bulk_syml<false><<<nblocks, 256, 0, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems, jsplit, gfine);
         } else {
             int nitems = 0;
             for (int J = 0; J < ncb; ++J) nitems += (rows_of(J) + RC_SW_ROWS - 1) / RC_SW_ROWS;
