@@ -58,6 +58,10 @@ typedef struct rc_sweep_stats {
 /* MCMCData constructor, src/types.jl:145-157.  Copies the n×n matrix D to HBM once, checks symmetry
  * (types.jl:149-151) and derives logD = log.(D - Diagonal(D) + I) on the device (types.jl:155; diagonal 0,
  * D's own diagonal kept as stored) unless the caller passes its own logD (e.g. MCMCData.logD).
+ * With logD_or_null == NULL and 64-bit storage the fixed-point logD is not stored at all: every consumer evaluates it
+ * from the stored D with one shared table-based log (DESIGN.md "Derived logD"; results are exact integers either way,
+ * the row reduction reads half the bytes).  rc_get_matrix(ctx, 1, ·) returns the values in use.  RC_STORED_LOG=1
+ * forces the stored form.
  * storage_bits: 64 (int64 fixed point; the Float64 path) or 32 (int32 fixed point: every entry rounded to
  * 2^-30 of the largest magnitude, half the HBM traffic; all sums stay exact 64-bit integers and scores stay f64
  * — the counterpart of BASELINE config 5's Float32 storage, which the reference itself does not have).
