@@ -120,3 +120,24 @@ def test_fallback_to_stored_log_when_an_entry_quantises_to_zero():
     ctx.gibbs_sweep(1.0, 0.5, 1, 0)
     assert ctx.bulk_kernel_info()[1] in (2 * 40 * 41 / 2 * 8, 2 * 40 * 40 * 8.0)     # two matrices are read: stored mode
     ctx.close()
+
+
+def test_two_contexts_stay_identical_over_a_long_moving_chain():
+    """Regression for the grid-barrier publication race (DESIGN.md "Grid barrier and global stores"): two contexts with
+    different kernels walk the same moving chain asynchronously for 1500 sweeps; every third sweep both states are
+    pulled and must agree, and each size table must match its own labels."""
+    n, K = 2048, 4
+    data = rc.generatemixture(n, K, seed=5, sigma=0.6, dim=6)
+    sh = np.random.default_rng(8).permutation(n)
+    D = np.ascontiguousarray(data["distancematrix"][np.ix_(sh, sh)]); truth = data["clusts"][sh]
+    P = dict(rc.likelihood_hyperparams(D, truth), maxK=12)
+    A = rc.Context(D, kcap=64); A.set_params(**P); A.set_state(truth)
+    B = rc.Context(D, kcap=64); B.set_params(**P); B.set_bulk_kernel("perm"); B.set_state(truth)
+    for t in range(1500):
+        A.gibbs_sweep(1.0, 0.5, 3, t, blocking=False); B.gibbs_sweep(1.0, 0.5, 3, t, blocking=False)
+        if t % 3 == 2:
+            a, b = A.get_state(), B.get_state()
+            assert np.array_equal(a[0], b[0]) and a[2] == b[2], t
+            assert np.array_equal(a[1], np.bincount(a[0], minlength=n + 1)[1:]), t
+            assert np.array_equal(b[1], np.bincount(b[0], minlength=n + 1)[1:]), t
+    A.close(); B.close()
