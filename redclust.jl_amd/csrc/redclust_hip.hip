@@ -302,7 +302,7 @@ __device__ __forceinline__ long long rc_qlog_finish(long long dq, const QlogPrep
 // logD entry (row, col) in internal order, stored or derived; xd = Dq(row, col) when the caller has it already
 __device__ __forceinline__ long long rc_load_L(const View &V, int row, int col, long long xd)
 {
-    if (V.derived) return row == col ? 0ll : rc_qlog(xd, V.qeD, V.qsL, V.ltab);
+    if (V.derived && !V.Lq) return row == col ? 0ll : rc_qlog(xd, V.qeD, V.qsL, V.ltab);
     const size_t e = (size_t)row * V.ld + col;
     return (V.bits == 64) ? ((const long long *)V.Lq)[e] : (long long)((const int *)V.Lq)[e];
 }
@@ -323,6 +323,19 @@ __global__ void k_derived_scan(const long long *__restrict__ Dq, int n, int ld, 
     }
     atomicMin((long long *)min_dq, mn);
     atomicMax((unsigned long long *)maxabs_bits, (unsigned long long)__double_as_longlong(mx));
+}
+
+// The derived values materialised once (same routine, so the same integers): the resolver's single-entry look-ups and
+// k_apply_moves read this copy, which costs them one load instead of a dependent load + ~30 instructions per entry;
+// the streaming row reduction keeps deriving on the fly and never touches it.
+__global__ void k_derived_fill(const long long *__restrict__ Dq, int n, int ld, int eD, double sL,
+                               const double2 *__restrict__ tab, long long *__restrict__ Lq)
+{
+    const size_t total = (size_t)n * n;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = t / n, j = t % n;
+        Lq[i * ld + j] = (i == j) ? 0ll : rc_qlog(Dq[i * ld + j], eD, sL, tab);
+    }
 }
 
 // dequantised logD for rc_get_matrix in the derived mode (caller's order: Dq_src)
@@ -1514,7 +1527,7 @@ __global__ __launch_bounds__(256) void k_apply_moves(View V, MoveList ML)
         if (a == b) continue;
         const size_t e = (size_t)x * V.ld + i;
         long long d0, d1, l0, l1;
-        if (V.derived) {
+        if (V.derived && !V.Lq) {
             const ll2 d = *(const ll2 *)((const long long *)V.Dq + e);
             d0 = d.x; d1 = d.y;
             l0 = rc_load_L(V, x, i, d0); l1 = rc_load_L(V, x, i + 1, d1);
@@ -1778,7 +1791,7 @@ __device__ bool commit_change(const View &V, const SweepArgs &sa, Tab &T, u64 ke
                     const int i = V.pi[io];
                     const size_t e = (size_t)ustar * V.ld + i;
                     long long x;
-                    if (job >= 2 && V.derived) x = rc_load_L(V, ustar, i, ((const long long *)V.Dq)[e]);
+                    if (job >= 2 && V.derived && !V.Lq) x = rc_load_L(V, ustar, i, ((const long long *)V.Dq)[e]);
                     else x = (V.bits == 64) ? ((const long long *)M)[e] : (long long)((const int *)M)[e];
                     const long long dx = (job & 1) ? x : -x;
                     So[(size_t)slot * V.ld + i] += dx;
@@ -2518,6 +2531,13 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
         c->eL = std::min(c->eL, 50 - ex);
     }
     c->derived = derived;
+    if (derived && !(getenv("RC_NO_LQ_COPY") && atoi(getenv("RC_NO_LQ_COPY")))) {
+        // random-access copy of the derived values for the resolver (see k_derived_fill); the row reduction ignores it
+        HIPCHK2(hipMalloc(&c->Lq, (size_t)n * ld * esz));
+        HIPCHK2(hipMalloc(&c->Lq_src, (size_t)n * ld * esz));
+        HIPCHK2(hipMemsetAsync(c->Lq_src, 0, (size_t)n * ld * esz, s));
+        k_derived_fill<<<gb, 256, 0, s>>>((const long long *)c->Dq_src, (int)n, c->ld, c->eD, std::ldexp(1.0, c->eL), c->ltab, (long long *)c->Lq_src);
+    }
     if (!derived) {
         HIPCHK2(hipMalloc(&c->Lq, (size_t)n * ld * esz));
         HIPCHK2(hipMalloc(&c->Lq_src, (size_t)n * ld * esz));
@@ -2532,7 +2552,7 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     HIPCHK2(hipMemcpyAsync(c->pi, c->h_pi.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
     HIPCHK2(hipMemcpyAsync(c->ipi, c->h_ipi.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
     HIPCHK2(hipMemcpyAsync(c->Dq, c->Dq_src, (size_t)n * ld * esz, hipMemcpyDeviceToDevice, s));
-    if (!derived) HIPCHK2(hipMemcpyAsync(c->Lq, c->Lq_src, (size_t)n * ld * esz, hipMemcpyDeviceToDevice, s));
+    if (c->Lq) HIPCHK2(hipMemcpyAsync(c->Lq, c->Lq_src, (size_t)n * ld * esz, hipMemcpyDeviceToDevice, s));
     HIPCHK2(hipMemcpyAsync(c->diagq, c->diag_src, (size_t)n * sizeof(long long), hipMemcpyDeviceToDevice, s));
     HIPCHK2(hipStreamSynchronize(s));
     HIPCHK2(hipGetLastError());
@@ -2783,7 +2803,7 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
         dim3 g((unsigned)std::min(64, (n + 255) / 256), (unsigned)n);
         if (c->bits == 64) {
             k_relayout<long long><<<g, 256, 0, c->sA>>>((const long long *)c->Dq_src, c->ipi, n, c->ld, (long long *)c->Dq);
-            if (!c->derived) k_relayout<long long><<<g, 256, 0, c->sA>>>((const long long *)c->Lq_src, c->ipi, n, c->ld, (long long *)c->Lq);
+            if (c->Lq) k_relayout<long long><<<g, 256, 0, c->sA>>>((const long long *)c->Lq_src, c->ipi, n, c->ld, (long long *)c->Lq);
         } else {
             k_relayout<int><<<g, 256, 0, c->sA>>>((const int *)c->Dq_src, c->ipi, n, c->ld, (int *)c->Dq);
             k_relayout<int><<<g, 256, 0, c->sA>>>((const int *)c->Lq_src, c->ipi, n, c->ld, (int *)c->Lq);
