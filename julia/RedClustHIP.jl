@@ -100,4 +100,82 @@ function runsampler_hip(data::MCMCData, options::MCMCOptionsList, params::PriorH
     end
 end
 
+# ---------------------------------------------------------------------------------------------------------------
+# The whole iteration loop in one call (rc_run_chain; src/mcmc.jl:533-556 incl. sample_r!/sample_p! on the library's
+# scalar stream and the split–merge step as written), and the point estimate afterwards.  Struct layouts mirror
+# rc_chain_options / rc_chain_outputs of include/redclust_hip.h.
+# ---------------------------------------------------------------------------------------------------------------
+struct RcChainOptions
+    numiters::Int64; burnin::Int64; thin::Int64; numGibbs::Int64; numMH::Int64
+    splitmerge_mode::Int32; pad_::Int32
+    seed::UInt64; first_iter::UInt64
+    r0::Cdouble; p0::Cdouble; proposalsd_r::Cdouble
+    r_trace::Ptr{Cdouble}; p_trace::Ptr{Cdouble}
+    max_samples::Int64
+end
+
+mutable struct RcChainOutputs
+    clusts::Ptr{Int64}; K::Ptr{Int64}; r::Ptr{Cdouble}; p::Ptr{Cdouble}; loglik::Ptr{Cdouble}; logposterior::Ptr{Cdouble}
+    r_acceptances::Ptr{UInt8}; splitmerge_acceptances::Ptr{UInt8}; splitmerge_splits::Ptr{UInt8}
+    r_all::Ptr{Cdouble}; p_all::Ptr{Cdouble}
+    num_samples::Int64; runtime_s::Cdouble; r_final::Cdouble; p_final::Cdouble
+end
+
+"""
+    run_chain_hip!(ctx, result, data, options, params, init; seed)
+
+Fills `result` (an `MCMCResult` allocated as `runsampler` does, src/mcmc.jl:515-531) from ONE call into the library.
+`ctx` must hold D (rc_create), the parameters (rc_set_params) and the initial labels (rc_set_state); for
+`options.numMH > 0` the host matrices are attached first (the proposal's scalar scans run on them, as in the reference).
+"""
+function run_chain_hip!(ctx::Ptr{Cvoid}, result, data, options, params, init; seed::Integer = 0)
+    n = size(data.D, 1)
+    ns = options.numsamples
+    clusts = Matrix{Int64}(undef, n, ns)                       # column j = sample j (row-major ns×n for the library)
+    racc = zeros(UInt8, options.numiters)
+    smacc = zeros(UInt8, options.numiters * options.numMH)
+    smspl = zeros(UInt8, options.numiters * options.numMH)
+    if options.numMH > 0
+        check(ctx, ccall((:rc_attach_host_matrices, LIB), Int32, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), ctx, data.D, data.logD))
+    end
+    opt = RcChainOptions(options.numiters, options.burnin, options.thin, options.numGibbs, options.numMH, 0, 0,
+                         UInt64(seed), 0, init.r, init.p, params.proposalsd_r, C_NULL, C_NULL, ns)
+    out = RcChainOutputs(pointer(clusts), pointer(result.K), pointer(result.r), pointer(result.p), pointer(result.loglik),
+                         pointer(result.logposterior), pointer(racc), pointer(smacc), pointer(smspl), C_NULL, C_NULL, 0, 0.0, 0.0, 0.0)
+    GC.@preserve clusts racc smacc smspl result begin
+        check(ctx, ccall((:rc_run_chain, LIB), Int32, (Ptr{Cvoid}, Ref{RcChainOptions}, Ref{RcChainOutputs}), ctx, opt, out))
+    end
+    for j in 1:ns
+        result.clusts[j] .= view(clusts, :, j)
+    end
+    result.r_acceptances .= racc .!= 0
+    result.splitmerge_acceptances .= smacc .!= 0
+    result.splitmerge_splits .= smspl .!= 0
+    result.runtime = out.runtime_s
+    result.mean_iter_time = out.runtime_s / options.numiters
+    return result
+end
+
+"""
+    getpointestimate_hip(result; loss = "VI", device = 0) -> (clust, i)
+
+`getpointestimate(result; method = "MPEL", loss)` (src/pointestimate.jl:49-58) with the numsamples² loss matrix computed
+on the GPU (rc_loss_matrix).
+"""
+function getpointestimate_hip(result; loss::String = "VI", device::Integer = 0)
+    code = Dict("binder" => 0, "omARI" => 1, "VI" => 2, "ID" => 3)
+    haskey(code, loss) || throw(ArgumentError("Invalid loss function specifier."))
+    m = length(result.clusts); n = length(result.clusts[1])
+    samples = Matrix{Int64}(undef, n, m)                        # column s = sample s: row-major m×n for the library
+    for s in 1:m
+        samples[:, s] .= result.clusts[s]
+    end
+    best = Ref{Int64}(0)
+    rc = ccall((:rc_loss_matrix, LIB), Int32,
+               (Int32, Ptr{Int64}, Int64, Int64, Int32, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Int64}, Ptr{Cdouble}),
+               device, samples, m, n, code[loss], C_NULL, C_NULL, best, C_NULL)
+    rc == 0 || error(unsafe_string(ccall((:rc_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))
+    return (result.clusts[best[] + 1], Int(best[]) + 1)
+end
+
 end # module

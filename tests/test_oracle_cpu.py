@@ -190,3 +190,16 @@ def test_generatemixture_shape_like_reference():
     for bad in (dict(N=0, K=1), dict(N=5, K=6), dict(N=5, K=2, dim=1), dict(N=5, K=2, sigma=0)):
         with pytest.raises(ValueError):
             rc.generatemixture(**bad)
+
+
+def test_julia_glue_binds_only_declared_symbols():
+    """Every symbol julia/RedClustHIP.jl ccalls is declared in include/redclust_hip.h (the glue cannot be executed in
+    this image, so at least its symbol names are checked against the ABI)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    jl = open(os.path.join(root, "julia", "RedClustHIP.jl")).read()
+    hdr = open(os.path.join(root, "include", "redclust_hip.h")).read()
+    used = set(re.findall(r"ccall\(\(:(rc_[a-z_0-9]+), LIB\)", jl))
+    assert used, "no ccall found"
+    declared = set(re.findall(r"\b(rc_[a-z_0-9]+)\s*\(", hdr))
+    assert used <= declared, used - declared
