@@ -976,7 +976,7 @@ __global__ __launch_bounds__(256) void k_bulk_syml(View V, int wgen, int zgen, i
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int j = lane + 64 * h;
-            *(double2 *)&tl[wv][j >> 6][(j >> 4) & 3][(j & 15) * RC_SL_O + 8] = V.ltab[j];
+            *(double2 *)(&tl[wv][0][0][0] + j * RC_SL_O + 8) = V.ltab[j];   // octets are contiguous: entry j sits in octet j
         }
     }
     (void)zgen;  // generations are cleared and work counters re-armed by k_resolve (SweepArgs.zero_gen)
@@ -1079,7 +1079,7 @@ __global__ __launch_bounds__(256) void k_bulk_syml(View V, int wgen, int zgen, i
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int j = pp[u].j;
-                        tv[u] = *(const double2 *)&tt[j >> 6][(j >> 4) & 3][(j & 15) * RC_SL_O + 8];
+                        tv[u] = *(const double2 *)(&tt[0][0][0] + j * RC_SL_O + 8);
                     }
                     y[h].x = rc_qlog_finish(x[h].x, pp[0], tv[0], qsL); y[h].y = rc_qlog_finish(x[h].y, pp[1], tv[1], qsL);
                     y[h + 1].x = rc_qlog_finish(x[h + 1].x, pp[2], tv[2], qsL); y[h + 1].y = rc_qlog_finish(x[h + 1].y, pp[3], tv[3], qsL);

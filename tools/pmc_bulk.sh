@@ -14,7 +14,7 @@ for f in sorted(glob.glob("$OUT/*/**/*counter_collection.csv", recursive=True)):
     acc = collections.defaultdict(lambda: [0.0, 0])
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0][:40]
-        if "k_bulk" not in k: continue
+        if "k_bulk" not in k and "k_resolve" not in k: continue
         a = acc[(k, row["Counter_Name"])]; a[0] += float(row["Counter_Value"]); a[1] += 1
     for (k, c), (v, cnt) in sorted(acc.items()):
         print(f"{k:42s} {c:24s} per-launch {v / cnt:14.1f}  (launches {cnt})")
