@@ -39,6 +39,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <unordered_map>
 #include <vector>
 
@@ -2954,6 +2955,26 @@ static int32_t ensure_S(rc_ctx *c, int *gen)
     return RC_OK;
 }
 
+// k_resolve synchronises its blocks with a grid barrier, so all of them must be resident at once.  One launch always
+// fits (G <= number of CUs), but two launches from different contexts of this process could each hold part of the
+// chip and wait for the rest for ever (until the bounded spin reports RC_DERR_BARRIER).  Resolver launches on one
+// device are therefore chained: each waits for the completion of the previous one, whichever context it came from.
+static std::mutex g_res_mutex;
+static hipEvent_t g_res_event[64] = {};
+
+static int32_t launch_resolve(rc_ctx *c, const View &V, const SweepArgs &sa, int res_threads, size_t lds)
+{
+    std::lock_guard<std::mutex> lock(g_res_mutex);
+    const int d = c->dev & 63;
+    if (g_res_event[d]) HIPCHK(c, hipStreamWaitEvent(c->sA, g_res_event[d], 0));
+    else HIPCHK(c, hipEventCreateWithFlags(&g_res_event[d], hipEventDisableTiming));
+    k_resolve<<<c->G, res_threads, lds, c->sA>>>(V, sa, c->G);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, RC_ERR_HIP, "k_resolve launch failed: %s", hipGetErrorString(e));
+    HIPCHK(c, hipEventRecord(g_res_event[d], c->sA));
+    return RC_OK;
+}
+
 static int32_t pull_labels(rc_ctx *c, std::vector<int64_t> &labels, std::vector<int64_t> &sizes, int64_t &K);
 
 extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t seed, uint64_t sweep_index)
@@ -3006,8 +3027,8 @@ extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t 
         sa.own_gen = c->inc_gen;
         sa.next_gen = -1;
         sa.zero_gen = -1;
-        k_resolve<<<c->G, res_threads, lds, c->sA>>>(V, sa, c->G);
-        HIPCHK(c, hipGetLastError());
+        rc = launch_resolve(c, V, sa, res_threads, lds);
+        if (rc != RC_OK) return rc;
         HIPCHK(c, hipEventRecord(c->ev_res[t & 3], c->sA));
         c->t_next = t + 1;
         c->state_version++;
@@ -3021,8 +3042,8 @@ extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t 
     sa.next_gen = (int)((t + 1) % 3);
     sa.zero_gen = (int)((t + 2) % 3);
     HIPCHK(c, hipStreamWaitEvent(c->sA, c->ev_bulk[t & 3], 0));
-    k_resolve<<<c->G, res_threads, lds, c->sA>>>(V, sa, c->G);
-    HIPCHK(c, hipGetLastError());
+    rc = launch_resolve(c, V, sa, res_threads, lds);
+    if (rc != RC_OK) return rc;
     HIPCHK(c, hipEventRecord(c->ev_res[t & 3], c->sA));
     c->t_next = t + 1;
     c->state_version++;
