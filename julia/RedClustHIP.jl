@@ -38,16 +38,20 @@ end
 Same contract as `RedClust.runsampler` with `options.numMH == 0` (pure Gibbs, test/test_sampler.jl:7).
 """
 function runsampler_hip(data::MCMCData, options::MCMCOptionsList, params::PriorHyperparamsList,
-                        init::MCMCState; verbose=true, seed::Integer=0, device::Integer=0, kcap::Integer=0)
+                        init::MCMCState; verbose=true, seed::Integer=0, device::Integer=0, kcap::Integer=0,
+                        exact_logD::Bool=false)
     options.numMH == 0 || error("split-merge steps are not offloaded yet: use MCMCOptionsList(numMH = 0)")
     n = size(data.D, 1)
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    # MCMCData keeps D and logD (src/types.jl:146-147); both are handed over so that the device copy is
-    # bit-for-bit the package's logD.  D is symmetric, so column-major == row-major.
+    # MCMCData keeps D and logD = log.(D - Diagonal(D) + I) (src/types.jl:146-147,155).  By default only D is handed
+    # over: the library then evaluates logD from its fixed-point D on the fly (DESIGN.md "Derived logD": half the HBM
+    # traffic per sweep, values within 1e-14 of the package's).  exact_logD = true hands data.logD over instead, so
+    # that the device copy is the package's logD rounded to the fixed-point grid.  D is symmetric, so column-major ==
+    # row-major.
     GC.@preserve data begin
         rc = ccall((:rc_create, LIB), Int32,
                    (Int64, Ptr{Cdouble}, Ptr{Cdouble}, Int32, Int32, Int64, Ref{Ptr{Cvoid}}),
-                   n, data.D, data.logD, 64, device, kcap, h)
+                   n, data.D, exact_logD ? pointer(data.logD) : Ptr{Cdouble}(C_NULL), 64, device, kcap, h)
     end
     check(Ptr{Cvoid}(C_NULL), rc)
     ctx = h[]
