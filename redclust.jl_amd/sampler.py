@@ -77,13 +77,18 @@ def _mean_and_var(x):
 def runsampler(data: MCMCData, options: MCMCOptionsList | None = None, params: PriorHyperparamsList | None = None,
                init: MCMCState | None = None, *, verbose: bool = True, seed: int = 0, rng=None, device: int = 0,
                kcap: int = 0, ctx: Context | None = None, rp_trace=None, splitmerge: str = "as_written",
-               host_logD=None, engine: str | None = None) -> MCMCResult:
+               host_logD=None, engine: str | None = None, mode: str = "incremental") -> MCMCResult:
     """runsampler(data, options, params, init; verbose) — src/mcmc.jl:501-590.
 
     seed keys the counter-based streams of the label draws, the split–merge proposals and the scalar r / p updates
     (DESIGN.md).  engine="native" (default) runs the whole iteration loop inside the library (rc_run_chain);
     engine="python" keeps the loop in this function and draws r / p from `rng` (a numpy Generator; giving `rng`
-    selects it).  rp_trace=(r_seq, p_seq) teacher-forces r and p instead (parity tests)."""
+    selects it).  rp_trace=(r_seq, p_seq) teacher-forces r and p instead (parity tests).
+    mode="incremental" (default) keeps the exact row-sum table up to date under label changes instead of recomputing it
+    from the matrices in every sweep — bit-identical results (integer sums), no matrix traffic while labels are stable;
+    mode="full" recomputes per sweep as the reference re-reads D and logD (the data flow bench.py measures)."""
+    if mode not in ("incremental", "full"):
+        raise ValueError("mode must be 'incremental' or 'full'")
     if engine is None:
         engine = "python" if rng is not None else "native"
     if engine not in ("native", "python"):
@@ -106,6 +111,7 @@ def runsampler(data: MCMCData, options: MCMCOptionsList | None = None, params: P
     try:
         ctx.set_params(**params.as_dict())
         ctx.set_state(init.clusts)
+        ctx.set_mode(mode)
         ctx.cocluster_reset()
         numMH = options.numMH
         if numMH > 0:

@@ -13,11 +13,11 @@ data = rc.MCMCData(D)
 out = {"n": N, "K": K}
 for numMH in (0, 1):
     for thin in (1, 10):
-        for eng in ("native", "python"):
+        for eng in ("native", "full"):
             it = iters if numMH == 0 else max(iters // 5, 50)
             opts = rc.MCMCOptionsList(numiters=it, burnin=0, thin=thin, numMH=numMH)
             t0 = time.perf_counter()
-            res = rc.runsampler(data, opts, params, rc.MCMCState(truth, 1.0, 0.5), verbose=False, seed=1, ctx=ctx, engine=eng)
+            res = rc.runsampler(data, opts, params, rc.MCMCState(truth, 1.0, 0.5), verbose=False, seed=1, ctx=ctx, engine="native", mode="full" if eng == "full" else "incremental")
             dt = time.perf_counter() - t0
             out[f"numMH={numMH} thin={thin} {eng}"] = {"it_per_s_loop": 1.0 / res.mean_iter_time, "it_per_s_call": it / dt}
 print(json.dumps(out, indent=1))
