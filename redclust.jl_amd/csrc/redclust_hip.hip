@@ -2512,7 +2512,10 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
         hipError_t e3 = hipStreamSynchronize(s);
         (void)hipFree(mn);
         HIPCHK2(e1); HIPCHK2(e2); HIPCHK2(e3);
-        if (n > 1 && hmn <= 0) derived = false;   // an off-diagonal entry quantises to zero: keep logD of the exact doubles
+        // log(Dq·2^-eD) differs from log(D) by the relative rounding of the entry, 1/(2·Dq): derive only when every
+        // off-diagonal entry is at least 2^32 quanta (error ≤ 1.2e-10 per entry, ≤ 1e-12 for entries within 2^-10 of the
+        // largest); a matrix with (near-)zero distances keeps logD of the exact doubles
+        if (n > 1 && hmn < (1ll << 32)) derived = false;
     }
     if (!derived && !log_staged) {
         // (stored mode reached through the fallback above: stage logD now)
