@@ -1,5 +1,6 @@
 // redclust_hip.hip — MI355X (gfx950 / CDNA4) implementation of RedClust.jl's Gibbs label sweep and its
-// observables behind the C ABI of include/redclust_hip.h.  Written for gfx950 only.
+// observables behind the C ABI of include/redclust_hip.h.  Written for gfx950 only.  (pointestimate.inc.hip and
+// chain.inc.hip — the MPEL loss matrix and the native iteration loop — are included at the end of this file.)
 //
 // Reference path (RedClust.jl v1.2.2, paths under the reference checkout):
 //   sample_labels_Gibbs!  src/mcmc.jl:158-256     loglik  src/mcmc.jl:1-56     logprior  src/mcmc.jl:58-78
@@ -12,20 +13,28 @@
 //     summation: launch geometry, atomics and incremental updates cannot change a single bit of a result.
 //   * S[k][i] = Σ_j D[i,j]·[c_j in slot k]  (and the same for logD) is the n×K sufficient-statistic
 //     table of the sweep (the matsum(D,[i],clust_k) of mcmc.jl:210-213 for every i and k at once).
-//     k_bulk recomputes it from the matrices once per sweep: this is the HBM-bound kernel (2·n²·8 B).
-//     It uses D's symmetry: lanes own columns i, the wave walks rows j grouped by cluster, so the
-//     per-cluster accumulator is a register and every load is a coalesced 16 B/lane row segment.
+//     A row-reduction kernel recomputes it from the matrices once per sweep; three of them, all exact:
+//       k_bulk       every entry of D and logD, any point order (lanes own columns, the wave walks rows grouped by
+//                    cluster: register accumulators, coalesced 16 B/lane loads, no LDS) — 2·n²·8 B;
+//       k_bulk_sym   upper triangle only, 32×128 LDS tiles read in both orientations, persistent blocks — n²·8 B;
+//       k_bulk_syml  upper triangle only, one WAVE per 64×128 unit, no block barriers, wave-private LDS transposition
+//                    + fused-DPP reduction; the default together with the DERIVED logD: when the caller gives only D,
+//                    logD is not stored — every consumer evaluates rint(log(Dq)·2^eL) with one shared table log
+//                    (rc_qlog), so this kernel reads only D's upper triangle, n²/2·8 B.
+//     Points are kept in an internal cluster-contiguous order (pi / ipi), invisible through the ABI.
 //   * The sequential dependence of the sweep is resolved exactly by speculation: every point is scored
 //     and drawn in parallel under "no earlier point of this sweep has changed"; the first point whose
 //     draw differs from its label is the true first change of the sequential sweep; it is committed,
 //     S is corrected for the two clusters involved (exactly — integers), and the points after it are
 //     re-drawn.  Draws are deterministic functions of (state, counter-based uniforms), so the result
-//     is identical to the sequential loop.  k_resolve runs this loop inside ONE persistent launch (one
-//     grid barrier per change); at stationarity it is a single scoring pass.
-//   * Sweeps are software-pipelined over two streams: k_resolve of sweep t runs concurrently with
-//     k_bulk of sweep t+1, which reduces the rows under the labels known before sweep t; the label
+//     is identical to the sequential loop.  k_resolve runs this loop inside ONE persistent launch (two
+//     grid barriers per batch of independent changes); at stationarity it is a single scoring pass.
+//   * Sweeps are software-pipelined over three streams: k_resolve of sweep t runs concurrently with the
+//     row reduction of sweep t+1, which reduces the rows under the labels known before sweep t; the label
 //     changes of sweep t are added to that table by k_resolve with the same commutative integer atomics,
-//     so the table k_resolve(t+1) reads is exactly the row sums under the labels after sweep t.
+//     so the table k_resolve(t+1) reads is exactly the row sums under the labels after sweep t.  Row
+//     reductions of consecutive sweeps alternate between two streams and overlap (k_resolve clears the
+//     generation two sweeps ahead).
 //   * Scores use the regrouped arithmetic of SURVEY.md §7 H2 (size-only lgamma terms tabulated on the
 //     host in long double; log(β+S) = log β + log1p(S/β)); terms common to all candidates (L2_i, the
 //     subtracted minimum) are dropped — they cannot change the Gumbel-max argmax.
