@@ -141,3 +141,26 @@ def test_two_contexts_stay_identical_over_a_long_moving_chain():
             assert np.array_equal(a[1], np.bincount(a[0], minlength=n + 1)[1:]), t
             assert np.array_equal(b[1], np.bincount(b[0], minlength=n + 1)[1:]), t
     A.close(); B.close()
+
+
+@pytest.mark.parametrize("kernel", ["perm", "sym"])
+def test_many_small_clusters_against_oracle(kernel):
+    """700 initial clusters of ~2 points (kcap = 1024): most 128-column segments span many clusters, so the symmetric
+    kernel runs on its element-wise slow path, and the sweeps are dominated by deaths (structural commits)."""
+    n = 1500
+    data = rc.generatemixture(n, 12, seed=3, sigma=0.4, dim=12)
+    D, truth = data["distancematrix"], data["clusts"]
+    P = rc.likelihood_hyperparams(D, truth)
+    init = np.random.default_rng(0).integers(1, 701, n).astype(np.int64)
+    ctx = rc.Context(D, kcap=1024)
+    ctx.set_params(**P); ctx.set_bulk_kernel(kernel); ctx.set_state(init)
+    L = ctx.get_matrix(1)
+    orc = O.Oracle(D, P, logD=L, eL=ctx.debug_rowsums(int(init[0]))[3])
+    orc.set_state(init)
+    for t in range(8):
+        ctx.gibbs_sweep(1.0, 0.5, 4, t)
+        orc.sweep_stable(1.0, 0.5, 4, t)
+        lab, sizes, K = ctx.get_state()
+        assert np.array_equal(lab, orc.clusts) and np.array_equal(sizes, orc.sizes) and K == orc.K, t
+    assert K < 400 and abs(ctx.loglik() - orc.loglik_stable()) <= 1e-9 * abs(orc.loglik_stable())
+    ctx.close()
