@@ -974,7 +974,7 @@ __device__ __forceinline__ void row16_sum4_dpp(long long &a, long long &b, long 
 }
 
 template <bool DERIVED>
-__global__ __launch_bounds__(256) void k_bulk_syml(View V, int wgen, int zgen, int sgen, int cgen, int nitems, int jsplit, int gfine)
+__global__ __launch_bounds__(256) void k_bulk_syml(View V, int wgen, int zgen, int sgen, int cgen, int nitems, int jsplit, int gfine, int gcoarse)
 {
     // [wave][matrix][row][octet-padded col]: 10 KiB per wave, 40 KiB per block = four blocks (16 waves) per CU exactly.
     // The log table of the derived mode (128 × 16 B) lives in the padding: entry j of a wave's private copy sits in
@@ -1014,9 +1014,9 @@ __global__ __launch_bounds__(256) void k_bulk_syml(View V, int wgen, int zgen, i
         // units — at most one per resident wave — and the light blocks below jsplit, which are handed out last, into
         // units of gfine (8..32) rows, so that the tail of the launch is a few tiles long instead of a whole 64-row unit
         // (and a small problem still spreads over the chip).
-        int J = ncb - 1, g = RC_SW_ROWS;
+        int J = ncb - 1, g = gcoarse;
         for (;; --J) {
-            g = (J >= jsplit) ? RC_SW_ROWS : gfine;
+            g = (J >= jsplit) ? gcoarse : gfine;
             const int cnt = (min(RC_SW_COLS * J + RC_SW_COLS, n) + g - 1) / g;
             if (item < cnt) break;
             item -= cnt;
@@ -2170,6 +2170,7 @@ struct rc_ctx {
     bool relayout = true;               // RC_NO_RELAYOUT=1 keeps the caller's point order
     int sym_variant = -1;               // RC_SYM_VARIANT: 2 k_bulk_syml (wave-private LDS transposition), 1 k_bulk_symw (DPP only), 0 block-tiled
                                         // k_bulk_sym; -1 (default): k_bulk_syml when logD is derived, k_bulk_sym when it is stored (measured best)
+    int sw_coarse = RC_SW_ROWS;          // RC_SW_COARSE: rows per coarse unit of k_bulk_syml (16..64, multiple of 4)
     int symw_per_cu = 4;                // RC_SYMW_PER_CU: resident blocks of k_bulk_syml / k_bulk_symw per CU (LDS: 40 KiB per block)
     bool derived = false;               // logD derived from Dq on the fly (rc_qlog), not stored
     double2 *ltab = nullptr;            // device table of rc_qlog
@@ -2597,6 +2598,7 @@ static int32_t alloc_ctx(int64_t n, int32_t storage_bits, int32_t device_id, int
     c->relayout = !(getenv("RC_NO_RELAYOUT") && atoi(getenv("RC_NO_RELAYOUT")));
     if (getenv("RC_SYM_VARIANT")) c->sym_variant = atoi(getenv("RC_SYM_VARIANT"));
     if (getenv("RC_SYMW_PER_CU")) c->symw_per_cu = std::max(1, atoi(getenv("RC_SYMW_PER_CU")));
+    if (getenv("RC_SW_COARSE")) c->sw_coarse = std::min(64, std::max(16, atoi(getenv("RC_SW_COARSE")) & ~3));
     if (getenv("RC_BULK_KERNEL")) c->bulk_kernel = !strcmp(getenv("RC_BULK_KERNEL"), "sym") ? 1 : (!strcmp(getenv("RC_BULK_KERNEL"), "perm") ? 0 : -1);
     if (getenv("RC_RES_THREADS")) c->res_threads = (atoi(getenv("RC_RES_THREADS")) == 256) ? 256 : 512;
     if (getenv("RC_SYM_ITEM_TILES")) c->sym_item_tiles = std::max(1, atoi(getenv("RC_SYM_ITEM_TILES")));
@@ -2888,11 +2890,16 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
         const int cap_blocks = c->symw_per_cu * c->num_cus;          // resident 4-wave blocks
         auto rows_of = [&](int J) { return std::min(RC_SW_COLS * J + RC_SW_COLS, c->n); };
         if (sym_variant == 2) {
-            // 64-row units for the heavy column blocks, as many as there are resident waves; 8-row units below
+            // 64-row units for the heavy column blocks — a whole number of rounds over the resident waves — and
+            // 8-row units for the light blocks below, which are handed out last
+            const int gc = c->sw_coarse;
+            int total_coarse = 0;
+            for (int J = 0; J < ncb; ++J) total_coarse += (rows_of(J) + gc - 1) / gc;
+            const int target = (total_coarse / (4 * cap_blocks)) * (4 * cap_blocks);
             int jsplit = ncb, coarse = 0;
             while (jsplit > 0) {
-                const int cnt = (rows_of(jsplit - 1) + RC_SW_ROWS - 1) / RC_SW_ROWS;
-                if (coarse + cnt > 4 * cap_blocks) break;
+                const int cnt = (rows_of(jsplit - 1) + gc - 1) / gc;
+                if (coarse + cnt > target) break;
                 coarse += cnt; --jsplit;
             }
             int gfine = RC_SW_FINE;
@@ -2907,8 +2914,8 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
             int nitems = coarse;
             for (int J = 0; J < jsplit; ++J) nitems += (rows_of(J) + gfine - 1) / gfine;
             const int nblocks = std::max(1, std::min((nitems + 3) / 4, cap_blocks));
-            if (c->derived) k_bulk_syml<true><<<nblocks, 256, 0, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems, jsplit, gfine);
-            else k_bulk_syml<false><<<nblocks, 256, 0, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems, jsplit, gfine);
+            if (c->derived) k_bulk_syml<true><<<nblocks, 256, 0, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems, jsplit, gfine, gc);
+            else k_bulk_syml<false><<<nblocks, 256, 0, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems, jsplit, gfine, gc);
         } else {
             int nitems = 0;
             for (int J = 0; J < ncb; ++J) nitems += (rows_of(J) + RC_SW_ROWS - 1) / RC_SW_ROWS;
