@@ -1024,6 +1024,16 @@ __global__ __launch_bounds__(256) void k_bulk_syml(View V, int wgen, int zgen, i
         const int c0 = J * RC_SW_COLS, a0 = item * g;
         const int a1 = min(a0 + g, min(c0 + RC_SW_COLS, n));            // rows a >= c0+128 have no column b > a here
         const int col0 = c0 + 2 * lane, col1 = col0 + 1;
+        ll2 d[RC_SL_R], l[RC_SL_R];
+        auto issue = [&](int a) {
+#pragma unroll
+            for (int u = 0; u < RC_SL_R; ++u) {
+                const int r = min(a + u, n - 1);
+                d[u] = __builtin_nontemporal_load((const ll2 *)(Dq + (size_t)r * ld + col0));
+                if (!DERIVED) l[u] = __builtin_nontemporal_load((const ll2 *)(Lq + (size_t)r * ld + col0));
+            }
+        };
+        issue(a0);                                                      // the first tile flies under the unit's set-up
         const int cs0 = col0 < n ? slot[col0] : -1, cs1 = col1 < n ? slot[col1] : -1;
         const int rowslots = (a0 + lane < n) ? slot[a0 + lane] : -1;   // slot of row a0 + lane (read back with readlane)
         // the (at most two) clusters that own the 128 columns; a third, fourth ... cluster goes the slow way
@@ -1036,15 +1046,14 @@ __global__ __launch_bounds__(256) void k_bulk_syml(View V, int wgen, int zgen, i
         }
         const bool rem0 = cs0 >= 0 && cs0 != dsA && cs0 != dsB, rem1 = cs1 >= 0 && cs1 != dsA && cs1 != dsB;
         const bool overflow = (__ballot(rem0) | __ballot(rem1)) != 0;   // uniform, rare
-        // classes of my eight transposed columns c0 + 8 tq + j: bit j of mB = belongs to cluster B; of mO = to neither
-        unsigned mB = 0, mO = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int cj = c0 + 8 * tq + j;
-            const int sj = cj < n ? slot[cj] : -1;
-            if (sj == dsB && dsB >= 0) mB |= 1u << j;
-            else if (sj != dsA) mO |= 1u << j;                          // other clusters and padding: not summed here
-        }
+        // classes of my eight transposed columns c0 + 8 tq + j (bit j of mB: cluster B; of mO: neither, or padding) from
+        // ballots over the lanes that hold those columns' slots (lane 4 tq + j/2, component j & 1): no second round of loads
+        const bool inB0 = dsB >= 0 && cs0 == dsB, inB1 = dsB >= 0 && cs1 == dsB;
+        const u64 bB0 = __ballot(inB0), bB1 = __ballot(inB1);
+        const u64 bO0 = __ballot(cs0 != dsA && !inB0), bO1 = __ballot(cs1 != dsA && !inB1);
+        auto spread4 = [](unsigned v) { return (v & 1u) | ((v & 2u) << 1) | ((v & 4u) << 2) | ((v & 8u) << 3); };
+        const unsigned mB = spread4((unsigned)(bB0 >> (4 * tq)) & 0xFu) | (spread4((unsigned)(bB1 >> (4 * tq)) & 0xFu) << 1);
+        const unsigned mO = spread4((unsigned)(bO0 >> (4 * tq)) & 0xFu) | (spread4((unsigned)(bO1 >> (4 * tq)) & 0xFu) << 1);
         long long aD0 = 0, aD1 = 0, aL0 = 0, aL1 = 0;                   // direction 1, slot `cur`
         long long rDA = 0, rLA = 0, rDB = 0, rLB = 0;                   // direction 2: row a0 + 4 (lane & 15) + (lane >> 4)
         int cur = -1;
@@ -1057,16 +1066,6 @@ __global__ __launch_bounds__(256) void k_bulk_syml(View V, int wgen, int zgen, i
             }
             aD0 = aD1 = aL0 = aL1 = 0;
         };
-        ll2 d[RC_SL_R], l[RC_SL_R];
-        auto issue = [&](int a) {
-#pragma unroll
-            for (int u = 0; u < RC_SL_R; ++u) {
-                const int r = min(a + u, n - 1);
-                d[u] = __builtin_nontemporal_load((const ll2 *)(Dq + (size_t)r * ld + col0));
-                if (!DERIVED) l[u] = __builtin_nontemporal_load((const ll2 *)(Lq + (size_t)r * ld + col0));
-            }
-        };
-        issue(a0);
         for (int a = a0; a < a1; a += RC_SL_R) {
             ll2 x[RC_SL_R], y[RC_SL_R];
 #pragma unroll
