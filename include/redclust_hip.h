@@ -76,6 +76,9 @@ int32_t rc_create_from_points(int64_t n, int64_t dim, const double *points, int3
                               int64_t kcap, rc_ctx **out);
 /* The matrix the device actually holds (which = 0: D, 1: logD), as doubles: value = q·2^-e exactly. */
 int32_t rc_get_matrix(rc_ctx *ctx, int32_t which, double *out_n_by_n);
+/* Selected rows (0-based, caller's point order) of the same matrix: out is nrows×n row-major.  For sizes where the
+ * n×n doubles of rc_get_matrix do not fit on the host (BASELINE config 5: 8 GiB). */
+int32_t rc_get_matrix_rows(rc_ctx *ctx, int32_t which, const int64_t *rows, int64_t nrows, double *out);
 int32_t rc_destroy(rc_ctx *ctx);
 
 /* Last error text of ctx (or of the calling thread's last failed rc_create when ctx == NULL). */

@@ -443,6 +443,107 @@ int orc_sweep_stable(int64_t n, const int64_t *Dq, const int64_t *Lq, int eD, in
     return 0;
 }
 
+/* The same sweep driven by a row-sum TABLE instead of the n×n matrices, for sizes at which the checker cannot hold
+ * the matrices (BASELINE config 5: 2 × 8 GiB as int64).  Same loop, same arithmetic (stable_score, orc_uniform,
+ * first-index argmax, smallest empty label) as orc_sweep_stable; only the source of matsum(·,[i],clust_k)
+ * (src/mcmc.jl:210-213) differs:
+ *   T_D / T_L  [nlab][n]  T[t][i] = Σ_j X[i,j]·[c_j = row_label[t]] under the labels at entry, j = i INCLUDED (D[i,i] as
+ *                         stored — diag[i]; logD's diagonal is 0, types.jl:155); row_label ascending = the non-empty labels.
+ *   A label change of point x (a → b) subtracts row x of each matrix from table row a and adds it to table row b.  The
+ *   caller supplies the matrix rows of the points that are allowed to change: xs (ascending point indices, 0-based),
+ *   XD / XL [nx][n] fixed point.  A change of any other point returns -3 (teacher forcing: the caller passes the set of
+ *   points the implementation under test changed, so -3 is itself a parity failure).
+ * Returns 0, or -2 (allocation), -3 (see above). */
+int orc_sweep_table(int64_t n, int64_t nlab, const int64_t *row_label, const int64_t *T_D, const int64_t *T_L,
+                    const int64_t *diag, int eD, int eL, const double *A, int64_t *clusts, int64_t *clustsizes,
+                    int64_t *K, const orc_params *P, double r, double p, uint64_t seed, uint64_t sweep, int64_t nx,
+                    const int64_t *xs, const int64_t *XD, const int64_t *XL, int64_t *n_changes)
+{
+    const int64_t cap = nlab + nx + 1;
+    int64_t *TD = malloc((size_t)cap * (size_t)n * sizeof(int64_t)), *TL = malloc((size_t)cap * (size_t)n * sizeof(int64_t));
+    int64_t *row_of = malloc((size_t)n * sizeof(int64_t));      /* label-1 -> table row, -1 = none */
+    int64_t *act = malloc((size_t)(n + 1) * sizeof(int64_t));   /* non-empty labels, ascending (C_i of mcmc.jl:195) */
+    int64_t *free_rows = malloc((size_t)cap * sizeof(int64_t));
+    if (!TD || !TL || !row_of || !act || !free_rows) { free(TD); free(TL); free(row_of); free(act); free(free_rows); return -2; }
+    memcpy(TD, T_D, (size_t)nlab * (size_t)n * sizeof(int64_t));
+    memcpy(TL, T_L, (size_t)nlab * (size_t)n * sizeof(int64_t));
+    memset(TD + nlab * n, 0, (size_t)(cap - nlab) * (size_t)n * sizeof(int64_t));
+    memset(TL + nlab * n, 0, (size_t)(cap - nlab) * (size_t)n * sizeof(int64_t));
+    for (int64_t k = 0; k < n; ++k) row_of[k] = -1;
+    for (int64_t t = 0; t < nlab; ++t) row_of[row_label[t] - 1] = t;
+    int64_t nfree = 0;
+    for (int64_t t = cap - 1; t >= nlab; --t) free_rows[nfree++] = t;
+    int64_t nact = 0;
+    for (int64_t k = 0; k < n; ++k) if (clustsizes[k] > 0) act[nact++] = k + 1;
+    const double scD = ldexp(1.0, -eD), scL = ldexp(1.0, -eL);
+    const double logp = log(p), log1mp = log(1 - p);
+    int64_t changes = 0;
+    int rc = 0;
+    for (int64_t i = 0; i < n && rc == 0; ++i) {
+        const int64_t old = clusts[i];
+        clustsizes[old - 1] -= 1;                                   /* mcmc.jl:193 */
+        clusts[i] = -1;                                             /* mcmc.jl:194 */
+        if (clustsizes[old - 1] == 0) {                             /* i was a singleton: its label leaves C_i */
+            int64_t q = 0;
+            while (act[q] != old) ++q;
+            memmove(act + q, act + q + 1, (size_t)(nact - q - 1) * sizeof(int64_t));
+            --nact;
+        }
+        const int64_t K_i = nact;
+        int64_t best = 0;
+        double bestv = 0;
+        for (int64_t t = 0; t < K_i; ++t) {
+            const int64_t c = act[t] - 1, row = row_of[c];
+            int64_t sd = TD[row * n + i], sl = TL[row * n + i];
+            if (c == old - 1) sd -= diag[i];                        /* i itself is not a member (clusts[i] = -1) */
+            double v = stable_score(P, A, clustsizes[c], (double)sd * scD, (double)sl * scL, logp, r);
+            double u = orc_uniform(seed, sweep, (uint64_t)i, (uint64_t)t);
+            v = v + (-log(-log(u)));
+            if (t == 0 || v > bestv) { bestv = v; best = t; }
+        }
+        int64_t newlab = 0;
+        if ((P->maxK == 0 || K_i < P->maxK) && K_i < n) {           /* mcmc.jl:198-203 */
+            int64_t e = 0;
+            while (clustsizes[e] != 0) ++e;
+            newlab = e + 1;
+            double v = log((double)(K_i + 1)) + r * log1mp;
+            double u = orc_uniform(seed, sweep, (uint64_t)i, (uint64_t)K_i);
+            v = v + (-log(-log(u)));
+            if (K_i == 0 || v > bestv) { bestv = v; best = K_i; }
+        }
+        const int64_t ci_new = (best < K_i) ? act[best] : newlab;
+        if (clustsizes[ci_new - 1] == 0) {                          /* label (re)enters C_i, ascending order kept */
+            int64_t q = 0;
+            while (q < nact && act[q] < ci_new) ++q;
+            memmove(act + q + 1, act + q, (size_t)(nact - q) * sizeof(int64_t));
+            act[q] = ci_new;
+            ++nact;
+        }
+        clusts[i] = ci_new;                                         /* mcmc.jl:250-252 */
+        clustsizes[ci_new - 1] += 1;
+        if (ci_new != old) {
+            ++changes;
+            int64_t lo = 0, hi = nx;
+            while (lo < hi) { const int64_t mid = (lo + hi) / 2; if (xs[mid] < i) lo = mid + 1; else hi = mid; }
+            if (lo >= nx || xs[lo] != i) { rc = -3; break; }
+            if (row_of[ci_new - 1] < 0) row_of[ci_new - 1] = free_rows[--nfree];   /* all-zero row */
+            const int64_t ra = row_of[old - 1], rb = row_of[ci_new - 1];
+            const int64_t *xd = XD + lo * n, *xl = XL + lo * n;
+            for (int64_t j = 0; j < n; ++j) {
+                TD[ra * n + j] -= xd[j]; TD[rb * n + j] += xd[j];
+                TL[ra * n + j] -= xl[j]; TL[rb * n + j] += xl[j];
+            }
+            if (clustsizes[old - 1] == 0) { free_rows[nfree++] = ra; row_of[old - 1] = -1; }   /* exactly zero again */
+        }
+    }
+    int64_t k = 0;
+    for (int64_t t = 0; t < n; ++t) k += clustsizes[t] > 0;
+    *K = k;
+    if (n_changes) *n_changes = changes;
+    free(TD); free(TL); free(row_of); free(act); free(free_rows);
+    return rc;
+}
+
 /* Stable per-candidate scores (no Gumbel) for one point of the current state; for cross-checks. */
 int64_t orc_point_scores_stable(int64_t n, const int64_t *Dq, const int64_t *Lq, int eD, int eL,
                                 const double *A, const int64_t *clusts, const int64_t *clustsizes,

@@ -80,6 +80,7 @@ SIGNATURES = {
     "rc_create": (C.c_int32, [C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_void_p)]),
     "rc_create_from_points": (C.c_int32, [C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_void_p)]),
     "rc_get_matrix": (C.c_int32, [C.c_void_p, C.c_int32, _dp]),
+    "rc_get_matrix_rows": (C.c_int32, [C.c_void_p, C.c_int32, _ip, C.c_int64, _dp]),
     "rc_destroy": (C.c_int32, [C.c_void_p]),
     "rc_last_error": (C.c_char_p, [C.c_void_p]),
     "rc_set_params": (C.c_int32, [C.c_void_p, C.POINTER(RcParams)]),
@@ -181,6 +182,14 @@ class Context:
     def get_matrix(self, which=0):
         out = np.zeros((self.n, self.n))
         self._chk(self.L.rc_get_matrix(self.h, int(which), out.reshape(-1)))
+        return out
+
+    def get_matrix_rows(self, which, rows):
+        """rows (0-based, caller's order) of the device's D (which=0) or logD (which=1) as an len(rows)×n array"""
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        out = np.zeros((len(rows), self.n))
+        if len(rows):
+            self._chk(self.L.rc_get_matrix_rows(self.h, int(which), rows, len(rows), out.reshape(-1)))
         return out
 
     def _chk(self, rc):

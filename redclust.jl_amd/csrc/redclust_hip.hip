@@ -359,6 +359,18 @@ __global__ void k_derived_matrix(const long long *__restrict__ Dq, int n, int ld
     }
 }
 
+// rows rows[0..nrows) of the device matrix (caller's order) as doubles, value = q·2^-e; derived logD through rc_qlog
+template <typename T>
+__global__ __launch_bounds__(256) void k_get_rows(const T *__restrict__ Q, const int *__restrict__ rows, int n, int ld, double scale,
+                                                  int derive, int eD, double sL, const double2 *__restrict__ tab, double *__restrict__ out)
+{
+    const int r = rows[blockIdx.y];
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+        const long long q = (long long)Q[(size_t)r * ld + j];
+        out[(size_t)blockIdx.y * n + j] = derive ? ((j == r) ? 0.0 : (double)rc_qlog(q, eD, sL, tab) * scale) : (double)q * scale;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_relayout(const T *__restrict__ src, const int *__restrict__ ipi, int n, int ld, T *__restrict__ out)
 {
@@ -2705,6 +2717,40 @@ extern "C" int32_t rc_get_matrix(rc_ctx *c, int32_t which, double *out_n_by_n)
     return RC_OK;
 }
 
+// Selected rows of the same matrices (rc_get_matrix needs n² doubles on the host: 8 GiB at n = 32768).
+extern "C" int32_t rc_get_matrix_rows(rc_ctx *c, int32_t which, const int64_t *rows, int64_t nrows, double *out)
+{
+    if (!c || !rows || !out) return fail(c, RC_ERR_ARG, "rc_get_matrix_rows: NULL argument");
+    if (which != 0 && which != 1) return fail(c, RC_ERR_ARG, "rc_get_matrix_rows: which must be 0 (D) or 1 (logD)");
+    if (nrows < 0 || nrows > 65535) return fail(c, RC_ERR_ARG, "rc_get_matrix_rows: nrows must be in 0..65535");
+    if (nrows == 0) return RC_OK;
+    std::vector<int> r32((size_t)nrows);
+    for (int64_t q = 0; q < nrows; ++q) {
+        if (rows[q] < 0 || rows[q] >= c->n) return fail(c, RC_ERR_ARG, "rc_get_matrix_rows: row %lld outside 0..n-1", (long long)rows[q]);
+        r32[(size_t)q] = (int)rows[q];
+    }
+    HIPCHK(c, hipSetDevice(c->dev));
+    int *drows = nullptr;
+    double *tmp = nullptr;
+    HIPCHK(c, hipMalloc(&drows, (size_t)nrows * sizeof(int)));
+    hipError_t e = hipMalloc(&tmp, (size_t)nrows * c->n * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(drows, r32.data(), (size_t)nrows * sizeof(int), hipMemcpyHostToDevice, c->sA);
+    if (e == hipSuccess) {
+        const bool derive = which && c->derived;
+        const void *Q = (which && !derive) ? c->Lq_src : c->Dq_src;
+        const double scale = std::ldexp(1.0, -(which ? c->eL : c->eD));
+        dim3 g((unsigned)std::min(64, (c->n + 255) / 256), (unsigned)nrows);
+        if (c->bits == 64) k_get_rows<long long><<<g, 256, 0, c->sA>>>((const long long *)Q, drows, c->n, c->ld, scale, derive ? 1 : 0, c->eD, std::ldexp(1.0, c->eL), c->ltab, tmp);
+        else k_get_rows<int><<<g, 256, 0, c->sA>>>((const int *)Q, drows, c->n, c->ld, scale, 0, c->eD, 0.0, c->ltab, tmp);
+        e = hipMemcpyAsync(out, tmp, (size_t)nrows * c->n * sizeof(double), hipMemcpyDeviceToHost, c->sA);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->sA);
+    (void)hipFree(drows);
+    if (tmp) (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(c, RC_ERR_HIP, "rc_get_matrix_rows: %s", hipGetErrorString(e));
+    return RC_OK;
+}
+
 extern "C" int32_t rc_set_params(rc_ctx *c, const rc_params *P)
 {
     if (!c || !P) return fail(c, RC_ERR_ARG, "rc_set_params: NULL argument");
@@ -2720,6 +2766,8 @@ extern "C" int32_t rc_set_params(rc_ctx *c, const rc_params *P)
     c->lg_memo2.clear();
     c->ll_cache.clear();
     c->ll_dim = 0;
+    c->ll_version = -1;   // cached log-likelihood / block sums belong to the old parameters
+    c->B_version = -2;
     // size table (see DESIGN.md "Score arithmetic"): long double on the host, once per parameter set
     std::vector<double> A((size_t)c->n + 1);
     const long double d1 = P->delta1, d2 = P->delta2, al = P->alpha, be = P->beta, ze = P->zeta, ga = P->gamma;

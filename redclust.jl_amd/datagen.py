@@ -9,7 +9,7 @@ from scipy.special import digamma, polygamma
 
 
 def generatemixture(N: int, K: int, *, alpha: float | None = None, dim: int | None = None, radius: float = 1.0,
-                    sigma: float = 0.1, seed: int = 0, dtype=np.float64):
+                    sigma: float = 0.1, seed: int = 0, dtype=np.float64, points_only: bool = False):
     if N < 1:
         raise ValueError("N must be greater than 1.")
     if K < 1 or K > N:
@@ -27,6 +27,8 @@ def generatemixture(N: int, K: int, *, alpha: float | None = None, dim: int | No
     clusts = np.sort(rng.choice(K, size=N, p=probs)) + 1          # utils.jl:114 (sorted labels)
     pts = rng.normal(0.0, sigma, size=(N, dim))                   # utils.jl:123-128
     pts[np.arange(N), clusts - 1] += radius                       # centre k = radius·e_k, utils.jl:117-120
+    if points_only:   # the n×n matrix is left to the device (MCMCData(points), rc_create_from_points)
+        return dict(points=pts, distancematrix=None, clusts=clusts.astype(np.int64), probs=probs)
     # pairwise Euclidean distances (utils.jl:144-145), built block-row-wise so that N = 32768 needs one N×N array
     sq = np.einsum("ij,ij->i", pts, pts)
     D = np.empty((N, N), dtype=np.float64)

@@ -60,6 +60,8 @@ def lib():
     L.orc_size_table.argtypes = [i64, PP, _dp]
     L.orc_sweep_stable.argtypes = [i64, _ip, _ip, i32, i32, _dp, _ip, _ip, C.POINTER(i64), PP, f64, f64,
                                    u64, u64, C.POINTER(i64)]
+    L.orc_sweep_table.argtypes = [i64, i64, _ip, _ip, _ip, _ip, i32, i32, _dp, _ip, _ip, C.POINTER(i64), PP, f64, f64, u64, u64,
+                                  i64, _ip, _ip, _ip, C.POINTER(i64)]
     L.orc_point_scores_stable.restype = i64
     L.orc_point_scores_stable.argtypes = [i64, _ip, _ip, i32, i32, _dp, _ip, _ip, PP, f64, f64, i64, _ip, _dp]
     L.orc_loglik_literal.restype = f64
@@ -141,6 +143,34 @@ def run_chain(orc, init, r, p, numiters, burnin, thin, numGibbs, numMH, seed, pr
             rec["clusts"].append(orc.sortlabels()); rec["K"].append(orc.K); rec["r"].append(r); rec["p"].append(p)
             rec["loglik"].append(ll); rec["logposterior"].append(ll + orc.logprior(r, p))
     return {k: np.array(v) for k, v in rec.items()}
+
+
+def sweep_table(P, A, row_label, T_D, T_L, diag, eD, eL, clusts, r, p, seed, sweep, xs, XD, XL):
+    """orc_sweep_table: one stable-arithmetic sweep driven by the row-sum table (rows = ascending non-empty labels,
+    j = i included) and the fixed-point matrix rows XD / XL of the points xs that may change.
+    Returns (labels, sizes, K, n_changes); raises AssertionError if a point outside xs changed."""
+    n = len(clusts)
+    c = np.ascontiguousarray(clusts, dtype=np.int64).copy()
+    sizes = np.bincount(c, minlength=n + 1)[1:].astype(np.int64)
+    K, ch = C.c_int64(), C.c_int64()
+    xs = np.ascontiguousarray(xs, dtype=np.int64)
+    XD = np.ascontiguousarray(XD, dtype=np.int64).reshape(-1) if len(xs) else np.zeros(1, np.int64)
+    XL = np.ascontiguousarray(XL, dtype=np.int64).reshape(-1) if len(xs) else np.zeros(1, np.int64)
+    rl = np.ascontiguousarray(row_label, dtype=np.int64)
+    rc = lib().orc_sweep_table(n, len(rl), rl, np.ascontiguousarray(T_D, dtype=np.int64).reshape(-1),
+                               np.ascontiguousarray(T_L, dtype=np.int64).reshape(-1),
+                               np.ascontiguousarray(diag, dtype=np.int64), int(eD), int(eL),
+                               np.ascontiguousarray(A, dtype=np.float64), c, sizes, C.byref(K), C.byref(params(P)),
+                               float(r), float(p), int(seed), int(sweep), len(xs), xs if len(xs) else np.zeros(1, np.int64),
+                               XD, XL, C.byref(ch))
+    assert rc == 0, f"orc_sweep_table returned {rc} (-3: a point outside the supplied change set moved)"
+    return c, sizes, K.value, ch.value
+
+
+def size_table(P, n):
+    A = np.zeros(n + 1)
+    lib().orc_size_table(n, C.byref(params(P)), A)
+    return A
 
 
 def pair_measures(a, b) -> dict:

@@ -1,0 +1,230 @@
+"""Oracle parity AT THE BENCHMARKED SIZES, on the code path bench.py times (-m gpu).
+
+* BASELINE config 3 (N=8192, K=50, the roofline configuration): the context is created exactly as bench.py creates it —
+  D only (logD derived on the fly), no forced kernel, so the automatic choice k_bulk_syml<true> + k_resolve runs — and is
+  compared with the CPU oracle sweep by sweep: labels / sizes / K / change counts exactly, fixed-point row sums of both
+  matrices bit for bit, loglik within 1e-9 (stable restatement) and 1e-6 (literal restatement) relative.
+* a size between the kernel-choice threshold (4096) and the headline size, on the automatic path across a re-layout.
+* BASELINE config 5 (N=32768, K=200, 32-bit storage) without an n×n host matrix: the context is built from the points
+  (rc_create_from_points) and the sweep is checked point by point by the table-driven oracle (orc_sweep_table), which is
+  handed the device's exact row-sum table and the matrix rows of the points that moved.
+The oracle is fed the device's own logD (rc_get_matrix / rc_get_matrix_rows), as in tests/test_gpu_derived_log.py: the
+library's table log differs from libm's by ≤ 5e-16 before quantisation, which is value-checked there.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import redclust_amd as rc
+from helpers import rp_schedule
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def headline():
+    n, K = 8192, 50
+    data = rc.generatemixture(n, K, seed=1)               # bench.py's data set
+    D, truth = data["distancematrix"], data["clusts"]
+    P = rc.likelihood_hyperparams(D, truth)
+    ctx = rc.Context(D, kcap=max(128, 2 * K))             # as bench.py: D only, automatic kernel
+    ctx.set_params(**P)
+    ctx.set_state(truth)
+    L = ctx.get_matrix(1)
+    eL = ctx.debug_rowsums(1)[3]
+    orc = O.Oracle(D, P, logD=L, eL=eL)
+    yield dict(n=n, K=K, D=D, truth=truth, P=P, ctx=ctx, orc=orc, L=L)
+    ctx.close()
+
+
+def _init(kind, truth, K):
+    n = len(truth)
+    if kind == "stationary":
+        return truth.copy()
+    if kind == "perturbed":                                # 2 % of the labels re-drawn
+        init = truth.copy()
+        idx = np.random.default_rng(11).choice(n, n // 50, replace=False)
+        init[idx] = np.random.default_rng(12).integers(1, K + 1, size=len(idx))
+        return init
+    return np.random.default_rng(13).integers(1, K + 1, size=n).astype(np.int64)   # uniform on 1..K
+
+
+@pytest.mark.parametrize("kind", ["stationary", "perturbed", "uniform"])
+def test_headline_config_against_oracle(headline, kind):
+    h = headline
+    n, K, ctx, orc = h["n"], h["K"], h["ctx"], h["orc"]
+    init = _init(kind, h["truth"], K)
+    ctx.set_state(init)
+    orc.set_state(init)
+    nsweeps = 4
+    names, moved = [], 0
+    for t in range(nsweeps):
+        r, p = rp_schedule(t)
+        ctx.gibbs_sweep(r, p, 8192, t)
+        names.append(ctx.bulk_kernel_name())
+        orc.sweep_stable(r, p, 8192, t)
+        lab, sizes, Kc = ctx.get_state()
+        assert np.array_equal(lab, orc.clusts), (kind, t, int(np.sum(lab != orc.clusts)))
+        assert np.array_equal(sizes, orc.sizes) and Kc == orc.K, (kind, t)
+        st = ctx.sweep_stats()
+        assert st["n_changes"] == orc.last_changes and st["K"] == orc.K, (kind, t, st, orc.last_changes)
+        moved += st["n_changes"]
+    # the sweep right after rc_set_state sees a cluster-contiguous layout: this is the kernel bench.py times
+    assert names[0] == "k_bulk_syml<true>", names
+    if kind == "stationary":
+        assert all(x == "k_bulk_syml<true>" for x in names), names
+    else:
+        assert moved > (50 if kind == "perturbed" else n // 2)
+    # the row-sum table after the corrections of four sweeps, both matrices, bit for bit
+    for k in np.unique(orc.clusts)[[0, 7, -1]]:
+        sd, sl, eD, eL = ctx.debug_rowsums(int(k))
+        m = orc.clusts == k
+        assert (eD, eL) == (orc.eD, orc.eL)
+        assert np.array_equal(sd, orc.Dq[:, m].sum(axis=1)) and np.array_equal(sl, orc.Lq[:, m].sum(axis=1)), (kind, k)
+    ll = ctx.loglik()
+    ref = orc.loglik_stable()
+    assert abs(ll - ref) <= 1e-9 * abs(ref), (ll, ref)               # tolerance: 1e-9 relative (north_star allows 1e-6)
+    lit = orc.loglik_literal()
+    assert abs(ll - lit) <= 1e-6 * abs(lit), (ll, lit)               # vs the reference's formulas as written
+    lp = ctx.logprior(*rp_schedule(nsweeps - 1))
+    assert abs(lp - orc.logprior(*rp_schedule(nsweeps - 1))) <= 1e-12 * abs(lp)
+    # the same sweeps enqueued without host synchronisation (what bench.py does) end in the same state
+    final = orc.clusts.copy()
+    ctx.set_state(init)
+    for t in range(nsweeps):
+        r, p = rp_schedule(t)
+        ctx.gibbs_sweep(r, p, 8192, t, blocking=False)
+    ctx.synchronize()
+    lab, sizes, Kc = ctx.get_state()
+    assert np.array_equal(lab, final) and Kc == orc.K and ctx.loglik() == ll
+
+
+def test_headline_rowsum_checksums(headline):
+    """Σ_k S[k][i] = Σ_j X[i,j] for both matrices (exact in fixed point) under the generating labels, from the kernel
+    bench.py times; co-clustering counts of two recorded samples."""
+    h = headline
+    n, ctx, orc, truth = h["n"], h["ctx"], h["orc"], h["truth"]
+    ctx.set_state(truth)
+    tot_d = np.zeros(n, np.int64); tot_l = np.zeros(n, np.int64)
+    for lab in np.unique(truth):
+        sd, sl, eD, eL = ctx.debug_rowsums(int(lab))
+        tot_d += sd; tot_l += sl
+    assert np.array_equal(tot_d, orc.Dq.sum(axis=1)) and np.array_equal(tot_l, orc.Lq.sum(axis=1))
+    assert ctx.bulk_kernel_name() == "k_bulk_syml<true>"
+    ctx.cocluster_reset()
+    ctx.record_sample(False)
+    ctx.gibbs_sweep(1.0, 0.5, 5, 0)
+    c = ctx.record_sample(True)
+    cnt = ctx.cocluster_counts()
+    lab = ctx.get_state()[0]
+    assert np.all(np.diag(cnt) == 2) and np.array_equal(cnt, cnt.T)
+    exp = (truth[:, None] == truth[None, :]).astype(np.uint32) + (lab[:, None] == lab[None, :])
+    assert np.array_equal(cnt, exp)
+    canon = np.zeros(n, np.int64)
+    O.lib().orc_sortlabels(n, lab, canon)
+    assert np.array_equal(c, canon)
+
+
+def test_auto_path_between_threshold_and_headline_size_crosses_relayout():
+    """n = 5000 (4096 < n < 8192), shuffled points, overlapping clusters: the automatic path starts on k_bulk_syml<true>,
+    label movement fragments the layout (the full-read kernel takes over), the library re-lays the points out after 32
+    sweeps and returns to the symmetric kernel — every sweep compared with the oracle."""
+    n, K = 5000, 5
+    data = rc.generatemixture(n, K, seed=17, sigma=0.55, dim=6)
+    sh = np.random.default_rng(4).permutation(n)
+    D = np.ascontiguousarray(data["distancematrix"][np.ix_(sh, sh)]); truth = data["clusts"][sh]
+    P = dict(rc.likelihood_hyperparams(D, truth), maxK=12)
+    ctx = rc.Context(D, kcap=64)
+    ctx.set_params(**P)
+    ctx.set_state(truth)
+    orc = O.Oracle(D, P, logD=ctx.get_matrix(1), eL=ctx.debug_rowsums(int(truth[0]))[3])
+    orc.set_state(truth)
+    l0 = ctx.layout_info()[0]
+    names, relaid_at = [], None
+    for t in range(40):
+        ctx.gibbs_sweep(1.0, 0.5, 3, t, blocking=(t % 2 == 0))
+        names.append(ctx.bulk_kernel_name())
+        orc.sweep_stable(1.0, 0.5, 3, t)
+        lab, sizes, Kc = ctx.get_state()
+        assert np.array_equal(lab, orc.clusts) and np.array_equal(sizes, orc.sizes) and Kc == orc.K, t
+        if relaid_at is None and ctx.layout_info()[0] > l0:
+            relaid_at = t
+    assert names[0] == "k_bulk_syml<true>" and "k_bulk<long long, true>" in names, names
+    assert relaid_at is not None and names[relaid_at] == "k_bulk_syml<true>", (relaid_at, names)
+    for k in np.unique(orc.clusts)[:3]:
+        sd, sl = ctx.debug_rowsums(int(k))[:2]
+        m = orc.clusts == k
+        assert np.array_equal(sd, orc.Dq[:, m].sum(axis=1)) and np.array_equal(sl, orc.Lq[:, m].sum(axis=1))
+    assert abs(ctx.loglik() - orc.loglik_stable()) <= 1e-9 * abs(orc.loglik_stable())
+    ctx.close()
+
+
+def _device_table(ctx, labels):
+    rows = np.unique(labels)
+    TD = np.empty((len(rows), ctx.n), np.int64); TL = np.empty((len(rows), ctx.n), np.int64)
+    eD = eL = None
+    for t, lab in enumerate(rows):
+        TD[t], TL[t], eD, eL = ctx.debug_rowsums(int(lab))
+    return rows, TD, TL, eD, eL
+
+
+def test_config5_against_table_oracle():
+    """BASELINE config 5: N=32768, K=200, 32-bit storage, built from the points (no n×n host matrix).
+    (i) the device's D rows agree with the host's pairwise distances; (ii) the row-sum table of k_bulk_sym32 equals, for
+    sampled points and every cluster, the bucketed sums of the device's own matrix rows (both matrices, exact);
+    (iii) one stationary and one perturbed sweep are re-enacted point by point by the table-driven oracle: labels, sizes,
+    K and the change count must match exactly; (iv) async == blocking."""
+    n, K = 32768, 200
+    data = rc.generatemixture(n, K, seed=1, points_only=True)
+    pts, truth = data["points"], data["clusts"]
+    ctx = rc.Context.from_points(pts, kcap=512, storage_bits=32)
+    P = rc.likelihood_hyperparams_device(ctx, truth)
+    ctx.set_params(**P)
+    A = O.size_table(P, n)
+    # (i) + (ii) on 48 sampled points
+    ctx.set_state(truth)
+    rows, TD, TL, eD, eL = _device_table(ctx, truth)
+    assert ctx.bulk_kernel_name() == "k_bulk_sym32"
+    sample = np.sort(np.random.default_rng(0).choice(n, 48, replace=False))
+    RD, RL = ctx.get_matrix_rows(0, sample), ctx.get_matrix_rows(1, sample)
+    sq = np.einsum("ij,ij->i", pts, pts)
+    host = np.sqrt(np.maximum(sq[sample][:, None] + sq[None, :] - 2.0 * pts[sample] @ pts.T, 0.0))
+    host[np.arange(len(sample)), sample] = 0.0
+    assert np.max(np.abs(RD - host)) <= 2.0 ** -29 * host.max()          # 32-bit grid: 2^-30 of the largest entry (+ f64 noise)
+    qD = np.rint(np.ldexp(RD, eD)).astype(np.int64); qL = np.rint(np.ldexp(RL, eL)).astype(np.int64)
+    assert np.array_equal(np.ldexp(qD.astype(np.float64), -eD), RD)      # value = q·2^-e exactly
+    onehot = (truth[:, None] == rows[None, :]).astype(np.int64)
+    assert np.array_equal(qD @ onehot, TD[:, sample].T) and np.array_equal(qL @ onehot, TL[:, sample].T)
+    diag = np.zeros(n, np.int64)                                        # pairwise distances: zero diagonal (checked on the sample)
+    assert np.all(qD[np.arange(len(sample)), sample] == 0)
+    idx = np.random.default_rng(0).choice(n, 500, replace=False)
+    perturbed = truth.copy()
+    perturbed[idx] = np.random.default_rng(1).integers(1, K + 1, size=500)
+    total_moved = 0
+    for name, init in (("stationary", truth), ("perturbed", perturbed)):
+        ctx.set_state(init)
+        rows, TD, TL, eD, eL = _device_table(ctx, init)
+        ctx.gibbs_sweep(1.0, 0.5, 42, 0)
+        lab, sizes, Kc = ctx.get_state()
+        st = ctx.sweep_stats()
+        xs = np.flatnonzero(lab != init)
+        XD = np.rint(np.ldexp(ctx.get_matrix_rows(0, xs), eD)).astype(np.int64)
+        XL = np.rint(np.ldexp(ctx.get_matrix_rows(1, xs), eL)).astype(np.int64)
+        got = O.sweep_table(P, A, rows, TD, TL, diag, eD, eL, init, 1.0, 0.5, 42, 0, xs, XD, XL)
+        assert np.array_equal(got[0], lab), (name, int(np.sum(got[0] != lab)))
+        assert np.array_equal(got[1], sizes) and got[2] == Kc and got[3] == st["n_changes"] == len(xs), (name, got[2:], st)
+        total_moved += len(xs)
+        # two more sweeps, then the same three enqueued back to back
+        for t in (1, 2):
+            ctx.gibbs_sweep(1.0, 0.5, 42, t)
+        c1, s1, K1 = ctx.get_state()
+        assert s1.sum() == n and K1 == np.sum(s1 > 0) and np.array_equal(np.bincount(c1, minlength=n + 1)[1:], s1)
+        ll1 = ctx.loglik()
+        ctx.set_state(init)
+        for t in range(3):
+            ctx.gibbs_sweep(1.0, 0.5, 42, t, blocking=False)
+        ctx.synchronize()
+        c2, s2, K2 = ctx.get_state()
+        assert np.array_equal(c1, c2) and K1 == K2 and ctx.loglik() == ll1, name
+    assert total_moved > 100
+    ctx.close()

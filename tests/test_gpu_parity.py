@@ -561,8 +561,9 @@ def test_incremental_mode_is_bit_identical():
 
 def test_full_size_properties():
     """BASELINE config 3 (N=8192, K=50): size-independent properties — Σ sizes = n, K = #non-empty, checksum of
-    the row-sum table (Σ_k S[k][i] = Σ_j D[i,j], exact in fixed point), stationarity of the generating labels,
-    async == blocking, co-clustering diagonal/symmetry."""
+    the row-sum table (Σ_k S[k][i] = Σ_j X[i,j] for D and logD, exact in fixed point), stationarity of the generating
+    labels, async == blocking, co-clustering diagonal/symmetry.  (The oracle comparison at this size is
+    tests/test_gpu_headline.py; config 5 is there too.)"""
     n, K = 8192, 50
     data = rc.generatemixture(n, K, seed=1)
     D, truth = data["distancematrix"], data["clusts"]
@@ -576,6 +577,8 @@ def test_full_size_properties():
         tot_d += sd; tot_l += sl
     ref_d = np.rint(np.ldexp(D, eD)).astype(np.int64).sum(axis=1)
     assert np.array_equal(tot_d, ref_d)
+    ref_l = np.rint(np.ldexp(ctx.get_matrix(1), eL)).astype(np.int64).sum(axis=1)   # the device's (derived) logD = q·2^-eL exactly
+    assert np.array_equal(tot_l, ref_l)
     for t in range(3):
         ctx.gibbs_sweep(1.0, 0.5, 42, t)
     c1, s1, K1 = ctx.get_state()
@@ -599,47 +602,6 @@ def test_full_size_properties():
     post = ctx.cocluster(2)
     assert np.all(np.diag(post) == 1.0) and np.array_equal(post, post.T)
     assert np.array_equal(post == 1.0, c3[:, None] == c3[None, :])
-    ctx.close()
-
-
-@pytest.mark.skipif(not os.environ.get("RC_TEST_BIG"), reason="BASELINE config 5 (N=32768, K=200, 8 GiB host matrix): set RC_TEST_BIG=1")
-def test_config5_properties():
-    """BASELINE config 5: N=32768, K=200, 32-bit storage.  Size-independent properties (no oracle at this size)."""
-    n, K = 32768, 200
-    data = rc.generatemixture(n, K, seed=1)
-    D, truth = data["distancematrix"], data["clusts"]
-    P = rc.likelihood_hyperparams(D, truth)
-    ctx = rc.Context(D, kcap=512, storage_bits=32)
-    ctx.set_params(**P)
-    ctx.set_state(truth)
-    tot = np.zeros(n, np.int64)
-    eD = None
-    for lab in np.unique(truth):
-        sd, sl, eD, eL = ctx.debug_rowsums(int(lab))
-        tot += sd
-    ref = np.zeros(n, np.int64)
-    for i0 in range(0, n, 2048):
-        ref[i0:i0 + 2048] = np.rint(np.ldexp(D[i0:i0 + 2048], eD)).astype(np.int64).sum(axis=1)
-    assert np.array_equal(tot, ref)                       # checksum of the whole row-sum table, exact
-    for t in range(3):
-        ctx.gibbs_sweep(1.0, 0.5, 42, t)
-    c1, s1, K1 = ctx.get_state()
-    assert s1.sum() == n and K1 == np.sum(s1 > 0) and np.array_equal(np.bincount(c1, minlength=n + 1)[1:], s1)
-    ll1 = ctx.loglik()
-    ctx.set_state(truth)
-    for t in range(3):
-        ctx.gibbs_sweep(1.0, 0.5, 42, t, blocking=False)
-    ctx.synchronize()
-    c2, s2, K2 = ctx.get_state()
-    assert np.array_equal(c1, c2) and ctx.loglik() == ll1
-    # perturb 500 labels: the sweep must move points and keep the invariants
-    init = truth.copy()
-    idx = np.random.default_rng(0).choice(n, 500, replace=False)
-    init[idx] = np.random.default_rng(1).integers(1, K + 1, size=500)
-    ctx.set_state(init)
-    ctx.gibbs_sweep(1.0, 0.5, 43, 0)
-    c3, s3, K3 = ctx.get_state()
-    assert s3.sum() == n and K3 == np.sum(s3 > 0) and ctx.sweep_stats()["n_changes"] > 0
     ctx.close()
 
 

@@ -203,3 +203,34 @@ def test_julia_glue_binds_only_declared_symbols():
     assert used, "no ccall found"
     declared = set(re.findall(r"\b(rc_[a-z_0-9]+)\s*\(", hdr))
     assert used <= declared, used - declared
+
+
+@pytest.mark.parametrize("tag", ["d1_random", "d1_singletons", "d1_maxK6", "d2_truth", "d3_random"])
+def test_table_driven_sweep_equals_matrix_driven_sweep(tag):
+    """orc_sweep_table (the checker used at sizes where the n×n matrices do not fit on the host, BASELINE config 5)
+    walks exactly the trajectory of orc_sweep_stable: same labels, sizes, K and change count after every sweep — births,
+    deaths, renames and maxK included — when it is handed the row-sum table of the labels at entry and the matrix rows
+    of the points that change; and it refuses (-3) when a changing point's row is withheld."""
+    g, d = load_golden()
+    D, P, init, seed = golden_case(g, d, tag)
+    n = len(init)
+    orc = O.Oracle(D, P)
+    orc.set_state(init)
+    diag = np.ascontiguousarray(np.diag(orc.Dq))
+    lab = init.copy()
+    for t in range(4):
+        r, p = rp_schedule(t)
+        before = orc.clusts.copy()
+        orc.sweep_stable(r, p, seed, t)
+        xs = np.flatnonzero(before != orc.clusts)
+        rows = np.unique(before)
+        onehot = (before[:, None] == rows[None, :]).astype(np.int64)
+        TD, TL = (orc.Dq @ onehot).T, (orc.Lq @ onehot).T        # [label row][point], j = i included
+        got = O.sweep_table(P, orc.A, rows, TD, TL, diag, orc.eD, orc.eL, before, r, p, seed, t, xs, orc.Dq[xs], orc.Lq[xs])
+        assert np.array_equal(got[0], orc.clusts) and np.array_equal(got[1], orc.sizes)
+        assert got[2] == orc.K and got[3] == orc.last_changes == len(xs)
+        if len(xs):
+            with pytest.raises(AssertionError):
+                O.sweep_table(P, orc.A, rows, TD, TL, diag, orc.eD, orc.eL, before, r, p, seed, t, xs[1:], orc.Dq[xs[1:]], orc.Lq[xs[1:]])
+        lab = orc.clusts
+    assert len(np.unique(lab)) >= 1
