@@ -49,6 +49,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
@@ -63,6 +64,11 @@ typedef unsigned long long u64;
 #define RC_MAX_KCAP 4096
 #define RC_MAXB 1024         // tentative changers validated per resolve round
 #define RC_SPIN_LIMIT (1u << 23)
+#ifdef RC_PROF_SYML   // profiling builds (tools/prof_syml.py): per-wave cycle stamps of k_bulk_syml behind the work counter
+#define RC_WORK_BYTES (512 + 8192 * 128)
+#else
+#define RC_WORK_BYTES 512
+#endif
 
 // error bits in DevScalars.err
 #define RC_DERR_CAPACITY 1
@@ -93,6 +99,8 @@ struct HostSummary {
 struct View {
     int n, ld, kcap;
     const void *Dq, *Lq;       // [n][ld] fixed point: int64 (bits = 64) or int32 (bits = 32); rows/columns in INTERNAL order
+    const long long *Dp, *Lp;  // the same matrices PANEL-major for k_bulk_syml / k_sweep: [ld/128][n][128], i.e. the 128 columns of a
+                               // column block are contiguous row after row (Lp only when logD is stored and those kernels are in use)
     int bits;
     const long long *diagq;    // [n] Dq[i][i]
     int derived;               // 1: logD is not stored; Lq(i,j) = rc_qlog(Dq(i,j)) for i != j, 0 on the diagonal
@@ -115,6 +123,8 @@ struct View {
     unsigned *rec;             // [n] (own slot << 16) | (target slot + 1) of a tentative changer (0 target = new cluster)
     int *tent;                 // [n] tentative target of every point (owner-private)
     unsigned *arrive[2];       // grid-barrier arrival counters (two generations)
+    u64 *fsync;                // k_sweep: [0], [1] blocks whose row reduction is complete (by sweep parity), [2] resolver blocks that
+                               // have finished; all monotonic since rc_set_state
     DevScalars *sc;
     HostSummary *hsum;         // device address of the host-mapped summary
     double scD, scL;           // 2^-eD, 2^-eL
@@ -130,6 +140,8 @@ struct SweepArgs {
     int own_gen, next_gen;  // S generation read (and corrected in place); generation being filled for the next sweep (-1: none)
     int zero_gen;           // S generation this launch clears for the row reduction two sweeps ahead (-1: none)
     int dbg;  // timing ablations only (RC_DEBUG_FLAGS): 1 = skip candidate loop, 2 = skip grid barrier, 4 = skip gumbel
+    u64 tgt_bulk, tgt_done;  // k_sweep: value of fsync[t & 1] once every block of this launch has reduced its rows; value of
+                             // fsync[2] once the previous sweep is complete
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -253,49 +265,30 @@ __global__ __launch_bounds__(256) void k_pairwise(const double *__restrict__ pts
 // Derived logD.  When the caller gives only D (MCMCData computes logD = log.(D − Diagonal(D) + I) itself,
 // types.jl:155), the fixed-point logD need not be stored at all: Lq(i,j) = rint(log(Dq(i,j)·2^-eD)·2^eL) is a pure
 // function of Dq(i,j), evaluated by every consumer with this one routine, so the row reduction reads HALF the bytes.
-// log(x), x = 2^k·m, m ∈ [1,2): j = top 7 fraction bits of m, c_j = 1 + (j+½)/128, r = m/c_j − 1 ∈ [−1/257, 1/257],
+// log(x), x = dq·2^-eD = 2^k·m, m ∈ [1,2): j = top 7 fraction bits of m, c_j = 1 + (j+½)/128, r = m/c_j − 1 ∈ [−1/257, 1/257],
 // log x = k·ln2 + log c_j + log1p(r) with the degree-6 Taylor polynomial of log1p (|error| < 3·10^-18) — ≈25 VALU
 // instructions and one 16-byte table read, against ≈100 for the libm log (tools/log_tune.hip: 268 MB of D streamed
 // with two of these per 16 B in 44.6 µs; with the libm log 119 µs; sum only 40.4 µs).  |result − libm log| ≤ 5·10^-16,
 // far below the quantum 2^-eL; what matters for exactness is only that every consumer uses this same function.
 // ltab[j] = (1/c_j, log c_j).
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ long long rc_qlog(long long dq, int eD, double sL, const double2 *__restrict__ tab)
-{
-    // integer front end (no int64 -> double conversion): normalise, split off exponent, table index and mantissa
-    const int lz = __clzll(dq);
-    const unsigned long long mant = (unsigned long long)dq << lz;           // leading one at bit 63
-    const int k = 63 - lz - eD;                                             // x = dq·2^-eD = m·2^k
-    const int j = (int)(mant >> 56) & 127;
-    const double m = __longlong_as_double((long long)((mant >> 11) & 0x000fffffffffffffull) | 0x3ff0000000000000ll);
-    const double2 t = tab[j];                                               // (1/c_j, log c_j)
-    const double r = fma(m, t.x, -1.0);
-    double p = fma(r, -1.0 / 6, 1.0 / 5);
-    p = fma(r, p, -1.0 / 4);
-    p = fma(r, p, 1.0 / 3);
-    p = fma(r, p, -1.0 / 2);
-    p = fma(r * r, p, r);
-    const double L = fma((double)k, 0.69314718055994530942, t.y + p);
-    // rint(L·2^eL) as an integer by the magic-number trick (|L·2^eL| < 2^51 by the choice of eL)
-    const double v = fma(L, sL, 0x1.8p52);
-    const long long q = __double_as_longlong(v) - __double_as_longlong(0x1.8p52);
-    return dq > 0 ? q : 0ll;   // padding and masked entries carry dq = 0
-}
-
-// The same function in two halves, so that a caller with several values can issue all table reads before the first
-// use (rc_qlog waits for its table entry before it can continue).
+// Front end: the fixed-point entry is an integer below 2^52 (create_impl caps eD accordingly in the derived mode), so
+// OR-ing it into the mantissa of 2^52 and subtracting 2^52 converts it to a double exactly in two instructions; exponent,
+// table index and mantissa then come from the HIGH dword of that double with 32-bit operations (no count-leading-zeros,
+// no 64-bit shifts).  dq = 0 (padding, masked entries) gives a finite value the callers discard.
 struct QlogPrep { int k, j; double m; };
 __device__ __forceinline__ QlogPrep rc_qlog_prep(long long dq, int eD)
 {
-    const int lz = __clzll(dq);
-    const unsigned long long mant = (unsigned long long)dq << lz;
+    const double x = __longlong_as_double(dq | 0x4330000000000000ll) - 0x1p52;
+    const unsigned hi = (unsigned)__double2hiint(x);
     QlogPrep P;
-    P.k = 63 - lz - eD;
-    P.j = (int)(mant >> 56) & 127;
-    P.m = __longlong_as_double((long long)((mant >> 11) & 0x000fffffffffffffull) | 0x3ff0000000000000ll);
+    P.k = (int)(hi >> 20) - (1023 + eD);                                    // x·2^-eD = m·2^k, m in [1,2)
+    P.j = (int)((hi >> 13) & 127u);                                         // top 7 fraction bits
+    P.m = __hiloint2double((int)((hi & 0x000fffffu) | 0x3ff00000u), __double2loint(x));
     return P;
 }
-__device__ __forceinline__ long long rc_qlog_finish(long long dq, const QlogPrep &P, double2 t, double sL)
+// the value rint(log(dq·2^-eD)·2^eL) for dq > 0 — no select on dq: callers that may hold dq <= 0 mask the result
+__device__ __forceinline__ long long rc_qlog_raw(const QlogPrep &P, double2 t, double sL)
 {
     const double r = fma(P.m, t.x, -1.0);
     double p = fma(r, -1.0 / 6, 1.0 / 5);
@@ -304,9 +297,18 @@ __device__ __forceinline__ long long rc_qlog_finish(long long dq, const QlogPrep
     p = fma(r, p, -1.0 / 2);
     p = fma(r * r, p, r);
     const double L = fma((double)P.k, 0.69314718055994530942, t.y + p);
+    // rint(L·2^eL) as an integer by the magic-number trick (|L·2^eL| < 2^51 by the choice of eL)
     const double v = fma(L, sL, 0x1.8p52);
-    const long long q = __double_as_longlong(v) - __double_as_longlong(0x1.8p52);
-    return dq > 0 ? q : 0ll;
+    return __double_as_longlong(v) - __double_as_longlong(0x1.8p52);
+}
+__device__ __forceinline__ long long rc_qlog_finish(long long dq, const QlogPrep &P, double2 t, double sL)
+{
+    return dq > 0 ? rc_qlog_raw(P, t, sL) : 0ll;                            // padding and masked entries carry dq = 0
+}
+__device__ __forceinline__ long long rc_qlog(long long dq, int eD, double sL, const double2 *__restrict__ tab)
+{
+    const QlogPrep P = rc_qlog_prep(dq, eD);
+    return rc_qlog_finish(dq, P, tab[P.j], sL);
 }
 
 // logD entry (row, col) in internal order, stored or derived; xd = Dq(row, col) when the caller has it already
@@ -377,6 +379,16 @@ __global__ __launch_bounds__(256) void k_relayout(const T *__restrict__ src, con
     const int w = blockIdx.y;
     const T *row = src + (size_t)ipi[w] * ld;
     for (int x = blockIdx.x * 256 + threadIdx.x; x < n; x += gridDim.x * 256) out[(size_t)w * ld + x] = row[ipi[x]];
+}
+
+// Panel-major copy for the wave-autonomous symmetric kernels: P[(J·n + r)·128 + c] = Q[r][128 J + c].  A 64×128 work
+// unit is then ONE contiguous 64 KiB (a tile 4 KiB) instead of 1 KiB pieces a whole matrix row apart — the difference
+// between ≈4.5 and ≈6 TB/s on this memory system (DRAM pages / channel bursts are used whole).
+__global__ __launch_bounds__(256) void k_panelize(const long long *__restrict__ Q, int n, int ld, long long *__restrict__ P)
+{
+    const int r = blockIdx.y;
+    for (int x = blockIdx.x * 256 + threadIdx.x; x < ld; x += gridDim.x * 256)
+        P[((size_t)(x >> 7) * n + r) * 128 + (x & 127)] = Q[(size_t)r * ld + x];
 }
 
 __global__ void k_gather_ll(const long long *__restrict__ src, const int *__restrict__ ipi, int n, long long *__restrict__ out)
@@ -952,6 +964,9 @@ __global__ __launch_bounds__(256) void k_bulk_symw(View V, int wgen, int zgen, i
 // them for tile k of the item, i.e. lane ℓ accumulates row a0 + 4(ℓ & 15) + (ℓ >> 4).
 // ---------------------------------------------------------------------------------------------------
 #define RC_SL_R 4
+#ifndef RC_SL_LOGS
+#define RC_SL_LOGS 2   // logs evaluated together (2 or 4): four need ~20 more VGPRs, which at the 128 of four waves per SIMD spill inside the tile loop
+#endif
 // LDS row of a tile: 16 column octets of 8 values, each padded to 10 (80 B): the transposed b128 reads of a quarter wave
 // (16 lanes, one octet each) then fall on 16 different 16-byte bank groups instead of 4
 #define RC_SL_O 10
@@ -985,69 +1000,86 @@ __device__ __forceinline__ void row16_sum4_dpp(long long &a, long long &b, long 
     c = (long long)(((u64)r5 << 32) | r4); d = (long long)(((u64)r7 << 32) | r6);
 }
 
+#ifdef RC_PROF_SYML
+#define RC_PF(stmt) stmt
+#else
+#define RC_PF(stmt)
+#endif
+
+// The unit loop of the wave-autonomous symmetric reduction, shared by k_bulk_syml (one launch per row reduction) and
+// k_sweep (row reduction + resolver in one persistent launch).  tt: the calling wave's private 10 KiB of LDS (log table in
+// the padding, see k_bulk_syml).
+//   Work units: column block J (heavy blocks first) × a range of rows.  Blocks J >= jsplit are cut into units of gcoarse
+//   rows and the light blocks below jsplit, which come last in the list, into units of gfine (8..32) rows, so that the
+//   tail of the launch is a few tiles long (and a small problem still spreads over the chip).
+//   Who takes which unit: unit `first_unit` is the wave's own; after that either every nwaves-th unit (dyn == nullptr:
+//   static round-robin — a single shared counter hit by thousands of waves at once serialises in L2, ~25 ns per
+//   returning atomic) or, in k_sweep, the next unit of the wave's group from one of eight counters 64 B apart
+//   (dyn[8·grp]; units nwaves + 8k + grp, k = 0, 1, ...): waves differ by up to 2× in speed, depending on what else is
+//   resident on their SIMD, and a persistent launch ends with its slowest wave.  The counter is read one unit ahead.
+//   Unit pipeline: while the last tile of a unit is reduced, the next unit's first tile and the slots of its columns and
+//   rows are already in flight (a unit's set-up otherwise costs a full memory round trip, ~20 % of a 64-row unit).
+//   A unit's column set-up (the two clusters that own its 128 columns, per-lane class masks) is done once; its rows are
+//   taken in 64-row halves (direction-2 totals live one row per lane).
 template <bool DERIVED>
-__global__ __launch_bounds__(256) void k_bulk_syml(View V, int wgen, int zgen, int sgen, int cgen, int nitems, int jsplit, int gfine, int gcoarse)
+__device__ __forceinline__ void syml_units(const View &V, long long (*tt)[RC_SL_R][RC_SL_P], int wgen, int sgen, int nitems,
+                                           int jsplit, int gfine, int gcoarse, int first_unit, int nwaves, u64 *dyn, int grp,
+                                           long long *pf_out)
 {
-    // [wave][matrix][row][octet-padded col]: 10 KiB per wave, 40 KiB per block = four blocks (16 waves) per CU exactly.
-    // The log table of the derived mode (128 × 16 B) lives in the padding: entry j of a wave's private copy sits in
-    // the two spare elements of octet (j & 15) of tile row (j >> 4) [matrix = j >> 6, row = (j >> 4) & 3].
-    __shared__ __attribute__((aligned(16))) long long tl[4][2][RC_SL_R][RC_SL_P];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lane = threadIdx.x & 63;
     const size_t ld = (size_t)V.ld;
-    if (DERIVED) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int j = lane + 64 * h;
-            *(double2 *)(&tl[wv][0][0][0] + j * RC_SL_O + 8) = V.ltab[j];   // octets are contiguous: entry j sits in octet j
-        }
-    }
-    (void)zgen;  // generations are cleared and work counters re-armed by k_resolve (SweepArgs.zero_gen)
-    __syncthreads();  // the table is visible; from here on the waves are on their own
-    long long (*tt)[RC_SL_R][RC_SL_P] = tl[wv];
-    const long long *__restrict__ Dq = (const long long *)V.Dq;
-    const long long *__restrict__ Lq = (const long long *)V.Lq;
+    const long long *__restrict__ Dp = V.Dp + 2 * lane;   // panel-major: (column block J, row r) starts at (J·n + r)·128
+    const long long *__restrict__ Lp = V.Lp + 2 * lane;
     const int *__restrict__ slot = V.snap[sgen];
     long long *SD = V.SD[wgen], *SL = V.SL[wgen];
     const int n = V.n;
     const int ncb = (n + RC_SW_COLS - 1) / RC_SW_COLS;
     const int qeD = V.qeD;
     const double qsL = V.qsL;
-    int *counter = V.work[cgen];
     const int tr = lane >> 4, tq = lane & 15;   // transposed role: tile row, column octet
     auto add64 = [](long long *p, long long v) { __hip_atomic_fetch_add((u64 *)p, (u64)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    // Units are dealt round-robin to the waves: a shared work counter would be hit by thousands of waves at once
-    // (a returning atomic on one address costs ~25 ns each in L2: 100 µs for 4096 waves) and all units of one
-    // granularity cost the same anyway.
-    const int nwaves = (int)gridDim.x * 4;
-    (void)counter;
-    for (int unit = (int)blockIdx.x * 4 + (tid >> 6); unit < nitems; unit += nwaves) {
-        int item = unit;
-        // Work units: column block J (heavy blocks first) × a range of rows.  Blocks J >= jsplit are cut into 64-row
-        // units — at most one per resident wave — and the light blocks below jsplit, which are handed out last, into
-        // units of gfine (8..32) rows, so that the tail of the launch is a few tiles long instead of a whole 64-row unit
-        // (and a small problem still spreads over the chip).
-        int J = ncb - 1, g = gcoarse;
+    RC_PF(long long pf_wait = 0; long long pf_tiles = 0; long long pf_setup = 0; long long pf_log = 0; long long pf_d2 = 0; long long pf_issue = 0; long long pf_ldsw = 0; long long pf_d1 = 0;)
+    RC_PF(const long long pf_t0 = __builtin_amdgcn_s_memtime(); const long long pf_r0 = __builtin_amdgcn_s_memrealtime();)
+    (void)pf_out;
+    // unit index -> (column block, first row, end row)
+    int c0 = 0, a0 = 0, a1 = 0, item = 0;
+    auto decode = [&](int u, int &oc0, int &oa0, int &oa1, int &oitem) {
+        int it = u, J = ncb - 1, g = gcoarse;
         for (;; --J) {
             g = (J >= jsplit) ? gcoarse : gfine;
             const int cnt = (min(RC_SW_COLS * J + RC_SW_COLS, n) + g - 1) / g;
-            if (item < cnt) break;
-            item -= cnt;
+            if (it < cnt) break;
+            it -= cnt;
         }
-        const int c0 = J * RC_SW_COLS, a0 = item * g;
-        const int a1 = min(a0 + g, min(c0 + RC_SW_COLS, n));            // rows a >= c0+128 have no column b > a here
-        const int col0 = c0 + 2 * lane, col1 = col0 + 1;
-        ll2 d[RC_SL_R], l[RC_SL_R];
-        auto issue = [&](int a) {
+        oc0 = J * RC_SW_COLS; oa0 = it * g; oitem = it;
+        oa1 = min(oa0 + g, min(oc0 + RC_SW_COLS, n));                  // rows a >= c0+128 have no column b > a here
+    };
+    ll2 d[RC_SL_R], l[RC_SL_R];
+    auto issue = [&](int a, int cb0) {   // the four rows of a tile are 4 KiB of consecutive addresses
+        const size_t pbase = (size_t)(cb0 >> 7) * (size_t)n;
 #pragma unroll
-            for (int u = 0; u < RC_SL_R; ++u) {
-                const int r = min(a + u, n - 1);
-                d[u] = __builtin_nontemporal_load((const ll2 *)(Dq + (size_t)r * ld + col0));
-                if (!DERIVED) l[u] = __builtin_nontemporal_load((const ll2 *)(Lq + (size_t)r * ld + col0));
-            }
-        };
-        issue(a0);                                                      // the first tile flies under the unit's set-up
-        const int cs0 = col0 < n ? slot[col0] : -1, cs1 = col1 < n ? slot[col1] : -1;
-        const int rowslots = (a0 + lane < n) ? slot[a0 + lane] : -1;   // slot of row a0 + lane (read back with readlane)
+        for (int u = 0; u < RC_SL_R; ++u) {
+            const int r = min(a + u, n - 1);
+            d[u] = __builtin_nontemporal_load((const ll2 *)(Dp + (pbase + (size_t)r) * RC_SW_COLS));
+            if (!DERIVED) l[u] = __builtin_nontemporal_load((const ll2 *)(Lp + (pbase + (size_t)r) * RC_SW_COLS));
+        }
+    };
+    int unit = first_unit;
+    int cs0 = -1, cs1 = -1, rowslots = -1;
+    if (unit < nitems) {
+        decode(unit, c0, a0, a1, item);
+        issue(a0, c0);
+        cs0 = (c0 + 2 * lane < n) ? slot[c0 + 2 * lane] : -1;
+        cs1 = (c0 + 2 * lane + 1 < n) ? slot[c0 + 2 * lane + 1] : -1;
+        rowslots = (a0 + lane < n) ? slot[a0 + lane] : -1;           // slot of row h0 + lane (read back with readlane)
+    }
+    while (unit < nitems) {
+        RC_PF(const long long pf_u0 = __builtin_amdgcn_s_memtime();)
+        // the index of the unit after this one: requested now, needed when this unit's last tile is reached
+        u64 fetched = 0;
+        if (dyn && lane == 0) fetched = __hip_atomic_fetch_add(dyn + 8 * grp, (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int nunit = unit + nwaves, nc0 = 0, na0 = 0, na1 = 0, nitem = 0, ncs0 = -1, ncs1 = -1, nrowslots = -1;
+        const int col0 = c0 + 2 * lane, col1 = col0 + 1;
         // the (at most two) clusters that own the 128 columns; a third, fourth ... cluster goes the slow way
         const int dsA = __builtin_amdgcn_readfirstlane(cs0);            // column c0 always exists
         const u64 notA0 = __ballot(cs0 >= 0 && cs0 != dsA), notA1 = __ballot(cs1 >= 0 && cs1 != dsA);
@@ -1066,9 +1098,9 @@ __global__ __launch_bounds__(256) void k_bulk_syml(View V, int wgen, int zgen, i
         auto spread4 = [](unsigned v) { return (v & 1u) | ((v & 2u) << 1) | ((v & 4u) << 2) | ((v & 8u) << 3); };
         const unsigned mB = spread4((unsigned)(bB0 >> (4 * tq)) & 0xFu) | (spread4((unsigned)(bB1 >> (4 * tq)) & 0xFu) << 1);
         const unsigned mO = spread4((unsigned)(bO0 >> (4 * tq)) & 0xFu) | (spread4((unsigned)(bO1 >> (4 * tq)) & 0xFu) << 1);
-        long long aD0 = 0, aD1 = 0, aL0 = 0, aL1 = 0;                   // direction 1, slot `cur`
-        long long rDA = 0, rLA = 0, rDB = 0, rLB = 0;                   // direction 2: row a0 + 4 (lane & 15) + (lane >> 4)
-        int cur = -1;
+        long long aD0 = 0, aD1 = 0, aL0 = 0, aL1 = 0;                   // direction 1, slot `cur` (carried down the whole unit)
+        long long rDA = 0, rLA = 0, rDB = 0, rLB = 0;                   // direction 2: row h0 + 4 (lane & 15) + (lane >> 4)
+        int cur = -1, h0 = a0;
         auto flush1 = [&]() {
             if (cur >= 0) {
                 if (aD0) add64(SD + (size_t)cur * ld + col0, aD0);
@@ -1078,49 +1110,80 @@ __global__ __launch_bounds__(256) void k_bulk_syml(View V, int wgen, int zgen, i
             }
             aD0 = aD1 = aL0 = aL1 = 0;
         };
-        for (int a = a0; a < a1; a += RC_SL_R) {
+        // after the loads of this unit's last tile have been taken: the next unit's first tile and slots
+        auto prefetch_next = [&]() {
+            if (dyn) nunit = nwaves + 8 * (int)__builtin_amdgcn_readfirstlane((unsigned)fetched) + grp;
+            if (nunit < nitems) {
+                decode(nunit, nc0, na0, na1, nitem);
+                issue(na0, nc0);
+                ncs0 = (nc0 + 2 * lane < n) ? slot[nc0 + 2 * lane] : -1;
+                ncs1 = (nc0 + 2 * lane + 1 < n) ? slot[nc0 + 2 * lane + 1] : -1;
+                nrowslots = (na0 + lane < n) ? slot[na0 + lane] : -1;
+            }
+        };
+        // One 4-row tile.  MASK = false for the units that lie entirely above the diagonal blocks, hold no padding column
+        // and a whole number of tiles (97 % of them at n = 8192): every entry is a live strictly-upper one, so the eight
+        // triangle selects and their compares per lane and row disappear.  In the derived mode the logs are taken from the
+        // raw entries and masked afterwards with the same predicate (a masked or padding entry would otherwise need its
+        // own dq > 0 test).
+        const int colm0 = col0 < n ? col0 : -1, colm1 = col1 < n ? col1 : -1;   // padding columns never pass `col > row`
+        auto tile = [&](auto maskc, int a) __attribute__((always_inline)) {
+            constexpr bool MASK = decltype(maskc)::value;
             ll2 x[RC_SL_R], y[RC_SL_R];
+            RC_PF({ const long long w0 = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pf_wait += __builtin_amdgcn_s_memtime() - w0; pf_tiles += 1; })
 #pragma unroll
             for (int u = 0; u < RC_SL_R; ++u) {
-                const int row = a + u;
                 x[u] = d[u];
                 if (!DERIVED) y[u] = l[u];
-                const bool live = row < a1;
-                if (!(live && col0 > row)) { x[u].x = 0; y[u].x = 0; }  // strictly upper triangle, rows of this item only
-                if (!(live && col1 > row)) { x[u].y = 0; y[u].y = 0; }
             }
-            if (a + RC_SL_R < a1) issue(a + RC_SL_R);                   // next tile in flight under this one's work
-            if (DERIVED) {   // the eight logs of this tile, four at a time: table reads first, then the arithmetic
+            RC_PF(const long long pi0 = __builtin_amdgcn_s_memtime();)
+            if (a + RC_SL_R < a1) issue(a + RC_SL_R, c0);               // next tile in flight under this one's work
+            else prefetch_next();
+            RC_PF(const long long pl0 = __builtin_amdgcn_s_memtime(); pf_issue += pl0 - pi0;)
+            if (DERIVED) {   // the eight logs of this tile, RC_SL_LOGS at a time: table reads first, then the arithmetic
 #pragma unroll
-                for (int h = 0; h < RC_SL_R; h += 2) {
-                    QlogPrep pp[4];
-                    double2 tv[4];
-                    pp[0] = rc_qlog_prep(x[h].x, qeD); pp[1] = rc_qlog_prep(x[h].y, qeD);
-                    pp[2] = rc_qlog_prep(x[h + 1].x, qeD); pp[3] = rc_qlog_prep(x[h + 1].y, qeD);
+                for (int h = 0; h < RC_SL_R; h += RC_SL_LOGS / 2) {
+                    QlogPrep pp[RC_SL_LOGS];
+                    double2 tv[RC_SL_LOGS];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int j = pp[u].j;
-                        tv[u] = *(const double2 *)(&tt[0][0][0] + j * RC_SL_O + 8);
+                    for (int u = 0; u < RC_SL_LOGS; ++u) pp[u] = rc_qlog_prep((u & 1) ? x[h + u / 2].y : x[h + u / 2].x, qeD);
+#pragma unroll
+                    for (int u = 0; u < RC_SL_LOGS; ++u) tv[u] = *(const double2 *)(&tt[0][0][0] + pp[u].j * RC_SL_O + 8);
+#pragma unroll
+                    for (int u = 0; u < RC_SL_LOGS; ++u) {
+                        const long long q = rc_qlog_raw(pp[u], tv[u], qsL);
+                        if (u & 1) y[h + u / 2].y = q; else y[h + u / 2].x = q;
                     }
-                    y[h].x = rc_qlog_finish(x[h].x, pp[0], tv[0], qsL); y[h].y = rc_qlog_finish(x[h].y, pp[1], tv[1], qsL);
-                    y[h + 1].x = rc_qlog_finish(x[h + 1].x, pp[2], tv[2], qsL); y[h + 1].y = rc_qlog_finish(x[h + 1].y, pp[3], tv[3], qsL);
                 }
             }
+            RC_PF(asm volatile("" ::: "memory"); pf_log += __builtin_amdgcn_s_memtime() - pl0;)
+            if (MASK) {
+#pragma unroll
+                for (int u = 0; u < RC_SL_R; ++u) {
+                    const int row = a + u;
+                    const bool live = row < a1;
+                    if (!(live && colm0 > row)) { x[u].x = 0; y[u].x = 0; }  // strictly upper triangle, rows of this item, no padding
+                    if (!(live && colm1 > row)) { x[u].y = 0; y[u].y = 0; }
+                }
+            }
+            RC_PF(const long long pw0 = __builtin_amdgcn_s_memtime();)
 #pragma unroll
             for (int u = 0; u < RC_SL_R; ++u) {
                 *(ll2 *)&tt[0][u][(lane >> 2) * RC_SL_O + (lane & 3) * 2] = x[u];
                 *(ll2 *)&tt[1][u][(lane >> 2) * RC_SL_O + (lane & 3) * 2] = y[u];
             }
+            RC_PF(const long long pw1 = __builtin_amdgcn_s_memtime(); pf_ldsw += pw1 - pw0;)
             // direction 1
 #pragma unroll
             for (int u = 0; u < RC_SL_R; ++u) {
                 const int row = a + u;
-                if (row < a1) {                                         // uniform
-                    const int sr = __builtin_amdgcn_readlane(rowslots, row - a0);
+                if (!MASK || row < a1) {                                // uniform
+                    const int sr = __builtin_amdgcn_readlane(rowslots, row - h0);
                     if (sr != cur) { flush1(); cur = sr; }
                     aD0 += x[u].x; aD1 += x[u].y; aL0 += y[u].x; aL1 += y[u].y;
                 }
             }
+            RC_PF(const long long pd0 = __builtin_amdgcn_s_memtime(); pf_d1 += pd0 - pw1;)
             // direction 2: transposed read of the wave's own tile (same-wave LDS operations execute in order)
             __builtin_amdgcn_wave_barrier();
             long long sDA = 0, sLA = 0, sDB = 0, sLB = 0;
@@ -1149,7 +1212,7 @@ __global__ __launch_bounds__(256) void k_bulk_syml(View V, int wgen, int zgen, i
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int cj = c0 + 8 * tq + j;
-                        if (((mO >> j) & 1) && cj < n && row < a1) {
+                        if (((mO >> j) & 1) && cj < n && (!MASK || row < a1)) {
                             const int sj = slot[cj];
                             if (vD[j]) add64(SD + (size_t)sj * ld + row, vD[j]);
                             if (vL[j]) add64(SL + (size_t)sj * ld + row, vL[j]);
@@ -1159,23 +1222,69 @@ __global__ __launch_bounds__(256) void k_bulk_syml(View V, int wgen, int zgen, i
             }
             __builtin_amdgcn_wave_barrier();
             row16_sum4_dpp(sDA, sLA, sDB, sLB);
-            if (tq == ((a - a0) >> 2)) { rDA += sDA; rLA += sLA; rDB += sDB; rLB += sLB; }
-        }
-        flush1();
-        {   // direction 2 write-out: lane ℓ holds the totals of row a0 + 4 (ℓ & 15) + (ℓ >> 4)
-            const int row = a0 + 4 * tq + tr;
-            if (row < a1) {
+            if (tq == ((a - h0) >> 2)) { rDA += sDA; rLA += sLA; rDB += sDB; rLB += sLB; }
+            RC_PF(pf_d2 += __builtin_amdgcn_s_memtime() - pd0;)
+        };
+        const bool interior = (a1 <= c0) && (c0 + RC_SW_COLS <= n) && (((a1 - a0) & (RC_SL_R - 1)) == 0);   // uniform
+        RC_PF(pf_setup += __builtin_amdgcn_s_memtime() - pf_u0;)
+        for (h0 = a0; h0 < a1; h0 += RC_SW_ROWS) {                      // 64-row halves of a longer unit
+            const int h1 = min(h0 + RC_SW_ROWS, a1);
+            if (h0 > a0) rowslots = (h0 + lane < n) ? slot[h0 + lane] : -1;
+            if (interior) { for (int a = h0; a < h1; a += RC_SL_R) tile(std::false_type{}, a); }
+            else { for (int a = h0; a < h1; a += RC_SL_R) tile(std::true_type{}, a); }
+            // direction 2 write-out: lane ℓ holds the totals of row h0 + 4 (ℓ & 15) + (ℓ >> 4)
+            const int row = h0 + 4 * tq + tr;
+            if (row < h1) {
                 if (rDA) add64(SD + (size_t)dsA * ld + row, rDA);
                 if (rLA) add64(SL + (size_t)dsA * ld + row, rLA);
                 if (dsB >= 0) { if (rDB) add64(SD + (size_t)dsB * ld + row, rDB); if (rLB) add64(SL + (size_t)dsB * ld + row, rLB); }
             }
+            rDA = rLA = rDB = rLB = 0;
         }
+        flush1();
         // diagonal (S includes j = i): D[a][a] -> S[slot_a][a]; logD's diagonal is 0 (types.jl:155)
         if (item == 0) {
             if (col0 < n) { const long long x = V.diagq[col0]; if (x) add64(SD + (size_t)cs0 * ld + col0, x); }
             if (col1 < n) { const long long x = V.diagq[col1]; if (x) add64(SD + (size_t)cs1 * ld + col1, x); }
         }
+        unit = nunit; c0 = nc0; a0 = na0; a1 = na1; item = nitem; cs0 = ncs0; cs1 = ncs1; rowslots = nrowslots;
     }
+    RC_PF(if (lane == 0 && pf_out) { pf_out[0] = __builtin_amdgcn_s_memtime() - pf_t0; pf_out[1] = pf_wait; pf_out[2] = pf_tiles; pf_out[3] = pf_setup;
+                                     pf_out[4] = __builtin_amdgcn_s_memrealtime() - pf_r0; pf_out[5] = pf_log; pf_out[6] = pf_d2;
+                                     pf_out[7] = (pf_r0 << 20) | (long long)((__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF) << 16) |
+                                                 (long long)(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (15 << 11)) & 0xFFFF);
+                                     pf_out[8] = pf_issue; pf_out[9] = pf_ldsw; pf_out[10] = pf_d1; })
+}
+
+// the log table of the derived mode into the padding of every wave's private tile (see k_bulk_syml)
+__device__ __forceinline__ void syml_load_table(const View &V, long long (*tl)[2][RC_SL_R][RC_SL_P])
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int j = lane + 64 * h;
+        *(double2 *)(&tl[wv][0][0][0] + j * RC_SL_O + 8) = V.ltab[j];   // octets are contiguous: entry j sits in octet j
+    }
+}
+
+#ifndef RC_SYML_MINWAVES
+#define RC_SYML_MINWAVES 4
+#endif
+template <bool DERIVED>
+__global__ __launch_bounds__(256, RC_SYML_MINWAVES) void k_bulk_syml(View V, int wgen, int dynamic, int sgen, int cgen, int nitems, int jsplit, int gfine, int gcoarse)
+{
+    // [wave][matrix][row][octet-padded col]: 10 KiB per wave, 40 KiB per block = four blocks (16 waves) per CU exactly.
+    // The log table of the derived mode (128 × 16 B) lives in the padding: entry j of a wave's private copy sits in
+    // the two spare elements of octet (j & 15) of tile row (j >> 4) [matrix = j >> 6, row = (j >> 4) & 3].
+    __shared__ __attribute__((aligned(16))) long long tl[4][2][RC_SL_R][RC_SL_P];
+    if (DERIVED) syml_load_table(V, tl);
+    __syncthreads();  // the table is visible; from here on the waves are on their own
+    // (S generations are cleared and the unit counters of this parity re-armed by k_resolve, SweepArgs.zero_gen)
+    const int w = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    long long *pf = nullptr;
+    RC_PF(if (w < 8192) pf = (long long *)((char *)V.work[cgen] + 512) + (size_t)w * 16;)
+    syml_units<DERIVED>(V, tl[threadIdx.x >> 6], wgen, sgen, nitems, jsplit, gfine, gcoarse, w, (int)gridDim.x * 4,
+                        dynamic ? (u64 *)V.work[cgen] : nullptr, (int)(blockIdx.x & 7), pf);
 }
 
 
@@ -1920,9 +2029,13 @@ __device__ void commit_batch(const View &V, const SweepArgs &sa, Tab &T, int nc,
 // chunk-word / barrier generation t%2 (and re-arms generation (t+1)%2), and leaves perm / snapshot generation t%2
 // describing the labels after the sweep.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(RC_RES_THREADS) void k_resolve(View V, SweepArgs sa, int G)
+// The resolver proper: called by k_resolve (its own launch) and by k_sweep (after the row reduction of the same launch).
+// smem: tab_bytes(kcap, n, blockDim.x / 64) bytes of LDS, at least 2·kcap ints.  All G blocks must be resident.
+__device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *smem)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // The resolver is the latency-critical part of a sweep and shares its SIMDs with the waves of a row reduction (of the
+    // next sweep, or of the other launch in flight): it takes instruction-issue priority over them.
+    __builtin_amdgcn_s_setprio(3);
     Tab T = tab_carve(smem, V.kcap, V.n, blockDim.x >> 6);
     const int t = sa.t, own_gen = sa.own_gen, next_gen = sa.next_gen, kg = t & 1;
     const long long *SD = V.SD[own_gen], *SL = V.SL[own_gen];
@@ -2043,7 +2156,7 @@ __global__ __launch_bounds__(RC_RES_THREADS) void k_resolve(View V, SweepArgs sa
     if (blockIdx.x == 0) {
         __syncthreads();
         // the row reduction of this sweep is complete (stream order): re-arm its work counter for sweep t+2
-        if (threadIdx.x == 0) *V.work[kg] = 0;
+        if (threadIdx.x < 8) ((u64 *)V.work[kg])[8 * threadIdx.x] = 0;   // (k_bulk_sym: one int; k_sweep: eight group counters)
         // re-arm the other key / chunk-word / barrier generation for the next sweep (its last user, sweep t-1, is done)
         for (int q = threadIdx.x; q < V.n + 2; q += blockDim.x) V.keys[kg ^ 1][q] = RC_KEY_NONE;
         for (int q = threadIdx.x; q < nchunks; q += blockDim.x) V.cword[kg ^ 1][q] = 0;
@@ -2069,6 +2182,80 @@ __global__ __launch_bounds__(RC_RES_THREADS) void k_resolve(View V, SweepArgs sa
             for (int p = threadIdx.x; p < V.n; p += blockDim.x) { V.perm[kg][p] = V.perm[kg ^ 1][p]; V.pslot[kg][p] = V.pslot[kg ^ 1][p]; }
         }
     }
+}
+
+#ifndef RC_RES_MINWAVES
+#define RC_RES_MINWAVES 2
+#endif
+__global__ __launch_bounds__(RC_RES_THREADS, RC_RES_MINWAVES) void k_resolve(View V, SweepArgs sa, int G)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    resolve_body(V, sa, G, smem);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_sweep — one whole sweep in ONE persistent launch: the row reduction of sweep t (syml_units, all blocks), a grid-wide
+// hand-over, then the resolver of sweep t (resolve_body, blocks 0..G-1; the others leave).  Two such launches are in
+// flight at a time — sweeps t and t+1 alternate between two streams, each launch sized to HALF the chip's resident
+// blocks — so the row reduction of sweep t+1 fills the machine while sweep t resolves, with no cross-stream event and no
+// launch gap on the critical path; the one cross-launch dependence, resolver(t+1) after resolver(t), is an in-kernel wait
+// on a completion counter.  (With separate launches the resolver could not become resident beside the next row
+// reduction — four reduction blocks take a CU's whole LDS and VGPR file — so the two serialised: 104 µs per sweep at
+// n = 8192 against 52 µs of row-reduction work per wave.)
+//   Residency: 40 KiB of LDS and 128 VGPRs per block = 4 blocks per CU; a launch has at most 2 per CU and the host keeps
+//   at most two launches in flight per device, so every block of both is resident and the spins below terminate.
+//   Memory model (MI355X_MICROARCH.md, inter-workgroup visibility): a block publishes with — every wave's
+//   s_waitcnt vmcnt(0), workgroup barrier, one lane's agent-scope release fence, s_waitcnt vmcnt(0), relaxed agent atomic
+//   add — and consumes with — relaxed agent poll, agent-scope acquire fence, s_waitcnt vmcnt(0), workgroup barrier, plain
+//   loads.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_publish(u64 *counter)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(counter, (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <bool DERIVED>
+__global__ __launch_bounds__(256, 4) __attribute__((amdgpu_num_vgpr(128))) void k_sweep(View V, SweepArgs sa, int G, int nitems, int jsplit, int gfine, int gcoarse)
+{
+    // exactly 40 KiB and 128 VGPRs: four blocks per CU, i.e. two launches of two blocks per CU
+    __shared__ __attribute__((aligned(16))) long long tl[4][2][RC_SL_R][RC_SL_P];   // tiles of the row reduction, then the resolver's tables
+    int *ok_sh = (int *)&tl[0][0][0][0];
+    if (DERIVED) syml_load_table(V, tl);
+    __syncthreads();
+    const int w = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    long long *pf = nullptr;
+    RC_PF(if (w < 8192) pf = (long long *)((char *)V.work[sa.t & 1] + 512) + (size_t)w * 16;)
+    syml_units<DERIVED>(V, tl[threadIdx.x >> 6], sa.own_gen, sa.t & 1, nitems, jsplit, gfine, gcoarse, w, (int)gridDim.x * 4,
+                        (u64 *)V.work[sa.t & 1], (int)(blockIdx.x & 7), pf);
+    // hand-over: this block's share of the row sums is in memory
+    block_publish(V.fsync + (sa.t & 1));
+    if ((int)blockIdx.x >= G) return;
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        int ok = 1;
+        while (__hip_atomic_load(V.fsync + (sa.t & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sa.tgt_bulk ||
+               __hip_atomic_load(V.fsync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sa.tgt_done) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > RC_SPIN_LIMIT) { ok = 0; atomicOr(&V.sc->err, RC_DERR_BARRIER); break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *ok_sh = ok;
+    }
+    __syncthreads();
+    const int ok = *ok_sh;
+    __syncthreads();
+    // A hand-over that timed out (bounded spin; the host surfaces RC_DERR_BARRIER) must not run the resolver on partial
+    // sums, but the block still reports completion so that a later launch does not wait for it in turn.
+    if (ok) resolve_body(V, sa, G, (char *)&tl[0][0][0][0]);
+    else if (blockIdx.x == 0 && threadIdx.x == 0) V.hsum->err = __hip_atomic_load(&V.sc->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    block_publish(V.fsync + 2);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2174,6 +2361,7 @@ struct rc_ctx {
                                // reduction fills is cleared by k_resolve two sweeps earlier), so they may overlap and no launch gap
                                // separates them
     void *Dq = nullptr, *Lq = nullptr;  // int64 or int32 fixed point, INTERNAL point order (what the kernels read)
+    long long *Dp = nullptr, *Lp = nullptr;  // panel-major copies (View::Dp, View::Lp)
     void *Dq_src = nullptr, *Lq_src = nullptr;  // the same matrices in the caller's point order (source of every re-layout)
     long long *diagq = nullptr, *diag_src = nullptr;
     int *pi = nullptr, *ipi = nullptr;  // device: original -> internal, internal -> original
@@ -2182,6 +2370,10 @@ struct rc_ctx {
     int sym_variant = -1;               // RC_SYM_VARIANT: 2 k_bulk_syml (wave-private LDS transposition), 1 k_bulk_symw (DPP only), 0 block-tiled
                                         // k_bulk_sym; -1 (default): k_bulk_syml when logD is derived, k_bulk_sym when it is stored (measured best)
     int sw_coarse = RC_SW_ROWS;          // RC_SW_COARSE: rows per coarse unit of k_bulk_syml (16..64, multiple of 4)
+    int sw_fine_dyn = 16;                // RC_SW_FINE_DYN: rows per fine unit at the end of k_sweep's dynamic unit list
+    int dyn_tail_den = 10;               // RC_DYN_TAIL: 1/x of all rows go into fine units
+    bool syml_dynamic = true;           // RC_SYML_DYNAMIC=0: static round-robin unit list in k_bulk_syml
+    size_t syml_pad = 0;                // RC_SYML_PAD: unused dynamic LDS per k_bulk_syml block (bytes), caps the blocks per CU
     int symw_per_cu = 4;                // RC_SYMW_PER_CU: resident blocks of k_bulk_syml / k_bulk_symw per CU (LDS: 40 KiB per block)
     bool derived = false;               // logD derived from Dq on the fly (rc_qlog), not stored
     double2 *ltab = nullptr;            // device table of rc_qlog
@@ -2216,6 +2408,15 @@ struct rc_ctx {
     int G = 256;
     int rows_per_split = 256;
     int num_cus = 256;
+    // fused sweeps (k_sweep): one persistent launch per sweep, two in flight on sB / sB2
+    u64 *fsync = nullptr;             // device: hand-over counters of k_sweep (View::fsync)
+    bool fused_ok = false;            // the device keeps 4 k_sweep blocks per CU and the resolver's tables fit its 40 KiB
+    bool fused_enabled = true;        // RC_FUSED=0 keeps the separate row-reduction / resolver launches
+    bool pipe_fused = false;          // the sweeps in flight since the last drain are fused launches
+    u64 f_tgt_bulk[2] = {0, 0};       // blocks launched so far on each parity (targets of fsync[0], fsync[1])
+    u64 f_tgt_done = 0;               // resolver blocks launched so far (target of fsync[2] for the next launch)
+    hipEvent_t ev_a = nullptr;        // marker on stream A: work that reads the state and must precede the next sweep
+    bool sA_dirty = false;
     // software pipeline
     long long t_next = 0;     // internal index of the next sweep (0 after rc_set_state)
     long long bulk_enq = -1;  // highest sweep index whose k_bulk has been enqueued
@@ -2285,11 +2486,11 @@ static View make_view(const rc_ctx *c)
 {
     View V{};
     V.n = c->n; V.ld = c->ld; V.kcap = c->kcap;
-    V.Dq = c->Dq; V.Lq = c->Lq; V.bits = c->bits; V.diagq = c->diagq; V.pi = c->pi;
+    V.Dq = c->Dq; V.Lq = c->Lq; V.Dp = c->Dp; V.Lp = c->Lp; V.bits = c->bits; V.diagq = c->diagq; V.pi = c->pi;
     V.derived = c->derived ? 1 : 0; V.qsD = std::ldexp(1.0, -c->eD); V.qsL = std::ldexp(1.0, c->eL); V.ltab = c->ltab; V.qeD = c->eD;
     for (int g = 0; g < 3; ++g) { V.SD[g] = c->SD[g]; V.SL[g] = c->SL[g]; }
     for (int g = 0; g < 2; ++g) { V.perm[g] = c->perm[g]; V.pslot[g] = c->pslot[g]; V.keys[g] = c->keys[g]; V.arrive[g] = c->arrive[g]; V.snap[g] = c->lsnap[g]; V.work[g] = c->work[g]; V.cword[g] = c->cword[g]; }
-    V.rec = c->rec; V.tent = c->tent;
+    V.rec = c->rec; V.tent = c->tent; V.fsync = c->fsync;
     V.slot_of = c->slot_of; V.slot_size = c->slot_size; V.slot_label = c->slot_label;
     V.slot_pos = c->slot_pos; V.slot_act = c->slot_act;
     V.A = c->A; V.sc = c->sc; V.hsum = c->hsum_dev;
@@ -2324,10 +2525,10 @@ static void free_all(rc_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->dev);
-    void *ptrs[] = {c->ltab, c->Dq, c->Lq, c->Dq_src, c->Lq_src, c->diag_src, c->pi, c->ipi, c->diagq, c->SD[0], c->SD[1], c->SD[2], c->SL[0], c->SL[1], c->SL[2], c->slot_of,
+    void *ptrs[] = {c->ltab, c->Dp, c->Lp, c->Dq, c->Lq, c->Dq_src, c->Lq_src, c->diag_src, c->pi, c->ipi, c->diagq, c->SD[0], c->SD[1], c->SD[2], c->SL[0], c->SL[1], c->SL[2], c->slot_of,
                     c->slot_size, c->slot_label, c->slot_pos, c->slot_act, c->perm[0], c->perm[1], c->pslot[0],
                     c->pslot[1], c->lsnap[0], c->lsnap[1], c->work[0], c->work[1], c->cword[0], c->cword[1], c->rec, c->tent, c->A, c->keys[0], c->keys[1], c->arrive[0], c->arrive[1], c->sc, c->blocks,
-                    c->counts, c->cc_out, c->snap, c->d_moves};
+                    c->counts, c->cc_out, c->snap, c->d_moves, c->fsync};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->hsum) (void)hipHostFree(c->hsum);
@@ -2338,6 +2539,7 @@ static void free_all(rc_ctx *c)
     }
     for (auto &e : c->ev_pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &e : c->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     for (int q = 0; q < 4; ++q) {
         if (c->ev_bulk[q]) (void)hipEventDestroy(c->ev_bulk[q]);
         if (c->ev_res[q]) (void)hipEventDestroy(c->ev_res[q]);
@@ -2377,6 +2579,19 @@ extern "C" int32_t rc_destroy(rc_ctx *ctx)
     if (ctx->sB) (void)hipStreamSynchronize(ctx->sB);
     if (ctx->sB2) (void)hipStreamSynchronize(ctx->sB2);
     free_all(ctx);
+    return RC_OK;
+}
+
+static int sym_variant_of(const rc_ctx *c);
+
+// (re)builds the panel-major copies from the internal row-major matrices, on stream A
+static int32_t panelize(rc_ctx *c)
+{
+    if (!c->Dp) return RC_OK;
+    dim3 g((unsigned)std::min(16, c->ld / 256), (unsigned)c->n);
+    k_panelize<<<g, 256, 0, c->sA>>>((const long long *)c->Dq, c->n, c->ld, c->Dp);
+    if (c->Lp) k_panelize<<<g, 256, 0, c->sA>>>((const long long *)c->Lq, c->n, c->ld, c->Lp);
+    HIPCHK(c, hipGetLastError());
     return RC_OK;
 }
 
@@ -2455,13 +2670,16 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
         HIPCHK2(hipMalloc(&c->perm[g], (size_t)n * sizeof(int)));
         HIPCHK2(hipMalloc(&c->pslot[g], (size_t)n * sizeof(int)));
         HIPCHK2(hipMalloc(&c->lsnap[g], (size_t)n * sizeof(int)));
-        HIPCHK2(hipMalloc(&c->work[g], 64));
-        HIPCHK2(hipMemsetAsync(c->work[g], 0, 64, s));
+        HIPCHK2(hipMalloc(&c->work[g], RC_WORK_BYTES));
+        HIPCHK2(hipMemsetAsync(c->work[g], 0, RC_WORK_BYTES, s));
         HIPCHK2(hipMalloc(&c->cword[g], ((size_t)(n + RC_PTS - 1) / RC_PTS + 1) * sizeof(u64)));
         HIPCHK2(hipMemsetAsync(c->cword[g], 0, ((size_t)(n + RC_PTS - 1) / RC_PTS + 1) * sizeof(u64), s));
         HIPCHK2(hipMalloc(&c->keys[g], (size_t)(n + 2) * sizeof(u64)));
         HIPCHK2(hipMalloc(&c->arrive[g], 64));
     }
+    HIPCHK2(hipMalloc(&c->fsync, 64));
+    HIPCHK2(hipMemsetAsync(c->fsync, 0, 64, s));
+    HIPCHK2(hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
     HIPCHK2(hipMalloc(&c->slot_of, (size_t)n * sizeof(int)));
     HIPCHK2(hipMalloc(&c->rec, (size_t)n * sizeof(unsigned)));
     HIPCHK2(hipMalloc(&c->tent, (size_t)n * sizeof(int)));
@@ -2519,6 +2737,11 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     double maxD, maxL = 0;
     std::memcpy(&maxD, &hmx[0], 8);
     c->eD = quant_exponent(n, maxD, c->bits);
+    if (derived && maxD > 0.0) {   // rc_qlog converts the entries to double through the mantissa of 2^52: every Dq < 2^51 (binding for n < 2048)
+        int ex;
+        std::frexp(maxD, &ex);
+        c->eD = std::min(c->eD, 51 - ex);
+    }
     if (c->bits == 64) k_quantize<long long><<<gb, 256, 0, s>>>(tmpD, (int)n, c->ld, c->eD, (long long *)c->Dq_src, c->diag_src);
     else k_quantize<int><<<gb, 256, 0, s>>>(tmpD, (int)n, c->ld, c->eD, (int *)c->Dq_src, c->diag_src);
     if (derived) {
@@ -2578,6 +2801,14 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     HIPCHK2(hipMemcpyAsync(c->ipi, c->h_ipi.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
     HIPCHK2(hipMemcpyAsync(c->Dq, c->Dq_src, (size_t)n * ld * esz, hipMemcpyDeviceToDevice, s));
     if (c->Lq) HIPCHK2(hipMemcpyAsync(c->Lq, c->Lq_src, (size_t)n * ld * esz, hipMemcpyDeviceToDevice, s));
+    if (c->bits == 64) {
+        HIPCHK2(hipMalloc(&c->Dp, (size_t)n * ld * sizeof(long long)));
+        if (!derived && sym_variant_of(c) == 2) HIPCHK2(hipMalloc(&c->Lp, (size_t)n * ld * sizeof(long long)));
+    }
+    {
+        int32_t rcp = panelize(c);
+        if (rcp != RC_OK) { cleanup(); return rcp; }
+    }
     HIPCHK2(hipMemcpyAsync(c->diagq, c->diag_src, (size_t)n * sizeof(long long), hipMemcpyDeviceToDevice, s));
     HIPCHK2(hipStreamSynchronize(s));
     HIPCHK2(hipGetLastError());
@@ -2609,6 +2840,11 @@ static int32_t alloc_ctx(int64_t n, int32_t storage_bits, int32_t device_id, int
     c->relayout = !(getenv("RC_NO_RELAYOUT") && atoi(getenv("RC_NO_RELAYOUT")));
     if (getenv("RC_SYM_VARIANT")) c->sym_variant = atoi(getenv("RC_SYM_VARIANT"));
     if (getenv("RC_SYMW_PER_CU")) c->symw_per_cu = std::max(1, atoi(getenv("RC_SYMW_PER_CU")));
+    if (getenv("RC_FUSED")) c->fused_enabled = atoi(getenv("RC_FUSED")) != 0;
+    if (getenv("RC_SYML_DYNAMIC")) c->syml_dynamic = atoi(getenv("RC_SYML_DYNAMIC")) != 0;
+    if (getenv("RC_SYML_PAD")) c->syml_pad = (size_t)std::max(0, atoi(getenv("RC_SYML_PAD")));
+    if (getenv("RC_SW_FINE_DYN")) c->sw_fine_dyn = std::min(64, std::max(4, atoi(getenv("RC_SW_FINE_DYN")) & ~3));
+    if (getenv("RC_DYN_TAIL")) c->dyn_tail_den = std::max(2, atoi(getenv("RC_DYN_TAIL")));
     if (getenv("RC_SW_COARSE")) c->sw_coarse = std::min(64, std::max(16, atoi(getenv("RC_SW_COARSE")) & ~3));
     if (getenv("RC_BULK_KERNEL")) c->bulk_kernel = !strcmp(getenv("RC_BULK_KERNEL"), "sym") ? 1 : (!strcmp(getenv("RC_BULK_KERNEL"), "perm") ? 0 : -1);
     if (getenv("RC_RES_THREADS")) c->res_threads = (atoi(getenv("RC_RES_THREADS")) == 256) ? 256 : 512;
@@ -2636,6 +2872,17 @@ static int32_t finish_create(rc_ctx *c)
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->bulk_lds);
             (void)hipFuncSetAttribute((const void *)k_bulk<long long, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->bulk_lds);
         }
+    }
+    {
+        // fused sweeps need the resolver's tables inside k_sweep's 40 KiB of static LDS and four resident blocks per CU
+        // (two launches of two blocks per CU each are in flight)
+        const size_t need = std::max(tab_bytes(c->kcap, c->n, 4), 2 * sizeof(int) * (size_t)c->kcap);
+        int occ_t = 0, occ_f = 0;
+        const hipError_t q1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_t, k_sweep<true>, 256, 0);
+        const hipError_t q2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_f, k_sweep<false>, 256, 0);
+        c->fused_ok = c->bits == 64 && need <= sizeof(long long) * 4 * 2 * RC_SL_R * RC_SL_P && q1 == hipSuccess && q2 == hipSuccess &&
+                      occ_t >= 4 && occ_f >= 4;
+        (void)hipGetLastError();
     }
     // kernels whose dynamic LDS can exceed the 64 KiB default (large kcap)
     const size_t lds_r = std::max(tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64), 2 * sizeof(int) * (size_t)c->kcap);
@@ -2802,6 +3049,7 @@ static int32_t drain_events(rc_ctx *c)
 // Waits for the resolve/observable stream (and for the k_bulk stream too when `both`), then surfaces device errors.
 static int32_t sync_and_check(rc_ctx *c, bool both = false)
 {
+    if (c->pipe_fused) both = true;   // fused sweeps run on the two row-reduction streams
     HIPCHK(c, hipStreamSynchronize(c->sA));
     if (both) {
         HIPCHK(c, hipStreamSynchronize(c->sB));
@@ -2871,6 +3119,10 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
             k_relayout<int><<<g, 256, 0, c->sA>>>((const int *)c->Lq_src, c->ipi, n, c->ld, (int *)c->Lq);
         }
         k_gather_ll<<<(n + 255) / 256, 256, 0, c->sA>>>(c->diag_src, c->ipi, n, c->diagq);
+        {
+            int32_t rcp = panelize(c);
+            if (rcp != RC_OK) return rcp;
+        }
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->sA));
     }
@@ -2893,7 +3145,7 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
         HIPCHK(c, hipMemsetAsync(c->keys[g], 0xFF, (size_t)(n + 2) * sizeof(u64), c->sA));
         HIPCHK(c, hipMemsetAsync(c->cword[g], 0, ((size_t)(n + RC_PTS - 1) / RC_PTS + 1) * sizeof(u64), c->sA));
         HIPCHK(c, hipMemsetAsync(c->arrive[g], 0, 64, c->sA));
-        HIPCHK(c, hipMemsetAsync(c->work[g], 0, 64, c->sA));
+        HIPCHK(c, hipMemsetAsync(c->work[g], 0, 512, c->sA));
     }
     View V = make_view(c);
     const size_t lds = std::max(tab_bytes(c->kcap, c->n, 1), 2 * sizeof(int) * (size_t)c->kcap);
@@ -2903,9 +3155,76 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
     c->last = s;
     c->t_next = 0;
     c->bulk_enq = -1;
+    HIPCHK(c, hipMemset(c->fsync, 0, 64));
+    c->f_tgt_bulk[0] = c->f_tgt_bulk[1] = c->f_tgt_done = 0;
+    c->pipe_fused = false;
     c->state_version++;
     c->have_state = true;
     return RC_OK;
+}
+
+// Kernel choice.  The symmetric kernels read half the bytes but want the points of a cluster to be contiguous in the
+// point order (few label runs); every kernel is exact for any labelling, so a stale run count only costs speed.
+// Small problems are launch- and latency-bound: with separate launches the full-read kernel (one pass, no per-unit
+// prologue) wins up to n = 4096 even though it reads and — in the derived mode — computes twice as much (measured:
+// n = 4096: 58 vs 75 µs per sweep, n = 6000: 102 vs 70).
+static bool choose_sym(const rc_ctx *c)
+{
+    return c->bulk_kernel == 1 || (c->bulk_kernel < 0 && (long long)c->hsum->runs * 32 <= (long long)c->n &&
+                                   !(c->derived && c->n <= 4096 && !(c->fused_enabled && c->fused_ok)));
+}
+static int sym_variant_of(const rc_ctx *c) { return c->sym_variant >= 0 ? c->sym_variant : (c->derived ? 2 : 0); }
+
+// Static unit list of the wave-autonomous symmetric reduction for `cap_blocks` resident 4-wave blocks: units of gc rows
+// for the heavy column blocks — a whole number of rounds over the resident waves — and gfine-row units for the light
+// blocks below jsplit, which are handed out last (syml_units decodes the same list).
+static void syml_geometry(const rc_ctx *c, int cap_blocks, int gc, int *nitems_out, int *jsplit_out, int *gfine_out)
+{
+    const int ncb = (c->n + RC_SW_COLS - 1) / RC_SW_COLS;
+    auto rows_of = [&](int J) { return std::min(RC_SW_COLS * J + RC_SW_COLS, c->n); };
+    int total_coarse = 0;
+    for (int J = 0; J < ncb; ++J) total_coarse += (rows_of(J) + gc - 1) / gc;
+    const int target = (total_coarse / (4 * cap_blocks)) * (4 * cap_blocks);
+    int jsplit = ncb, coarse = 0;
+    while (jsplit > 0) {
+        const int cnt = (rows_of(jsplit - 1) + gc - 1) / gc;
+        if (coarse + cnt > target) break;
+        coarse += cnt; --jsplit;
+    }
+    int gfine = RC_SW_FINE;
+    if (coarse < 2 * cap_blocks) {   // small problem: fine units everywhere, as large as still fills the resident waves
+        jsplit = ncb; coarse = 0;
+        for (int g = 32; g > RC_SW_FINE; g >>= 1) {
+            int cnt = 0;
+            for (int J = 0; J < ncb; ++J) cnt += (rows_of(J) + g - 1) / g;
+            if (cnt >= 4 * cap_blocks) { gfine = g; break; }
+        }
+    }
+    int nitems = coarse;
+    for (int J = 0; J < jsplit; ++J) nitems += (rows_of(J) + gfine - 1) / gfine;
+    *nitems_out = nitems; *jsplit_out = jsplit; *gfine_out = gfine;
+}
+
+// Unit list for DYNAMIC hand-out (syml_units with counters): gc-row units, and the lightest column blocks, holding
+// 1/dyn_tail_den of all rows, cut into sw_fine_dyn-row units at the end of the list, so that the launch's waves finish
+// within a few tiles of each other whatever their individual speed.
+static void syml_geometry_dyn(const rc_ctx *c, int cap_blocks, int gc, int *nitems_out, int *jsplit_out, int *gfine_out)
+{
+    const int ncb = (c->n + RC_SW_COLS - 1) / RC_SW_COLS;
+    const int gfine = c->sw_fine_dyn;
+    auto rows_of = [&](int J) { return std::min(RC_SW_COLS * J + RC_SW_COLS, c->n); };
+    long long total_rows = 0, acc = 0;
+    int jsplit = 0;
+    for (int J = 0; J < ncb; ++J) total_rows += rows_of(J);
+    while (jsplit < ncb && acc * c->dyn_tail_den < total_rows) acc += rows_of(jsplit++);
+    long long items = 0;
+    for (int J = 0; J < ncb; ++J) items += (rows_of(J) + (J >= jsplit ? gc : gfine) - 1) / (J >= jsplit ? gc : gfine);
+    if (items < 4ll * cap_blocks) {   // small problem: fine units everywhere (the launch shrinks to the units there are)
+        jsplit = ncb;
+        items = 0;
+        for (int J = 0; J < ncb; ++J) items += (rows_of(J) + gfine - 1) / gfine;
+    }
+    *nitems_out = (int)items; *jsplit_out = jsplit; *gfine_out = gfine;
 }
 
 // k_bulk of sweep t on stream B: fills S generation t%3 from perm generation t%2 (labels after sweep t-2),
@@ -2923,46 +3242,21 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
         else { HIPCHK(c, hipEventCreate(&ev.first)); HIPCHK(c, hipEventCreate(&ev.second)); }
         HIPCHK(c, hipEventRecord(ev.first, sb));
     }
-    // Kernel choice.  k_bulk_sym reads half the bytes but wants the points of a cluster to be contiguous in the
-    // point order (few label runs); both kernels are exact for any labelling, so a stale run count only costs speed.
-    // Small problems are launch- and latency-bound: the full-read kernel (one pass, no per-unit prologue) wins up to
-    // n = 4096 even though it reads and — in the derived mode — computes twice as much (measured: n = 4096: 58 vs 75 µs
-    // per sweep, n = 6000: 102 vs 70).
-    bool use_sym = (c->bulk_kernel == 1 || (c->bulk_kernel < 0 && (long long)c->hsum->runs * 32 <= (long long)c->n &&
-                                            !(c->derived && c->n <= 4096)));
+    const bool use_sym = choose_sym(c);
     c->last_bulk_kernel = use_sym ? 1 : 0;
-    const int sym_variant = c->sym_variant >= 0 ? c->sym_variant : (c->derived ? 2 : 0);
+    const int sym_variant = sym_variant_of(c);
     if (use_sym && c->bits == 64 && sym_variant >= 1) {
         const int ncb = (c->n + RC_SW_COLS - 1) / RC_SW_COLS;
         const int cap_blocks = c->symw_per_cu * c->num_cus;          // resident 4-wave blocks
         auto rows_of = [&](int J) { return std::min(RC_SW_COLS * J + RC_SW_COLS, c->n); };
         if (sym_variant == 2) {
-            // 64-row units for the heavy column blocks — a whole number of rounds over the resident waves — and
-            // 8-row units for the light blocks below, which are handed out last
             const int gc = c->sw_coarse;
-            int total_coarse = 0;
-            for (int J = 0; J < ncb; ++J) total_coarse += (rows_of(J) + gc - 1) / gc;
-            const int target = (total_coarse / (4 * cap_blocks)) * (4 * cap_blocks);
-            int jsplit = ncb, coarse = 0;
-            while (jsplit > 0) {
-                const int cnt = (rows_of(jsplit - 1) + gc - 1) / gc;
-                if (coarse + cnt > target) break;
-                coarse += cnt; --jsplit;
-            }
-            int gfine = RC_SW_FINE;
-            if (coarse < 2 * cap_blocks) {   // small problem: fine units everywhere, as large as still fills the resident waves
-                jsplit = ncb; coarse = 0;
-                for (int g = 32; g > RC_SW_FINE; g >>= 1) {
-                    int cnt = 0;
-                    for (int J = 0; J < ncb; ++J) cnt += (rows_of(J) + g - 1) / g;
-                    if (cnt >= 4 * cap_blocks) { gfine = g; break; }
-                }
-            }
-            int nitems = coarse;
-            for (int J = 0; J < jsplit; ++J) nitems += (rows_of(J) + gfine - 1) / gfine;
+            int nitems = 0, jsplit = 0, gfine = 0;
+            if (c->syml_dynamic) syml_geometry_dyn(c, cap_blocks, gc, &nitems, &jsplit, &gfine);
+            else syml_geometry(c, cap_blocks, gc, &nitems, &jsplit, &gfine);
             const int nblocks = std::max(1, std::min((nitems + 3) / 4, cap_blocks));
-            if (c->derived) k_bulk_syml<true><<<nblocks, 256, 0, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems, jsplit, gfine, gc);
-            else k_bulk_syml<false><<<nblocks, 256, 0, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems, jsplit, gfine, gc);
+            if (c->derived) k_bulk_syml<true><<<nblocks, 256, c->syml_pad, sb>>>(V, (int)(t % 3), c->syml_dynamic ? 1 : 0, (int)(t & 1), (int)(t & 1), nitems, jsplit, gfine, gc);
+            else k_bulk_syml<false><<<nblocks, 256, c->syml_pad, sb>>>(V, (int)(t % 3), c->syml_dynamic ? 1 : 0, (int)(t & 1), (int)(t & 1), nitems, jsplit, gfine, gc);
         } else {
             int nitems = 0;
             for (int J = 0; J < ncb; ++J) nitems += (rows_of(J) + RC_SW_ROWS - 1) / RC_SW_ROWS;
@@ -3004,9 +3298,23 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
     return RC_OK;
 }
 
+// Work about to be enqueued on stream A reads the state the sweeps enqueued so far leave behind.  Separate launches
+// keep the resolver on stream A itself; fused sweeps run on the row-reduction streams, so stream A waits for the last
+// one, and the next sweep is made to wait for stream A in turn (sA_dirty, see launch_sweep_fused).
+static int32_t order_A_after_sweeps(rc_ctx *c)
+{
+    if (c->pipe_fused && c->t_next > 0) HIPCHK(c, hipStreamWaitEvent(c->sA, c->ev_res[(c->t_next - 1) & 3], 0));
+    c->sA_dirty = true;
+    return RC_OK;
+}
+
 // Makes the S generation of the CURRENT labels available to work enqueued on stream A; returns its index.
 static int32_t ensure_S(rc_ctx *c, int *gen)
 {
+    {
+        int32_t rc0 = order_A_after_sweeps(c);
+        if (rc0 != RC_OK) return rc0;
+    }
     if (c->incremental && c->bulk_enq >= 0 && c->t_next > 0) {
         *gen = c->inc_gen;
         return RC_OK;
@@ -3032,12 +3340,20 @@ static int32_t ensure_S(rc_ctx *c, int *gen)
 static std::mutex g_res_mutex;
 static hipEvent_t g_res_event[64] = {};
 
+// The same holds for fused sweeps (k_sweep hands over through grid-wide counters): a launch takes two of a CU's four
+// block slots, so at most TWO may be in flight per device — launch k waits for launch k-2, whichever context issued it
+// (within one context that is the stream order anyway) — and a separate resolver launch waits for both and is waited for.
+static hipEvent_t g_fused_event[64][2] = {};
+static unsigned long long g_fused_count[64] = {};
+
 static int32_t launch_resolve(rc_ctx *c, const View &V, const SweepArgs &sa, int res_threads, size_t lds)
 {
     std::lock_guard<std::mutex> lock(g_res_mutex);
     const int d = c->dev & 63;
     if (g_res_event[d]) HIPCHK(c, hipStreamWaitEvent(c->sA, g_res_event[d], 0));
     else HIPCHK(c, hipEventCreateWithFlags(&g_res_event[d], hipEventDisableTiming));
+    for (int q = 0; q < 2; ++q)
+        if (g_fused_event[d][q]) HIPCHK(c, hipStreamWaitEvent(c->sA, g_fused_event[d][q], 0));
     k_resolve<<<c->G, res_threads, lds, c->sA>>>(V, sa, c->G);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(c, RC_ERR_HIP, "k_resolve launch failed: %s", hipGetErrorString(e));
@@ -3046,6 +3362,60 @@ static int32_t launch_resolve(rc_ctx *c, const View &V, const SweepArgs &sa, int
 }
 
 static int32_t pull_labels(rc_ctx *c, std::vector<int64_t> &labels, std::vector<int64_t> &sizes, int64_t &K);
+
+// Sweep t as ONE launch (k_sweep) on the row-reduction stream of its parity.  Sweep t-2 precedes it in stream order;
+// sweep t-1 runs beside it on the other stream and is waited for inside the kernel (SweepArgs::tgt_done).
+static int32_t launch_sweep_fused(rc_ctx *c, const View &V, SweepArgs sa, long long t)
+{
+    const hipStream_t sx = (t & 1) ? c->sB2 : c->sB;
+    if (t >= 2) HIPCHK(c, hipStreamWaitEvent(sx, c->ev_res[(t - 2) & 3], 0));   // a no-op unless the pipeline was switched
+    if (c->sA_dirty) {   // recorded samples, log-likelihoods ... enqueued on stream A read the state this sweep changes
+        HIPCHK(c, hipEventRecord(c->ev_a, c->sA));
+        HIPCHK(c, hipStreamWaitEvent(sx, c->ev_a, 0));
+        c->sA_dirty = false;
+    }
+    const int cap_blocks = 2 * c->num_cus;                       // half of the 4 resident blocks per CU
+    const int gc = c->sw_coarse;
+    int nitems = 0, jsplit = 0, gfine = 0;
+    syml_geometry_dyn(c, cap_blocks, gc, &nitems, &jsplit, &gfine);
+    const int nblocks = std::max(1, std::min(cap_blocks, std::max((nitems + 3) / 4, c->G)));
+    const int G = std::min(c->G, nblocks);
+    sa.tgt_bulk = (c->f_tgt_bulk[t & 1] += (u64)nblocks);
+    sa.tgt_done = c->f_tgt_done;
+    c->f_tgt_done += (u64)G;
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    const bool timed = c->timing && (c->timing_every <= 1 || (t % c->timing_every) == 0);
+    std::lock_guard<std::mutex> lock(g_res_mutex);
+    const int d = c->dev & 63;
+    const int q = (int)(g_fused_count[d] & 1ull);
+    if (g_fused_event[d][q]) HIPCHK(c, hipStreamWaitEvent(sx, g_fused_event[d][q], 0));
+    else HIPCHK(c, hipEventCreateWithFlags(&g_fused_event[d][q], hipEventDisableTiming));
+    if (g_res_event[d]) HIPCHK(c, hipStreamWaitEvent(sx, g_res_event[d], 0));
+    if (timed) {
+        if (!c->ev_free.empty()) { ev = c->ev_free.back(); c->ev_free.pop_back(); }
+        else { HIPCHK(c, hipEventCreate(&ev.first)); HIPCHK(c, hipEventCreate(&ev.second)); }
+        HIPCHK(c, hipEventRecord(ev.first, sx));
+    }
+    if (c->derived) k_sweep<true><<<nblocks, 256, 0, sx>>>(V, sa, G, nitems, jsplit, gfine, gc);
+    else k_sweep<false><<<nblocks, 256, 0, sx>>>(V, sa, G, nitems, jsplit, gfine, gc);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, RC_ERR_HIP, "k_sweep launch failed: %s", hipGetErrorString(e));
+    if (timed) {
+        HIPCHK(c, hipEventRecord(ev.second, sx));
+        c->ev_pending.push_back(ev);
+    }
+    HIPCHK(c, hipEventRecord(g_fused_event[d][q], sx));
+    g_fused_count[d] += 1;
+    HIPCHK(c, hipEventRecord(c->ev_res[t & 3], sx));
+    c->last_bulk_kernel = 1;
+    return RC_OK;
+}
+
+// the pipeline sweep t would use: fused launches need the wave-autonomous symmetric kernel (64-bit storage)
+static bool want_fused(const rc_ctx *c)
+{
+    return c->fused_enabled && c->fused_ok && !c->incremental && c->bits == 64 && choose_sym(c) && sym_variant_of(c) == 2;
+}
 
 extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t seed, uint64_t sweep_index)
 {
@@ -3085,6 +3455,9 @@ extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t 
     int res_threads = c->res_threads;
     if (res_threads == 0)
         res_threads = (!c->incremental && c->prefetch && c->last_bulk_kernel == 1 && c->hsum->n_changes <= 32) ? 256 : 512;
+    if (c->incremental && c->pipe_fused) {   // (rc_set_mode drained the streams)
+        c->pipe_fused = false;
+    }
     if (c->incremental) {
         // exact incremental mode: the row-sum table of the current labels already exists (one k_bulk after
         // rc_set_state) and every label change corrects it in place — no matrix traffic at all in this sweep
@@ -3104,20 +3477,39 @@ extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t 
         c->state_version++;
         return RC_OK;
     }
+    sa.own_gen = (int)(t % 3);
+    sa.next_gen = (int)((t + 1) % 3);
+    sa.zero_gen = (int)((t + 2) % 3);
+    sa.tgt_bulk = sa.tgt_done = 0;
+    // Pipeline of this sweep: one fused launch (k_sweep) where the wave-autonomous symmetric kernel applies, separate
+    // row-reduction and resolver launches otherwise.  Both leave the same state behind (S generations, label snapshots,
+    // perm generations by sweep parity); a change of pipeline drains the streams first.  A sweep whose row reduction has
+    // already been enqueued by the other pipeline's prefetch stays with it.
+    const bool fused = want_fused(c) && c->bulk_enq < t;
+    if (fused != c->pipe_fused && t > 0) {
+        rc = sync_and_check(c, true);
+        if (rc != RC_OK) return rc;
+    }
+    c->pipe_fused = fused;
+    if (fused) {
+        rc = launch_sweep_fused(c, V, sa, t);
+        if (rc != RC_OK) return rc;
+        c->bulk_enq = t;
+        c->t_next = t + 1;
+        c->state_version++;
+        return RC_OK;
+    }
     if (c->bulk_enq < t) {
         rc = enqueue_bulk(c, V, t);
         if (rc != RC_OK) return rc;
     }
-    sa.own_gen = (int)(t % 3);
-    sa.next_gen = (int)((t + 1) % 3);
-    sa.zero_gen = (int)((t + 2) % 3);
     HIPCHK(c, hipStreamWaitEvent(c->sA, c->ev_bulk[t & 3], 0));
     rc = launch_resolve(c, V, sa, res_threads, lds);
     if (rc != RC_OK) return rc;
     HIPCHK(c, hipEventRecord(c->ev_res[t & 3], c->sA));
     c->t_next = t + 1;
     c->state_version++;
-    if (c->prefetch) {
+    if (c->prefetch && !want_fused(c)) {
         // software pipeline: the row reduction of the next sweep starts now, under the labels known before
         // this sweep; k_resolve adds this sweep's label changes to it (exact integer atomics)
         rc = enqueue_bulk(c, V, t + 1);
@@ -3414,6 +3806,8 @@ extern "C" int32_t rc_record_sample(rc_ctx *c, int64_t *canonical_out)
     if (!c->have_state) return fail(c, RC_ERR_STATE, "rc_record_sample: no state set");
     HIPCHK(c, hipSetDevice(c->dev));
     int32_t rc = ensure_counts(c);
+    if (rc != RC_OK) return rc;
+    rc = order_A_after_sweeps(c);
     if (rc != RC_OK) return rc;
     k_snapshot<<<(c->ldc + 255) / 256, 256, 0, c->sA>>>(c->slot_of, c->pi, c->n, c->ldc, c->snap + (size_t)c->snap_cnt * c->ldc);
     HIPCHK(c, hipGetLastError());
@@ -4084,7 +4478,7 @@ extern "C" int32_t rc_set_mode(rc_ctx *c, int32_t mode)
             HIPCHK(c, hipMemsetAsync(c->keys[g], 0xFF, (size_t)(c->n + 2) * sizeof(u64), c->sA));
             HIPCHK(c, hipMemsetAsync(c->cword[g], 0, ((size_t)(c->n + RC_PTS - 1) / RC_PTS + 1) * sizeof(u64), c->sA));
             HIPCHK(c, hipMemsetAsync(c->arrive[g], 0, 64, c->sA));
-            HIPCHK(c, hipMemsetAsync(c->work[g], 0, 64, c->sA));
+            HIPCHK(c, hipMemsetAsync(c->work[g], 0, 512, c->sA));
         }
         const int minus1 = -1;
         HIPCHK(c, hipMemcpyAsync(&c->sc->last_change_sweep, &minus1, sizeof(int), hipMemcpyHostToDevice, c->sA));
@@ -4095,6 +4489,9 @@ extern "C" int32_t rc_set_mode(rc_ctx *c, int32_t mode)
         HIPCHK(c, hipStreamSynchronize(c->sA));
         c->t_next = 0;
         c->bulk_enq = -1;
+        HIPCHK(c, hipMemset(c->fsync, 0, 64));
+        c->f_tgt_bulk[0] = c->f_tgt_bulk[1] = c->f_tgt_done = 0;
+        c->pipe_fused = false;
     }
     return RC_OK;
 }
@@ -4156,6 +4553,16 @@ extern "C" int32_t rc_event_overhead_ms(rc_ctx *c, double *out)
     *out = c->ev_overhead_ms;
     return RC_OK;
 }
+
+#ifdef RC_PROF_SYML
+extern "C" int32_t rc_debug_prof(rc_ctx *c, int32_t gen, long long *out /* 8192 x 4 */)
+{
+    HIPCHK(c, hipSetDevice(c->dev));
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(out, (char *)c->work[gen & 1] + 512, 8192 * 128, hipMemcpyDeviceToHost));
+    return RC_OK;
+}
+#endif
 
 #include "pointestimate.inc.hip"
 #include "chain.inc.hip"

@@ -200,7 +200,8 @@ def params(P: dict) -> OrcParams:
 class Oracle:
     """Convenience wrapper holding one dataset (D, logD, fixed-point copies) and one label state."""
 
-    def __init__(self, D: np.ndarray, P: dict, logD: np.ndarray | None = None, bits: int = 64, eL: int | None = None):
+    def __init__(self, D: np.ndarray, P: dict, logD: np.ndarray | None = None, bits: int = 64, eL: int | None = None,
+                 eD: int | None = None):
         self.L = lib()
         self.n = int(D.shape[0])
         self.D = np.ascontiguousarray(D, dtype=np.float64)
@@ -219,6 +220,8 @@ class Oracle:
             self.eL = self.L.orc_quant_exponent32(self.logD.ravel(), nn)
         if eL is not None:   # the library's derived-logD mode caps the exponent (|logD·2^eL| < 2^51)
             self.eL = int(eL)
+        if eD is not None:   # ... and D's (every Dq < 2^51, binding for n <= 1024): take the exponents the library reports
+            self.eD = int(eD)
         self.Dq = np.empty((self.n, self.n), np.int64)
         self.Lq = np.empty((self.n, self.n), np.int64)
         self.L.orc_quantize(self.D.ravel(), nn, self.eD, self.Dq.reshape(-1))

@@ -18,8 +18,8 @@ def derived_pair(D, P, init, kcap=0):
     L = ctx.get_matrix(1)
     ctx.set_params(**P)
     ctx.set_state(init)
-    eL = ctx.debug_rowsums(int(init[0]))[3]         # the library's exponent (capped at 50 - exponent(max|logD|))
-    orc = O.Oracle(D, P, logD=L, eL=eL)
+    eD, eL = ctx.debug_rowsums(int(init[0]))[2:4]   # the library's exponents (derived mode: eL capped at 50 - exponent(max|logD|), eD at 51 - exponent(max D))
+    orc = O.Oracle(D, P, logD=L, eL=eL, eD=eD)
     ctx.set_params(**P)
     ctx.set_state(init)
     orc.set_state(init)
@@ -155,7 +155,8 @@ def test_many_small_clusters_against_oracle(kernel):
     ctx = rc.Context(D, kcap=1024)
     ctx.set_params(**P); ctx.set_bulk_kernel(kernel); ctx.set_state(init)
     L = ctx.get_matrix(1)
-    orc = O.Oracle(D, P, logD=L, eL=ctx.debug_rowsums(int(init[0]))[3])
+    eD, eL = ctx.debug_rowsums(int(init[0]))[2:4]
+    orc = O.Oracle(D, P, logD=L, eL=eL, eD=eD)
     orc.set_state(init)
     for t in range(8):
         ctx.gibbs_sweep(1.0, 0.5, 4, t)

@@ -31,8 +31,8 @@ def headline():
     ctx.set_params(**P)
     ctx.set_state(truth)
     L = ctx.get_matrix(1)
-    eL = ctx.debug_rowsums(1)[3]
-    orc = O.Oracle(D, P, logD=L, eL=eL)
+    eD, eL = ctx.debug_rowsums(1)[2:4]
+    orc = O.Oracle(D, P, logD=L, eL=eL, eD=eD)
     yield dict(n=n, K=K, D=D, truth=truth, P=P, ctx=ctx, orc=orc, L=L)
     ctx.close()
 
@@ -137,7 +137,8 @@ def test_auto_path_between_threshold_and_headline_size_crosses_relayout():
     ctx = rc.Context(D, kcap=64)
     ctx.set_params(**P)
     ctx.set_state(truth)
-    orc = O.Oracle(D, P, logD=ctx.get_matrix(1), eL=ctx.debug_rowsums(int(truth[0]))[3])
+    eD, eL = ctx.debug_rowsums(int(truth[0]))[2:4]
+    orc = O.Oracle(D, P, logD=ctx.get_matrix(1), eL=eL, eD=eD)
     orc.set_state(truth)
     l0 = ctx.layout_info()[0]
     names, relaid_at = [], None
