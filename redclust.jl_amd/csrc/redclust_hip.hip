@@ -55,6 +55,22 @@
 
 #include "../../include/redclust_hip.h"
 
+#ifdef RC_POISON   // diagnostic builds: every device allocation starts out filled with 0xAB, so that a read of memory that
+                   // was never initialised gives the same wrong answer on every machine instead of depending on what the
+                   // allocator recycled
+static hipError_t rc_poison_malloc(void **p, size_t sz, const char *site)
+{
+    hipError_t e = (hipMalloc)(p, sz);
+    const char *only = getenv("RC_POISON_ONLY");   // poison just the allocation sites whose text contains this string
+    if (e == hipSuccess && (!only || strstr(site, only))) {
+        e = hipMemset(*p, 0xAB, sz);
+        if (e == hipSuccess) e = hipDeviceSynchronize();   // the library's streams are non-blocking: not ordered after the null stream
+    }
+    return e;
+}
+#define hipMalloc(p, sz) rc_poison_malloc((void **)(p), (sz), #p)
+#endif
+
 typedef long long ll2 __attribute__((ext_vector_type(2)));
 typedef unsigned long long u64;
 
@@ -64,10 +80,10 @@ typedef unsigned long long u64;
 #define RC_MAX_KCAP 4096
 #define RC_MAXB 1024         // tentative changers validated per resolve round
 #define RC_SPIN_LIMIT (1u << 23)
-#ifdef RC_PROF_SYML   // profiling builds (tools/prof_syml.py): per-wave cycle stamps of k_bulk_syml behind the work counter
-#define RC_WORK_BYTES (512 + 8192 * 128)
+#if defined(RC_PROF_SYML) || defined(RC_TRACE_RESOLVE)   // profiling / diagnostic builds: records behind the work counter
+#define RC_WORK_BYTES (64 + 8192 * 128)
 #else
-#define RC_WORK_BYTES 512
+#define RC_WORK_BYTES 64
 #endif
 
 // error bits in DevScalars.err
@@ -99,8 +115,6 @@ struct HostSummary {
 struct View {
     int n, ld, kcap;
     const void *Dq, *Lq;       // [n][ld] fixed point: int64 (bits = 64) or int32 (bits = 32); rows/columns in INTERNAL order
-    const long long *Dp, *Lp;  // the same matrices PANEL-major for k_bulk_syml / k_sweep: [ld/128][n][128], i.e. the 128 columns of a
-                               // column block are contiguous row after row (Lp only when logD is stored and those kernels are in use)
     int bits;
     const long long *diagq;    // [n] Dq[i][i]
     int derived;               // 1: logD is not stored; Lq(i,j) = rc_qlog(Dq(i,j)) for i != j, 0 on the diagonal
@@ -119,12 +133,10 @@ struct View {
     int *work[2];              // work-item counters of k_bulk_sym (two generations)
     const double *A;           // [n+1] size table
     u64 *keys[2];              // [n+2] one word per resolve round: first violation (batch rounds) (two generations)
-    u64 *cword[2];             // [nchunks] per 32-point chunk: (round stamp << 32) | mask of tentative changers (two generations)
-    unsigned *rec;             // [n] (own slot << 16) | (target slot + 1) of a tentative changer (0 target = new cluster)
+    u64 *cword[2];             // [2][nchunks + 1] per round parity and 32-point chunk: (round stamp << 32) | mask of tentative changers (two generations)
+    unsigned *rec;             // [2][n] per round parity: (own slot << 16) | (target slot + 1) of a tentative changer (0 target = new cluster)
     int *tent;                 // [n] tentative target of every point (owner-private)
     unsigned *arrive[2];       // grid-barrier arrival counters (two generations)
-    u64 *fsync;                // k_sweep: [0], [1] blocks whose row reduction is complete (by sweep parity), [2] resolver blocks that
-                               // have finished; all monotonic since rc_set_state
     DevScalars *sc;
     HostSummary *hsum;         // device address of the host-mapped summary
     double scD, scL;           // 2^-eD, 2^-eL
@@ -140,8 +152,6 @@ struct SweepArgs {
     int own_gen, next_gen;  // S generation read (and corrected in place); generation being filled for the next sweep (-1: none)
     int zero_gen;           // S generation this launch clears for the row reduction two sweeps ahead (-1: none)
     int dbg;  // timing ablations only (RC_DEBUG_FLAGS): 1 = skip candidate loop, 2 = skip grid barrier, 4 = skip gumbel
-    u64 tgt_bulk, tgt_done;  // k_sweep: value of fsync[t & 1] once every block of this launch has reduced its rows; value of
-                             // fsync[2] once the previous sweep is complete
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -379,16 +389,6 @@ __global__ __launch_bounds__(256) void k_relayout(const T *__restrict__ src, con
     const int w = blockIdx.y;
     const T *row = src + (size_t)ipi[w] * ld;
     for (int x = blockIdx.x * 256 + threadIdx.x; x < n; x += gridDim.x * 256) out[(size_t)w * ld + x] = row[ipi[x]];
-}
-
-// Panel-major copy for the wave-autonomous symmetric kernels: P[(J·n + r)·128 + c] = Q[r][128 J + c].  A 64×128 work
-// unit is then ONE contiguous 64 KiB (a tile 4 KiB) instead of 1 KiB pieces a whole matrix row apart — the difference
-// between ≈4.5 and ≈6 TB/s on this memory system (DRAM pages / channel bursts are used whole).
-__global__ __launch_bounds__(256) void k_panelize(const long long *__restrict__ Q, int n, int ld, long long *__restrict__ P)
-{
-    const int r = blockIdx.y;
-    for (int x = blockIdx.x * 256 + threadIdx.x; x < ld; x += gridDim.x * 256)
-        P[((size_t)(x >> 7) * n + r) * 128 + (x & 127)] = Q[(size_t)r * ld + x];
 }
 
 __global__ void k_gather_ll(const long long *__restrict__ src, const int *__restrict__ ipi, int n, long long *__restrict__ out)
@@ -1006,30 +1006,26 @@ __device__ __forceinline__ void row16_sum4_dpp(long long &a, long long &b, long 
 #define RC_PF(stmt)
 #endif
 
-// The unit loop of the wave-autonomous symmetric reduction, shared by k_bulk_syml (one launch per row reduction) and
-// k_sweep (row reduction + resolver in one persistent launch).  tt: the calling wave's private 10 KiB of LDS (log table in
+// The unit loop of the wave-autonomous symmetric reduction (k_bulk_syml).  tt: the calling wave's private 10 KiB of LDS (log table in
 // the padding, see k_bulk_syml).
 //   Work units: column block J (heavy blocks first) × a range of rows.  Blocks J >= jsplit are cut into units of gcoarse
 //   rows and the light blocks below jsplit, which come last in the list, into units of gfine (8..32) rows, so that the
 //   tail of the launch is a few tiles long (and a small problem still spreads over the chip).
-//   Who takes which unit: unit `first_unit` is the wave's own; after that either every nwaves-th unit (dyn == nullptr:
-//   static round-robin — a single shared counter hit by thousands of waves at once serialises in L2, ~25 ns per
-//   returning atomic) or, in k_sweep, the next unit of the wave's group from one of eight counters 64 B apart
-//   (dyn[8·grp]; units nwaves + 8k + grp, k = 0, 1, ...): waves differ by up to 2× in speed, depending on what else is
-//   resident on their SIMD, and a persistent launch ends with its slowest wave.  The counter is read one unit ahead.
+//   Units are dealt round-robin to the waves (first_unit, first_unit + nwaves, ...): a shared work counter hit by
+//   thousands of waves at once serialises in L2 (~25 ns per returning atomic), and handing units out dynamically from
+//   eight counters with a graded tail measured SLOWER than this static list (serial sweep 117-130 µs against 111).
 //   Unit pipeline: while the last tile of a unit is reduced, the next unit's first tile and the slots of its columns and
 //   rows are already in flight (a unit's set-up otherwise costs a full memory round trip, ~20 % of a 64-row unit).
 //   A unit's column set-up (the two clusters that own its 128 columns, per-lane class masks) is done once; its rows are
 //   taken in 64-row halves (direction-2 totals live one row per lane).
 template <bool DERIVED>
 __device__ __forceinline__ void syml_units(const View &V, long long (*tt)[RC_SL_R][RC_SL_P], int wgen, int sgen, int nitems,
-                                           int jsplit, int gfine, int gcoarse, int first_unit, int nwaves, u64 *dyn, int grp,
-                                           long long *pf_out)
+                                           int jsplit, int gfine, int gcoarse, int first_unit, int nwaves, long long *pf_out)
 {
     const int lane = threadIdx.x & 63;
     const size_t ld = (size_t)V.ld;
-    const long long *__restrict__ Dp = V.Dp + 2 * lane;   // panel-major: (column block J, row r) starts at (J·n + r)·128
-    const long long *__restrict__ Lp = V.Lp + 2 * lane;
+    const long long *__restrict__ Dq = (const long long *)V.Dq + 2 * lane;
+    const long long *__restrict__ Lq = (const long long *)V.Lq + 2 * lane;
     const int *__restrict__ slot = V.snap[sgen];
     long long *SD = V.SD[wgen], *SL = V.SL[wgen];
     const int n = V.n;
@@ -1055,13 +1051,12 @@ __device__ __forceinline__ void syml_units(const View &V, long long (*tt)[RC_SL_
         oa1 = min(oa0 + g, min(oc0 + RC_SW_COLS, n));                  // rows a >= c0+128 have no column b > a here
     };
     ll2 d[RC_SL_R], l[RC_SL_R];
-    auto issue = [&](int a, int cb0) {   // the four rows of a tile are 4 KiB of consecutive addresses
-        const size_t pbase = (size_t)(cb0 >> 7) * (size_t)n;
+    auto issue = [&](int a, int cb0) {
 #pragma unroll
         for (int u = 0; u < RC_SL_R; ++u) {
             const int r = min(a + u, n - 1);
-            d[u] = __builtin_nontemporal_load((const ll2 *)(Dp + (pbase + (size_t)r) * RC_SW_COLS));
-            if (!DERIVED) l[u] = __builtin_nontemporal_load((const ll2 *)(Lp + (pbase + (size_t)r) * RC_SW_COLS));
+            d[u] = __builtin_nontemporal_load((const ll2 *)(Dq + (size_t)r * ld + cb0));
+            if (!DERIVED) l[u] = __builtin_nontemporal_load((const ll2 *)(Lq + (size_t)r * ld + cb0));
         }
     };
     int unit = first_unit;
@@ -1075,10 +1070,8 @@ __device__ __forceinline__ void syml_units(const View &V, long long (*tt)[RC_SL_
     }
     while (unit < nitems) {
         RC_PF(const long long pf_u0 = __builtin_amdgcn_s_memtime();)
-        // the index of the unit after this one: requested now, needed when this unit's last tile is reached
-        u64 fetched = 0;
-        if (dyn && lane == 0) fetched = __hip_atomic_fetch_add(dyn + 8 * grp, (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int nunit = unit + nwaves, nc0 = 0, na0 = 0, na1 = 0, nitem = 0, ncs0 = -1, ncs1 = -1, nrowslots = -1;
+        const int nunit = unit + nwaves;
+        int nc0 = 0, na0 = 0, na1 = 0, nitem = 0, ncs0 = -1, ncs1 = -1, nrowslots = -1;
         const int col0 = c0 + 2 * lane, col1 = col0 + 1;
         // the (at most two) clusters that own the 128 columns; a third, fourth ... cluster goes the slow way
         const int dsA = __builtin_amdgcn_readfirstlane(cs0);            // column c0 always exists
@@ -1112,7 +1105,6 @@ __device__ __forceinline__ void syml_units(const View &V, long long (*tt)[RC_SL_
         };
         // after the loads of this unit's last tile have been taken: the next unit's first tile and slots
         auto prefetch_next = [&]() {
-            if (dyn) nunit = nwaves + 8 * (int)__builtin_amdgcn_readfirstlane((unsigned)fetched) + grp;
             if (nunit < nitems) {
                 decode(nunit, nc0, na0, na1, nitem);
                 issue(na0, nc0);
@@ -1271,20 +1263,20 @@ __device__ __forceinline__ void syml_load_table(const View &V, long long (*tl)[2
 #define RC_SYML_MINWAVES 4
 #endif
 template <bool DERIVED>
-__global__ __launch_bounds__(256, RC_SYML_MINWAVES) void k_bulk_syml(View V, int wgen, int dynamic, int sgen, int cgen, int nitems, int jsplit, int gfine, int gcoarse)
+__global__ __launch_bounds__(256, RC_SYML_MINWAVES) void k_bulk_syml(View V, int wgen, int zgen, int sgen, int cgen, int nitems, int jsplit, int gfine, int gcoarse)
 {
     // [wave][matrix][row][octet-padded col]: 10 KiB per wave, 40 KiB per block = four blocks (16 waves) per CU exactly.
     // The log table of the derived mode (128 × 16 B) lives in the padding: entry j of a wave's private copy sits in
     // the two spare elements of octet (j & 15) of tile row (j >> 4) [matrix = j >> 6, row = (j >> 4) & 3].
     __shared__ __attribute__((aligned(16))) long long tl[4][2][RC_SL_R][RC_SL_P];
     if (DERIVED) syml_load_table(V, tl);
+    (void)zgen;  // generations are cleared and work counters re-armed by k_resolve (SweepArgs.zero_gen)
     __syncthreads();  // the table is visible; from here on the waves are on their own
-    // (S generations are cleared and the unit counters of this parity re-armed by k_resolve, SweepArgs.zero_gen)
     const int w = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
     long long *pf = nullptr;
-    RC_PF(if (w < 8192) pf = (long long *)((char *)V.work[cgen] + 512) + (size_t)w * 16;)
-    syml_units<DERIVED>(V, tl[threadIdx.x >> 6], wgen, sgen, nitems, jsplit, gfine, gcoarse, w, (int)gridDim.x * 4,
-                        dynamic ? (u64 *)V.work[cgen] : nullptr, (int)(blockIdx.x & 7), pf);
+    RC_PF(if (w < 8192) pf = (long long *)((char *)V.work[cgen] + 64) + (size_t)w * 16;)
+    (void)cgen;
+    syml_units<DERIVED>(V, tl[threadIdx.x >> 6], wgen, sgen, nitems, jsplit, gfine, gcoarse, w, (int)gridDim.x * 4, pf);
 }
 
 
@@ -1515,6 +1507,12 @@ __device__ Tab tab_carve(char *smem, int kcap, int n, int nw)
     return T;
 }
 
+__device__ inline size_t tab_bytes_dev(int kcap, int n, int nw)
+{
+    size_t off[18];
+    return tab_layout(kcap, n, nw, off);
+}
+
 static size_t tab_bytes(int kcap, int n, int nw)
 {
     size_t off[18];
@@ -1718,7 +1716,7 @@ __device__ __forceinline__ void best_merge(double &bv, int &bp, int &bs, double 
 //   it (exact integer corrections of the two row sums and the sizes involved); a decision that differs from the
 //   tentative one is a violation (block-local minimum in T.blk_key).  Points outside (lo, hi] are skipped.
 __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long long *SD, const long long *SL,
-                           int chunk, int lo, int hi, int mode, int nb, u64 *cword, unsigned stamp)
+                           int chunk, int lo, int hi, int mode, int nb, u64 *cword, unsigned *rec, unsigned stamp)
 {
     const int pt = threadIdx.x & (RC_PTS - 1), st = threadIdx.x >> 5, NS = blockDim.x >> 5;
     const int wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
@@ -1825,7 +1823,7 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
         if (mode == 0) {
             if (half == 0 && valid) {
                 V.tent[i] = target;
-                if (changed) __hip_atomic_store(V.rec + i, ((unsigned)own << 16) | (unsigned)(target + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (changed) __hip_atomic_store(rec + i, ((unsigned)own << 16) | (unsigned)(target + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             const u64 m = __ballot(changed) & 0xFFFFFFFFull;
             if (m) {
@@ -2029,18 +2027,31 @@ __device__ void commit_batch(const View &V, const SweepArgs &sa, Tab &T, int nc,
 // chunk-word / barrier generation t%2 (and re-arms generation (t+1)%2), and leaves perm / snapshot generation t%2
 // describing the labels after the sweep.
 // ---------------------------------------------------------------------------------------------------
-// The resolver proper: called by k_resolve (its own launch) and by k_sweep (after the row reduction of the same launch).
-// smem: tab_bytes(kcap, n, blockDim.x / 64) bytes of LDS, at least 2·kcap ints.  All G blocks must be resident.
+// The resolver proper (k_resolve is its launch wrapper).  smem: tab_bytes(kcap, n, blockDim.x / 64) bytes of LDS, at
+// least 2·kcap ints.  All G blocks must be resident.
+// Chaos builds (-DRC_CHAOS=sites): block-dependent pseudo-random delays at chosen points of the resolver's rounds, to shake
+// out orderings between blocks that the usual lock-step timing hides (tools/chaos.sh).  Bit k of RC_CHAOS enables site k.
+#ifdef RC_CHAOS
+__device__ __forceinline__ void chaos_delay(int site, int round)
+{
+    if (!((RC_CHAOS >> site) & 1)) return;
+    unsigned h = (unsigned)blockIdx.x * 2654435761u ^ (unsigned)round * 40503u ^ (unsigned)site * 97u;
+    h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+    const unsigned reps = h & 63u;                       // 0..63 x ~0.5 µs
+    for (unsigned q = 0; q < reps; ++q) __builtin_amdgcn_s_sleep(16);
+}
+#define RC_CHAOS_AT(site) chaos_delay(site, round)
+#else
+#define RC_CHAOS_AT(site)
+#endif
+
 __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *smem)
 {
-    // The resolver is the latency-critical part of a sweep and shares its SIMDs with the waves of a row reduction (of the
-    // next sweep, or of the other launch in flight): it takes instruction-issue priority over them.
-    __builtin_amdgcn_s_setprio(3);
     Tab T = tab_carve(smem, V.kcap, V.n, blockDim.x >> 6);
     const int t = sa.t, own_gen = sa.own_gen, next_gen = sa.next_gen, kg = t & 1;
     const long long *SD = V.SD[own_gen], *SL = V.SL[own_gen];
     u64 *keys = V.keys[kg];
-    u64 *cword = V.cword[kg];
+    u64 *const cword_gen = V.cword[kg];
     unsigned *arrive = V.arrive[kg];
     tab_load(V, T);
     tab_bases(V, sa, T);
@@ -2049,13 +2060,22 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
     bool ok = true;
     for (;;) {
         const unsigned stamp = (unsigned)round + 1u;
+        // The announcements of a round (chunk words, changer records) live in the buffers of the round's PARITY: after a
+        // structural commit the blocks go on to the next round without a second barrier, and a block that is ahead must
+        // not overwrite what a block that is behind is still reading (it cannot get two rounds ahead: the next round's
+        // first barrier holds it).
+        u64 *const cword = cword_gen + (size_t)(round & 1) * (size_t)(nchunks + 1);
+        unsigned *const rec = V.rec + (size_t)(round & 1) * (size_t)V.n;
+        RC_CHAOS_AT(0);
         // 1. tentative decisions of the points after `after`
         for (int c = blockIdx.x; c < nchunks; c += G)
-            if (c * RC_PTS + RC_PTS - 1 > after) eval_chunk(V, sa, T, SD, SL, c, after, V.n, 0, 0, cword, stamp);
+            if (c * RC_PTS + RC_PTS - 1 > after) eval_chunk(V, sa, T, SD, SL, c, after, V.n, 0, 0, cword, rec, stamp);
         if (sa.dbg & 2) break;
         ok = grid_barrier(V, T, arrive, (unsigned)G * (unsigned)(++nbar), RC_KEY_NONE, keys + round);
         if (!ok) break;
+        RC_CHAOS_AT(1);
         // 2. the ordered batch of tentative changers
+        int any = 0;
         for (int c = threadIdx.x; c <= nchunks; c += blockDim.x) {
             int cnt = 0;
             if (c < nchunks && c * RC_PTS + RC_PTS - 1 > after) {
@@ -2063,16 +2083,33 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
                 if ((unsigned)(w >> 32) == stamp) cnt = __popc((unsigned)w);
             }
             T.ccnt[c] = cnt;
+            any |= cnt;
         }
         for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) T.affected[k] = 0;
+        if (threadIdx.x == 0) T.misc[2] = 0;
         __syncthreads();
-        if (threadIdx.x == 0) {  // exclusive offsets (nchunks <= 1024 for n <= 32768)
-            int o = 0;
-            for (int c = 0; c <= nchunks; ++c) { const int x = T.ccnt[c]; T.ccnt[c] = o; o += x; }
+        if (any) T.misc[2] = 1;
+        __syncthreads();
+        const int any_all = T.misc[2];
+        __syncthreads();
+        if (!any_all) break;  // no point wants to move: the sweep is complete (the stationary fast path)
+        // exclusive offsets by wave 0: every lane scans its run of chunks, the lanes' totals by shuffles (a scan by one
+        // thread costs two LDS round trips per chunk: 14 µs at n = 8192, half of a stationary resolver pass)
+        if (threadIdx.x < 64) {
+            const int per = (nchunks + 1 + 63) / 64, c0_ = (int)threadIdx.x * per, c1_ = min(c0_ + per, nchunks + 1);
+            int sum = 0;
+            for (int c = c0_; c < c1_; ++c) sum += T.ccnt[c];
+            int incl = sum;
+#pragma unroll
+            for (int d_ = 1; d_ < 64; d_ <<= 1) {
+                const int up = __shfl_up(incl, d_);
+                if ((int)threadIdx.x >= d_) incl += up;
+            }
+            int o = incl - sum;
+            for (int c = c0_; c < c1_; ++c) { const int x = T.ccnt[c]; T.ccnt[c] = o; o += x; }
         }
         __syncthreads();
         const int total = T.ccnt[nchunks];
-        if (total == 0) break;  // no point wants to move: the sweep is complete
         for (int c = threadIdx.x; c < nchunks; c += blockDim.x) {
             int o = T.ccnt[c];
             if (T.ccnt[c + 1] > o && o < RC_MAXB + 1) {
@@ -2082,7 +2119,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
                     m &= m - 1;
                     const int x = c * RC_PTS + bit;
                     if (o < RC_MAXB) {
-                        const unsigned rc = __hip_atomic_load(V.rec + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned rc = __hip_atomic_load(rec + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         T.bx[o] = x; T.bu[o] = V.pi[x]; T.ba[o] = (int)(rc >> 16); T.bb[o] = (int)(rc & 0xFFFFu) - 1;
                     } else {
                         T.misc[2] = x;  // first changer that does not fit into the batch
@@ -2107,6 +2144,13 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         }
         __syncthreads();
         const int nb = T.misc[3], hi = T.misc[4];
+        RC_CHAOS_AT(2);
+#ifdef RC_TRACE_RESOLVE   // diagnostic builds: per-round record of block RC_TRACE_BLOCK (default 0) behind the work counter
+        if ((int)blockIdx.x == (sa.dbg >> 8) && threadIdx.x == 0 && round < 120) {   // kept in LDS until the sweep is over
+            int *tr = (int *)(smem + tab_bytes_dev(V.kcap, V.n, blockDim.x >> 6)) + (size_t)round * 8;
+            tr[0] = round; tr[1] = total; tr[2] = nb; tr[3] = hi; tr[4] = T.bx[0]; tr[5] = after; tr[6] = T.ba[0]; tr[7] = T.bb[0];
+        }
+#endif
         if (nb == 0) {
             // the first changer is structural: commit it alone (tables are rebuilt); its successors are re-drawn next round
             const u64 key = ((u64)(unsigned)T.bx[0] << 32) | ((u64)(unsigned)T.ba[0] << 16) | (u64)(unsigned)(T.bb[0] + 1);
@@ -2122,11 +2166,12 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         // 3. validation of the points after the first changer, each under the changers that precede it
         const int first = T.bx[0];
         for (int c = blockIdx.x; c < nchunks; c += G)
-            if (c * RC_PTS + RC_PTS - 1 > first && c * RC_PTS <= hi) eval_chunk(V, sa, T, SD, SL, c, first, hi, 1, nb, cword, stamp);
+            if (c * RC_PTS + RC_PTS - 1 > first && c * RC_PTS <= hi) eval_chunk(V, sa, T, SD, SL, c, first, hi, 1, nb, cword, rec, stamp);
         __syncthreads();
         const u64 mine = *T.blk_key;
         ok = grid_barrier(V, T, arrive, (unsigned)G * (unsigned)(++nbar), mine, keys + round);
         if (!ok) break;
+        RC_CHAOS_AT(3);
         // 4. commit the changers before the first violation
         const u64 vk = __hip_atomic_load(keys + round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int limit = (vk == RC_KEY_NONE) ? hi + 1 : (int)vk;   // points < limit are final
@@ -2142,6 +2187,15 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         ++round;
         if (round > V.n) break;  // cannot happen: every round finalises at least the first changer
     }
+#ifdef RC_TRACE_RESOLVE
+    __syncthreads();
+    if ((int)blockIdx.x == (sa.dbg >> 8)) {
+        const int *tr = (const int *)(smem + tab_bytes_dev(V.kcap, V.n, blockDim.x >> 6));
+        long long *out = (long long *)((char *)V.work[kg] + 64);
+        for (int q = threadIdx.x; q < 120 * 8; q += blockDim.x) out[q] = (q / 8 <= round) ? tr[q] : -7;
+    }
+    __syncthreads();
+#endif
     if (sa.zero_gen >= 0 && (blockIdx.x > 0 || G == 1)) {
         // The blocks that have no epilogue work clear the S generation that held the sums of the labels before this
         // sweep: nobody reads it any more, the row reduction of sweep t+2 fills it and k_resolve(t+1) adds its
@@ -2156,10 +2210,10 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
     if (blockIdx.x == 0) {
         __syncthreads();
         // the row reduction of this sweep is complete (stream order): re-arm its work counter for sweep t+2
-        if (threadIdx.x < 8) ((u64 *)V.work[kg])[8 * threadIdx.x] = 0;   // (k_bulk_sym: one int; k_sweep: eight group counters)
+        if (threadIdx.x == 0) *V.work[kg] = 0;
         // re-arm the other key / chunk-word / barrier generation for the next sweep (its last user, sweep t-1, is done)
         for (int q = threadIdx.x; q < V.n + 2; q += blockDim.x) V.keys[kg ^ 1][q] = RC_KEY_NONE;
-        for (int q = threadIdx.x; q < nchunks; q += blockDim.x) V.cword[kg ^ 1][q] = 0;
+        for (int q = threadIdx.x; q < 2 * (nchunks + 1); q += blockDim.x) V.cword[kg ^ 1][q] = 0;
         if (threadIdx.x == 0) *V.arrive[kg ^ 1] = 0u;
         tab_store(V, T);
         const int last = V.sc->last_change_sweep;
@@ -2191,71 +2245,6 @@ __global__ __launch_bounds__(RC_RES_THREADS, RC_RES_MINWAVES) void k_resolve(Vie
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     resolve_body(V, sa, G, smem);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// k_sweep — one whole sweep in ONE persistent launch: the row reduction of sweep t (syml_units, all blocks), a grid-wide
-// hand-over, then the resolver of sweep t (resolve_body, blocks 0..G-1; the others leave).  Two such launches are in
-// flight at a time — sweeps t and t+1 alternate between two streams, each launch sized to HALF the chip's resident
-// blocks — so the row reduction of sweep t+1 fills the machine while sweep t resolves, with no cross-stream event and no
-// launch gap on the critical path; the one cross-launch dependence, resolver(t+1) after resolver(t), is an in-kernel wait
-// on a completion counter.  (With separate launches the resolver could not become resident beside the next row
-// reduction — four reduction blocks take a CU's whole LDS and VGPR file — so the two serialised: 104 µs per sweep at
-// n = 8192 against 52 µs of row-reduction work per wave.)
-//   Residency: 40 KiB of LDS and 128 VGPRs per block = 4 blocks per CU; a launch has at most 2 per CU and the host keeps
-//   at most two launches in flight per device, so every block of both is resident and the spins below terminate.
-//   Memory model (MI355X_MICROARCH.md, inter-workgroup visibility): a block publishes with — every wave's
-//   s_waitcnt vmcnt(0), workgroup barrier, one lane's agent-scope release fence, s_waitcnt vmcnt(0), relaxed agent atomic
-//   add — and consumes with — relaxed agent poll, agent-scope acquire fence, s_waitcnt vmcnt(0), workgroup barrier, plain
-//   loads.
-// ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void block_publish(u64 *counter)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(counter, (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-template <bool DERIVED>
-__global__ __launch_bounds__(256, 4) __attribute__((amdgpu_num_vgpr(128))) void k_sweep(View V, SweepArgs sa, int G, int nitems, int jsplit, int gfine, int gcoarse)
-{
-    // exactly 40 KiB and 128 VGPRs: four blocks per CU, i.e. two launches of two blocks per CU
-    __shared__ __attribute__((aligned(16))) long long tl[4][2][RC_SL_R][RC_SL_P];   // tiles of the row reduction, then the resolver's tables
-    int *ok_sh = (int *)&tl[0][0][0][0];
-    if (DERIVED) syml_load_table(V, tl);
-    __syncthreads();
-    const int w = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
-    long long *pf = nullptr;
-    RC_PF(if (w < 8192) pf = (long long *)((char *)V.work[sa.t & 1] + 512) + (size_t)w * 16;)
-    syml_units<DERIVED>(V, tl[threadIdx.x >> 6], sa.own_gen, sa.t & 1, nitems, jsplit, gfine, gcoarse, w, (int)gridDim.x * 4,
-                        (u64 *)V.work[sa.t & 1], (int)(blockIdx.x & 7), pf);
-    // hand-over: this block's share of the row sums is in memory
-    block_publish(V.fsync + (sa.t & 1));
-    if ((int)blockIdx.x >= G) return;
-    if (threadIdx.x == 0) {
-        unsigned spins = 0;
-        int ok = 1;
-        while (__hip_atomic_load(V.fsync + (sa.t & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sa.tgt_bulk ||
-               __hip_atomic_load(V.fsync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sa.tgt_done) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > RC_SPIN_LIMIT) { ok = 0; atomicOr(&V.sc->err, RC_DERR_BARRIER); break; }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        *ok_sh = ok;
-    }
-    __syncthreads();
-    const int ok = *ok_sh;
-    __syncthreads();
-    // A hand-over that timed out (bounded spin; the host surfaces RC_DERR_BARRIER) must not run the resolver on partial
-    // sums, but the block still reports completion so that a later launch does not wait for it in turn.
-    if (ok) resolve_body(V, sa, G, (char *)&tl[0][0][0][0]);
-    else if (blockIdx.x == 0 && threadIdx.x == 0) V.hsum->err = __hip_atomic_load(&V.sc->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    block_publish(V.fsync + 2);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2361,7 +2350,6 @@ struct rc_ctx {
                                // reduction fills is cleared by k_resolve two sweeps earlier), so they may overlap and no launch gap
                                // separates them
     void *Dq = nullptr, *Lq = nullptr;  // int64 or int32 fixed point, INTERNAL point order (what the kernels read)
-    long long *Dp = nullptr, *Lp = nullptr;  // panel-major copies (View::Dp, View::Lp)
     void *Dq_src = nullptr, *Lq_src = nullptr;  // the same matrices in the caller's point order (source of every re-layout)
     long long *diagq = nullptr, *diag_src = nullptr;
     int *pi = nullptr, *ipi = nullptr;  // device: original -> internal, internal -> original
@@ -2370,9 +2358,6 @@ struct rc_ctx {
     int sym_variant = -1;               // RC_SYM_VARIANT: 2 k_bulk_syml (wave-private LDS transposition), 1 k_bulk_symw (DPP only), 0 block-tiled
                                         // k_bulk_sym; -1 (default): k_bulk_syml when logD is derived, k_bulk_sym when it is stored (measured best)
     int sw_coarse = RC_SW_ROWS;          // RC_SW_COARSE: rows per coarse unit of k_bulk_syml (16..64, multiple of 4)
-    int sw_fine_dyn = 16;                // RC_SW_FINE_DYN: rows per fine unit at the end of k_sweep's dynamic unit list
-    int dyn_tail_den = 10;               // RC_DYN_TAIL: 1/x of all rows go into fine units
-    bool syml_dynamic = true;           // RC_SYML_DYNAMIC=0: static round-robin unit list in k_bulk_syml
     size_t syml_pad = 0;                // RC_SYML_PAD: unused dynamic LDS per k_bulk_syml block (bytes), caps the blocks per CU
     int symw_per_cu = 4;                // RC_SYMW_PER_CU: resident blocks of k_bulk_syml / k_bulk_symw per CU (LDS: 40 KiB per block)
     bool derived = false;               // logD derived from Dq on the fly (rc_qlog), not stored
@@ -2408,15 +2393,6 @@ struct rc_ctx {
     int G = 256;
     int rows_per_split = 256;
     int num_cus = 256;
-    // fused sweeps (k_sweep): one persistent launch per sweep, two in flight on sB / sB2
-    u64 *fsync = nullptr;             // device: hand-over counters of k_sweep (View::fsync)
-    bool fused_ok = false;            // the device keeps 4 k_sweep blocks per CU and the resolver's tables fit its 40 KiB
-    bool fused_enabled = true;        // RC_FUSED=0 keeps the separate row-reduction / resolver launches
-    bool pipe_fused = false;          // the sweeps in flight since the last drain are fused launches
-    u64 f_tgt_bulk[2] = {0, 0};       // blocks launched so far on each parity (targets of fsync[0], fsync[1])
-    u64 f_tgt_done = 0;               // resolver blocks launched so far (target of fsync[2] for the next launch)
-    hipEvent_t ev_a = nullptr;        // marker on stream A: work that reads the state and must precede the next sweep
-    bool sA_dirty = false;
     // software pipeline
     long long t_next = 0;     // internal index of the next sweep (0 after rc_set_state)
     long long bulk_enq = -1;  // highest sweep index whose k_bulk has been enqueued
@@ -2486,11 +2462,11 @@ static View make_view(const rc_ctx *c)
 {
     View V{};
     V.n = c->n; V.ld = c->ld; V.kcap = c->kcap;
-    V.Dq = c->Dq; V.Lq = c->Lq; V.Dp = c->Dp; V.Lp = c->Lp; V.bits = c->bits; V.diagq = c->diagq; V.pi = c->pi;
+    V.Dq = c->Dq; V.Lq = c->Lq; V.bits = c->bits; V.diagq = c->diagq; V.pi = c->pi;
     V.derived = c->derived ? 1 : 0; V.qsD = std::ldexp(1.0, -c->eD); V.qsL = std::ldexp(1.0, c->eL); V.ltab = c->ltab; V.qeD = c->eD;
     for (int g = 0; g < 3; ++g) { V.SD[g] = c->SD[g]; V.SL[g] = c->SL[g]; }
     for (int g = 0; g < 2; ++g) { V.perm[g] = c->perm[g]; V.pslot[g] = c->pslot[g]; V.keys[g] = c->keys[g]; V.arrive[g] = c->arrive[g]; V.snap[g] = c->lsnap[g]; V.work[g] = c->work[g]; V.cword[g] = c->cword[g]; }
-    V.rec = c->rec; V.tent = c->tent; V.fsync = c->fsync;
+    V.rec = c->rec; V.tent = c->tent;
     V.slot_of = c->slot_of; V.slot_size = c->slot_size; V.slot_label = c->slot_label;
     V.slot_pos = c->slot_pos; V.slot_act = c->slot_act;
     V.A = c->A; V.sc = c->sc; V.hsum = c->hsum_dev;
@@ -2525,10 +2501,10 @@ static void free_all(rc_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->dev);
-    void *ptrs[] = {c->ltab, c->Dp, c->Lp, c->Dq, c->Lq, c->Dq_src, c->Lq_src, c->diag_src, c->pi, c->ipi, c->diagq, c->SD[0], c->SD[1], c->SD[2], c->SL[0], c->SL[1], c->SL[2], c->slot_of,
+    void *ptrs[] = {c->ltab, c->Dq, c->Lq, c->Dq_src, c->Lq_src, c->diag_src, c->pi, c->ipi, c->diagq, c->SD[0], c->SD[1], c->SD[2], c->SL[0], c->SL[1], c->SL[2], c->slot_of,
                     c->slot_size, c->slot_label, c->slot_pos, c->slot_act, c->perm[0], c->perm[1], c->pslot[0],
                     c->pslot[1], c->lsnap[0], c->lsnap[1], c->work[0], c->work[1], c->cword[0], c->cword[1], c->rec, c->tent, c->A, c->keys[0], c->keys[1], c->arrive[0], c->arrive[1], c->sc, c->blocks,
-                    c->counts, c->cc_out, c->snap, c->d_moves, c->fsync};
+                    c->counts, c->cc_out, c->snap, c->d_moves};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->hsum) (void)hipHostFree(c->hsum);
@@ -2539,7 +2515,6 @@ static void free_all(rc_ctx *c)
     }
     for (auto &e : c->ev_pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &e : c->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     for (int q = 0; q < 4; ++q) {
         if (c->ev_bulk[q]) (void)hipEventDestroy(c->ev_bulk[q]);
         if (c->ev_res[q]) (void)hipEventDestroy(c->ev_res[q]);
@@ -2579,19 +2554,6 @@ extern "C" int32_t rc_destroy(rc_ctx *ctx)
     if (ctx->sB) (void)hipStreamSynchronize(ctx->sB);
     if (ctx->sB2) (void)hipStreamSynchronize(ctx->sB2);
     free_all(ctx);
-    return RC_OK;
-}
-
-static int sym_variant_of(const rc_ctx *c);
-
-// (re)builds the panel-major copies from the internal row-major matrices, on stream A
-static int32_t panelize(rc_ctx *c)
-{
-    if (!c->Dp) return RC_OK;
-    dim3 g((unsigned)std::min(16, c->ld / 256), (unsigned)c->n);
-    k_panelize<<<g, 256, 0, c->sA>>>((const long long *)c->Dq, c->n, c->ld, c->Dp);
-    if (c->Lp) k_panelize<<<g, 256, 0, c->sA>>>((const long long *)c->Lq, c->n, c->ld, c->Lp);
-    HIPCHK(c, hipGetLastError());
     return RC_OK;
 }
 
@@ -2672,16 +2634,13 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
         HIPCHK2(hipMalloc(&c->lsnap[g], (size_t)n * sizeof(int)));
         HIPCHK2(hipMalloc(&c->work[g], RC_WORK_BYTES));
         HIPCHK2(hipMemsetAsync(c->work[g], 0, RC_WORK_BYTES, s));
-        HIPCHK2(hipMalloc(&c->cword[g], ((size_t)(n + RC_PTS - 1) / RC_PTS + 1) * sizeof(u64)));
-        HIPCHK2(hipMemsetAsync(c->cword[g], 0, ((size_t)(n + RC_PTS - 1) / RC_PTS + 1) * sizeof(u64), s));
+        HIPCHK2(hipMalloc(&c->cword[g], 2 * ((size_t)(n + RC_PTS - 1) / RC_PTS + 1) * sizeof(u64)));
+        HIPCHK2(hipMemsetAsync(c->cword[g], 0, 2 * ((size_t)(n + RC_PTS - 1) / RC_PTS + 1) * sizeof(u64), s));
         HIPCHK2(hipMalloc(&c->keys[g], (size_t)(n + 2) * sizeof(u64)));
         HIPCHK2(hipMalloc(&c->arrive[g], 64));
     }
-    HIPCHK2(hipMalloc(&c->fsync, 64));
-    HIPCHK2(hipMemsetAsync(c->fsync, 0, 64, s));
-    HIPCHK2(hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
     HIPCHK2(hipMalloc(&c->slot_of, (size_t)n * sizeof(int)));
-    HIPCHK2(hipMalloc(&c->rec, (size_t)n * sizeof(unsigned)));
+    HIPCHK2(hipMalloc(&c->rec, 2 * (size_t)n * sizeof(unsigned)));
     HIPCHK2(hipMalloc(&c->tent, (size_t)n * sizeof(int)));
     HIPCHK2(hipMalloc(&c->slot_size, (size_t)c->kcap * sizeof(int)));
     HIPCHK2(hipMalloc(&c->slot_label, (size_t)c->kcap * sizeof(int)));
@@ -2801,14 +2760,6 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     HIPCHK2(hipMemcpyAsync(c->ipi, c->h_ipi.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
     HIPCHK2(hipMemcpyAsync(c->Dq, c->Dq_src, (size_t)n * ld * esz, hipMemcpyDeviceToDevice, s));
     if (c->Lq) HIPCHK2(hipMemcpyAsync(c->Lq, c->Lq_src, (size_t)n * ld * esz, hipMemcpyDeviceToDevice, s));
-    if (c->bits == 64) {
-        HIPCHK2(hipMalloc(&c->Dp, (size_t)n * ld * sizeof(long long)));
-        if (!derived && sym_variant_of(c) == 2) HIPCHK2(hipMalloc(&c->Lp, (size_t)n * ld * sizeof(long long)));
-    }
-    {
-        int32_t rcp = panelize(c);
-        if (rcp != RC_OK) { cleanup(); return rcp; }
-    }
     HIPCHK2(hipMemcpyAsync(c->diagq, c->diag_src, (size_t)n * sizeof(long long), hipMemcpyDeviceToDevice, s));
     HIPCHK2(hipStreamSynchronize(s));
     HIPCHK2(hipGetLastError());
@@ -2840,11 +2791,7 @@ static int32_t alloc_ctx(int64_t n, int32_t storage_bits, int32_t device_id, int
     c->relayout = !(getenv("RC_NO_RELAYOUT") && atoi(getenv("RC_NO_RELAYOUT")));
     if (getenv("RC_SYM_VARIANT")) c->sym_variant = atoi(getenv("RC_SYM_VARIANT"));
     if (getenv("RC_SYMW_PER_CU")) c->symw_per_cu = std::max(1, atoi(getenv("RC_SYMW_PER_CU")));
-    if (getenv("RC_FUSED")) c->fused_enabled = atoi(getenv("RC_FUSED")) != 0;
-    if (getenv("RC_SYML_DYNAMIC")) c->syml_dynamic = atoi(getenv("RC_SYML_DYNAMIC")) != 0;
     if (getenv("RC_SYML_PAD")) c->syml_pad = (size_t)std::max(0, atoi(getenv("RC_SYML_PAD")));
-    if (getenv("RC_SW_FINE_DYN")) c->sw_fine_dyn = std::min(64, std::max(4, atoi(getenv("RC_SW_FINE_DYN")) & ~3));
-    if (getenv("RC_DYN_TAIL")) c->dyn_tail_den = std::max(2, atoi(getenv("RC_DYN_TAIL")));
     if (getenv("RC_SW_COARSE")) c->sw_coarse = std::min(64, std::max(16, atoi(getenv("RC_SW_COARSE")) & ~3));
     if (getenv("RC_BULK_KERNEL")) c->bulk_kernel = !strcmp(getenv("RC_BULK_KERNEL"), "sym") ? 1 : (!strcmp(getenv("RC_BULK_KERNEL"), "perm") ? 0 : -1);
     if (getenv("RC_RES_THREADS")) c->res_threads = (atoi(getenv("RC_RES_THREADS")) == 256) ? 256 : 512;
@@ -2872,17 +2819,6 @@ static int32_t finish_create(rc_ctx *c)
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->bulk_lds);
             (void)hipFuncSetAttribute((const void *)k_bulk<long long, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->bulk_lds);
         }
-    }
-    {
-        // fused sweeps need the resolver's tables inside k_sweep's 40 KiB of static LDS and four resident blocks per CU
-        // (two launches of two blocks per CU each are in flight)
-        const size_t need = std::max(tab_bytes(c->kcap, c->n, 4), 2 * sizeof(int) * (size_t)c->kcap);
-        int occ_t = 0, occ_f = 0;
-        const hipError_t q1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_t, k_sweep<true>, 256, 0);
-        const hipError_t q2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_f, k_sweep<false>, 256, 0);
-        c->fused_ok = c->bits == 64 && need <= sizeof(long long) * 4 * 2 * RC_SL_R * RC_SL_P && q1 == hipSuccess && q2 == hipSuccess &&
-                      occ_t >= 4 && occ_f >= 4;
-        (void)hipGetLastError();
     }
     // kernels whose dynamic LDS can exceed the 64 KiB default (large kcap)
     const size_t lds_r = std::max(tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64), 2 * sizeof(int) * (size_t)c->kcap);
@@ -3049,7 +2985,6 @@ static int32_t drain_events(rc_ctx *c)
 // Waits for the resolve/observable stream (and for the k_bulk stream too when `both`), then surfaces device errors.
 static int32_t sync_and_check(rc_ctx *c, bool both = false)
 {
-    if (c->pipe_fused) both = true;   // fused sweeps run on the two row-reduction streams
     HIPCHK(c, hipStreamSynchronize(c->sA));
     if (both) {
         HIPCHK(c, hipStreamSynchronize(c->sB));
@@ -3119,10 +3054,6 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
             k_relayout<int><<<g, 256, 0, c->sA>>>((const int *)c->Lq_src, c->ipi, n, c->ld, (int *)c->Lq);
         }
         k_gather_ll<<<(n + 255) / 256, 256, 0, c->sA>>>(c->diag_src, c->ipi, n, c->diagq);
-        {
-            int32_t rcp = panelize(c);
-            if (rcp != RC_OK) return rcp;
-        }
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->sA));
     }
@@ -3143,9 +3074,9 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
     }
     for (int g = 0; g < 2; ++g) {
         HIPCHK(c, hipMemsetAsync(c->keys[g], 0xFF, (size_t)(n + 2) * sizeof(u64), c->sA));
-        HIPCHK(c, hipMemsetAsync(c->cword[g], 0, ((size_t)(n + RC_PTS - 1) / RC_PTS + 1) * sizeof(u64), c->sA));
+        HIPCHK(c, hipMemsetAsync(c->cword[g], 0, 2 * ((size_t)(n + RC_PTS - 1) / RC_PTS + 1) * sizeof(u64), c->sA));
         HIPCHK(c, hipMemsetAsync(c->arrive[g], 0, 64, c->sA));
-        HIPCHK(c, hipMemsetAsync(c->work[g], 0, 512, c->sA));
+        HIPCHK(c, hipMemsetAsync(c->work[g], 0, 64, c->sA));
     }
     View V = make_view(c);
     const size_t lds = std::max(tab_bytes(c->kcap, c->n, 1), 2 * sizeof(int) * (size_t)c->kcap);
@@ -3155,9 +3086,6 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
     c->last = s;
     c->t_next = 0;
     c->bulk_enq = -1;
-    HIPCHK(c, hipMemset(c->fsync, 0, 64));
-    c->f_tgt_bulk[0] = c->f_tgt_bulk[1] = c->f_tgt_done = 0;
-    c->pipe_fused = false;
     c->state_version++;
     c->have_state = true;
     return RC_OK;
@@ -3171,7 +3099,7 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
 static bool choose_sym(const rc_ctx *c)
 {
     return c->bulk_kernel == 1 || (c->bulk_kernel < 0 && (long long)c->hsum->runs * 32 <= (long long)c->n &&
-                                   !(c->derived && c->n <= 4096 && !(c->fused_enabled && c->fused_ok)));
+                                   !(c->derived && c->n <= 4096));
 }
 static int sym_variant_of(const rc_ctx *c) { return c->sym_variant >= 0 ? c->sym_variant : (c->derived ? 2 : 0); }
 
@@ -3205,28 +3133,6 @@ static void syml_geometry(const rc_ctx *c, int cap_blocks, int gc, int *nitems_o
     *nitems_out = nitems; *jsplit_out = jsplit; *gfine_out = gfine;
 }
 
-// Unit list for DYNAMIC hand-out (syml_units with counters): gc-row units, and the lightest column blocks, holding
-// 1/dyn_tail_den of all rows, cut into sw_fine_dyn-row units at the end of the list, so that the launch's waves finish
-// within a few tiles of each other whatever their individual speed.
-static void syml_geometry_dyn(const rc_ctx *c, int cap_blocks, int gc, int *nitems_out, int *jsplit_out, int *gfine_out)
-{
-    const int ncb = (c->n + RC_SW_COLS - 1) / RC_SW_COLS;
-    const int gfine = c->sw_fine_dyn;
-    auto rows_of = [&](int J) { return std::min(RC_SW_COLS * J + RC_SW_COLS, c->n); };
-    long long total_rows = 0, acc = 0;
-    int jsplit = 0;
-    for (int J = 0; J < ncb; ++J) total_rows += rows_of(J);
-    while (jsplit < ncb && acc * c->dyn_tail_den < total_rows) acc += rows_of(jsplit++);
-    long long items = 0;
-    for (int J = 0; J < ncb; ++J) items += (rows_of(J) + (J >= jsplit ? gc : gfine) - 1) / (J >= jsplit ? gc : gfine);
-    if (items < 4ll * cap_blocks) {   // small problem: fine units everywhere (the launch shrinks to the units there are)
-        jsplit = ncb;
-        items = 0;
-        for (int J = 0; J < ncb; ++J) items += (rows_of(J) + gfine - 1) / gfine;
-    }
-    *nitems_out = (int)items; *jsplit_out = jsplit; *gfine_out = gfine;
-}
-
 // k_bulk of sweep t on stream B: fills S generation t%3 from perm generation t%2 (labels after sweep t-2),
 // clears generation (t+1)%3.  Needs k_resolve(t-2) (perm, and the last reader of the generation being cleared).
 static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
@@ -3252,11 +3158,10 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
         if (sym_variant == 2) {
             const int gc = c->sw_coarse;
             int nitems = 0, jsplit = 0, gfine = 0;
-            if (c->syml_dynamic) syml_geometry_dyn(c, cap_blocks, gc, &nitems, &jsplit, &gfine);
-            else syml_geometry(c, cap_blocks, gc, &nitems, &jsplit, &gfine);
+            syml_geometry(c, cap_blocks, gc, &nitems, &jsplit, &gfine);
             const int nblocks = std::max(1, std::min((nitems + 3) / 4, cap_blocks));
-            if (c->derived) k_bulk_syml<true><<<nblocks, 256, c->syml_pad, sb>>>(V, (int)(t % 3), c->syml_dynamic ? 1 : 0, (int)(t & 1), (int)(t & 1), nitems, jsplit, gfine, gc);
-            else k_bulk_syml<false><<<nblocks, 256, c->syml_pad, sb>>>(V, (int)(t % 3), c->syml_dynamic ? 1 : 0, (int)(t & 1), (int)(t & 1), nitems, jsplit, gfine, gc);
+            if (c->derived) k_bulk_syml<true><<<nblocks, 256, c->syml_pad, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems, jsplit, gfine, gc);
+            else k_bulk_syml<false><<<nblocks, 256, c->syml_pad, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems, jsplit, gfine, gc);
         } else {
             int nitems = 0;
             for (int J = 0; J < ncb; ++J) nitems += (rows_of(J) + RC_SW_ROWS - 1) / RC_SW_ROWS;
@@ -3298,23 +3203,9 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
     return RC_OK;
 }
 
-// Work about to be enqueued on stream A reads the state the sweeps enqueued so far leave behind.  Separate launches
-// keep the resolver on stream A itself; fused sweeps run on the row-reduction streams, so stream A waits for the last
-// one, and the next sweep is made to wait for stream A in turn (sA_dirty, see launch_sweep_fused).
-static int32_t order_A_after_sweeps(rc_ctx *c)
-{
-    if (c->pipe_fused && c->t_next > 0) HIPCHK(c, hipStreamWaitEvent(c->sA, c->ev_res[(c->t_next - 1) & 3], 0));
-    c->sA_dirty = true;
-    return RC_OK;
-}
-
 // Makes the S generation of the CURRENT labels available to work enqueued on stream A; returns its index.
 static int32_t ensure_S(rc_ctx *c, int *gen)
 {
-    {
-        int32_t rc0 = order_A_after_sweeps(c);
-        if (rc0 != RC_OK) return rc0;
-    }
     if (c->incremental && c->bulk_enq >= 0 && c->t_next > 0) {
         *gen = c->inc_gen;
         return RC_OK;
@@ -3340,20 +3231,12 @@ static int32_t ensure_S(rc_ctx *c, int *gen)
 static std::mutex g_res_mutex;
 static hipEvent_t g_res_event[64] = {};
 
-// The same holds for fused sweeps (k_sweep hands over through grid-wide counters): a launch takes two of a CU's four
-// block slots, so at most TWO may be in flight per device — launch k waits for launch k-2, whichever context issued it
-// (within one context that is the stream order anyway) — and a separate resolver launch waits for both and is waited for.
-static hipEvent_t g_fused_event[64][2] = {};
-static unsigned long long g_fused_count[64] = {};
-
 static int32_t launch_resolve(rc_ctx *c, const View &V, const SweepArgs &sa, int res_threads, size_t lds)
 {
     std::lock_guard<std::mutex> lock(g_res_mutex);
     const int d = c->dev & 63;
     if (g_res_event[d]) HIPCHK(c, hipStreamWaitEvent(c->sA, g_res_event[d], 0));
     else HIPCHK(c, hipEventCreateWithFlags(&g_res_event[d], hipEventDisableTiming));
-    for (int q = 0; q < 2; ++q)
-        if (g_fused_event[d][q]) HIPCHK(c, hipStreamWaitEvent(c->sA, g_fused_event[d][q], 0));
     k_resolve<<<c->G, res_threads, lds, c->sA>>>(V, sa, c->G);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(c, RC_ERR_HIP, "k_resolve launch failed: %s", hipGetErrorString(e));
@@ -3362,60 +3245,6 @@ static int32_t launch_resolve(rc_ctx *c, const View &V, const SweepArgs &sa, int
 }
 
 static int32_t pull_labels(rc_ctx *c, std::vector<int64_t> &labels, std::vector<int64_t> &sizes, int64_t &K);
-
-// Sweep t as ONE launch (k_sweep) on the row-reduction stream of its parity.  Sweep t-2 precedes it in stream order;
-// sweep t-1 runs beside it on the other stream and is waited for inside the kernel (SweepArgs::tgt_done).
-static int32_t launch_sweep_fused(rc_ctx *c, const View &V, SweepArgs sa, long long t)
-{
-    const hipStream_t sx = (t & 1) ? c->sB2 : c->sB;
-    if (t >= 2) HIPCHK(c, hipStreamWaitEvent(sx, c->ev_res[(t - 2) & 3], 0));   // a no-op unless the pipeline was switched
-    if (c->sA_dirty) {   // recorded samples, log-likelihoods ... enqueued on stream A read the state this sweep changes
-        HIPCHK(c, hipEventRecord(c->ev_a, c->sA));
-        HIPCHK(c, hipStreamWaitEvent(sx, c->ev_a, 0));
-        c->sA_dirty = false;
-    }
-    const int cap_blocks = 2 * c->num_cus;                       // half of the 4 resident blocks per CU
-    const int gc = c->sw_coarse;
-    int nitems = 0, jsplit = 0, gfine = 0;
-    syml_geometry_dyn(c, cap_blocks, gc, &nitems, &jsplit, &gfine);
-    const int nblocks = std::max(1, std::min(cap_blocks, std::max((nitems + 3) / 4, c->G)));
-    const int G = std::min(c->G, nblocks);
-    sa.tgt_bulk = (c->f_tgt_bulk[t & 1] += (u64)nblocks);
-    sa.tgt_done = c->f_tgt_done;
-    c->f_tgt_done += (u64)G;
-    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
-    const bool timed = c->timing && (c->timing_every <= 1 || (t % c->timing_every) == 0);
-    std::lock_guard<std::mutex> lock(g_res_mutex);
-    const int d = c->dev & 63;
-    const int q = (int)(g_fused_count[d] & 1ull);
-    if (g_fused_event[d][q]) HIPCHK(c, hipStreamWaitEvent(sx, g_fused_event[d][q], 0));
-    else HIPCHK(c, hipEventCreateWithFlags(&g_fused_event[d][q], hipEventDisableTiming));
-    if (g_res_event[d]) HIPCHK(c, hipStreamWaitEvent(sx, g_res_event[d], 0));
-    if (timed) {
-        if (!c->ev_free.empty()) { ev = c->ev_free.back(); c->ev_free.pop_back(); }
-        else { HIPCHK(c, hipEventCreate(&ev.first)); HIPCHK(c, hipEventCreate(&ev.second)); }
-        HIPCHK(c, hipEventRecord(ev.first, sx));
-    }
-    if (c->derived) k_sweep<true><<<nblocks, 256, 0, sx>>>(V, sa, G, nitems, jsplit, gfine, gc);
-    else k_sweep<false><<<nblocks, 256, 0, sx>>>(V, sa, G, nitems, jsplit, gfine, gc);
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(c, RC_ERR_HIP, "k_sweep launch failed: %s", hipGetErrorString(e));
-    if (timed) {
-        HIPCHK(c, hipEventRecord(ev.second, sx));
-        c->ev_pending.push_back(ev);
-    }
-    HIPCHK(c, hipEventRecord(g_fused_event[d][q], sx));
-    g_fused_count[d] += 1;
-    HIPCHK(c, hipEventRecord(c->ev_res[t & 3], sx));
-    c->last_bulk_kernel = 1;
-    return RC_OK;
-}
-
-// the pipeline sweep t would use: fused launches need the wave-autonomous symmetric kernel (64-bit storage)
-static bool want_fused(const rc_ctx *c)
-{
-    return c->fused_enabled && c->fused_ok && !c->incremental && c->bits == 64 && choose_sym(c) && sym_variant_of(c) == 2;
-}
 
 extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t seed, uint64_t sweep_index)
 {
@@ -3448,16 +3277,17 @@ extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t 
     sa.sw_lo = (unsigned)sweep_index; sa.sw_hi = (unsigned)(sweep_index >> 32);
     sa.t = (int)t;
     sa.dbg = c->dbg;
+#ifdef RC_TRACE_RESOLVE
+    const size_t lds = std::max(tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64), 2 * sizeof(int) * (size_t)c->kcap) + 4096;
+#else
     const size_t lds = std::max(tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64), 2 * sizeof(int) * (size_t)c->kcap);
+#endif
     // Resolver block size.  With 256 threads (one wave per SIMD, 112 VGPRs) a k_resolve block fits on a CU beside two
     // k_bulk_sym blocks, so the resolver of sweep t really overlaps the row reduction of sweep t+1 (config 5:
     // 1.36 -> 0.99 ms per sweep).  With many label changes per sweep the rounds dominate and 512 threads are faster.
     int res_threads = c->res_threads;
     if (res_threads == 0)
         res_threads = (!c->incremental && c->prefetch && c->last_bulk_kernel == 1 && c->hsum->n_changes <= 32) ? 256 : 512;
-    if (c->incremental && c->pipe_fused) {   // (rc_set_mode drained the streams)
-        c->pipe_fused = false;
-    }
     if (c->incremental) {
         // exact incremental mode: the row-sum table of the current labels already exists (one k_bulk after
         // rc_set_state) and every label change corrects it in place — no matrix traffic at all in this sweep
@@ -3480,25 +3310,6 @@ extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t 
     sa.own_gen = (int)(t % 3);
     sa.next_gen = (int)((t + 1) % 3);
     sa.zero_gen = (int)((t + 2) % 3);
-    sa.tgt_bulk = sa.tgt_done = 0;
-    // Pipeline of this sweep: one fused launch (k_sweep) where the wave-autonomous symmetric kernel applies, separate
-    // row-reduction and resolver launches otherwise.  Both leave the same state behind (S generations, label snapshots,
-    // perm generations by sweep parity); a change of pipeline drains the streams first.  A sweep whose row reduction has
-    // already been enqueued by the other pipeline's prefetch stays with it.
-    const bool fused = want_fused(c) && c->bulk_enq < t;
-    if (fused != c->pipe_fused && t > 0) {
-        rc = sync_and_check(c, true);
-        if (rc != RC_OK) return rc;
-    }
-    c->pipe_fused = fused;
-    if (fused) {
-        rc = launch_sweep_fused(c, V, sa, t);
-        if (rc != RC_OK) return rc;
-        c->bulk_enq = t;
-        c->t_next = t + 1;
-        c->state_version++;
-        return RC_OK;
-    }
     if (c->bulk_enq < t) {
         rc = enqueue_bulk(c, V, t);
         if (rc != RC_OK) return rc;
@@ -3509,7 +3320,7 @@ extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t 
     HIPCHK(c, hipEventRecord(c->ev_res[t & 3], c->sA));
     c->t_next = t + 1;
     c->state_version++;
-    if (c->prefetch && !want_fused(c)) {
+    if (c->prefetch) {
         // software pipeline: the row reduction of the next sweep starts now, under the labels known before
         // this sweep; k_resolve adds this sweep's label changes to it (exact integer atomics)
         rc = enqueue_bulk(c, V, t + 1);
@@ -3806,8 +3617,6 @@ extern "C" int32_t rc_record_sample(rc_ctx *c, int64_t *canonical_out)
     if (!c->have_state) return fail(c, RC_ERR_STATE, "rc_record_sample: no state set");
     HIPCHK(c, hipSetDevice(c->dev));
     int32_t rc = ensure_counts(c);
-    if (rc != RC_OK) return rc;
-    rc = order_A_after_sweeps(c);
     if (rc != RC_OK) return rc;
     k_snapshot<<<(c->ldc + 255) / 256, 256, 0, c->sA>>>(c->slot_of, c->pi, c->n, c->ldc, c->snap + (size_t)c->snap_cnt * c->ldc);
     HIPCHK(c, hipGetLastError());
@@ -4476,9 +4285,9 @@ extern "C" int32_t rc_set_mode(rc_ctx *c, int32_t mode)
         }
         for (int g = 0; g < 2; ++g) {
             HIPCHK(c, hipMemsetAsync(c->keys[g], 0xFF, (size_t)(c->n + 2) * sizeof(u64), c->sA));
-            HIPCHK(c, hipMemsetAsync(c->cword[g], 0, ((size_t)(c->n + RC_PTS - 1) / RC_PTS + 1) * sizeof(u64), c->sA));
+            HIPCHK(c, hipMemsetAsync(c->cword[g], 0, 2 * ((size_t)(c->n + RC_PTS - 1) / RC_PTS + 1) * sizeof(u64), c->sA));
             HIPCHK(c, hipMemsetAsync(c->arrive[g], 0, 64, c->sA));
-            HIPCHK(c, hipMemsetAsync(c->work[g], 0, 512, c->sA));
+            HIPCHK(c, hipMemsetAsync(c->work[g], 0, 64, c->sA));
         }
         const int minus1 = -1;
         HIPCHK(c, hipMemcpyAsync(&c->sc->last_change_sweep, &minus1, sizeof(int), hipMemcpyHostToDevice, c->sA));
@@ -4489,9 +4298,6 @@ extern "C" int32_t rc_set_mode(rc_ctx *c, int32_t mode)
         HIPCHK(c, hipStreamSynchronize(c->sA));
         c->t_next = 0;
         c->bulk_enq = -1;
-        HIPCHK(c, hipMemset(c->fsync, 0, 64));
-        c->f_tgt_bulk[0] = c->f_tgt_bulk[1] = c->f_tgt_done = 0;
-        c->pipe_fused = false;
     }
     return RC_OK;
 }
@@ -4554,12 +4360,12 @@ extern "C" int32_t rc_event_overhead_ms(rc_ctx *c, double *out)
     return RC_OK;
 }
 
-#ifdef RC_PROF_SYML
+#if defined(RC_PROF_SYML) || defined(RC_TRACE_RESOLVE)
 extern "C" int32_t rc_debug_prof(rc_ctx *c, int32_t gen, long long *out /* 8192 x 4 */)
 {
     HIPCHK(c, hipSetDevice(c->dev));
     HIPCHK(c, hipDeviceSynchronize());
-    HIPCHK(c, hipMemcpy(out, (char *)c->work[gen & 1] + 512, 8192 * 128, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out, (char *)c->work[gen & 1] + 64, 8192 * 128, hipMemcpyDeviceToHost));
     return RC_OK;
 }
 #endif

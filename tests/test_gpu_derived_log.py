@@ -92,14 +92,19 @@ def test_derived_equals_stored_given_the_same_logD_and_modes_agree():
     for t in range(25):
         for x in (a, b, c):
             x.gibbs_sweep(1.0, 0.5, 7, t)
+        orc.sweep_stable(1.0, 0.5, 7, t)
+        for name, x in (("derived", a), ("stored", b), ("incremental", c)):
+            lab = x.get_state()[0]
+            assert np.array_equal(lab, orc.clusts), (name, t, np.flatnonzero(lab != orc.clusts)[:8], x.sweep_stats(), orc.last_changes,
+                                                     x.bulk_kernel_name())
         if t % 5 == 4:
+            inf = orc.mh_proposal(1.0, 0.5, 5, 7, t, 0, mode=1)
             ra = a.splitmerge(1.0, 0.5, 5, 7, t, 0); rb = b.splitmerge(1.0, 0.5, 5, 7, t, 0)
-            assert ra == rb
-            if not ra[0]:
-                sa, sc = a.get_state(), c.get_state()
-                assert np.array_equal(sa[0], sc[0])
-            else:
+            assert ra == rb == (bool(inf.accept), bool(inf.split)), (t, ra, rb)
+            if ra[0]:
                 c.set_state(a.get_state()[0])
+            for name, x in (("derived", a), ("stored", b)):
+                assert np.array_equal(x.get_state()[0], orc.clusts), (name, "after the proposal of iteration", t)
         sa, sb = a.get_state(), b.get_state()
         assert np.array_equal(sa[0], sb[0]) and sa[2] == sb[2]
     assert a.loglik() == b.loglik() == c.loglik()
