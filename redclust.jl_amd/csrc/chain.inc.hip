@@ -131,6 +131,8 @@ static int32_t record_enqueue(rc_ctx *c, Pending &R, bool want_labels)
         R.slabel[(size_t)k] = c->hsum->size_label[2 * k + 1];
     }
     unsigned short *row = c->snap + (size_t)c->snap_cnt * c->ldc;
+    rc = order_A_after_sweeps(c);
+    if (rc != RC_OK) return rc;
     k_snapshot<<<(c->ldc + 255) / 256, 256, 0, c->sA>>>(c->slot_of, c->pi, c->n, c->ldc, row);
     HIPCHK(c, hipGetLastError());
     if (want_labels) HIPCHK(c, hipMemcpyAsync(c->pinLab[REC_SLOT], row, (size_t)c->n * sizeof(unsigned short), hipMemcpyDeviceToHost, c->sA));

@@ -2047,6 +2047,13 @@ __device__ __forceinline__ void chaos_delay(int site, int round)
 
 __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *smem)
 {
+    // The resolver is the latency-critical part of a sweep and shares its SIMDs with the waves of the other stream's row
+    // reduction (three of those and one of these per SIMD): it takes instruction-issue priority over them — without it a
+    // stationary pass that takes 11 µs alone took 40 µs beside the reduction.
+#ifndef RC_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    RC_PF(long long ps[8]; ps[0] = __builtin_amdgcn_s_memrealtime();)
     Tab T = tab_carve(smem, V.kcap, V.n, blockDim.x >> 6);
     const int t = sa.t, own_gen = sa.own_gen, next_gen = sa.next_gen, kg = t & 1;
     const long long *SD = V.SD[own_gen], *SL = V.SL[own_gen];
@@ -2055,6 +2062,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
     unsigned *arrive = V.arrive[kg];
     tab_load(V, T);
     tab_bases(V, sa, T);
+    RC_PF(ps[1] = __builtin_amdgcn_s_memrealtime();)
     const int nchunks = (V.n + RC_PTS - 1) / RC_PTS;
     int after = -1, round = 0, changes = 0, nbar = 0;
     bool ok = true;
@@ -2071,7 +2079,9 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         for (int c = blockIdx.x; c < nchunks; c += G)
             if (c * RC_PTS + RC_PTS - 1 > after) eval_chunk(V, sa, T, SD, SL, c, after, V.n, 0, 0, cword, rec, stamp);
         if (sa.dbg & 2) break;
+        RC_PF(if (round == 0) ps[2] = __builtin_amdgcn_s_memrealtime();)
         ok = grid_barrier(V, T, arrive, (unsigned)G * (unsigned)(++nbar), RC_KEY_NONE, keys + round);
+        RC_PF(if (round == 0) ps[3] = __builtin_amdgcn_s_memrealtime();)
         if (!ok) break;
         RC_CHAOS_AT(1);
         // 2. the ordered batch of tentative changers
@@ -2196,6 +2206,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
     }
     __syncthreads();
 #endif
+    RC_PF(ps[4] = __builtin_amdgcn_s_memrealtime();)
     if (sa.zero_gen >= 0 && (blockIdx.x > 0 || G == 1)) {
         // The blocks that have no epilogue work clear the S generation that held the sums of the labels before this
         // sweep: nobody reads it any more, the row reduction of sweep t+2 fills it and k_resolve(t+1) adds its
@@ -2236,10 +2247,16 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
             for (int p = threadIdx.x; p < V.n; p += blockDim.x) { V.perm[kg][p] = V.perm[kg ^ 1][p]; V.pslot[kg][p] = V.pslot[kg ^ 1][p]; }
         }
     }
+    RC_PF(if (threadIdx.x == 0 && blockIdx.x < 256) { long long *o = (long long *)((char *)V.work[kg] + 64) + (size_t)(8192 - 256 + blockIdx.x) * 16;
+                                                       ps[5] = __builtin_amdgcn_s_memrealtime(); for (int q = 0; q < 6; ++q) o[q] = ps[q]; })
 }
 
+// 128 VGPRs (four waves per SIMD): a 256-thread resolver block — one wave per SIMD — then fits on a CU beside THREE blocks
+// of the wave-autonomous row reduction (3 x 128 + 128 = the SIMD's 512 registers; 3 x 40 KiB + 26 KiB of LDS), so the
+// resolver of sweep t is resident at once and runs beside the row reduction of sweep t+1 instead of waiting for its
+// blocks to retire (four reduction blocks take the whole CU: the two then serialised).
 #ifndef RC_RES_MINWAVES
-#define RC_RES_MINWAVES 2
+#define RC_RES_MINWAVES 4
 #endif
 __global__ __launch_bounds__(RC_RES_THREADS, RC_RES_MINWAVES) void k_resolve(View V, SweepArgs sa, int G)
 {
@@ -2357,9 +2374,9 @@ struct rc_ctx {
     bool relayout = true;               // RC_NO_RELAYOUT=1 keeps the caller's point order
     int sym_variant = -1;               // RC_SYM_VARIANT: 2 k_bulk_syml (wave-private LDS transposition), 1 k_bulk_symw (DPP only), 0 block-tiled
                                         // k_bulk_sym; -1 (default): k_bulk_syml when logD is derived, k_bulk_sym when it is stored (measured best)
-    int sw_coarse = RC_SW_ROWS;          // RC_SW_COARSE: rows per coarse unit of k_bulk_syml (16..64, multiple of 4)
+    int sw_coarse = 0;                   // RC_SW_COARSE: rows per unit of k_bulk_syml (8..128, multiple of 4); 0 = chosen by syml_geometry
     size_t syml_pad = 0;                // RC_SYML_PAD: unused dynamic LDS per k_bulk_syml block (bytes), caps the blocks per CU
-    int symw_per_cu = 4;                // RC_SYMW_PER_CU: resident blocks of k_bulk_syml / k_bulk_symw per CU (LDS: 40 KiB per block)
+    int symw_per_cu = 3;                // RC_SYMW_PER_CU: blocks of k_bulk_syml / k_bulk_symw per CU (LDS: 40 KiB per block; the fourth slot is the resolver's)
     bool derived = false;               // logD derived from Dq on the fly (rc_qlog), not stored
     double2 *ltab = nullptr;            // device table of rc_qlog
     int n_relayouts = 0;                // re-layouts done so far (rc_set_state + automatic ones)
@@ -2394,6 +2411,9 @@ struct rc_ctx {
     int rows_per_split = 256;
     int num_cus = 256;
     // software pipeline
+    hipStream_t s_res_last = nullptr; // stream of the last resolver launch (sB / sB2 by sweep parity, sA in incremental mode)
+    hipEvent_t ev_a = nullptr;        // marker on stream A: work that reads the state and must precede the next resolver
+    bool sA_dirty = false;
     long long t_next = 0;     // internal index of the next sweep (0 after rc_set_state)
     long long bulk_enq = -1;  // highest sweep index whose k_bulk has been enqueued
     bool prefetch = true;     // enqueue k_bulk(t+1) together with k_resolve(t)
@@ -2515,6 +2535,7 @@ static void free_all(rc_ctx *c)
     }
     for (auto &e : c->ev_pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &e : c->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     for (int q = 0; q < 4; ++q) {
         if (c->ev_bulk[q]) (void)hipEventDestroy(c->ev_bulk[q]);
         if (c->ev_res[q]) (void)hipEventDestroy(c->ev_res[q]);
@@ -2576,6 +2597,7 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
         if (getenv("RC_ONE_BULK_STREAM") && atoi(getenv("RC_ONE_BULK_STREAM"))) c->sB2 = c->sB;
         else HIPCHK(c, hipStreamCreateWithPriority(&c->sB2, hipStreamNonBlocking, pr_least));
     }
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
     for (int q = 0; q < 4; ++q) {
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_bulk[q], hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_res[q], hipEventDisableTiming));
@@ -2792,7 +2814,7 @@ static int32_t alloc_ctx(int64_t n, int32_t storage_bits, int32_t device_id, int
     if (getenv("RC_SYM_VARIANT")) c->sym_variant = atoi(getenv("RC_SYM_VARIANT"));
     if (getenv("RC_SYMW_PER_CU")) c->symw_per_cu = std::max(1, atoi(getenv("RC_SYMW_PER_CU")));
     if (getenv("RC_SYML_PAD")) c->syml_pad = (size_t)std::max(0, atoi(getenv("RC_SYML_PAD")));
-    if (getenv("RC_SW_COARSE")) c->sw_coarse = std::min(64, std::max(16, atoi(getenv("RC_SW_COARSE")) & ~3));
+    if (getenv("RC_SW_COARSE")) c->sw_coarse = std::min(128, std::max(8, atoi(getenv("RC_SW_COARSE")) & ~3));
     if (getenv("RC_BULK_KERNEL")) c->bulk_kernel = !strcmp(getenv("RC_BULK_KERNEL"), "sym") ? 1 : (!strcmp(getenv("RC_BULK_KERNEL"), "perm") ? 0 : -1);
     if (getenv("RC_RES_THREADS")) c->res_threads = (atoi(getenv("RC_RES_THREADS")) == 256) ? 256 : 512;
     if (getenv("RC_SYM_ITEM_TILES")) c->sym_item_tiles = std::max(1, atoi(getenv("RC_SYM_ITEM_TILES")));
@@ -2985,6 +3007,7 @@ static int32_t drain_events(rc_ctx *c)
 // Waits for the resolve/observable stream (and for the k_bulk stream too when `both`), then surfaces device errors.
 static int32_t sync_and_check(rc_ctx *c, bool both = false)
 {
+    if (c->s_res_last && c->s_res_last != c->sA) HIPCHK(c, hipStreamSynchronize(c->s_res_last));   // the last sweep's resolver
     HIPCHK(c, hipStreamSynchronize(c->sA));
     if (both) {
         HIPCHK(c, hipStreamSynchronize(c->sB));
@@ -3086,6 +3109,7 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
     c->last = s;
     c->t_next = 0;
     c->bulk_enq = -1;
+    c->s_res_last = nullptr;
     c->state_version++;
     c->have_state = true;
     return RC_OK;
@@ -3103,34 +3127,25 @@ static bool choose_sym(const rc_ctx *c)
 }
 static int sym_variant_of(const rc_ctx *c) { return c->sym_variant >= 0 ? c->sym_variant : (c->derived ? 2 : 0); }
 
-// Static unit list of the wave-autonomous symmetric reduction for `cap_blocks` resident 4-wave blocks: units of gc rows
-// for the heavy column blocks — a whole number of rounds over the resident waves — and gfine-row units for the light
-// blocks below jsplit, which are handed out last (syml_units decodes the same list).
-static void syml_geometry(const rc_ctx *c, int cap_blocks, int gc, int *nitems_out, int *jsplit_out, int *gfine_out)
+// Static unit list of the wave-autonomous symmetric reduction for `cap_blocks` resident 4-wave blocks.  Every column block
+// is cut into units of gc rows, gc chosen so that the list is a whole number of rounds over the resident waves with the
+// shortest makespan: rounds · (gc + overhead), overhead ≈ 4 rows for a unit's set-up and flushes.  (n = 8192: 68-row units
+// = one round over 4096 waves, 88-row units over 3072; the earlier scheme — 64-row units plus a tail of 8-row units —
+// lost 12 % at four blocks per CU and 55 % at three, where a quarter of all rows ended up in 8-row units.)
+static void syml_geometry(const rc_ctx *c, int cap_blocks, int *gc_out, int *nitems_out)
 {
-    const int ncb = (c->n + RC_SW_COLS - 1) / RC_SW_COLS;
+    const int ncb = (c->n + RC_SW_COLS - 1) / RC_SW_COLS, nwaves = 4 * cap_blocks;
     auto rows_of = [&](int J) { return std::min(RC_SW_COLS * J + RC_SW_COLS, c->n); };
-    int total_coarse = 0;
-    for (int J = 0; J < ncb; ++J) total_coarse += (rows_of(J) + gc - 1) / gc;
-    const int target = (total_coarse / (4 * cap_blocks)) * (4 * cap_blocks);
-    int jsplit = ncb, coarse = 0;
-    while (jsplit > 0) {
-        const int cnt = (rows_of(jsplit - 1) + gc - 1) / gc;
-        if (coarse + cnt > target) break;
-        coarse += cnt; --jsplit;
+    long long best_cost = -1;
+    int best_g = RC_SW_ROWS, best_items = 0;
+    for (int g = (c->sw_coarse > 0 ? c->sw_coarse : 8); g <= (c->sw_coarse > 0 ? c->sw_coarse : 2 * RC_SW_ROWS); g += 4) {
+        long long items = 0;
+        for (int J = 0; J < ncb; ++J) items += (rows_of(J) + g - 1) / g;
+        const long long rounds = (items + nwaves - 1) / nwaves;
+        const long long cost = rounds * (g + 4);
+        if (best_cost < 0 || cost < best_cost || (cost == best_cost && g > best_g)) { best_cost = cost; best_g = g; best_items = (int)items; }
     }
-    int gfine = RC_SW_FINE;
-    if (coarse < 2 * cap_blocks) {   // small problem: fine units everywhere, as large as still fills the resident waves
-        jsplit = ncb; coarse = 0;
-        for (int g = 32; g > RC_SW_FINE; g >>= 1) {
-            int cnt = 0;
-            for (int J = 0; J < ncb; ++J) cnt += (rows_of(J) + g - 1) / g;
-            if (cnt >= 4 * cap_blocks) { gfine = g; break; }
-        }
-    }
-    int nitems = coarse;
-    for (int J = 0; J < jsplit; ++J) nitems += (rows_of(J) + gfine - 1) / gfine;
-    *nitems_out = nitems; *jsplit_out = jsplit; *gfine_out = gfine;
+    *gc_out = best_g; *nitems_out = best_items;
 }
 
 // k_bulk of sweep t on stream B: fills S generation t%3 from perm generation t%2 (labels after sweep t-2),
@@ -3156,9 +3171,9 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
         const int cap_blocks = c->symw_per_cu * c->num_cus;          // resident 4-wave blocks
         auto rows_of = [&](int J) { return std::min(RC_SW_COLS * J + RC_SW_COLS, c->n); };
         if (sym_variant == 2) {
-            const int gc = c->sw_coarse;
-            int nitems = 0, jsplit = 0, gfine = 0;
-            syml_geometry(c, cap_blocks, gc, &nitems, &jsplit, &gfine);
+            int gc = 0, nitems = 0;
+            const int jsplit = 0, gfine = 8;   // (every column block in gc-row units)
+            syml_geometry(c, cap_blocks, &gc, &nitems);
             const int nblocks = std::max(1, std::min((nitems + 3) / 4, cap_blocks));
             if (c->derived) k_bulk_syml<true><<<nblocks, 256, c->syml_pad, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems, jsplit, gfine, gc);
             else k_bulk_syml<false><<<nblocks, 256, c->syml_pad, sb>>>(V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems, jsplit, gfine, gc);
@@ -3203,9 +3218,26 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
     return RC_OK;
 }
 
+// Stream roles.  Sweep t lives on ONE stream — sB for even t, sB2 for odd t: its row reduction, then its resolver — so the
+// chain that bounds the sweep rate, row reduction(t) -> resolver(t) -> row reduction(t+2), runs in stream order (a kernel
+// boundary of ~2 µs) instead of through two cross-stream events of 10-17 µs each; the one cross-stream dependence left,
+// resolver(t) after resolver(t-1), is normally satisfied long before it is needed.  Stream A carries everything else
+// (log-likelihood block sums, recorded samples, state edits): work enqueued there that reads the state first waits for the
+// last resolver, and the next resolver is made to wait for stream A in turn (sA_dirty -> ev_a).
+static int32_t order_A_after_sweeps(rc_ctx *c)
+{
+    if (c->s_res_last && c->s_res_last != c->sA && c->t_next > 0) HIPCHK(c, hipStreamWaitEvent(c->sA, c->ev_res[(c->t_next - 1) & 3], 0));
+    c->sA_dirty = true;
+    return RC_OK;
+}
+
 // Makes the S generation of the CURRENT labels available to work enqueued on stream A; returns its index.
 static int32_t ensure_S(rc_ctx *c, int *gen)
 {
+    {
+        int32_t rc0 = order_A_after_sweeps(c);
+        if (rc0 != RC_OK) return rc0;
+    }
     if (c->incremental && c->bulk_enq >= 0 && c->t_next > 0) {
         *gen = c->inc_gen;
         return RC_OK;
@@ -3231,16 +3263,24 @@ static int32_t ensure_S(rc_ctx *c, int *gen)
 static std::mutex g_res_mutex;
 static hipEvent_t g_res_event[64] = {};
 
-static int32_t launch_resolve(rc_ctx *c, const View &V, const SweepArgs &sa, int res_threads, size_t lds)
+static int32_t launch_resolve(rc_ctx *c, const View &V, const SweepArgs &sa, int res_threads, size_t lds, hipStream_t sx)
 {
+    if (sx != c->sA && c->sA_dirty) {   // recorded samples, block sums ... enqueued on stream A read the state this sweep changes
+        HIPCHK(c, hipEventRecord(c->ev_a, c->sA));
+        HIPCHK(c, hipStreamWaitEvent(sx, c->ev_a, 0));
+    }
+    c->sA_dirty = false;
+    if (sa.t >= 1 && c->s_res_last && c->s_res_last != sx) HIPCHK(c, hipStreamWaitEvent(sx, c->ev_res[(sa.t - 1) & 3], 0));
     std::lock_guard<std::mutex> lock(g_res_mutex);
     const int d = c->dev & 63;
-    if (g_res_event[d]) HIPCHK(c, hipStreamWaitEvent(c->sA, g_res_event[d], 0));
+    if (g_res_event[d]) HIPCHK(c, hipStreamWaitEvent(sx, g_res_event[d], 0));
     else HIPCHK(c, hipEventCreateWithFlags(&g_res_event[d], hipEventDisableTiming));
-    k_resolve<<<c->G, res_threads, lds, c->sA>>>(V, sa, c->G);
+    k_resolve<<<c->G, res_threads, lds, sx>>>(V, sa, c->G);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(c, RC_ERR_HIP, "k_resolve launch failed: %s", hipGetErrorString(e));
-    HIPCHK(c, hipEventRecord(g_res_event[d], c->sA));
+    HIPCHK(c, hipEventRecord(g_res_event[d], sx));
+    HIPCHK(c, hipEventRecord(c->ev_res[sa.t & 3], sx));
+    c->s_res_last = sx;
     return RC_OK;
 }
 
@@ -3300,9 +3340,8 @@ extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t 
         sa.own_gen = c->inc_gen;
         sa.next_gen = -1;
         sa.zero_gen = -1;
-        rc = launch_resolve(c, V, sa, res_threads, lds);
+        rc = launch_resolve(c, V, sa, res_threads, lds, c->sA);
         if (rc != RC_OK) return rc;
-        HIPCHK(c, hipEventRecord(c->ev_res[t & 3], c->sA));
         c->t_next = t + 1;
         c->state_version++;
         return RC_OK;
@@ -3314,10 +3353,9 @@ extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t 
         rc = enqueue_bulk(c, V, t);
         if (rc != RC_OK) return rc;
     }
-    HIPCHK(c, hipStreamWaitEvent(c->sA, c->ev_bulk[t & 3], 0));
-    rc = launch_resolve(c, V, sa, res_threads, lds);
+    const hipStream_t sx = (t & 1) ? c->sB2 : c->sB;            // the stream of sweep t: its row reduction is already on it
+    rc = launch_resolve(c, V, sa, res_threads, lds, sx);
     if (rc != RC_OK) return rc;
-    HIPCHK(c, hipEventRecord(c->ev_res[t & 3], c->sA));
     c->t_next = t + 1;
     c->state_version++;
     if (c->prefetch) {
@@ -3617,6 +3655,8 @@ extern "C" int32_t rc_record_sample(rc_ctx *c, int64_t *canonical_out)
     if (!c->have_state) return fail(c, RC_ERR_STATE, "rc_record_sample: no state set");
     HIPCHK(c, hipSetDevice(c->dev));
     int32_t rc = ensure_counts(c);
+    if (rc != RC_OK) return rc;
+    rc = order_A_after_sweeps(c);
     if (rc != RC_OK) return rc;
     k_snapshot<<<(c->ldc + 255) / 256, 256, 0, c->sA>>>(c->slot_of, c->pi, c->n, c->ldc, c->snap + (size_t)c->snap_cnt * c->ldc);
     HIPCHK(c, hipGetLastError());
@@ -4298,6 +4338,7 @@ extern "C" int32_t rc_set_mode(rc_ctx *c, int32_t mode)
         HIPCHK(c, hipStreamSynchronize(c->sA));
         c->t_next = 0;
         c->bulk_enq = -1;
+        c->s_res_last = nullptr;
     }
     return RC_OK;
 }
