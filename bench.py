@@ -110,7 +110,10 @@ def main():
         ctx.gibbs_sweep(r, p, chain_seed, sweep, blocking=False)
         sweep += 1
     ctx.synchronize()
-    ctx.kernel_timing(enable=0 if os.environ.get('RC_BENCH_NO_TIMING') else int(os.environ.get('RC_BENCH_TIME_EVERY', 8)))
+    # HIP events around the row-reduction kernel, on the stream it is launched on: every launch for short runs (the driver's
+    # --steps 20), every 4th otherwise (an event pair costs the stream a few microseconds)
+    time_every = int(os.environ.get('RC_BENCH_TIME_EVERY', 1 if args.steps < 64 else 4))
+    ctx.kernel_timing(enable=0 if os.environ.get('RC_BENCH_NO_TIMING') else time_every)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -151,7 +154,43 @@ def main():
         dt = float(tmax.item())
         diag_ok = bool((counts.diagonal() == world).all().item())
     else:
-        diag_ok = True
+        # the one recorded sample: every point co-clusters with itself once, and the matrix is symmetric
+        counts = rc.device_counts_tensor(ctx, local_rank)
+        diag_ok = bool((counts.diagonal() == 1).all().item()) and bool((counts[:, :n] == counts[:, :n].T).all().item())
+
+    # Second figure ("exercises movement"): the same N, K with overlapping clusters (sigma = 0.2 instead of 0.1:
+    # about 0.5 % of the labels move per sweep and clusters are born and die), burn-in from the generating labels excluded from the timing.
+    moving = None
+    if rank == 0 and not os.environ.get("RC_BENCH_NO_MOVING"):
+        sig = float(os.environ.get("RC_BENCH_MOVING_SIGMA", 0.2))
+        dm = rc.generatemixture(n, K, seed=2, sigma=sig)
+        Dm, tm = dm["distancematrix"], dm["clusts"]
+        Pm = rc.likelihood_hyperparams(Dm, tm)
+        cm = rc.Context(Dm, device=local_rank, kcap=max(512, 8 * K), storage_bits=BITS)
+        cm.set_params(**Pm)
+        cm.set_state(tm)
+        sw = 0
+        for _ in range(60):                               # burn-in to the moving equilibrium
+            cm.gibbs_sweep(r, p, 7, sw, blocking=False); sw += 1
+        cm.synchronize()
+        msteps = max(20, min(args.steps, 200))
+        ch = rounds = 0
+        t1 = time.perf_counter()
+        for _ in range(msteps):
+            cm.gibbs_sweep(r, p, 7, sw, blocking=True); sw += 1   # blocking: the change count of every sweep is read
+            st = cm.sweep_stats(); ch += st["n_changes"]; rounds += st["n_rounds"]
+        t_block = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        for _ in range(msteps):
+            cm.gibbs_sweep(r, p, 7, sw, blocking=False); sw += 1
+        cm.synchronize()
+        t_async = time.perf_counter() - t1
+        moving = {"sigma": sig, "sweeps_per_s": msteps / t_async, "ms_per_sweep": t_async / msteps * 1e3,
+                  "sweeps_per_s_blocking": msteps / t_block, "label_changes_per_sweep": ch / msteps,
+                  "resolve_rounds_per_sweep": rounds / msteps, "K": cm.sweep_stats()["K"], "steps": msteps,
+                  "note": "overlapping clusters, equilibrium after 60 burn-in sweeps from the generating labels"}
+        cm.close()
+        del Dm
 
     if rank == 0:
         # bytes of matrix data the selected row-reduction kernel has to read per sweep: k_bulk reads every entry of D
@@ -169,15 +208,17 @@ def main():
         bulk_avg_ms = bulk_ms / max(bulk_launches, 1)
         achieved = survey_bytes / (bulk_avg_ms * 1e-3) / 1e9 if bulk_launches else None       # §8(d) bytes ÷ kernel time
         achieved_read = alg_bytes / (bulk_avg_ms * 1e-3) / 1e9 if bulk_launches else None     # bytes actually read ÷ kernel time
-        traffic = None
+        # HBM bytes per launch of that kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 FETCH_SIZE
+        # correction applied): collected OFFLINE with this same command (tools/prof_r02.sh) and committed — not measured in
+        # this run; `traffic_source` names the file
+        traffic = traffic_source = None
         tag = kernel_name.replace("<", "_").replace(">", "").replace(", ", "_").replace(" ", "")
-        pmc = os.path.join(ROOT, "profiles", "r01", f"pmc_traffic_n{n}_{tag}.json")
-        if not os.path.exists(pmc):   # files of the earlier kernels (stored logD) are named by family
-            pmc = os.path.join(ROOT, "profiles", "r01", f"pmc_traffic_n{n}_{kernel_family}.json") if not derived else pmc
-        if os.path.exists(pmc) and BITS == 64:
-            # HBM bytes per k_bulk launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950
-            # FETCH_SIZE correction applied); collected offline with the same command, see the file's "source"
-            traffic = json.load(open(pmc))["k_bulk_hbm_bytes_per_launch"]
+        for rnd in ("r02", "r01"):
+            for name in (f"pmc_traffic_n{n}_{tag}.json", f"pmc_traffic_n{n}_{kernel_family}.json"):
+                f = os.path.join(ROOT, "profiles", rnd, name)
+                if traffic is None and os.path.exists(f) and BITS == 64 and (name.endswith(f"{tag}.json") or not derived):
+                    traffic = json.load(open(f))["k_bulk_hbm_bytes_per_launch"]
+                    traffic_source = f"profiles/{rnd}/{name} (rocprofv3 --pmc, collected offline with the same command)"
         out = {
             "metric": "Gibbs sweeps/sec (n×n distM)", "value": value, "unit": "sweeps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -192,6 +233,7 @@ def main():
             "sweep_GBps_on_bytes_read": value / world * alg_bytes / 1e9,
             "sweep_GBps_vs_reference_dataflow": value / world * full_bytes / 1e9,  # 2·n²·sizeof per sweep, what the reference reads
             "label_changes_last_sweep": stats["n_changes"], "K_final": stats["K"],
+            "moving_regime": moving,
             "incremental_mode_sweeps_per_s_rank0": inc_sweeps_per_s,
             "coclustering_allreduce_ms": allreduce_ms, "coclustering_diag_ok": diag_ok,
             # roofline of the dominant kernel.  `achieved` / `frac` use the algorithmic bytes SURVEY.md §8(d) prescribes
@@ -199,7 +241,11 @@ def main():
             # symmetric matrix — so the physical figures (bytes it must read ÷ time) are given beside them, and
             # `traffic` is the HBM bytes per launch measured with the PMC counters.
             "roofline": {"kernel": kernel_name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
+                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic, "traffic_source": traffic_source,
+                         "pricing": "achieved / frac: SURVEY.md §8(d) algorithmic bytes per sweep (n²·sizeof when logD is derived on the fly, "
+                                    "2·n²·sizeof when stored) ÷ mean launch duration; *_on_bytes_read: the bytes this kernel has to read "
+                                    "(the upper triangle only) ÷ the same duration",
+                         "timed_every_nth_launch": time_every,
                          "avg_launch_ms": bulk_avg_ms, "launches": bulk_launches,
                          "algorithmic_bytes_per_launch": survey_bytes,
                          "bytes_read_by_kernel_per_launch": alg_bytes,
