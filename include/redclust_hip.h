@@ -16,8 +16,8 @@
  *   - the caller owns every host buffer and keeps it alive for the duration of the call; the library owns
  *     all device memory behind rc_ctx.  One rc_ctx is not thread-safe; distinct contexts are independent.
  *   - uniforms: the m uniforms sample_logweights (src/utils.jl:4) draws for point i (0-based) of sweep t
- *     are Philox4x32-10(key = seed)(counter = (pos, i, t_lo, t_hi)), pos = 0..m-1 in candidate order,
- *     u = (top 52 bits + 0.5) * 2^-52  (DESIGN.md "Uniform stream").
+ *     are Philox4x32-10(key = seed)(counter = (key, i, t_lo, t_hi)), key = the candidate cluster's label
+ *     (1..n), 0 for the new-cluster candidate; u = (top 52 bits + 0.5) * 2^-52  (DESIGN.md "Uniform stream").
  */
 #ifndef REDCLUST_HIP_H
 #define REDCLUST_HIP_H

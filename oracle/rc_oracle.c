@@ -44,9 +44,13 @@ typedef struct {
 /* ------------------------------------------------------------------------------------------------
  * Uniform source.  Julia's task-local RNG cannot be reproduced outside Julia, so
  * "identical RNG seeds" is defined at the uniform-stream level: the m uniforms that
- * sample_logweights (src/utils.jl:4) draws for point i in sweep t are u(seed, t, i, pos), pos =
- * 0..m-1 in candidate order, from Philox4x32-10 (Salmon et al., SC'11) keyed by the seed with the
- * counter (pos, i, t_lo, t_hi).  Strictly inside (0,1).
+ * sample_logweights (src/utils.jl:4) draws for point i in sweep t are u(seed, t, i, key), one per
+ * candidate, key = the candidate's cluster LABEL (1..n) for an existing cluster and 0 for the
+ * new-cluster candidate, from Philox4x32-10 (Salmon et al., SC'11) keyed by the seed with the counter
+ * (key, i, t_lo, t_hi).  Strictly inside (0,1).  (Keying by label, not by position in the candidate
+ * list: m independent uniforms either way, but a candidate keeps its uniform when some other cluster
+ * is born or dies earlier in the sweep, which is what lets the device resolver validate such changes
+ * in batches.)
  * ---------------------------------------------------------------------------------------------- */
 static inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
 {
@@ -155,7 +159,8 @@ void orc_quantize(const double *x, int64_t count, int e, int64_t *q)
  * sample_logweights (src/utils.jl:2-6), literal: lp .-= minimum(lp); u = rand(m);
  * argmax(-log.(-log.(u)) .+ lp), first index wins ties.  Returns 0-based position.
  * ---------------------------------------------------------------------------------------------- */
-static int64_t draw_literal(double *lp, int64_t m, uint64_t seed, uint64_t sweep, uint64_t i)
+static int64_t draw_literal(double *lp, int64_t m, uint64_t seed, uint64_t sweep, uint64_t i,
+                            const int64_t *cand, int64_t K_i)
 {
     double mn = lp[0];
     for (int64_t k = 1; k < m; ++k) if (lp[k] < mn) mn = lp[k];
@@ -163,7 +168,7 @@ static int64_t draw_literal(double *lp, int64_t m, uint64_t seed, uint64_t sweep
     double bestv = 0;
     for (int64_t k = 0; k < m; ++k) {
         lp[k] -= mn;
-        double u = orc_uniform(seed, sweep, i, (uint64_t)k);
+        double u = orc_uniform(seed, sweep, i, k < K_i ? (uint64_t)cand[k] : 0u);  /* label; 0 = new cluster */
         double v = -log(-log(u)) + lp[k];
         if (k == 0 || v > bestv) { bestv = v; best = k; }
     }
@@ -307,7 +312,9 @@ int orc_sweep_literal_range(int64_t n, const double *D, const double *logD, int6
         clustsizes[clusts[i] - 1] -= 1;                         /* mcmc.jl:193 */
         clusts[i] = -1;                                         /* mcmc.jl:194 */
         int64_t m = lit_point_scores(n, D, logD, clusts, clustsizes, P, r, p, i, cost_mode, &w);
-        int64_t k = draw_literal(w.logprobs, m, seed, sweep, (uint64_t)i);        /* mcmc.jl:249 */
+        int64_t K_i = 0;
+        for (int64_t t = 0; t < n; ++t) K_i += clustsizes[t] > 0;
+        int64_t k = draw_literal(w.logprobs, m, seed, sweep, (uint64_t)i, w.cand, K_i);  /* mcmc.jl:249 */
         int64_t ci_new = w.cand[k];
         clusts[i] = ci_new;                                     /* mcmc.jl:251 */
         clustsizes[ci_new - 1] += 1;                            /* mcmc.jl:252 */
@@ -414,7 +421,7 @@ int orc_sweep_stable(int64_t n, const int64_t *Dq, const int64_t *Lq, int eD, in
         for (int64_t t = 0; t < K_i; ++t) {
             int64_t c = C_i[t] - 1;
             double v = stable_score(P, A, clustsizes[c], (double)sD[c] * scD, (double)sL[c] * scL, logp, r);
-            double u = orc_uniform(seed, sweep, (uint64_t)i, (uint64_t)t);
+            double u = orc_uniform(seed, sweep, (uint64_t)i, (uint64_t)C_i[t]);
             v = v + (-log(-log(u)));
             if (t == 0 || v > bestv) { bestv = v; best = t; }
         }
@@ -424,7 +431,7 @@ int orc_sweep_stable(int64_t n, const int64_t *Dq, const int64_t *Lq, int eD, in
             while (clustsizes[e] != 0) ++e;
             newlab = e + 1;
             double v = log((double)(K_i + 1)) + r * log1mp;
-            double u = orc_uniform(seed, sweep, (uint64_t)i, (uint64_t)K_i);
+            double u = orc_uniform(seed, sweep, (uint64_t)i, 0u);
             v = v + (-log(-log(u)));
             if (K_i == 0 || v > bestv) { bestv = v; best = K_i; }
             m = K_i + 1;
@@ -497,7 +504,7 @@ int orc_sweep_table(int64_t n, int64_t nlab, const int64_t *row_label, const int
             int64_t sd = TD[row * n + i], sl = TL[row * n + i];
             if (c == old - 1) sd -= diag[i];                        /* i itself is not a member (clusts[i] = -1) */
             double v = stable_score(P, A, clustsizes[c], (double)sd * scD, (double)sl * scL, logp, r);
-            double u = orc_uniform(seed, sweep, (uint64_t)i, (uint64_t)t);
+            double u = orc_uniform(seed, sweep, (uint64_t)i, (uint64_t)act[t]);
             v = v + (-log(-log(u)));
             if (t == 0 || v > bestv) { bestv = v; best = t; }
         }
@@ -507,7 +514,7 @@ int orc_sweep_table(int64_t n, int64_t nlab, const int64_t *row_label, const int
             while (clustsizes[e] != 0) ++e;
             newlab = e + 1;
             double v = log((double)(K_i + 1)) + r * log1mp;
-            double u = orc_uniform(seed, sweep, (uint64_t)i, (uint64_t)K_i);
+            double u = orc_uniform(seed, sweep, (uint64_t)i, 0u);
             v = v + (-log(-log(u)));
             if (K_i == 0 || v > bestv) { bestv = v; best = K_i; }
         }

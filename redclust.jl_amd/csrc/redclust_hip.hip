@@ -78,7 +78,7 @@ typedef unsigned long long u64;
 #define RC_RES_THREADS 512  // k_resolve block: 32 points x 16 candidate streams; 2 waves/SIMD so it co-resides with k_bulk
 #define RC_PTS 32           // points per chunk (lanes of a half wave)
 #define RC_MAX_KCAP 4096
-#define RC_MAXB 1024         // tentative changers validated per resolve round
+#define RC_MAXB 512          // tentative changers validated per resolve round
 #define RC_SPIN_LIMIT (1u << 23)
 #if defined(RC_PROF_SYML) || defined(RC_TRACE_RESOLVE)   // profiling / diagnostic builds: records behind the work counter
 #define RC_WORK_BYTES (64 + 8192 * 128)
@@ -1073,13 +1073,33 @@ __device__ __forceinline__ void syml_units(const View &V, long long (*tt)[RC_SL_
         const int nunit = unit + nwaves;
         int nc0 = 0, na0 = 0, na1 = 0, nitem = 0, ncs0 = -1, ncs1 = -1, nrowslots = -1;
         const int col0 = c0 + 2 * lane, col1 = col0 + 1;
-        // the (at most two) clusters that own the 128 columns; a third, fourth ... cluster goes the slow way
-        const int dsA = __builtin_amdgcn_readfirstlane(cs0);            // column c0 always exists
-        const u64 notA0 = __ballot(cs0 >= 0 && cs0 != dsA), notA1 = __ballot(cs1 >= 0 && cs1 != dsA);
-        int dsB = -1;
-        if (notA0 | notA1) {
-            const int l0 = notA0 ? __ffsll((long long)notA0) - 1 : 64, l1 = notA1 ? __ffsll((long long)notA1) - 1 : 64;
-            dsB = (l0 <= l1) ? __builtin_amdgcn_readlane(cs0, l0 & 63) : __builtin_amdgcn_readlane(cs1, l1 & 63);
+        // The two clusters that own most of the 128 columns (A, B); columns of any other cluster go the slow way, element by
+        // element.  Candidates: the clusters of the first, middle and last column and of the first column that differs
+        // from the first; the two with the most columns win.  (Taking simply "the first column's cluster and the first that
+        // differs" made one stray point ahead of a cluster boundary push the whole second cluster down the slow path:
+        // 40 strays among 8192 points cost a factor of 4.)
+        int dsA, dsB = -1;
+        {
+            const int k0 = __builtin_amdgcn_readfirstlane(cs0);         // column c0 always exists
+            const u64 not0 = __ballot(cs0 >= 0 && cs0 != k0), not1 = __ballot(cs1 >= 0 && cs1 != k0);
+            int k1 = -1;
+            if (not0 | not1) {
+                const int l0 = not0 ? __ffsll((long long)not0) - 1 : 64, l1 = not1 ? __ffsll((long long)not1) - 1 : 64;
+                k1 = (l0 <= l1) ? __builtin_amdgcn_readlane(cs0, l0 & 63) : __builtin_amdgcn_readlane(cs1, l1 & 63);
+            }
+            dsA = k0; dsB = k1;
+            if (k1 >= 0) {
+                const int k2 = __builtin_amdgcn_readlane(cs0, 32), k3 = __builtin_amdgcn_readlane(cs1, 63);
+                auto count = [&](int k) { return k < 0 ? 0 : __popcll(__ballot(cs0 == k)) + __popcll(__ballot(cs1 == k)); };
+                const int n0 = count(k0), n1 = count(k1), n2 = (k2 == k0 || k2 == k1) ? 0 : count(k2),
+                          n3 = (k3 == k0 || k3 == k1 || k3 == k2) ? 0 : count(k3);
+                // largest and second largest of (k0,n0) (k1,n1) (k2,n2) (k3,n3)
+                int ka = k0, na = n0, kb = k1, nbb = n1;
+                if (nbb > na) { int t_ = ka; ka = kb; kb = t_; t_ = na; na = nbb; nbb = t_; }
+                if (n2 > na) { kb = ka; nbb = na; ka = k2; na = n2; } else if (n2 > nbb) { kb = k2; nbb = n2; }
+                if (n3 > na) { kb = ka; nbb = na; ka = k3; na = n3; } else if (n3 > nbb) { kb = k3; nbb = n3; }
+                dsA = ka; dsB = kb;
+            }
         }
         const bool rem0 = cs0 >= 0 && cs0 != dsA && cs0 != dsB, rem1 = cs1 >= 0 && cs1 != dsA && cs1 != dsB;
         const bool overflow = (__ballot(rem0) | __ballot(rem1)) != 0;   // uniform, rare
@@ -1199,13 +1219,15 @@ __device__ __forceinline__ void syml_units(const View &V, long long (*tt)[RC_SL_
                         if (isB) { sDB += vD[j]; sLB += vL[j]; } else if (!isO) { sDA += vD[j]; sLA += vL[j]; }
                     }
                 }
-                if (overflow && mO) {   // columns of a third cluster: element-wise atomics (rare)
+                if (overflow) {   // columns of a third cluster: element-wise atomics (uniform branch: every lane shuffles)
                     const int row = a + tr;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int cj = c0 + 8 * tq + j;
+                        // slot of column cj from the lane that holds it (lane 4 tq + j/2, component j & 1): an LDS-crossbar
+                        // shuffle, not a load — a global load here would make the wave wait for the next tile's prefetch too
+                        const int sj = __shfl((j & 1) ? cs1 : cs0, 4 * tq + (j >> 1));
                         if (((mO >> j) & 1) && cj < n && (!MASK || row < a1)) {
-                            const int sj = slot[cj];
                             if (vD[j]) add64(SD + (size_t)sj * ld + row, vD[j]);
                             if (vL[j]) add64(SL + (size_t)sj * ld + row, vL[j]);
                         }
@@ -1456,20 +1478,30 @@ struct Tab {
     short *act;      // [kcap] act[pos] = slot
     double *base_o;  // [kcap] A[s] + log p + log(s-1+r), s = size          (candidate cluster of another point)
     double *base_s;  // [kcap] same with s = size-1                          (the point's own cluster, itself removed)
-    unsigned *used;  // [(n+31)/32] label occupancy bitset, bit (label-1); built only when a birth/death/rename needs it
+    unsigned *used;  // [(n+31)/32] label occupancy bitset, bit (label-1); built when a round has changers
     double *red_v;   // [NW][32] reduction scratch (NW = waves per block)
     int *red_pos, *red_slot;
-    int *misc;       // [0]=K [1]=smallest_empty [2]=scratch min [3]=b [4]=structural [5]=fail [6]=barrier ok [7]=slot_hi
+    int *misc;       // [0]=K [1]=smallest_empty [2]=scratch [3]=nb [4]=hi [5]=fail [6]=barrier ok [7]=slot_hi [8]=#births [9]=#effective
     u64 *blk_key;    // block-local minimum (first violation)
-    // batch of tentative changers of the current round (identical in every block)
-    int *bx, *ba, *bb;        // [RC_MAXB] point (original index), source slot, target slot, ascending in point index
-    int *bu;                  // [RC_MAXB] internal index of the point
-    unsigned char *affected;  // [kcap] slot is a source or target of a batch changer
+    // batch of tentative changers of the current round (identical in every block), ascending in point index
+    int *bx, *bu;             // [RC_MAXB] point (original index), its internal index
+    short *ba, *bb;           // [RC_MAXB] source slot; target slot (after batch_sim: the slot it really goes to)
+    int *blab, *bold;         // [RC_MAXB] label the entry takes (birth / rename) and label it frees (death / rename), 0 = none
+    short *bK;                // [RC_MAXB] number of clusters after the entry
+    unsigned char *bflag;     // [RC_MAXB] RC_BF_* bits
+    short *birth;             // [RC_MAXB] the entries that create a cluster, ascending
+    short *nexta, *nextb;     // [RC_MAXB] next entry (ascending) that touches the same source / target slot, -1 = none
+    short *head;              // [kcap] first entry that touches the slot, -1 = none
     int *ccnt;                // [nchunks + 1] scratch: changers per chunk / exclusive offsets
 };
+#define RC_BF_DEATH 1   // the source cluster becomes empty
+#define RC_BF_BIRTH 2   // the target is a new cluster (slot bb, label blab)
+#define RC_BF_RENAME 4  // a singleton that takes a fresh, smaller label (slot unchanged, label blab)
+#define RC_BF_NOOP 8    // a singleton that draws "new cluster" and keeps its label: nothing changes
 
 #define RC_A16(x) (((x) + 15) & ~(size_t)15)
-__host__ __device__ inline size_t tab_layout(int kcap, int n, int nw, size_t *off /*18*/)
+#define RC_TAB_NOFF 26
+__host__ __device__ inline size_t tab_layout(int kcap, int n, int nw, size_t *off /*RC_TAB_NOFF*/)
 {
     size_t o = 0;
     off[0] = o; o = RC_A16(o + sizeof(double) * kcap);          // base_o
@@ -1481,41 +1513,52 @@ __host__ __device__ inline size_t tab_layout(int kcap, int n, int nw, size_t *of
     off[6] = o; o = RC_A16(o + sizeof(int) * nw * RC_PTS);      // red_pos
     off[7] = o; o = RC_A16(o + sizeof(int) * nw * RC_PTS);      // red_slot
     off[8] = o; o = RC_A16(o + sizeof(unsigned) * ((n + 31) / 32));  // used
-    off[9] = o; o = RC_A16(o + sizeof(int) * 8);                // misc
+    off[9] = o; o = RC_A16(o + sizeof(int) * 16);               // misc
     off[10] = o; o = RC_A16(o + sizeof(short) * kcap);          // pos
     off[11] = o; o = RC_A16(o + sizeof(short) * kcap);          // act
     off[12] = o; o = RC_A16(o + sizeof(int) * RC_MAXB);         // bx
-    off[13] = o; o = RC_A16(o + sizeof(int) * RC_MAXB);         // ba
-    off[14] = o; o = RC_A16(o + sizeof(int) * RC_MAXB);         // bb
-    off[15] = o; o = RC_A16(o + (size_t)kcap);                  // affected
+    off[13] = o; o = RC_A16(o + sizeof(short) * RC_MAXB);       // ba
+    off[14] = o; o = RC_A16(o + sizeof(short) * RC_MAXB);       // bb
+    off[15] = o; o = RC_A16(o + sizeof(short) * kcap);          // head
     off[16] = o; o = RC_A16(o + sizeof(int) * ((n + RC_PTS - 1) / RC_PTS + 1));  // ccnt
     off[17] = o; o = RC_A16(o + sizeof(int) * RC_MAXB);         // bu
+    off[18] = o; o = RC_A16(o + sizeof(int) * RC_MAXB);         // blab
+    off[19] = o; o = RC_A16(o + sizeof(int) * RC_MAXB);         // bold
+    off[20] = o; o = RC_A16(o + sizeof(short) * RC_MAXB);       // bK
+    off[21] = o; o = RC_A16(o + (size_t)RC_MAXB);               // bflag
+    off[22] = o; o = RC_A16(o + sizeof(short) * RC_MAXB);       // birth
+    off[23] = o; o = RC_A16(o + sizeof(short) * RC_MAXB);       // nexta
+    off[24] = o; o = RC_A16(o + sizeof(short) * RC_MAXB);       // nextb
+    off[25] = o;
     return o;
 }
 
 __device__ Tab tab_carve(char *smem, int kcap, int n, int nw)
 {
-    size_t off[18];
+    size_t off[RC_TAB_NOFF];
     tab_layout(kcap, n, nw, off);
     Tab T;
     T.base_o = (double *)(smem + off[0]); T.base_s = (double *)(smem + off[1]); T.red_v = (double *)(smem + off[2]);
     T.blk_key = (u64 *)(smem + off[3]); T.size = (int *)(smem + off[4]); T.label = (int *)(smem + off[5]);
     T.red_pos = (int *)(smem + off[6]); T.red_slot = (int *)(smem + off[7]); T.used = (unsigned *)(smem + off[8]);
     T.misc = (int *)(smem + off[9]); T.pos = (short *)(smem + off[10]); T.act = (short *)(smem + off[11]);
-    T.bx = (int *)(smem + off[12]); T.ba = (int *)(smem + off[13]); T.bb = (int *)(smem + off[14]);
-    T.affected = (unsigned char *)(smem + off[15]); T.ccnt = (int *)(smem + off[16]); T.bu = (int *)(smem + off[17]);
+    T.bx = (int *)(smem + off[12]); T.ba = (short *)(smem + off[13]); T.bb = (short *)(smem + off[14]);
+    T.head = (short *)(smem + off[15]); T.ccnt = (int *)(smem + off[16]); T.bu = (int *)(smem + off[17]);
+    T.blab = (int *)(smem + off[18]); T.bold = (int *)(smem + off[19]); T.bK = (short *)(smem + off[20]);
+    T.bflag = (unsigned char *)(smem + off[21]); T.birth = (short *)(smem + off[22]);
+    T.nexta = (short *)(smem + off[23]); T.nextb = (short *)(smem + off[24]);
     return T;
 }
 
 __device__ inline size_t tab_bytes_dev(int kcap, int n, int nw)
 {
-    size_t off[18];
+    size_t off[RC_TAB_NOFF];
     return tab_layout(kcap, n, nw, off);
 }
 
 static size_t tab_bytes(int kcap, int n, int nw)
 {
-    size_t off[18];
+    size_t off[RC_TAB_NOFF];
     return tab_layout(kcap, n, nw, off);
 }
 
@@ -1710,11 +1753,21 @@ __device__ __forceinline__ void best_merge(double &bv, int &bp, int &bs, double 
     if (s != -2 && (bs == -2 || v > bv || (v == bv && p < bp))) { bv = v; bp = p; bs = s; }
 }
 
-// mode 0 (tentative): decisions under the committed state; the target of every point goes to V.tent, changers to
-//   V.rec and the chunk's stamped mask word.
-// mode 1 (validate): point i is evaluated under the committed state PLUS the first nb_i batch changers that precede
-//   it (exact integer corrections of the two row sums and the sizes involved); a decision that differs from the
-//   tentative one is a violation (block-local minimum in T.blk_key).  Points outside (lo, hi] are skipped.
+// Gumbel noise of a candidate: the uniform of (sweep, point, LABEL of the candidate cluster); key 0 is the "new cluster"
+// candidate.  Keying by label rather than by position in the candidate list keeps the noise of every other candidate
+// unchanged when a cluster is born, dies or takes a new label, so such a change invalidates the tentative draws of the
+// later points no more than a plain move does (include/redclust_hip.h, oracle/rc_oracle.c: orc_uniform).
+// mode 0 (tentative): decisions under the committed state; the target of every point goes to V.tent (-1 = new cluster),
+//   changers to rec and the chunk's stamped mask word.  A singleton that draws "new cluster" is announced as a changer
+//   too: whether it keeps its label or takes a smaller free one depends on the changers before it (batch_sim decides).
+// mode 1 (validate): point i is evaluated under the committed state PLUS the first j batch changers that precede it:
+//   exact integer corrections of the row sums and sizes of the clusters they touch, the clusters they create (singletons:
+//   their row sums are matrix entries), the labels they change, the clusters they empty, the cluster count.  A decision
+//   that differs from the tentative one is a violation (block-local minimum in T.blk_key).  Points outside (lo, hi] are
+//   skipped.
+#define RC_NEWKEY 0x7ffffffe   // order key of the new-cluster candidate: after every label (utils.jl:5 first-index rule)
+__device__ __forceinline__ int batch_next(const Tab &T, int q, int k) { return (T.ba[q] == k) ? T.nexta[q] : T.nextb[q]; }
+
 __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long long *SD, const long long *SL,
                            int chunk, int lo, int hi, int mode, int nb, u64 *cword, unsigned *rec, unsigned stamp)
 {
@@ -1725,7 +1778,7 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
     const int K = T.misc[0];
     double bestv = -INFINITY;
     int bestpos = 0x7fffffff, bestslot = -2;
-    int own = 0, Ki = K, single = 0;
+    int own = 0;
     if (valid) {
         const int u = V.pi[i];  // matrices, S and slot_of are stored in the internal (cluster-contiguous) point order
         own = V.slot_of[u];
@@ -1738,34 +1791,34 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
             j = lo_;
         }
         int so = T.size[own];
-        if (mode == 1 && T.affected[own])
-            for (int q = 0; q < j; ++q) so += (T.bb[q] == own) - (T.ba[q] == own);
-        single = (so == 1);
-        const int pown = T.pos[own];
-        Ki = K - single;
+        if (mode == 1)
+            for (int q = T.head[own]; q >= 0 && q < j; q = batch_next(T, q, own)) so += (T.bb[q] == own) - (T.ba[q] == own);
+        const int single = (so == 1);
+        const int Ki = ((mode == 1 && j > 0) ? (int)T.bK[j - 1] : K) - single;
         const long long dg = V.diagq[u];
         for (int pos = st; pos < ((a.dbg & 1) ? 0 : K); pos += NS) {
             const int k = T.act[pos];
             const int isown = (k == own);
-            int sz = T.size[k];
+            int sz = T.size[k], lab = T.label[k];
             long long sd = SD[(size_t)k * ld + u], sl = SL[(size_t)k * ld + u];
             bool touched = false;
-            if (mode == 1 && T.affected[k]) {
-                for (int q = 0; q < j; ++q) {
+            if (mode == 1) {
+                for (int q = T.head[k]; q >= 0 && q < j; q = batch_next(T, q, k)) {
                     const int qa = T.ba[q], qb = T.bb[q];
-                    if (qa == k || qb == k) {
+                    if (qa != qb) {
                         const size_t e = (size_t)T.bu[q] * ld + u;
                         const long long xd = (V.bits == 64) ? ((const long long *)V.Dq)[e] : (long long)((const int *)V.Dq)[e];
                         const long long xl = rc_load_L(V, T.bu[q], u, xd);
                         const int sg = (qb == k) - (qa == k);
                         sd += sg * xd; sl += sg * xl; sz += sg;
                         touched = true;
+                    } else {
+                        lab = T.blab[q];   // the singleton took a new label
                     }
                 }
             }
             const int s = sz - isown;
-            if (s == 0) continue;  // own singleton cluster: not a candidate once i is removed (mcmc.jl:193-196)
-            const int pe = pos - (single && pos > pown);
+            if (s == 0) continue;  // empty once i is removed (its own singleton cluster, mcmc.jl:193-196) or emptied by the batch
             sd -= (isown ? dg : 0);                                              // i itself excluded (clusts[i] = -1)
             const double SDr = (double)sd * V.scD, SLr = (double)sl * V.scL;      // logD diagonal is 0 (types.jl:155)
             const double base = touched ? tab_base(V, a, s) : (isown ? T.base_s[k] : T.base_o[k]);
@@ -1773,16 +1826,36 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
             if (V.repulsion) lik += (V.zeta + V.delta2 * (double)s) * log1p(SDr / V.gamma);
             double v = base + lik;
             if (!(a.dbg & 4)) {
-                const double u = rc_uniform(a, (unsigned)i, (unsigned)pe);
-                v = v + (-log(-log(u)));
+                const double un = rc_uniform(a, (unsigned)i, (unsigned)lab);
+                v = v + (-log(-log(un)));
             }
-            if (v > bestv) { bestv = v; bestpos = pe; bestslot = k; }
+            if (bestslot == -2 || v > bestv || (v == bestv && lab < bestpos)) { bestv = v; bestpos = lab; bestslot = k; }
         }
-        // new-cluster candidate, last position (mcmc.jl:198-203, 228-230); one stream handles it
+        // clusters created by the changers before i: singletons {x_q}, row sums = row x_q of the matrices
+        if (mode == 1 && j > 0) {
+            int lo_ = 0, hi_ = T.misc[8];
+            while (lo_ < hi_) { const int mid = (lo_ + hi_) >> 1; if (T.birth[mid] < j) lo_ = mid + 1; else hi_ = mid; }
+            for (int bi = st; bi < lo_; bi += NS) {
+                const int q = T.birth[bi], lab = T.blab[q];
+                const size_t e = (size_t)T.bu[q] * ld + u;
+                const long long xd = (V.bits == 64) ? ((const long long *)V.Dq)[e] : (long long)((const int *)V.Dq)[e];
+                const long long xl = rc_load_L(V, T.bu[q], u, xd);
+                const double SDr = (double)xd * V.scD, SLr = (double)xl * V.scL;
+                double lik = V.cL * SLr - (V.alpha + V.delta1) * log1p(SDr / V.beta);
+                if (V.repulsion) lik += (V.zeta + V.delta2) * log1p(SDr / V.gamma);
+                double v = tab_base(V, a, 1) + lik;
+                if (!(a.dbg & 4)) {
+                    const double un = rc_uniform(a, (unsigned)i, (unsigned)lab);
+                    v = v + (-log(-log(un)));
+                }
+                if (bestslot == -2 || v > bestv || (v == bestv && lab < bestpos)) { bestv = v; bestpos = lab; bestslot = T.bb[q]; }
+            }
+        }
+        // new-cluster candidate, last in the candidate order (mcmc.jl:198-203, 228-230); one stream handles it
         if (st == (K % NS) && (V.maxK == 0 || (long long)Ki < V.maxK) && Ki < V.n) {
-            const double u = rc_uniform(a, (unsigned)i, (unsigned)Ki);
-            const double v = (log((double)(Ki + 1)) + a.r * a.log1mp) + (-log(-log(u)));
-            if (v > bestv || bestslot == -2) { bestv = v; bestpos = Ki; bestslot = -1; }
+            const double un = rc_uniform(a, (unsigned)i, 0u);
+            const double v = (log((double)(Ki + 1)) + a.r * a.log1mp) + (-log(-log(un)));
+            if (v > bestv || bestslot == -2) { bestv = v; bestpos = RC_NEWKEY; bestslot = -1; }
         }
     }
     // reduce over the candidate streams: the two halves of each wave by shuffle, then the waves through LDS
@@ -1809,16 +1882,8 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
         bool changed = false;
         int target = own;
         if (half == 0 && valid) {
-            if (bs >= 0) {
-                changed = (bs != own);
-                target = bs;
-            } else {
-                // new label = smallest empty label once i is removed (mcmc.jl:199)
-                const int se = T.misc[1];
-                const int newlab = single ? min(T.label[own], se) : se;
-                changed = !(single && newlab == T.label[own]);
-                target = changed ? -1 : own;
-            }
+            target = (bs >= 0) ? bs : -1;      // -1: new cluster (label = smallest empty label once i is removed, mcmc.jl:199)
+            changed = (target != own);
         }
         if (mode == 0) {
             if (half == 0 && valid) {
@@ -1835,103 +1900,6 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
         }
     }
     __syncthreads();
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Commit of the first change (i*, own slot a, target) — executed identically by every block on its LDS
-// copy of the tables; each block then corrects S for the points it owns: the generation it is reading
-// (plain read-modify-write: nobody else touches those words) and the NEXT generation, which the
-// concurrently running k_bulk of the following sweep is filling from the pre-change labels (64-bit integer
-// atomics commute with k_bulk's, so the sum is exact whatever the interleaving).
-// Returns false on capacity overflow (flag set).  mcmc.jl:250-252 plus the findall bookkeeping.
-// ---------------------------------------------------------------------------------------------------
-__device__ bool commit_change(const View &V, const SweepArgs &sa, Tab &T, u64 key, int G, int own_gen, int next_gen)
-{
-    const int istar = (int)(key >> 32);
-    const int a = (int)((key >> 16) & 0xFFFFu);
-    const int tgt = (int)(key & 0xFFFFu) - 1;
-    int &sh_b = T.misc[3], &sh_struct = T.misc[4], &sh_fail = T.misc[5];
-    if (threadIdx.x == 0) {
-        sh_fail = 0;
-        int st = 0, b = tgt;
-        if (tgt >= 0) {
-            T.size[a] -= 1;
-            T.size[b] += 1;
-            if (T.size[a] == 0) {  // death
-                T.label[a] = 0;
-                T.misc[0] -= 1;
-                st = 1;
-            }
-        } else if (T.size[a] == 1) {  // singleton moves to a fresh (smaller) label: rename the slot, S column unchanged
-            T.label[a] = T.misc[1];
-            b = a;
-            st = 1;
-        } else {  // birth
-            int f = -1;
-            for (int k = 0; k < V.kcap; ++k)
-                if (T.label[k] == 0) { f = k; break; }
-            if (f < 0) {
-                sh_fail = 1;
-            } else {
-                b = f;
-                T.label[b] = T.misc[1];
-                T.size[b] = 1;
-                T.size[a] -= 1;
-                T.misc[0] += 1;
-                if (b + 1 > T.misc[7]) T.misc[7] = b + 1;
-                st = 1;
-            }
-        }
-        sh_b = b;
-        sh_struct = st;
-    }
-    __syncthreads();
-    if (sh_fail) {
-        if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(&V.sc->err, RC_DERR_CAPACITY);
-        return false;
-    }
-    const int b = sh_b;
-    if (sh_struct) {
-        tab_structural(V, T);
-        tab_bases(V, sa, T);
-    } else {
-        if (threadIdx.x < 2) {
-            const int k = threadIdx.x == 0 ? a : b;
-            const int s = T.size[k];
-            T.base_o[k] = tab_base(V, sa, s);
-            T.base_s[k] = (s >= 2) ? tab_base(V, sa, s - 1) : 0.0;
-        }
-        __syncthreads();
-    }
-    // S correction for the points this block owns: S[a][i] -= x[i*,i], S[b][i] += x[i*,i] (exact)
-    if (a != b) {
-        const int nchunks = (V.n + RC_PTS - 1) / RC_PTS;
-        const int pt = threadIdx.x & (RC_PTS - 1), job = threadIdx.x >> 5;  // jobs 0..3: (D,a) (D,b) (L,a) (L,b)
-        if (job < 4) {
-            const void *M = (job < 2) ? V.Dq : V.Lq;
-            long long *So = (job < 2) ? V.SD[own_gen] : V.SL[own_gen];
-            long long *Sn = (job < 2) ? V.SD[next_gen < 0 ? own_gen : next_gen] : V.SL[next_gen < 0 ? own_gen : next_gen];
-            const int slot = (job & 1) ? b : a;
-            const int ustar = V.pi[istar];
-            for (int c = blockIdx.x; c < nchunks; c += G) {
-                const int io = c * RC_PTS + pt;
-                if (io < V.n) {
-                    const int i = V.pi[io];
-                    const size_t e = (size_t)ustar * V.ld + i;
-                    long long x;
-                    if (job >= 2 && V.derived && !V.Lq) x = rc_load_L(V, ustar, i, ((const long long *)V.Dq)[e]);
-                    else x = (V.bits == 64) ? ((const long long *)M)[e] : (long long)((const int *)M)[e];
-                    const long long dx = (job & 1) ? x : -x;
-                    So[(size_t)slot * V.ld + i] += dx;
-                    if (next_gen >= 0)
-                        __hip_atomic_fetch_add((u64 *)(Sn + (size_t)slot * V.ld + i), (u64)dx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
-    }
-    if (threadIdx.x == 0) V.slot_of[V.pi[istar]] = b;  // same value from every block
-    __syncthreads();
-    return true;
 }
 
 // Grid barrier: monotonic arrival counter; lane 0 of each block arrives after its (returning) atomicMin
@@ -1964,13 +1932,96 @@ __device__ bool grid_barrier(const View &V, Tab &T, unsigned *arrive, unsigned t
     return sh_ok != 0;
 }
 
-// Commit of the first `nc` batch changers (all of them plain moves between existing clusters that stay non-empty):
-// sizes, per-slot constants, slot_of, and the S corrections for every point this block owns (both generations).
-__device__ void commit_batch(const View &V, const SweepArgs &sa, Tab &T, int nc, int G, int own_gen, int next_gen)
+// smallest label > lab (1-based) whose bit is clear in the occupancy bitset; n + 1 if none
+__device__ int next_empty_label(const Tab &T, int n, int lab)
 {
-    if (threadIdx.x == 0)
-        for (int q = 0; q < nc; ++q) { T.size[T.ba[q]] -= 1; T.size[T.bb[q]] += 1; }
+    const int nw = (n + 31) / 32;
+    int w = lab >> 5;                              // bit index of label lab+1 is lab
+    if (w >= nw) return n + 1;
+    unsigned inv = ~T.used[w] & ~((1u << (lab & 31)) - 1u);
+    while (!inv) {
+        if (++w >= nw) return n + 1;
+        inv = ~T.used[w];
+    }
+    const int r = w * 32 + __ffs((int)inv);       // 1-based label
+    return r <= n ? r : n + 1;
+}
+
+// What every changer of the batch does when the batch is applied in order (one thread; identical in every block): moves
+// between clusters, deaths, births (slot = next free slot of the committed table, label = smallest empty label at that
+// moment, mcmc.jl:199), singletons that take a smaller label or keep theirs.  Fills bb (real target slot), blab / bold /
+// bflag / bK, the list of births and the per-slot entry lists; the batch is cut before an entry whose target cluster an
+// earlier entry emptied (that point has to be drawn again) or that finds no free slot.  Sizes and the label bitset are
+// used in place and restored.  misc: [3] entries kept, [4] last point covered, [5] capacity failure, [8] births,
+// [9] entries that change something, [10] index of the first of them.
+__device__ void batch_sim(const View &V, Tab &T, int total)
+{
+    const int nb0 = min(total, RC_MAXB);
+    int K = T.misc[0], se = T.misc[1], fcur = 0, nbirth = 0, neff = 0, first_eff = -1;
+    int nb = nb0, hi = (total > RC_MAXB) ? T.misc[2] - 1 : V.n - 1, fail = 0;
+    for (int q = 0; q < nb0; ++q) {
+        const int a = T.ba[q], tgt = T.bb[q];
+        int b = tgt, flag = 0, lab = 0, old = 0;
+        if (tgt >= 0) {
+            if (T.size[tgt] == 0) { nb = q; hi = T.bx[q] - 1; break; }
+            if (T.size[a] == 1) { flag = RC_BF_DEATH; old = T.label[a]; K -= 1; }
+        } else if (T.size[a] == 1) {
+            b = a;
+            if (se < T.label[a]) { flag = RC_BF_RENAME; lab = se; old = T.label[a]; }
+            else flag = RC_BF_NOOP;
+        } else {
+            while (fcur < V.kcap && T.label[fcur] != 0) ++fcur;
+            if (fcur >= V.kcap) { fail = (q == 0); nb = q; hi = T.bx[q] - 1; break; }
+            b = fcur++; flag = RC_BF_BIRTH; lab = se; K += 1;
+        }
+        if (lab) T.used[(lab - 1) >> 5] |= 1u << ((lab - 1) & 31);
+        if (old) T.used[(old - 1) >> 5] &= ~(1u << ((old - 1) & 31));
+        if (lab) se = next_empty_label(T, V.n, lab);
+        else if (old && old < se) se = old;
+        if (a != b) { T.size[a] -= 1; T.size[b] += 1; }
+        T.bb[q] = (short)b; T.blab[q] = lab; T.bold[q] = old; T.bflag[q] = (unsigned char)flag; T.bK[q] = (short)K;
+        if (flag & RC_BF_BIRTH) T.birth[nbirth++] = (short)q;
+        if (!(flag & RC_BF_NOOP)) { if (first_eff < 0) first_eff = q; ++neff; }
+    }
+    // restore (reverse order: a label freed by one entry may have been taken by a later one) and thread the entry lists
+    for (int q = nb - 1; q >= 0; --q) {
+        const int a = T.ba[q], b = T.bb[q], lab = T.blab[q], old = T.bold[q];
+        if (a != b) { T.size[a] += 1; T.size[b] -= 1; }
+        if (lab) T.used[(lab - 1) >> 5] &= ~(1u << ((lab - 1) & 31));
+        if (old) T.used[(old - 1) >> 5] |= 1u << ((old - 1) & 31);
+        if (!(T.bflag[q] & RC_BF_NOOP)) {
+            T.nexta[q] = T.head[a]; T.head[a] = (short)q;
+            if (b != a) { T.nextb[q] = T.head[b]; T.head[b] = (short)q; }
+        }
+    }
+    T.misc[3] = nb; T.misc[4] = hi; T.misc[5] = fail; T.misc[8] = nbirth; T.misc[9] = neff; T.misc[10] = first_eff;
+}
+
+// Commit of the first `nc` batch changers: sizes, labels, cluster count, per-slot constants, slot_of, and the S
+// corrections S[a][i] -= x[i*,i], S[b][i] += x[i*,i] (exact) for every point this block owns, in the generation it is
+// reading (plain read-modify-write: nobody else touches those words) and in the NEXT generation, which the concurrently
+// running row reduction of the following sweep is filling from the pre-change labels (64-bit integer atomics commute
+// with its own, so the sum is exact whatever the interleaving).  A row of a cluster that dies ends as exact zeros, a
+// new cluster's row starts from zeros (invariant: rows of free slots are zero).  mcmc.jl:250-252 plus the bookkeeping.
+// Returns the number of label changes among the nc entries.
+__device__ int commit_batch(const View &V, const SweepArgs &sa, Tab &T, int nc, int G, int own_gen, int next_gen)
+{
+    if (threadIdx.x == 0) {
+        int structural = 0, hi = T.misc[7], eff = 0;
+        for (int q = 0; q < nc; ++q) {
+            const int a = T.ba[q], b = T.bb[q], flag = T.bflag[q];
+            if (a != b) { T.size[a] -= 1; T.size[b] += 1; }
+            if (flag & RC_BF_DEATH) T.label[a] = 0;
+            if (flag & RC_BF_BIRTH) { T.label[b] = T.blab[q]; if (b + 1 > hi) hi = b + 1; }
+            if (flag & RC_BF_RENAME) T.label[a] = T.blab[q];
+            structural |= flag & (RC_BF_DEATH | RC_BF_BIRTH | RC_BF_RENAME);
+            eff += !(flag & RC_BF_NOOP);
+        }
+        if (nc) T.misc[0] = T.bK[nc - 1];
+        T.misc[7] = hi; T.misc[11] = structural; T.misc[12] = eff;
+    }
     __syncthreads();
+    if (T.misc[11]) tab_structural(V, T);
     tab_bases(V, sa, T);
     const int nchunks = (V.n + RC_PTS - 1) / RC_PTS;
     const int pt = threadIdx.x & (RC_PTS - 1), st = threadIdx.x >> 5, NS = blockDim.x >> 5;
@@ -1985,6 +2036,7 @@ __device__ void commit_batch(const View &V, const SweepArgs &sa, Tab &T, int nc,
         // because the row reduction of the following sweep is adding to it concurrently.
         for (int q = 0; q < nc; ++q) {
             const int a = T.ba[q], b = T.bb[q];
+            if (a == b) continue;
             const bool da = (a % NS) == st, db = (b % NS) == st;
             if (!da && !db) continue;
             const size_t e = (size_t)T.bu[q] * V.ld + i;
@@ -2007,8 +2059,10 @@ __device__ void commit_batch(const View &V, const SweepArgs &sa, Tab &T, int nc,
             }
         }
     }
-    for (int q = threadIdx.x; q < nc; q += blockDim.x) V.slot_of[T.bu[q]] = T.bb[q];  // same values from every block
+    for (int q = threadIdx.x; q < nc; q += blockDim.x)
+        if (T.ba[q] != T.bb[q]) V.slot_of[T.bu[q]] = T.bb[q];  // same values from every block
     __syncthreads();
+    return T.misc[12];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2065,7 +2119,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
     RC_PF(ps[1] = __builtin_amdgcn_s_memrealtime();)
     const int nchunks = (V.n + RC_PTS - 1) / RC_PTS;
     int after = -1, round = 0, changes = 0, nbar = 0;
-    bool ok = true;
+    bool ok = true, used_ok = false;
     for (;;) {
         const unsigned stamp = (unsigned)round + 1u;
         // The announcements of a round (chunk words, changer records) live in the buffers of the round's PARITY: after a
@@ -2095,7 +2149,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
             T.ccnt[c] = cnt;
             any |= cnt;
         }
-        for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) T.affected[k] = 0;
+        for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) T.head[k] = -1;
         if (threadIdx.x == 0) T.misc[2] = 0;
         __syncthreads();
         if (any) T.misc[2] = 1;
@@ -2130,7 +2184,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
                     const int x = c * RC_PTS + bit;
                     if (o < RC_MAXB) {
                         const unsigned rc = __hip_atomic_load(rec + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        T.bx[o] = x; T.bu[o] = V.pi[x]; T.ba[o] = (int)(rc >> 16); T.bb[o] = (int)(rc & 0xFFFFu) - 1;
+                        T.bx[o] = x; T.bu[o] = V.pi[x]; T.ba[o] = (short)(rc >> 16); T.bb[o] = (short)((int)(rc & 0xFFFFu) - 1);
                     } else {
                         T.misc[2] = x;  // first changer that does not fit into the batch
                     }
@@ -2139,17 +2193,20 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
             }
         }
         __syncthreads();
-        // cut before the first structural changer (target = new cluster, or the source cluster would become empty)
-        if (threadIdx.x == 0) {
-            const int nb0 = min(total, RC_MAXB);
-            int nb = nb0, hi = (total > RC_MAXB) ? T.misc[2] - 1 : V.n - 1;
-            for (int q = 0; q < nb0; ++q) {
-                const int a = T.ba[q], b = T.bb[q];
-                if (b < 0 || T.size[a] <= 1) { nb = q; hi = T.bx[q] - 1; break; }
-                T.size[a] -= 1; T.size[b] += 1;  // simulated; undone below
+        // what every changer does when the batch is applied in order; the label bitset is needed for the labels of births
+        if (!used_ok) {
+            const int nw_ = (V.n + 31) / 32;
+            for (int w = threadIdx.x; w < nw_; w += blockDim.x) T.used[w] = 0u;
+            __syncthreads();
+            for (int k = threadIdx.x; k < T.misc[7]; k += blockDim.x) {
+                const int lab = T.label[k];
+                if (lab > 0) atomicOr(&T.used[(lab - 1) >> 5], 1u << ((lab - 1) & 31));
             }
-            for (int q = 0; q < nb; ++q) { T.size[T.ba[q]] += 1; T.size[T.bb[q]] -= 1; T.affected[T.ba[q]] = 1; T.affected[T.bb[q]] = 1; }
-            T.misc[3] = nb; T.misc[4] = hi;
+            used_ok = true;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            batch_sim(V, T, total);
             *T.blk_key = RC_KEY_NONE;
         }
         __syncthreads();
@@ -2158,23 +2215,24 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
 #ifdef RC_TRACE_RESOLVE   // diagnostic builds: per-round record of block RC_TRACE_BLOCK (default 0) behind the work counter
         if ((int)blockIdx.x == (sa.dbg >> 8) && threadIdx.x == 0 && round < 120) {   // kept in LDS until the sweep is over
             int *tr = (int *)(smem + tab_bytes_dev(V.kcap, V.n, blockDim.x >> 6)) + (size_t)round * 8;
-            tr[0] = round; tr[1] = total; tr[2] = nb; tr[3] = hi; tr[4] = T.bx[0]; tr[5] = after; tr[6] = T.ba[0]; tr[7] = T.bb[0];
+            tr[0] = round; tr[1] = total; tr[2] = nb; tr[3] = hi; tr[4] = T.bx[0]; tr[5] = after; tr[6] = T.misc[9]; tr[7] = T.misc[8];
         }
 #endif
-        if (nb == 0) {
-            // the first changer is structural: commit it alone (tables are rebuilt); its successors are re-drawn next round
-            const u64 key = ((u64)(unsigned)T.bx[0] << 32) | ((u64)(unsigned)T.ba[0] << 16) | (u64)(unsigned)(T.bb[0] + 1);
-            const int x0 = T.bx[0];
-            __syncthreads();
-            ok = commit_change(V, sa, T, key, G, own_gen, next_gen);
-            if (!ok) break;
-            after = x0;
-            ++round; ++changes;
+        if (T.misc[5]) {   // the first changer needs a slot and every slot is taken
+            if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(&V.sc->err, RC_DERR_CAPACITY);
+            ok = false;
+            break;
+        }
+        if (T.misc[9] == 0) {
+            // only singletons that drew "new cluster" and keep their labels: nothing to validate or commit
+            if (hi == V.n - 1) break;
+            after = hi;
+            ++round;
             if (round > V.n) break;
             continue;
         }
         // 3. validation of the points after the first changer, each under the changers that precede it
-        const int first = T.bx[0];
+        const int first = T.bx[T.misc[10]];   // the points up to the first effective changer saw no change at all
         for (int c = blockIdx.x; c < nchunks; c += G)
             if (c * RC_PTS + RC_PTS - 1 > first && c * RC_PTS <= hi) eval_chunk(V, sa, T, SD, SL, c, first, hi, 1, nb, cword, rec, stamp);
         __syncthreads();
@@ -2191,8 +2249,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
             while (lo_ < hi_) { const int mid = (lo_ + hi_) >> 1; if (T.bx[mid] < limit) lo_ = mid + 1; else hi_ = mid; }
             nc = lo_;
         }
-        commit_batch(V, sa, T, nc, G, own_gen, next_gen);
-        changes += nc;
+        changes += commit_batch(V, sa, T, nc, G, own_gen, next_gen);
         after = limit - 1;
         ++round;
         if (round > V.n) break;  // cannot happen: every round finalises at least the first changer

@@ -146,9 +146,10 @@ def point_scores(D, logD, clusts, sizes, P, r, p, i):
     return cands, logprobs
 
 
-def sample_logweights(logprobs, seed, sweep, i):
+def sample_logweights(logprobs, seed, sweep, i, keys):
+    """keys[k]: the uniform of candidate k is u(seed, sweep, i, keys[k]) — its cluster label, 0 for the new cluster."""
     lp = logprobs - logprobs.min()
-    g = np.array([-np.log(-np.log(uniform(seed, sweep, i, k))) for k in range(len(lp))])
+    g = np.array([-np.log(-np.log(uniform(seed, sweep, i, int(keys[k])))) for k in range(len(lp))])
     return int(np.argmax(g + lp))  # first maximum
 
 
@@ -157,7 +158,10 @@ def sweep(D, logD, clusts, sizes, P, r, p, seed, sweep_index):
     n = len(clusts)
     for i in range(n):
         cands, lp = point_scores(D, logD, clusts, sizes, P, r, p, i)
-        k = sample_logweights(lp, seed, sweep_index, i)
+        removed = sizes.copy()
+        removed[clusts[i] - 1] -= 1
+        keys = [c if removed[c - 1] > 0 else 0 for c in cands]   # the new-cluster candidate (last) has key 0
+        k = sample_logweights(lp, seed, sweep_index, i, keys)
         sizes[clusts[i] - 1] -= 1
         clusts[i] = cands[k]
         sizes[cands[k] - 1] += 1
