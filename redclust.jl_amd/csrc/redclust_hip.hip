@@ -1488,10 +1488,12 @@ struct Tab {
     short *ba, *bb;           // [RC_MAXB] source slot; target slot (after batch_sim: the slot it really goes to)
     int *blab, *bold;         // [RC_MAXB] label the entry takes (birth / rename) and label it frees (death / rename), 0 = none
     short *bK;                // [RC_MAXB] number of clusters after the entry
+    int *bse;                 // [RC_MAXB] smallest empty label after the entry
     unsigned char *bflag;     // [RC_MAXB] RC_BF_* bits
     short *birth;             // [RC_MAXB] the entries that create a cluster, ascending
-    short *nexta, *nextb;     // [RC_MAXB] next entry (ascending) that touches the same source / target slot, -1 = none
-    short *head;              // [kcap] first entry that touches the slot, -1 = none
+    short *nexta, *nextb;     // [RC_MAXB] previous entry that touches the same source / target slot, -1 = none
+    short *head;              // [kcap] last entry that touches the slot, -1 = none
+    unsigned char *joined;    // [kcap] some entry of the batch moves a point INTO the slot
     int *ccnt;                // [nchunks + 1] scratch: changers per chunk / exclusive offsets
 };
 #define RC_BF_DEATH 1   // the source cluster becomes empty
@@ -1500,7 +1502,7 @@ struct Tab {
 #define RC_BF_NOOP 8    // a singleton that draws "new cluster" and keeps its label: nothing changes
 
 #define RC_A16(x) (((x) + 15) & ~(size_t)15)
-#define RC_TAB_NOFF 26
+#define RC_TAB_NOFF 28
 __host__ __device__ inline size_t tab_layout(int kcap, int n, int nw, size_t *off /*RC_TAB_NOFF*/)
 {
     size_t o = 0;
@@ -1529,7 +1531,9 @@ __host__ __device__ inline size_t tab_layout(int kcap, int n, int nw, size_t *of
     off[22] = o; o = RC_A16(o + sizeof(short) * RC_MAXB);       // birth
     off[23] = o; o = RC_A16(o + sizeof(short) * RC_MAXB);       // nexta
     off[24] = o; o = RC_A16(o + sizeof(short) * RC_MAXB);       // nextb
-    off[25] = o;
+    off[25] = o; o = RC_A16(o + sizeof(int) * RC_MAXB);         // bse
+    off[26] = o; o = RC_A16(o + (size_t)kcap);                  // joined
+    off[27] = o;
     return o;
 }
 
@@ -1546,7 +1550,8 @@ __device__ Tab tab_carve(char *smem, int kcap, int n, int nw)
     T.head = (short *)(smem + off[15]); T.ccnt = (int *)(smem + off[16]); T.bu = (int *)(smem + off[17]);
     T.blab = (int *)(smem + off[18]); T.bold = (int *)(smem + off[19]); T.bK = (short *)(smem + off[20]);
     T.bflag = (unsigned char *)(smem + off[21]); T.birth = (short *)(smem + off[22]);
-    T.nexta = (short *)(smem + off[23]); T.nextb = (short *)(smem + off[24]);
+    T.nexta = (short *)(smem + off[23]); T.nextb = (short *)(smem + off[24]); T.bse = (int *)(smem + off[25]);
+    T.joined = (unsigned char *)(smem + off[26]);
     return T;
 }
 
@@ -1792,7 +1797,7 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
         }
         int so = T.size[own];
         if (mode == 1)
-            for (int q = T.head[own]; q >= 0 && q < j; q = batch_next(T, q, own)) so += (T.bb[q] == own) - (T.ba[q] == own);
+            for (int q = T.head[own]; q >= 0; q = batch_next(T, q, own)) if (q < j) so += (T.bb[q] == own) - (T.ba[q] == own);
         const int single = (so == 1);
         const int Ki = ((mode == 1 && j > 0) ? (int)T.bK[j - 1] : K) - single;
         const long long dg = V.diagq[u];
@@ -1803,7 +1808,8 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
             long long sd = SD[(size_t)k * ld + u], sl = SL[(size_t)k * ld + u];
             bool touched = false;
             if (mode == 1) {
-                for (int q = T.head[k]; q >= 0 && q < j; q = batch_next(T, q, k)) {
+                for (int q = T.head[k]; q >= 0; q = batch_next(T, q, k)) {   // newest first
+                    if (q >= j) continue;
                     const int qa = T.ba[q], qb = T.bb[q];
                     if (qa != qb) {
                         const size_t e = (size_t)T.bu[q] * ld + u;
@@ -1882,7 +1888,11 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
         bool changed = false;
         int target = own;
         if (half == 0 && valid) {
-            target = (bs >= 0) ? bs : -1;      // -1: new cluster (label = smallest empty label once i is removed, mcmc.jl:199)
+            // -1: new cluster, label = smallest empty label once i is removed (mcmc.jl:199).  A singleton that draws "new
+            // cluster" gets min(its own label, smallest empty label) — often its own label, i.e. no change at all; it is
+            // announced as a changer all the same and batch_sim decides (deciding here, under the labels free at this
+            // point's turn, makes every such singleton after a death a violation: 4 -> 14 rounds per sweep measured).
+            target = (bs >= 0) ? bs : -1;
             changed = (target != own);
         }
         if (mode == 0) {
@@ -1947,54 +1957,94 @@ __device__ int next_empty_label(const Tab &T, int n, int lab)
     return r <= n ? r : n + 1;
 }
 
-// What every changer of the batch does when the batch is applied in order (one thread; identical in every block): moves
-// between clusters, deaths, births (slot = next free slot of the committed table, label = smallest empty label at that
-// moment, mcmc.jl:199), singletons that take a smaller label or keep theirs.  Fills bb (real target slot), blab / bold /
-// bflag / bK, the list of births and the per-slot entry lists; the batch is cut before an entry whose target cluster an
-// earlier entry emptied (that point has to be drawn again) or that finds no free slot.  Sizes and the label bitset are
-// used in place and restored.  misc: [3] entries kept, [4] last point covered, [5] capacity failure, [8] births,
-// [9] entries that change something, [10] index of the first of them.
+// What every changer of the batch does when the batch is applied in order (identical in every block): moves between
+// clusters, deaths, births (slot = next free slot of the committed table, label = smallest empty label at that moment,
+// mcmc.jl:199), singletons that take a smaller label or keep theirs.  Fills bb (real target slot), blab / bold / bflag /
+// bK / bse, the list of births and the per-slot entry lists (newest entry first); the batch is cut before an entry whose
+// target cluster an earlier entry emptied (that point has to be drawn again) or that finds no free slot.
+// Run by wave 0 with all lanes in step: 64 entries at a time are fetched lane-parallel (source, target, the source's
+// label) and then applied one after the other from registers, so that an entry costs one LDS round trip (the current sizes
+// and list heads of its two slots) instead of the ten of a plain one-thread loop (60 -> 12 µs for 165 entries).
+// T.size is used in place (the caller restores it from the entries), T.used is scratch (the caller builds it).
+// misc: [3] entries kept, [4] last point covered, [5] capacity failure, [8] births, [9] entries that change something,
+// [10] index of the first of them.
 __device__ void batch_sim(const View &V, Tab &T, int total)
 {
+    const int lane = threadIdx.x & 63;
     const int nb0 = min(total, RC_MAXB);
     int K = T.misc[0], se = T.misc[1], fcur = 0, nbirth = 0, neff = 0, first_eff = -1;
     int nb = nb0, hi = (total > RC_MAXB) ? T.misc[2] - 1 : V.n - 1, fail = 0;
-    for (int q = 0; q < nb0; ++q) {
-        const int a = T.ba[q], tgt = T.bb[q];
-        int b = tgt, flag = 0, lab = 0, old = 0;
-        if (tgt >= 0) {
-            if (T.size[tgt] == 0) { nb = q; hi = T.bx[q] - 1; break; }
-            if (T.size[a] == 1) { flag = RC_BF_DEATH; old = T.label[a]; K -= 1; }
-        } else if (T.size[a] == 1) {
-            b = a;
-            if (se < T.label[a]) { flag = RC_BF_RENAME; lab = se; old = T.label[a]; }
-            else flag = RC_BF_NOOP;
-        } else {
-            while (fcur < V.kcap && T.label[fcur] != 0) ++fcur;
-            if (fcur >= V.kcap) { fail = (q == 0); nb = q; hi = T.bx[q] - 1; break; }
-            b = fcur++; flag = RC_BF_BIRTH; lab = se; K += 1;
+    bool stop = false;
+    for (int q0 = 0; q0 < nb0 && !stop; q0 += 64) {
+        int va = 0, vt = -1, vla = 0;
+        bool vfast = false;
+        if (q0 + lane < nb0) {
+            va = T.ba[q0 + lane]; vt = T.bb[q0 + lane]; vla = T.label[va];
+            // a singleton nobody in the batch joins, drawing "new cluster": alone at its turn whatever happened before
+            vfast = vt < 0 && T.size[va] == 1 && !T.joined[va];
         }
-        if (lab) T.used[(lab - 1) >> 5] |= 1u << ((lab - 1) & 31);
-        if (old) T.used[(old - 1) >> 5] &= ~(1u << ((old - 1) & 31));
-        if (lab) se = next_empty_label(T, V.n, lab);
-        else if (old && old < se) se = old;
-        if (a != b) { T.size[a] -= 1; T.size[b] += 1; }
-        T.bb[q] = (short)b; T.blab[q] = lab; T.bold[q] = old; T.bflag[q] = (unsigned char)flag; T.bK[q] = (short)K;
-        if (flag & RC_BF_BIRTH) T.birth[nbirth++] = (short)q;
-        if (!(flag & RC_BF_NOOP)) { if (first_eff < 0) first_eff = q; ++neff; }
-    }
-    // restore (reverse order: a label freed by one entry may have been taken by a later one) and thread the entry lists
-    for (int q = nb - 1; q >= 0; --q) {
-        const int a = T.ba[q], b = T.bb[q], lab = T.blab[q], old = T.bold[q];
-        if (a != b) { T.size[a] += 1; T.size[b] -= 1; }
-        if (lab) T.used[(lab - 1) >> 5] &= ~(1u << ((lab - 1) & 31));
-        if (old) T.used[(old - 1) >> 5] |= 1u << ((old - 1) & 31);
-        if (!(T.bflag[q] & RC_BF_NOOP)) {
-            T.nexta[q] = T.head[a]; T.head[a] = (short)q;
-            if (b != a) { T.nextb[q] = T.head[b]; T.head[b] = (short)q; }
+        const u64 fastmask = __ballot(vfast);
+        int ob = 0, olab = 0, oold = 0, oflag = 0, oK = 0, ose = 0;   // results of entry q0 + lane (stored after the chunk)
+        const int cnt = min(64, nb0 - q0);
+        int done = cnt;
+        for (int e = 0; e < cnt; ++e) {
+            const int q = q0 + e;
+            const int a = __builtin_amdgcn_readlane(va, e), la = __builtin_amdgcn_readlane(vla, e);
+            int b, flag = 0, lab = 0, old = 0;
+            if (((fastmask >> e) & 1) && se >= la) {
+                b = a; flag = RC_BF_NOOP;                               // keeps its label: registers only
+            } else {
+                const int tgt = __builtin_amdgcn_readlane(vt, e);
+                const int sza = T.size[a], szt = T.size[tgt >= 0 ? tgt : a];
+                const int hda = T.head[a], hdt = T.head[tgt >= 0 ? tgt : a];
+                int hdb = hdt;
+                b = tgt;
+                if (tgt >= 0) {
+                    if (szt == 0) { nb = q; hi = T.bx[q] - 1; stop = true; done = e; break; }
+                    if (sza == 1) { flag = RC_BF_DEATH; old = la; K -= 1; }
+                } else if (sza == 1) {
+                    b = a;
+                    if (se < la) { flag = RC_BF_RENAME; lab = se; old = la; }
+                    else flag = RC_BF_NOOP;
+                } else {
+                    // next free slot of the committed table, 64 slots per step
+                    int f = -1;
+                    while (fcur < V.kcap) {
+                        const int k = fcur + lane;
+                        const u64 fr = __ballot(k < V.kcap && T.label[k] == 0);
+                        if (fr) { f = fcur + __ffsll((long long)fr) - 1; break; }
+                        fcur += 64;
+                    }
+                    if (f < 0) { fail = (q == 0); nb = q; hi = T.bx[q] - 1; stop = true; done = e; break; }
+                    fcur = f + 1;   // (a partial step is re-read from f + 1 on: harmless)
+                    b = f; flag = RC_BF_BIRTH; lab = se; K += 1; hdb = -1;
+                }
+                // (one lane writes: 64 lanes storing to one LDS address are serialised)
+                if (lane == 0) {
+                    if (lab) T.used[(lab - 1) >> 5] |= 1u << ((lab - 1) & 31);
+                    if (old) T.used[(old - 1) >> 5] &= ~(1u << ((old - 1) & 31));
+                }
+                if (lab) se = next_empty_label(T, V.n, lab);
+                else if (old && old < se) se = old;
+                if (lane == 0) {
+                    if (a != b) { T.size[a] = sza - 1; T.size[b] = ((flag & RC_BF_BIRTH) ? 0 : szt) + 1; }
+                    if (flag & RC_BF_BIRTH) T.birth[nbirth] = (short)q;
+                    if (!(flag & RC_BF_NOOP)) {
+                        T.nexta[q] = (short)hda; T.head[a] = (short)q;
+                        if (b != a) { T.nextb[q] = (short)hdb; T.head[b] = (short)q; }
+                    }
+                }
+                if (flag & RC_BF_BIRTH) ++nbirth;
+                if (!(flag & RC_BF_NOOP)) { if (first_eff < 0) first_eff = q; ++neff; }
+            }
+            if (lane == e) { ob = b; olab = lab; oold = old; oflag = flag; oK = K; ose = se; }
+        }
+        if (lane < done) {
+            const int q = q0 + lane;
+            T.bb[q] = (short)ob; T.blab[q] = olab; T.bold[q] = oold; T.bflag[q] = (unsigned char)oflag; T.bK[q] = (short)oK; T.bse[q] = ose;
         }
     }
-    T.misc[3] = nb; T.misc[4] = hi; T.misc[5] = fail; T.misc[8] = nbirth; T.misc[9] = neff; T.misc[10] = first_eff;
+    if (lane == 0) { T.misc[3] = nb; T.misc[4] = hi; T.misc[5] = fail; T.misc[8] = nbirth; T.misc[9] = neff; T.misc[10] = first_eff; }
 }
 
 // Commit of the first `nc` batch changers: sizes, labels, cluster count, per-slot constants, slot_of, and the S
@@ -2006,19 +2056,18 @@ __device__ void batch_sim(const View &V, Tab &T, int total)
 // Returns the number of label changes among the nc entries.
 __device__ int commit_batch(const View &V, const SweepArgs &sa, Tab &T, int nc, int G, int own_gen, int next_gen)
 {
-    if (threadIdx.x == 0) {
-        int structural = 0, hi = T.misc[7], eff = 0;
-        for (int q = 0; q < nc; ++q) {
-            const int a = T.ba[q], b = T.bb[q], flag = T.bflag[q];
-            if (a != b) { T.size[a] -= 1; T.size[b] += 1; }
-            if (flag & RC_BF_DEATH) T.label[a] = 0;
-            if (flag & RC_BF_BIRTH) { T.label[b] = T.blab[q]; if (b + 1 > hi) hi = b + 1; }
-            if (flag & RC_BF_RENAME) T.label[a] = T.blab[q];
-            structural |= flag & (RC_BF_DEATH | RC_BF_BIRTH | RC_BF_RENAME);
-            eff += !(flag & RC_BF_NOOP);
-        }
-        if (nc) T.misc[0] = T.bK[nc - 1];
-        T.misc[7] = hi; T.misc[11] = structural; T.misc[12] = eff;
+    if (threadIdx.x == 0) { T.misc[11] = 0; T.misc[12] = 0; if (nc) T.misc[0] = T.bK[nc - 1]; }
+    __syncthreads();
+    // one thread per entry: a slot's label is written by at most one entry of a batch (a cluster dies, is born or is
+    // relabelled at most once), sizes by LDS atomics
+    for (int q = threadIdx.x; q < nc; q += blockDim.x) {
+        const int a = T.ba[q], b = T.bb[q], flag = T.bflag[q];
+        if (a != b) { atomicSub(&T.size[a], 1); atomicAdd(&T.size[b], 1); }
+        if (flag & RC_BF_DEATH) T.label[a] = 0;
+        if (flag & RC_BF_BIRTH) { T.label[b] = T.blab[q]; atomicMax(&T.misc[7], b + 1); }
+        if (flag & RC_BF_RENAME) T.label[a] = T.blab[q];
+        if (flag & (RC_BF_DEATH | RC_BF_BIRTH | RC_BF_RENAME)) T.misc[11] = 1;
+        if (!(flag & RC_BF_NOOP)) atomicAdd(&T.misc[12], 1);
     }
     __syncthreads();
     if (T.misc[11]) tab_structural(V, T);
@@ -2107,7 +2156,8 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
 #ifndef RC_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);
 #endif
-    RC_PF(long long ps[8]; ps[0] = __builtin_amdgcn_s_memrealtime();)
+    RC_PF(long long ps[16]; for (int q_ = 0; q_ < 16; ++q_) ps[q_] = 0; ps[0] = __builtin_amdgcn_s_memrealtime(); long long pt_ = ps[0];)
+#define RC_PHASE(k) RC_PF({ const long long now_ = __builtin_amdgcn_s_memrealtime(); ps[k] += now_ - pt_; pt_ = now_; })
     Tab T = tab_carve(smem, V.kcap, V.n, blockDim.x >> 6);
     const int t = sa.t, own_gen = sa.own_gen, next_gen = sa.next_gen, kg = t & 1;
     const long long *SD = V.SD[own_gen], *SL = V.SL[own_gen];
@@ -2119,7 +2169,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
     RC_PF(ps[1] = __builtin_amdgcn_s_memrealtime();)
     const int nchunks = (V.n + RC_PTS - 1) / RC_PTS;
     int after = -1, round = 0, changes = 0, nbar = 0;
-    bool ok = true, used_ok = false;
+    bool ok = true;
     for (;;) {
         const unsigned stamp = (unsigned)round + 1u;
         // The announcements of a round (chunk words, changer records) live in the buffers of the round's PARITY: after a
@@ -2129,13 +2179,16 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         u64 *const cword = cword_gen + (size_t)(round & 1) * (size_t)(nchunks + 1);
         unsigned *const rec = V.rec + (size_t)(round & 1) * (size_t)V.n;
         RC_CHAOS_AT(0);
+        RC_PF(pt_ = __builtin_amdgcn_s_memrealtime(); ps[13] += 1;)
         // 1. tentative decisions of the points after `after`
         for (int c = blockIdx.x; c < nchunks; c += G)
             if (c * RC_PTS + RC_PTS - 1 > after) eval_chunk(V, sa, T, SD, SL, c, after, V.n, 0, 0, cword, rec, stamp);
         if (sa.dbg & 2) break;
+        RC_PHASE(6)
         RC_PF(if (round == 0) ps[2] = __builtin_amdgcn_s_memrealtime();)
         ok = grid_barrier(V, T, arrive, (unsigned)G * (unsigned)(++nbar), RC_KEY_NONE, keys + round);
         RC_PF(if (round == 0) ps[3] = __builtin_amdgcn_s_memrealtime();)
+        RC_PHASE(7)
         if (!ok) break;
         RC_CHAOS_AT(1);
         // 2. the ordered batch of tentative changers
@@ -2149,7 +2202,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
             T.ccnt[c] = cnt;
             any |= cnt;
         }
-        for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) T.head[k] = -1;
+        for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) { T.head[k] = -1; T.joined[k] = 0; }
         if (threadIdx.x == 0) T.misc[2] = 0;
         __syncthreads();
         if (any) T.misc[2] = 1;
@@ -2185,6 +2238,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
                     if (o < RC_MAXB) {
                         const unsigned rc = __hip_atomic_load(rec + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         T.bx[o] = x; T.bu[o] = V.pi[x]; T.ba[o] = (short)(rc >> 16); T.bb[o] = (short)((int)(rc & 0xFFFFu) - 1);
+                        if (rc & 0xFFFFu) T.joined[(rc & 0xFFFFu) - 1] = 1;
                     } else {
                         T.misc[2] = x;  // first changer that does not fit into the batch
                     }
@@ -2193,8 +2247,9 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
             }
         }
         __syncthreads();
-        // what every changer does when the batch is applied in order; the label bitset is needed for the labels of births
-        if (!used_ok) {
+        // what every changer does when the batch is applied in order.  The label bitset (for the labels of births) is
+        // scratch of batch_sim: rebuilt from the committed labels every time
+        {
             const int nw_ = (V.n + 31) / 32;
             for (int w = threadIdx.x; w < nw_; w += blockDim.x) T.used[w] = 0u;
             __syncthreads();
@@ -2202,15 +2257,20 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
                 const int lab = T.label[k];
                 if (lab > 0) atomicOr(&T.used[(lab - 1) >> 5], 1u << ((lab - 1) & 31));
             }
-            used_ok = true;
             __syncthreads();
         }
-        if (threadIdx.x == 0) {
-            batch_sim(V, T, total);
-            *T.blk_key = RC_KEY_NONE;
+        RC_PHASE(8)
+        if (threadIdx.x < 64) batch_sim(V, T, total);
+        if (threadIdx.x == 0) *T.blk_key = RC_KEY_NONE;
+        __syncthreads();
+        // the simulated sizes back to the committed ones
+        for (int q = threadIdx.x; q < T.misc[3]; q += blockDim.x) {
+            const int a_ = T.ba[q], b_ = T.bb[q];
+            if (a_ != b_) { atomicAdd(&T.size[a_], 1); atomicSub(&T.size[b_], 1); }
         }
         __syncthreads();
         const int nb = T.misc[3], hi = T.misc[4];
+        RC_PHASE(9)
         RC_CHAOS_AT(2);
 #ifdef RC_TRACE_RESOLVE   // diagnostic builds: per-round record of block RC_TRACE_BLOCK (default 0) behind the work counter
         if ((int)blockIdx.x == (sa.dbg >> 8) && threadIdx.x == 0 && round < 120) {   // kept in LDS until the sweep is over
@@ -2236,8 +2296,10 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         for (int c = blockIdx.x; c < nchunks; c += G)
             if (c * RC_PTS + RC_PTS - 1 > first && c * RC_PTS <= hi) eval_chunk(V, sa, T, SD, SL, c, first, hi, 1, nb, cword, rec, stamp);
         __syncthreads();
+        RC_PHASE(10)
         const u64 mine = *T.blk_key;
         ok = grid_barrier(V, T, arrive, (unsigned)G * (unsigned)(++nbar), mine, keys + round);
+        RC_PHASE(11)
         if (!ok) break;
         RC_CHAOS_AT(3);
         // 4. commit the changers before the first violation
@@ -2250,6 +2312,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
             nc = lo_;
         }
         changes += commit_batch(V, sa, T, nc, G, own_gen, next_gen);
+        RC_PHASE(12)
         after = limit - 1;
         ++round;
         if (round > V.n) break;  // cannot happen: every round finalises at least the first changer
@@ -2305,7 +2368,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         }
     }
     RC_PF(if (threadIdx.x == 0 && blockIdx.x < 256) { long long *o = (long long *)((char *)V.work[kg] + 64) + (size_t)(8192 - 256 + blockIdx.x) * 16;
-                                                       ps[5] = __builtin_amdgcn_s_memrealtime(); for (int q = 0; q < 6; ++q) o[q] = ps[q]; })
+                                                       ps[5] = __builtin_amdgcn_s_memrealtime(); for (int q = 0; q < 16; ++q) o[q] = ps[q]; })
 }
 
 // 128 VGPRs (four waves per SIMD): a 256-thread resolver block — one wave per SIMD — then fits on a CU beside THREE blocks

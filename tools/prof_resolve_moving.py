@@ -1,0 +1,31 @@
+"""Per-phase time of k_resolve summed over the rounds of a sweep, moving regime (profiling build -DRC_PROF_SYML):
+RC_LIB_PATH=build_exp/lib_prof.so python3 tools/prof_resolve_moving.py [sigma] [kcap] [incremental]"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import redclust_amd as rc
+n, K = 8192, 50
+sig = float(sys.argv[1]) if len(sys.argv) > 1 else 0.2
+kcap = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+inc = len(sys.argv) > 3 and sys.argv[3] == "incremental"
+d = rc.generatemixture(n, K, seed=2, sigma=sig); D, truth = d["distancematrix"], d["clusts"]
+P = rc.likelihood_hyperparams(D, truth)
+ctx = rc.Context(D, kcap=kcap); ctx.set_params(**P); ctx.set_state(truth)
+if inc: ctx.set_mode("incremental")
+for t in range(60): ctx.gibbs_sweep(1.0, 0.5, 7, t, blocking=False)
+ctx.synchronize()
+L = rc.lib()
+out = np.zeros((8192, 16), np.int64)
+L.rc_debug_prof.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+names = {6: "eval tentative", 7: "barrier 1", 8: "assemble batch", 9: "batch_sim", 10: "eval validate", 11: "barrier 2", 12: "commit"}
+acc = {k: [] for k in names}; mx = {k: [] for k in names}; mn = {k: [] for k in names}; rounds = []; tot = []
+for t in range(60, 80):
+    ctx.gibbs_sweep(1.0, 0.5, 7, t, blocking=True)
+    st = ctx.sweep_stats()
+    L.rc_debug_prof(ctx.h, t & 1, out.ctypes.data_as(C.c_void_p))
+    o = out[8192 - 256:, :].astype(np.float64) / 100.0
+    o = o[o[:, 0] > 0]
+    for k in names: acc[k].append(np.median(o[:, k])); mx[k].append(o[:, k].max()); mn[k].append(o[:, k].min())
+    rounds.append(st["n_rounds"]); tot.append(np.median(o[:, 4] - o[:, 0]))
+print(f"sigma {sig} kcap {kcap} K {st['K']} rounds/sweep {np.mean(rounds):.1f}  loop total {np.mean(tot):.1f} us (median block)")
+for k, nm in names.items(): print(f"   {nm:16s} {np.mean(acc[k]):8.1f} us per sweep   {np.mean(acc[k]) / np.mean(rounds):7.1f} per round   (blocks: min {np.mean(mn[k]):7.1f} max {np.mean(mx[k]):7.1f} per sweep)")
