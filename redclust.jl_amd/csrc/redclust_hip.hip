@@ -1491,8 +1491,8 @@ struct Tab {
     int *bse;                 // [RC_MAXB] smallest empty label after the entry
     unsigned char *bflag;     // [RC_MAXB] RC_BF_* bits
     short *birth;             // [RC_MAXB] the entries that create a cluster, ascending
-    short *nexta, *nextb;     // [RC_MAXB] previous entry that touches the same source / target slot, -1 = none
-    short *head;              // [kcap] last entry that touches the slot, -1 = none
+    short *nexta, *nextb;     // [RC_MAXB] next entry (ascending) that touches the same source / target slot, -1 = none
+    short *head;              // [kcap] first entry that touches the slot, -1 = none
     unsigned char *joined;    // [kcap] some entry of the batch moves a point INTO the slot
     int *ccnt;                // [nchunks + 1] scratch: changers per chunk / exclusive offsets
 };
@@ -1797,7 +1797,7 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
         }
         int so = T.size[own];
         if (mode == 1)
-            for (int q = T.head[own]; q >= 0; q = batch_next(T, q, own)) if (q < j) so += (T.bb[q] == own) - (T.ba[q] == own);
+            for (int q = T.head[own]; q >= 0 && q < j; q = batch_next(T, q, own)) so += (T.bb[q] == own) - (T.ba[q] == own);
         const int single = (so == 1);
         const int Ki = ((mode == 1 && j > 0) ? (int)T.bK[j - 1] : K) - single;
         const long long dg = V.diagq[u];
@@ -1808,8 +1808,7 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
             long long sd = SD[(size_t)k * ld + u], sl = SL[(size_t)k * ld + u];
             bool touched = false;
             if (mode == 1) {
-                for (int q = T.head[k]; q >= 0; q = batch_next(T, q, k)) {   // newest first
-                    if (q >= j) continue;
+                for (int q = T.head[k]; q >= 0 && q < j; q = batch_next(T, q, k)) {
                     const int qa = T.ba[q], qb = T.bb[q];
                     if (qa != qb) {
                         const size_t e = (size_t)T.bu[q] * ld + u;
@@ -1968,12 +1967,12 @@ __device__ int next_empty_label(const Tab &T, int n, int lab)
 // T.size is used in place (the caller restores it from the entries), T.used is scratch (the caller builds it).
 // misc: [3] entries kept, [4] last point covered, [5] capacity failure, [8] births, [9] entries that change something,
 // [10] index of the first of them.
-__device__ void batch_sim(const View &V, Tab &T, int total)
+__device__ void batch_sim(const View &V, Tab &T, int total, int cap)
 {
     const int lane = threadIdx.x & 63;
-    const int nb0 = min(total, RC_MAXB);
+    const int nb0 = min(total, cap);
     int K = T.misc[0], se = T.misc[1], fcur = 0, nbirth = 0, neff = 0, first_eff = -1;
-    int nb = nb0, hi = (total > RC_MAXB) ? T.misc[2] - 1 : V.n - 1, fail = 0;
+    int nb = nb0, hi = (total > cap) ? T.misc[2] - 1 : V.n - 1, fail = 0;
     bool stop = false;
     for (int q0 = 0; q0 < nb0 && !stop; q0 += 64) {
         int va = 0, vt = -1, vla = 0;
@@ -1996,8 +1995,6 @@ __device__ void batch_sim(const View &V, Tab &T, int total)
             } else {
                 const int tgt = __builtin_amdgcn_readlane(vt, e);
                 const int sza = T.size[a], szt = T.size[tgt >= 0 ? tgt : a];
-                const int hda = T.head[a], hdt = T.head[tgt >= 0 ? tgt : a];
-                int hdb = hdt;
                 b = tgt;
                 if (tgt >= 0) {
                     if (szt == 0) { nb = q; hi = T.bx[q] - 1; stop = true; done = e; break; }
@@ -2017,7 +2014,7 @@ __device__ void batch_sim(const View &V, Tab &T, int total)
                     }
                     if (f < 0) { fail = (q == 0); nb = q; hi = T.bx[q] - 1; stop = true; done = e; break; }
                     fcur = f + 1;   // (a partial step is re-read from f + 1 on: harmless)
-                    b = f; flag = RC_BF_BIRTH; lab = se; K += 1; hdb = -1;
+                    b = f; flag = RC_BF_BIRTH; lab = se; K += 1;
                 }
                 // (one lane writes: 64 lanes storing to one LDS address are serialised)
                 if (lane == 0) {
@@ -2029,10 +2026,6 @@ __device__ void batch_sim(const View &V, Tab &T, int total)
                 if (lane == 0) {
                     if (a != b) { T.size[a] = sza - 1; T.size[b] = ((flag & RC_BF_BIRTH) ? 0 : szt) + 1; }
                     if (flag & RC_BF_BIRTH) T.birth[nbirth] = (short)q;
-                    if (!(flag & RC_BF_NOOP)) {
-                        T.nexta[q] = (short)hda; T.head[a] = (short)q;
-                        if (b != a) { T.nextb[q] = (short)hdb; T.head[b] = (short)q; }
-                    }
                 }
                 if (flag & RC_BF_BIRTH) ++nbirth;
                 if (!(flag & RC_BF_NOOP)) { if (first_eff < 0) first_eff = q; ++neff; }
@@ -2042,6 +2035,23 @@ __device__ void batch_sim(const View &V, Tab &T, int total)
         if (lane < done) {
             const int q = q0 + lane;
             T.bb[q] = (short)ob; T.blab[q] = olab; T.bold[q] = oold; T.bflag[q] = (unsigned char)oflag; T.bK[q] = (short)oK; T.bse[q] = ose;
+        }
+    }
+    // per-slot lists of the entries that change something, ascending (threaded back to front)
+    for (int q1 = ((nb + 63) & ~63); q1 > 0; q1 -= 64) {
+        const int q0 = q1 - 64;
+        int va = 0, vb = 0, vf = RC_BF_NOOP;
+        if (q0 + lane < nb) { va = T.ba[q0 + lane]; vb = T.bb[q0 + lane]; vf = T.bflag[q0 + lane]; }
+        u64 todo = __ballot(!(vf & RC_BF_NOOP));
+        while (todo) {
+            const int e = 63 - __clzll((long long)todo);
+            todo &= ~(1ull << e);
+            const int a = __builtin_amdgcn_readlane(va, e), b = __builtin_amdgcn_readlane(vb, e), q = q0 + e;
+            const int hda = T.head[a], hdb = T.head[b];
+            if (lane == 0) {
+                T.nexta[q] = (short)hda; T.head[a] = (short)q;
+                if (b != a) { T.nextb[q] = (short)hdb; T.head[b] = (short)q; }
+            }
         }
     }
     if (lane == 0) { T.misc[3] = nb; T.misc[4] = hi; T.misc[5] = fail; T.misc[8] = nbirth; T.misc[9] = neff; T.misc[10] = first_eff; }
@@ -2169,6 +2179,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
     RC_PF(ps[1] = __builtin_amdgcn_s_memrealtime();)
     const int nchunks = (V.n + RC_PTS - 1) / RC_PTS;
     int after = -1, round = 0, changes = 0, nbar = 0;
+    int cap = RC_MAXB;   // changers taken into the next batch (adaptive, identical in every block)
     bool ok = true;
     for (;;) {
         const unsigned stamp = (unsigned)round + 1u;
@@ -2229,13 +2240,13 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         const int total = T.ccnt[nchunks];
         for (int c = threadIdx.x; c < nchunks; c += blockDim.x) {
             int o = T.ccnt[c];
-            if (T.ccnt[c + 1] > o && o < RC_MAXB + 1) {
+            if (T.ccnt[c + 1] > o && o < cap + 1) {
                 unsigned m = (unsigned)__hip_atomic_load(cword + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                while (m && o <= RC_MAXB) {
+                while (m && o <= cap) {
                     const int bit = __ffs((int)m) - 1;
                     m &= m - 1;
                     const int x = c * RC_PTS + bit;
-                    if (o < RC_MAXB) {
+                    if (o < cap) {
                         const unsigned rc = __hip_atomic_load(rec + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         T.bx[o] = x; T.bu[o] = V.pi[x]; T.ba[o] = (short)(rc >> 16); T.bb[o] = (short)((int)(rc & 0xFFFFu) - 1);
                         if (rc & 0xFFFFu) T.joined[(rc & 0xFFFFu) - 1] = 1;
@@ -2260,7 +2271,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
             __syncthreads();
         }
         RC_PHASE(8)
-        if (threadIdx.x < 64) batch_sim(V, T, total);
+        if (threadIdx.x < 64) batch_sim(V, T, total, cap);
         if (threadIdx.x == 0) *T.blk_key = RC_KEY_NONE;
         __syncthreads();
         // the simulated sizes back to the committed ones
@@ -2313,6 +2324,10 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         }
         changes += commit_batch(V, sa, T, nc, G, own_gen, next_gen);
         RC_PHASE(12)
+        // Validation costs (points covered) x (changers before them); everything behind the first violation is wasted.
+        // When less than a third of a batch could be committed the next one is cut to three times what was (at least 64),
+        // otherwise it doubles.
+        cap = (3 * nc < nb) ? max(64, 3 * nc) : min(RC_MAXB, 2 * cap);
         after = limit - 1;
         ++round;
         if (round > V.n) break;  // cannot happen: every round finalises at least the first changer
