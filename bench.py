@@ -67,6 +67,24 @@ def cpu_baseline(D, P, labels, r, p, max_seconds=20.0):
                       f"mcmc.jl:158-256, single thread, {dt:.1f} s), scaled to a full sweep; host has {os.cpu_count()} cores"}
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """fd 1 points at stderr inside the block (C-level prints of libraries included); stdout is restored afterwards."""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    sys.stdout.flush(); libc.fflush(None)
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush(); libc.fflush(None)
+        os.dup2(saved, 1); os.close(saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,7 +103,10 @@ def main():
     torch.cuda.set_device(local_rank)
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        with stdout_to_stderr():      # RCCL's version banner (C stdout, first communicator) must not land beside the JSON line
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+            torch.cuda.synchronize()
 
     import redclust_amd as rc
     n, K = N_POINTS, N_CLUST
@@ -139,24 +160,45 @@ def main():
         inc_sweeps_per_s = args.steps / (time.perf_counter() - t1)
         ctx.set_mode("full")
 
-    # recorded sample + the one collective of the path: sum all-reduce of the integer co-clustering counts
+    # recorded sample + the one collective of the path: sum all-reduce of the integer co-clustering counts, through the
+    # LIBRARY's communicator (rc_comm_create / rc_comm_allreduce_counts: RCCL inside libredclust_hip.so; torch.distributed
+    # only carries the 128-byte unique id).  Also at N = 1: a real communicator of size 1.  If the library path cannot be
+    # set up on every rank the counts are merged with torch.distributed instead and the line says so.
     ctx.record_sample(False)
-    allreduce_ms = None
+    allreduce_ms, merge_path = None, None
+    lib_ok = 1
+    try:
+        rc.Comm.unique_id()                                  # opens librccl: every rank checks before anyone commits
+    except Exception as e:                                   # noqa: BLE001
+        lib_ok, merge_path = 0, f"torch.distributed all_reduce (library RCCL unavailable: {e})"
     if distributed:
+        flag = torch.tensor([lib_ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        lib_ok = int(flag.item())
+    total_samples = None
+    if lib_ok:
+        # RCCL prints a version banner on the C stdout when its first communicator comes up: keep this process's stdout
+        # for the one JSON line (fd 1 points at stderr while the communicator is built)
+        with stdout_to_stderr():
+            total_samples, allreduce_ms = rc.library_merge(ctx, local_rank, 1)
+        merge_path = "libredclust_hip.so rc_comm_allreduce_counts (RCCL ncclAllReduce sum uint32, in place)"
+    elif distributed:
         counts = rc.device_counts_tensor(ctx, local_rank)   # zero-copy view of the library's device buffer
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize()
         allreduce_ms = (time.perf_counter() - t1) * 1e3
+        total_samples = world
+        merge_path = merge_path or "torch.distributed all_reduce (library RCCL unavailable on some rank)"
+    if distributed:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        diag_ok = bool((counts.diagonal() == world).all().item())
-    else:
-        # the one recorded sample: every point co-clusters with itself once, and the matrix is symmetric
-        counts = rc.device_counts_tensor(ctx, local_rank)
-        diag_ok = bool((counts.diagonal() == 1).all().item()) and bool((counts[:, :n] == counts[:, :n].T).all().item())
+    # every chain recorded one sample: each point co-clusters with itself once per chain, and the matrix is symmetric
+    counts = rc.device_counts_tensor(ctx, local_rank)
+    diag_ok = (bool((counts.diagonal() == world).all().item()) and bool((counts[:, :n] == counts[:, :n].T).all().item())
+               and (total_samples in (None, world)))
 
     # Second figure ("exercises movement"): the same N, K with overlapping clusters (sigma = 0.2 instead of 0.1:
     # about 0.5 % of the labels move per sweep and clusters are born and die), burn-in from the generating labels excluded from the timing.
@@ -235,7 +277,7 @@ def main():
             "label_changes_last_sweep": stats["n_changes"], "K_final": stats["K"],
             "moving_regime": moving,
             "incremental_mode_sweeps_per_s_rank0": inc_sweeps_per_s,
-            "coclustering_allreduce_ms": allreduce_ms, "coclustering_diag_ok": diag_ok,
+            "coclustering_allreduce_ms": allreduce_ms, "coclustering_merge_path": merge_path, "coclustering_diag_ok": diag_ok,
             # roofline of the dominant kernel.  `achieved` / `frac` use the algorithmic bytes SURVEY.md §8(d) prescribes
             # (see survey_bytes above).  The kernel itself reads less than that — only the upper triangle of the
             # symmetric matrix — so the physical figures (bytes it must read ÷ time) are given beside them, and

@@ -230,6 +230,51 @@ typedef struct rc_chain_outputs {
 
 int32_t rc_run_chain(rc_ctx *ctx, const rc_chain_options *opt, rc_chain_outputs *out);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Chain-parallel execution: independent chains, one per GPU; the single exchange step is the SUM
+ * all-reduce of the n×n uint32 co-clustering counts (and of the numbers of recorded samples) over RCCL.  The reference
+ * has no multi-chain driver (runsampler, /root/reference/src/mcmc.jl:501-590, is one chain); the merged estimate is
+ * Σ_chains counts / Σ_chains numsamples — what mcmc.jl:560 forms for one chain.
+ * ------------------------------------------------------------------------------------------------------------- */
+#define RC_COMM_ID_BYTES 128   /* sizeof(ncclUniqueId) */
+typedef struct rc_comm rc_comm;
+
+/* Rank 0 of a multi-process job calls this and sends the bytes to the other processes (MPI, a TCP store, a file ...). */
+int32_t rc_comm_unique_id(uint8_t *id_out /* RC_COMM_ID_BYTES */);
+
+/* A communicator over world_size chains; this process owns chains rank_offset .. rank_offset + n_local - 1, one per
+ * entry of device_ids (distinct devices: one chain per GPU).  unique_id_or_null == NULL: all chains live in this
+ * process (rank_offset = 0, world_size = n_local; ncclCommInitAll).  Collective over all participating processes. */
+int32_t rc_comm_create(int32_t n_local, const int32_t *device_ids, int32_t rank_offset, int32_t world_size,
+                       const uint8_t *unique_id_or_null, rc_comm **out);
+int32_t rc_comm_destroy(rc_comm *comm);
+
+/* In-place SUM all-reduce of the co-clustering counts of the n_local contexts (ctxs[i] on device_ids[i]) over all
+ * chains, and of their numbers of recorded samples.  Afterwards every context holds the merged counts:
+ * rc_cocluster(ctx, out, *total_samples) is the merged posterior co-clustering matrix.  elapsed_ms may be NULL. */
+int32_t rc_comm_allreduce_counts(rc_comm *comm, rc_ctx *const *ctxs, const int64_t *num_samples /* n_local */,
+                                 int64_t *total_samples, double *elapsed_ms);
+
+typedef struct rc_chains_input {
+    int64_t n;
+    const double *D;             /* n×n, or NULL when points are given */
+    const double *logD_or_null;  /* as rc_create */
+    const double *points;        /* n×dim (rc_create_from_points), used when D == NULL */
+    int64_t dim;
+    int32_t storage_bits;        /* 64 or 32 */
+    int32_t pad_;
+    int64_t kcap;                /* 0 = default */
+    const rc_params *params;
+    const int64_t *init_clusts;  /* n labels: every chain starts from them (MCMCState.clusts) */
+} rc_chains_input;
+
+/* n_chains chains in this process: one host thread and one context per device runs rc_run_chain with seed
+ * opt->seed + chain index (outs[chain] as for rc_run_chain), then the counts are merged over RCCL.
+ * posterior_coclustering (n×n, may be NULL): Σ counts / Σ numsamples.  total_samples, allreduce_ms may be NULL. */
+int32_t rc_run_chains(int32_t n_chains, const int32_t *device_ids, const rc_chains_input *in, const rc_chain_options *opt,
+                      rc_chain_outputs *outs /* n_chains */, double *posterior_coclustering, int64_t *total_samples,
+                      double *allreduce_ms);
+
 /* One sample_r + sample_p pair exactly as rc_run_chain draws them (tests; host only, no GPU needed).  sizes: the K
  * non-empty cluster sizes in ascending label order. */
 int32_t rc_scalar_updates(uint64_t seed, uint64_t iter, double r, double p, const int64_t *sizes, int64_t K, int64_t n,

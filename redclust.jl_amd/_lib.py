@@ -25,6 +25,15 @@ class RedClustHIPError(RuntimeError):
         self.code = code
 
 
+class RedClustDomainError(RedClustHIPError, ValueError):
+    """RC_ERR_DOMAIN: the input violates what MCMCData requires (src/types.jl:145-157) — the reference throws
+    ArgumentError there, so this one is a ValueError as well."""
+
+
+def _error(code, msg):
+    return (RedClustDomainError if code == -4 else RedClustHIPError)(code, msg)
+
+
 class RcParams(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("delta1", "delta2", "alpha", "beta", "zeta", "gamma", "eta", "sigma",
                                           "u", "v")] + [("maxK", C.c_int64), ("repulsion", C.c_uint8),
@@ -54,6 +63,12 @@ class RcChainOutputs(C.Structure):
                 ("num_samples", C.c_int64), ("runtime_s", C.c_double), ("r_final", C.c_double), ("p_final", C.c_double)]
 
 
+class RcChainsInput(C.Structure):
+    _fields_ = [("n", C.c_int64), ("D", C.c_void_p), ("logD_or_null", C.c_void_p), ("points", C.c_void_p), ("dim", C.c_int64),
+                ("storage_bits", C.c_int32), ("pad_", C.c_int32), ("kcap", C.c_int64), ("params", C.POINTER(RcParams)),
+                ("init_clusts", C.c_void_p)]
+
+
 class RcSweepStats(C.Structure):
     _fields_ = [("n_changes", C.c_int64), ("n_rounds", C.c_int64), ("K", C.c_int64)]
 
@@ -61,7 +76,7 @@ class RcSweepStats(C.Structure):
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, "redclust_hip.hip"), os.path.join(CSRC, "pointestimate.inc.hip"),
-            os.path.join(CSRC, "chain.inc.hip"), HEADER]
+            os.path.join(CSRC, "chain.inc.hip"), os.path.join(CSRC, "chains.inc.hip"), HEADER]
     if not force and os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(s) for s in srcs):
         return SO
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", SO, srcs[0]]
@@ -109,6 +124,13 @@ SIGNATURES = {
     "rc_bulk_kernel_name": (C.c_char_p, [C.c_void_p]),
     "rc_within_between": (C.c_int32, [C.c_void_p, C.POINTER(RcWbStats)]),
     "rc_run_chain": (C.c_int32, [C.c_void_p, C.POINTER(RcChainOptions), C.POINTER(RcChainOutputs)]),
+    "rc_comm_unique_id": (C.c_int32, [C.c_void_p]),
+    "rc_comm_create": (C.c_int32, [C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "rc_comm_destroy": (C.c_int32, [C.c_void_p]),
+    "rc_comm_allreduce_counts": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                             C.POINTER(C.c_double)]),
+    "rc_run_chains": (C.c_int32, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(RcChainsInput), C.POINTER(RcChainOptions),
+                                  C.POINTER(RcChainOutputs), C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "rc_scalar_updates": (C.c_int32, [C.c_uint64, C.c_uint64, C.c_double, C.c_double, _ip, C.c_int64, C.c_int64, C.c_double,
                                       C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), C.POINTER(C.c_uint8)]),
@@ -159,7 +181,7 @@ class Context:
         h = C.c_void_p()
         rc = self.L.rc_create(self.n, D.ctypes.data_as(C.c_void_p), lp, storage_bits, device, kcap, C.byref(h))
         if rc != RC_OK:
-            raise RedClustHIPError(rc, self.L.rc_last_error(None).decode())
+            raise _error(rc, self.L.rc_last_error(None).decode())
         self.h = h
 
     @classmethod
@@ -175,7 +197,7 @@ class Context:
         rc = self.L.rc_create_from_points(self.n, int(pts.shape[1]), pts.ctypes.data_as(C.c_void_p), storage_bits, device,
                                           kcap, C.byref(h))
         if rc != RC_OK:
-            raise RedClustHIPError(rc, self.L.rc_last_error(None).decode())
+            raise _error(rc, self.L.rc_last_error(None).decode())
         self.h = h
         return self
 
@@ -194,7 +216,7 @@ class Context:
 
     def _chk(self, rc):
         if rc != RC_OK:
-            raise RedClustHIPError(rc, self.L.rc_last_error(self.h).decode())
+            raise _error(rc, self.L.rc_last_error(self.h).decode())
 
     def close(self):
         if getattr(self, "h", None):
@@ -370,6 +392,110 @@ class Context:
         cnt = C.c_int64()
         self._chk(self.L.rc_kernel_timing(self.h, int(enable), C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+
+def _chain_buffers(n, numiters, burnin, thin, numMH):
+    ns = max((numiters - burnin) // thin, 0) if thin > 0 else 0
+    res = dict(clusts=np.zeros((ns, n), np.int64), K=np.zeros(ns, np.int64), r=np.zeros(ns), p=np.zeros(ns),
+               loglik=np.zeros(ns), logposterior=np.zeros(ns), r_acceptances=np.zeros(numiters, np.uint8),
+               splitmerge_acceptances=np.zeros(numiters * numMH, np.uint8),
+               splitmerge_splits=np.zeros(numiters * numMH, np.uint8), r_all=np.zeros(numiters), p_all=np.zeros(numiters))
+    out = RcChainOutputs()
+    for k in res:
+        setattr(out, k, res[k].ctypes.data if res[k].size else None)
+    return ns, res, out
+
+
+class Comm:
+    """rc_comm: the RCCL communicator of the chains (one per GPU).  In one process: Comm(device_ids).  One process per
+    GPU: rank 0 calls Comm.unique_id(), moves the bytes to the others, every rank calls Comm([device], rank, world, id)."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        rc = lib().rc_comm_unique_id(buf)
+        if rc != RC_OK:
+            raise _error(rc, lib().rc_last_error(None).decode())
+        return bytes(buf)
+
+    def __init__(self, device_ids, rank_offset: int = 0, world_size: int | None = None, unique_id: bytes | None = None):
+        self.L = lib()
+        self.devices = [int(d) for d in device_ids]
+        world = len(self.devices) if world_size is None else int(world_size)
+        devs = (C.c_int32 * len(self.devices))(*self.devices)
+        idb = (C.c_uint8 * 128)(*unique_id) if unique_id is not None else None
+        h = C.c_void_p()
+        rc = self.L.rc_comm_create(len(self.devices), devs, int(rank_offset), world, idb, C.byref(h))
+        if rc != RC_OK:
+            raise _error(rc, self.L.rc_last_error(None).decode())
+        self.h = h
+
+    def allreduce_counts(self, ctxs, num_samples):
+        """In-place merge of the contexts' co-clustering counts over all chains.  Returns (total_samples, elapsed_ms)."""
+        hs = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+        ns = (C.c_int64 * len(ctxs))(*[int(x) for x in num_samples])
+        tot, ms = C.c_int64(0), C.c_double(0)
+        rc = self.L.rc_comm_allreduce_counts(self.h, hs, ns, C.byref(tot), C.byref(ms))
+        if rc != RC_OK:
+            raise _error(rc, self.L.rc_last_error(None).decode())
+        return int(tot.value), float(ms.value)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rc_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def run_chains(device_ids, params: dict, init_clusts, numiters, burnin, thin, numGibbs, numMH, seed, r0, p0, proposalsd_r, *,
+               D=None, logD=None, points=None, storage_bits: int = 64, kcap: int = 0, splitmerge="as_written",
+               want_posterior: bool = True):
+    """rc_run_chains: len(device_ids) chains in this process (one host thread + context per GPU, chain c seeded seed + c),
+    merged over RCCL.  Returns (list of per-chain dicts as Context.run_chain, merged posterior co-clustering or None,
+    total number of samples, all-reduce milliseconds)."""
+    L = lib()
+    devs = [int(d) for d in device_ids]
+    nch = len(devs)
+    inp = RcChainsInput()
+    keep = []
+    if D is not None:
+        D = np.ascontiguousarray(D, dtype=np.float64); keep.append(D)
+        n = int(D.shape[0]); inp.D = D.ctypes.data
+        if logD is not None:
+            logD = np.ascontiguousarray(logD, dtype=np.float64); keep.append(logD); inp.logD_or_null = logD.ctypes.data
+    else:
+        points = np.ascontiguousarray(points, dtype=np.float64); keep.append(points)
+        n = int(points.shape[0]); inp.points = points.ctypes.data; inp.dim = int(points.shape[1])
+    g = params.get
+    prm = RcParams(g("delta1"), g("delta2"), g("alpha"), g("beta"), g("zeta"), g("gamma"), g("eta", 1.0), g("sigma", 1.0),
+                   g("u", 1.0), g("v", 1.0), int(g("maxK", 0)), int(bool(g("repulsion", True))))
+    init = np.ascontiguousarray(init_clusts, dtype=np.int64); keep.append(init)
+    inp.n, inp.storage_bits, inp.kcap, inp.params, inp.init_clusts = n, int(storage_bits), int(kcap), C.pointer(prm), init.ctypes.data
+    ns = 0
+    ress, outs = [], (RcChainOutputs * nch)()
+    for c in range(nch):
+        ns, res, out = _chain_buffers(n, numiters, burnin, thin, numMH)
+        ress.append(res); outs[c] = out
+    o = RcChainOptions(numiters, burnin, thin, numGibbs, numMH, {"as_written": 0, "intended": 1}[splitmerge], 0,
+                       int(seed), 0, float(r0), float(p0), float(proposalsd_r), None, None, ns)
+    post = np.zeros((n, n)) if want_posterior else None
+    tot, ms = C.c_int64(0), C.c_double(0)
+    rc = L.rc_run_chains(nch, (C.c_int32 * nch)(*devs), C.byref(inp), C.byref(o), outs,
+                         post.ctypes.data if post is not None else None, C.byref(tot), C.byref(ms))
+    if rc != RC_OK:
+        raise _error(rc, L.rc_last_error(None).decode())
+    for c, res in enumerate(ress):
+        res["num_samples"], res["runtime_s"] = int(outs[c].num_samples), float(outs[c].runtime_s)
+        res["r_final"], res["p_final"] = float(outs[c].r_final), float(outs[c].p_final)
+        for k in ("r_acceptances", "splitmerge_acceptances", "splitmerge_splits"):
+            res[k] = res[k].astype(bool)
+    del keep
+    return ress, post, int(tot.value), float(ms.value)
 
 
 def loss_matrix(samples, loss: int, device: int = 0, want_matrix: bool = True):

@@ -39,9 +39,35 @@ def merge_chains(counts, numsamples: int, traces: dict, group=None):
     return counts, int(ns.item()), gathered
 
 
+def library_merge(ctx, local_device: int, num_samples: int, group=None):
+    """The exchange step through the LIBRARY's RCCL communicator (rc_comm_*): torch.distributed (any backend) only
+    carries the 128-byte unique id from rank 0 to the others.  Returns (total_samples, allreduce_ms); ctx then holds the
+    merged counts.  Works without torch.distributed too (one chain: a real communicator of size 1)."""
+    from ._lib import Comm
+    rank, world = 0, 1
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+    except ImportError:
+        dist = None
+    uid = None
+    if world > 1:
+        box = [Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        uid = box[0]
+    comm = Comm([local_device], rank_offset=rank, world_size=world, unique_id=uid)
+    try:
+        return comm.allreduce_counts([ctx], [num_samples])
+    finally:
+        comm.close()
+
+
 def run_chains(data, options, params, init, *, base_seed: int = 1, verbose: bool = False, kcap: int = 0):
-    """One chain per rank on its own GPU (LOCAL_RANK), then the RCCL all-reduce of the counts.
-    Returns (local MCMCResult, merged posterior_coclustering (n×n float64), per-chain traces)."""
+    """One chain per rank on its own GPU (LOCAL_RANK): a thin caller of the library — the chain runs through
+    runsampler(ctx=...), the counts are merged by rc_comm_allreduce_counts (RCCL inside libredclust_hip.so) and the
+    merged matrix is rc_cocluster of the merged counts.  Returns (local MCMCResult, merged posterior_coclustering
+    (n×n float64), per-chain traces)."""
     import os
     import torch
     import torch.distributed as dist
@@ -49,16 +75,37 @@ def run_chains(data, options, params, init, *, base_seed: int = 1, verbose: bool
     from .sampler import runsampler
     rank = dist.get_rank() if dist.is_initialized() else 0
     local = int(os.environ.get("LOCAL_RANK", 0))
+    # one chain per GPU: the resolver's grid barrier needs the whole chip, and RCCL refuses two ranks on one device
+    ndev = torch.cuda.device_count()
+    if local >= ndev:
+        raise RuntimeError(f"run_chains: LOCAL_RANK={local} but only {ndev} GPU(s) are visible — launch one process per GPU")
     ctx = (Context.from_points(data.points, device=local, kcap=kcap) if data.points is not None
            else Context(data.D, device=local, kcap=kcap))
     try:
         res = runsampler(data, options, params, init, verbose=verbose and rank == 0,
                          seed=chain_seed(base_seed, rank), ctx=ctx)
-        counts = device_counts_tensor(ctx, local)
         traces = dict(rank=rank, K=res.K, r=res.r, p=res.p, loglik=res.loglik, logposterior=res.logposterior)
-        counts, total, chains = merge_chains(counts, options.numsamples, traces)
-        n = data.n
-        merged = counts[:, :n].to(torch.float64).cpu().numpy() / max(total, 1)
+        total, _ms = library_merge(ctx, local, options.numsamples)
+        merged = ctx.cocluster(max(total, 1))
+        chains = [traces]
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            chains = [None] * dist.get_world_size()
+            dist.all_gather_object(chains, traces)
         return res, merged, chains
     finally:
         ctx.close()
+
+
+def run_chains_single_process(data, options, params, init, device_ids, *, base_seed: int = 1, kcap: int = 0,
+                              splitmerge: str = "as_written"):
+    """All chains from ONE process (rc_run_chains: one host thread + context per device, ncclCommInitAll, one in-place
+    all-reduce).  Returns (per-chain dicts of traces, merged posterior_coclustering, total number of samples)."""
+    from ._lib import run_chains as _native
+    P = dict(delta1=params.delta1, delta2=params.delta2, alpha=params.alpha, beta=params.beta, zeta=params.zeta,
+             gamma=params.gamma, eta=params.eta, sigma=params.sigma, u=params.u, v=params.v,
+             repulsion=params.repulsion, maxK=params.maxK)
+    kw = dict(points=data.points) if data.points is not None and options.numMH == 0 else dict(D=data.D)
+    chains, merged, total, _ms = _native(device_ids, P, init.clusts, options.numiters, options.burnin, options.thin,
+                                         options.numGibbs, options.numMH, base_seed, init.r, init.p, params.proposalsd_r,
+                                         kcap=kcap, splitmerge=splitmerge, **kw)
+    return chains, merged, total

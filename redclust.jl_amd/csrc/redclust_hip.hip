@@ -49,6 +49,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <string>
 #include <type_traits>
 #include <unordered_map>
 #include <vector>
@@ -2848,7 +2849,7 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     if (hflags[0] & 2u) { cleanup(); return fail(c, RC_ERR_DOMAIN, "D must be finite."); }
     if (!logD && (hflags[0] & 4u)) {
         cleanup();
-        return fail(c, RC_ERR_DOMAIN, "off-diagonal entries of D must be positive (log D = -Inf / NaN otherwise).");
+        return fail(c, RC_ERR_DOMAIN, "off-diagonal entries of D must be positive: log D = -Inf / NaN otherwise (duplicate observations? remove them or add a small jitter).");
     }
     double maxD, maxL = 0;
     std::memcpy(&maxD, &hmx[0], 8);
@@ -4548,3 +4549,4 @@ extern "C" int32_t rc_debug_prof(rc_ctx *c, int32_t gen, long long *out /* 8192 
 
 #include "pointestimate.inc.hip"
 #include "chain.inc.hip"
+#include "chains.inc.hip"

@@ -98,6 +98,15 @@ class MCMCData:
             raise ValueError("D must be a square matrix.")
         if np.any(D != D.T):
             raise ValueError("D must be symmetric.")
+        # Zero (or negative) off-diagonal distances.  The reference accepts them silently: log.(D - Diagonal(D) + I)
+        # (types.jl:155) is -Inf there, every log-weight that touches such a pair becomes -Inf or NaN (mcmc.jl:223-247,
+        # 0 * -Inf when δ1 = 1) and sample_logweights (utils.jl:2-6) then draws from NaNs.  This implementation refuses the
+        # input instead (rc_create returns RC_ERR_DOMAIN for the same reason): DESIGN.md "Zero distances".
+        bad = int(np.count_nonzero(D <= 0)) - int(np.count_nonzero(np.diagonal(D) <= 0))
+        if bad or not np.all(np.isfinite(D)):
+            raise ValueError(f"D must be finite with positive off-diagonal entries ({bad} are zero or negative: log D = -Inf "
+                             "there, which the reference would propagate as -Inf / NaN log-weights).  Remove duplicate "
+                             "observations or add a small jitter to them.")
         self._D = np.ascontiguousarray(D)
 
     @property

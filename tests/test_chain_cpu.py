@@ -92,3 +92,35 @@ def test_golden_chain_oracle(tag):
         assert np.array_equal(rec["sm_acc"], g[f"{tag}_sm_acc"]) and np.array_equal(rec["sm_split"], g[f"{tag}_sm_split"])
         assert rec["sm_acc"].sum() >= 1
     assert np.allclose(rec["loglik"], g[f"{tag}_loglik"], rtol=1e-10) and np.allclose(rec["logposterior"], g[f"{tag}_logposterior"], rtol=1e-10)
+
+
+def test_mcmcdata_refuses_zero_off_diagonal_distances():
+    """The zero-distance decision (DESIGN.md "Zero distances", src/types.jl:145-157): the reference takes log(0) = -Inf
+    silently; the glue refuses the input with the ArgumentError-class exception and says what to do."""
+    import redclust_amd as rc
+    rng = np.random.default_rng(3)
+    pts = rng.normal(size=(30, 2))
+    D = np.sqrt(((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1))
+    assert rc.MCMCData(D).n == 30
+    z = D.copy(); z[5, 9] = z[9, 5] = 0.0
+    with pytest.raises(ValueError, match="jitter"):
+        rc.MCMCData(z)
+    bad = D.copy(); bad[1, 2] += 1e-9
+    with pytest.raises(ValueError, match="symmetric"):
+        rc.MCMCData(bad)
+    inf = D.copy(); inf[3, 4] = inf[4, 3] = np.inf
+    with pytest.raises(ValueError, match="finite"):
+        rc.MCMCData(inf)
+    assert issubclass(rc.RedClustDomainError, ValueError) and issubclass(rc.RedClustDomainError, rc.RedClustHIPError)
+
+
+def test_run_chains_argument_checks_need_no_gpu():
+    """rc_run_chains / rc_comm_create validate their arguments before they touch a device."""
+    import ctypes as C
+    import redclust_amd as rc
+    L = rc.lib()
+    assert L.rc_run_chains(0, None, None, None, None, None, None, None) == -1          # RC_ERR_ARG
+    assert b"n_chains" in L.rc_last_error(None)
+    h = C.c_void_p()
+    assert L.rc_comm_create(0, None, 0, 0, None, C.byref(h)) == -1
+    assert L.rc_comm_destroy(None) == 0

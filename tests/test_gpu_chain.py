@@ -122,3 +122,42 @@ def test_runsampler_engines_agree():
     assert len(free.clusts) == 30 and np.all(free.K > 0) and np.all(np.isfinite(free.logposterior))
     assert 0 < free.r_acceptance_rate < 1 and np.all((free.p > 0) & (free.p < 1)) and free.mean_iter_time > 0
     assert np.all(np.diag(free.posterior_coclustering) == 1.0)
+
+
+def test_run_chains_in_the_library_one_chain_over_a_real_rccl_communicator():
+    """rc_run_chains with n_chains = 1 — all this pool can run: the chain equals rc_run_chain on a context
+    of the caller's, the merge goes through a real RCCL communicator of size 1 (ncclCommInitAll inside the library; the
+    unique-id / ncclCommInitRank path is exercised too), and the merged matrix is counts / samples."""
+    D, truth = paper(1)
+    P = T.likelihood_hyperparams(D, truth)
+    init = np.random.default_rng(7).integers(1, 11, 100).astype(np.int64)
+    orc, ctx = make(D, P, init)
+    ctx.attach_host_matrices(D, orc.logD)
+    one = ctx.run_chain(40, 10, 3, 5, 1, 11, 1.0, 0.5, 0.7)
+    chains, post, total, ms = rc._lib.run_chains([0], P, init, 40, 10, 3, 5, 1, 11, 1.0, 0.5, 0.7, D=D, logD=orc.logD)
+    assert len(chains) == 1 and total == one["num_samples"] == 10 and ms >= 0
+    for k in ("clusts", "K", "r", "p", "loglik", "logposterior", "r_acceptances", "splitmerge_acceptances", "splitmerge_splits"):
+        assert np.array_equal(chains[0][k], one[k]), k
+    assert np.array_equal(post, ctx.cocluster(10)) and np.all(np.diag(post) == 1.0)
+    # the communicator layer on the caller's context: size-1 all-reduce leaves the counts as they are
+    before = ctx.cocluster_counts().copy()
+    for comm in (rc.Comm([0]), rc.Comm([0], rank_offset=0, world_size=1, unique_id=rc.Comm.unique_id())):
+        tot, _ = comm.allreduce_counts([ctx], [10])
+        assert tot == 10 and np.array_equal(ctx.cocluster_counts(), before)
+        comm.close()
+    assert rc.library_merge(ctx, 0, 10)[0] == 10
+    # one chain per GPU: a device listed twice, a device that does not exist, a split world without the id
+    for bad in (dict(device_ids=[0, 0]), dict(device_ids=[99]), dict(device_ids=[0], rank_offset=1, world_size=2)):
+        with pytest.raises(rc.RedClustHIPError, match="RC_ERR_ARG"):
+            rc.Comm(**bad)
+    with pytest.raises(rc.RedClustHIPError, match="twice"):
+        rc._lib.run_chains([0, 0], P, init, 5, 0, 1, 5, 0, 1, 1.0, 0.5, 0.7, D=D)
+    # the points path and the thin Python caller
+    pts = np.random.default_rng(1).normal(size=(60, 3))
+    data = rc.MCMCData(pts)
+    Pp = rc.likelihood_hyperparams(data.D, np.arange(60) % 4 + 1)
+    params = rc.PriorHyperparamsList(**{k: Pp[k] for k in ("delta1", "delta2", "alpha", "beta", "zeta", "gamma")})
+    ch, merged, tot = rc.run_chains_single_process(data, rc.MCMCOptionsList(numiters=20, burnin=4, thin=2, numMH=0), params,
+                                                   rc.MCMCState(np.arange(60) % 4 + 1, 1.0, 0.5), [0], base_seed=3)
+    assert tot == 8 and merged.shape == (60, 60) and np.all(np.diag(merged) == 1.0) and np.array_equal(merged, merged.T)
+    ctx.close()

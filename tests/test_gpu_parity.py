@@ -223,6 +223,15 @@ def test_edge_cases_and_errors():
     z = D.copy(); z[2, 3] = z[3, 2] = 0.0
     with pytest.raises(rc.RedClustHIPError, match="positive"):
         rc.Context(z)
+    # the zero-distance decision (DESIGN.md "Zero distances"): a ValueError like the reference's ArgumentError class of
+    # input errors, raised by the library for a matrix and for duplicate points alike, and by the MCMCData glue
+    with pytest.raises(ValueError, match="jitter"):
+        rc.Context(z)
+    pts = np.random.default_rng(0).normal(size=(50, 3)); pts[17] = pts[4]
+    with pytest.raises(ValueError, match="positive"):
+        rc.Context.from_points(pts)
+    with pytest.raises(ValueError, match="jitter"):
+        rc.MCMCData(z)
     ctx = rc.Context(D)
     with pytest.raises(rc.RedClustHIPError, match="RC_ERR_STATE"):
         ctx.gibbs_sweep(1.0, 0.5, 1, 0)
