@@ -1,17 +1,22 @@
 # RedClustHIP.jl — Julia-side binding of libredclust_hip.so (include/redclust_hip.h).
 #
-# Drop-in for the label path of RedClust.jl: defines `runsampler_hip(data, options, params, init; ...)`, which
-# has the signature and the result of `RedClust.runsampler` (src/mcmc.jl:501-590) but runs the Gibbs sweep,
-# loglik, label canonicalisation and co-clustering accumulation on an MI355X through `ccall`.  The structs
-# MCMCData / MCMCOptionsList / PriorHyperparamsList / MCMCState / MCMCResult are RedClust's own, unchanged.
+# Drop-in for the sampler of RedClust.jl: `runsampler_hip` has the signature, the defaults and the result of
+# `RedClust.runsampler` (src/mcmc.jl:501-590) and runs the whole iteration loop — sample_r!, sample_p!, the split–merge
+# proposals, the Gibbs sweep, loglik / logprior of the recorded samples, sortlabels and the co-clustering matrix — in one
+# call into the library (rc_run_chain) on an MI355X.  The structs MCMCData / MCMCOptionsList / PriorHyperparamsList /
+# MCMCState / MCMCResult are RedClust's own, unchanged; fitprior and the k-medoids initialisation are RedClust's own
+# functions, called here exactly as runsampler calls them.
 #
-# NOT TESTED IN THE BUILD IMAGE (no julia binary there) — it is the binding a maintainer would add; the same
-# C entry points are exercised by the Python host (redclust.jl_amd/) and its tests.
+# NOT EXECUTED IN THE BUILD IMAGE (no julia binary there).  What is checked instead: every ccall below is compared —
+# symbol, arity, argument and return types, struct layouts — with the prototypes of include/redclust_hip.h by
+# tests/test_oracle_cpu.py::test_julia_glue_ccalls_match_the_header, and the same entry points are exercised by the
+# Python host (redclust.jl_amd/) and its GPU tests.
 module RedClustHIP
 
 using RedClust
-using RedClust: MCMCData, MCMCOptionsList, PriorHyperparamsList, MCMCState, MCMCResult,
-                sample_r!, sample_p!, iac_ess_acf
+using RedClust: MCMCData, MCMCOptionsList, PriorHyperparamsList, MCMCState, MCMCResult, fitprior, iac_ess_acf
+using Clustering: kmedoids
+using Distributions: Beta, Gamma
 using StatsBase: mean, mean_and_var
 
 const LIB = get(ENV, "REDCLUST_HIP_LIB", "libredclust_hip.so")
@@ -21,33 +26,128 @@ struct RcParams                      # struct rc_params
     eta::Cdouble; sigma::Cdouble; u::Cdouble; v::Cdouble
     maxK::Int64
     repulsion::UInt8
-    pad::NTuple{7,UInt8}
+    pad_::NTuple{7,UInt8}
 end
 RcParams(p::PriorHyperparamsList) = RcParams(p.δ1, p.δ2, p.α, p.β, p.ζ, p.γ, p.η, p.σ, p.u, p.v,
                                              p.maxK, UInt8(p.repulsion), ntuple(_ -> 0x00, 7))
 
+struct RcChainOptions                # struct rc_chain_options
+    numiters::Int64; burnin::Int64; thin::Int64
+    numGibbs::Int64; numMH::Int64
+    splitmerge_mode::Int32
+    pad_::Int32
+    seed::UInt64
+    first_iter::UInt64
+    r0::Cdouble; p0::Cdouble
+    proposalsd_r::Cdouble
+    r_trace::Ptr{Cdouble}; p_trace::Ptr{Cdouble}
+    max_samples::Int64
+end
+
+struct RcChainOutputs                # struct rc_chain_outputs (isbits: a Ref or a Vector of them is the C object)
+    clusts::Ptr{Int64}
+    K::Ptr{Int64}
+    r::Ptr{Cdouble}; p::Ptr{Cdouble}; loglik::Ptr{Cdouble}; logposterior::Ptr{Cdouble}
+    r_acceptances::Ptr{UInt8}
+    splitmerge_acceptances::Ptr{UInt8}; splitmerge_splits::Ptr{UInt8}
+    r_all::Ptr{Cdouble}; p_all::Ptr{Cdouble}
+    num_samples::Int64
+    runtime_s::Cdouble
+    r_final::Cdouble; p_final::Cdouble
+end
+
+struct RcChainsInput                 # struct rc_chains_input
+    n::Int64
+    D::Ptr{Cdouble}
+    logD_or_null::Ptr{Cdouble}
+    points::Ptr{Cdouble}
+    dim::Int64
+    storage_bits::Int32
+    pad_::Int32
+    kcap::Int64
+    params::Ptr{RcParams}
+    init_clusts::Ptr{Int64}
+end
+
+# error classes of include/redclust_hip.h: RC_ERR_ARG (-1) and RC_ERR_DOMAIN (-4) are the caller's input — the reference
+# throws ArgumentError for those (src/types.jl:149-154); the rest are run-time failures
 function check(ctx::Ptr{Cvoid}, rc::Int32)
     rc == 0 && return
     msg = unsafe_string(ccall((:rc_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx))
-    rc == -1 ? throw(ArgumentError(msg)) : error(msg)
+    (rc == -1 || rc == -4) ? throw(ArgumentError(msg)) : error(msg)
+end
+
+# runsampler's defaults, verbatim (src/mcmc.jl:516-527): fitprior on the data, k-medoids labels, r and p from their priors
+function default_params_init(data::MCMCData, params, init; verbose)
+    if isnothing(params)
+        params = fitprior(data.D, "k-medoids", true; verbose=verbose)
+    end
+    if isnothing(init)
+        init = MCMCState(
+            clusts=kmedoids(data.D,
+                (params.maxK > 0 ? minimum([params.maxK, params.K_initial]) : params.K_initial);
+                maxiter=1000).assignments,
+            r=rand(Gamma(params.η, 1 / params.σ)),
+            p=rand(Beta(params.u, params.v))
+        )
+    end
+    return params, init
+end
+
+# the summary block of runsampler after the loop (src/mcmc.jl:562-587), unchanged
+function summarise!(result::MCMCResult, options::MCMCOptionsList, params::PriorHyperparamsList, runtime::Real)
+    result.K_iac, result.K_ess, result.K_acf = iac_ess_acf(result.K)
+    result.K_mean, result.K_variance = mean_and_var(result.K)
+    result.r_iac, result.r_ess, result.r_acf = iac_ess_acf(result.r)
+    result.r_mean, result.r_variance = mean_and_var(result.r)
+    result.p_iac, result.p_ess, result.p_acf = iac_ess_acf(result.p)
+    result.p_mean, result.p_variance = mean_and_var(result.p)
+    result.splitmerge_acceptance_rate = options.numMH > 0 ? mean(result.splitmerge_acceptances) : 0
+    result.r_acceptance_rate = mean(result.r_acceptances)
+    result.options = options
+    result.params = params
+    result.runtime = runtime
+    result.mean_iter_time = runtime / options.numiters
+    return result
 end
 
 """
-    runsampler_hip(data, options, params, init; verbose=true, seed=0, device=0, kcap=0) -> MCMCResult
+    runsampler_hip(data, options = MCMCOptionsList(), params = nothing, init = nothing;
+                   verbose = true, seed = rand(UInt64), device = 0, kcap = 0, exact_logD = false,
+                   splitmerge = :as_written) -> MCMCResult
 
-Same contract as `RedClust.runsampler` with `options.numMH == 0` (pure Gibbs, test/test_sampler.jl:7).
+`RedClust.runsampler` (src/mcmc.jl:501-590) with the iteration loop on the GPU.  Same positional arguments and defaults:
+the default `MCMCOptionsList()` (numMH = 1, numGibbs = 5) is accepted as is, `params = nothing` calls `fitprior` and
+`init = nothing` the k-medoids initialisation, exactly as the reference does.  Every field of the result is filled.
+
+Differences, all in the random streams (DESIGN.md "Uniform stream"): the label draws, the split–merge draws and the r / p
+updates come from the library's counter-based streams keyed by `seed` (drawn from Julia's RNG by default, so
+`Random.seed!` still fixes a run), not from Julia's task-local RNG — same distributions, different numbers.
+`splitmerge = :intended` keeps accepted proposals (the reference as written discards them, SURVEY.md §3.2 Q1).
+A distance matrix with zero off-diagonal entries is refused with an ArgumentError (the reference would carry
+log(0) = -Inf into every log-weight): remove duplicate observations or jitter them.
 """
-function runsampler_hip(data::MCMCData, options::MCMCOptionsList, params::PriorHyperparamsList,
-                        init::MCMCState; verbose=true, seed::Integer=0, device::Integer=0, kcap::Integer=0,
-                        exact_logD::Bool=false)
-    options.numMH == 0 || error("split-merge steps are not offloaded yet: use MCMCOptionsList(numMH = 0)")
+function runsampler_hip(data::MCMCData,
+    options::MCMCOptionsList=MCMCOptionsList(),
+    params::Union{PriorHyperparamsList,Nothing}=nothing,
+    init::Union{MCMCState,Nothing}=nothing;
+    verbose=true, seed::Integer=rand(UInt64), device::Integer=0, kcap::Integer=0, exact_logD::Bool=false,
+    splitmerge::Symbol=:as_written)::MCMCResult
+    ostream = verbose ? stdout : devnull
+    splitmerge in (:as_written, :intended) || throw(ArgumentError("splitmerge must be :as_written or :intended"))
+    params, init = default_params_init(data, params, init; verbose=verbose)
     n = size(data.D, 1)
+    ns = options.numsamples
+    result = MCMCResult(data, options, params)
+    printstyled(ostream, "Run MCMC\n"; bold=true, color=:blue)
+    printstyled(ostream, "Setup: "; bold=true)
+    println(ostream, "$(options.numiters) iterations, $ns samples, $n observations.")
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    # MCMCData keeps D and logD = log.(D - Diagonal(D) + I) (src/types.jl:146-147,155).  By default only D is handed
-    # over: the library then evaluates logD from its fixed-point D on the fly (DESIGN.md "Derived logD": half the HBM
-    # traffic per sweep, values within 1e-14 of the package's).  exact_logD = true hands data.logD over instead, so
-    # that the device copy is the package's logD rounded to the fixed-point grid.  D is symmetric, so column-major ==
-    # row-major.
+    # MCMCData keeps D and logD = log.(D - Diagonal(D) + I) (src/types.jl:146-147,155).  By default only D is handed over:
+    # the library then evaluates logD from its fixed-point D on the fly (DESIGN.md "Derived logD": half the HBM traffic per
+    # sweep; each entry within 2^-33 ≈ 1.2e-10 of the package's value, within 1e-12 for entries near the largest).
+    # exact_logD = true hands data.logD over instead: the device copy is then the package's logD rounded to the
+    # fixed-point grid.  D is symmetric, so column-major == row-major.
     GC.@preserve data begin
         rc = ccall((:rc_create, LIB), Int32,
                    (Int64, Ptr{Cdouble}, Ptr{Cdouble}, Int32, Int32, Int64, Ref{Ptr{Cvoid}}),
@@ -59,105 +159,93 @@ function runsampler_hip(data::MCMCData, options::MCMCOptionsList, params::PriorH
         check(ctx, ccall((:rc_set_params, LIB), Int32, (Ptr{Cvoid}, Ref{RcParams}), ctx, Ref(RcParams(params))))
         check(ctx, ccall((:rc_set_state, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), ctx, init.clusts))
         check(ctx, ccall((:rc_cocluster_reset, LIB), Int32, (Ptr{Cvoid},), ctx))
-        result = MCMCResult(data, options, params)
-        state = init
-        K = Ref{Int64}(0)
-        ll = Ref{Cdouble}(0.0); lp = Ref{Cdouble}(0.0)
-        j = 1
-        runtime = @elapsed for i in 1:options.numiters
-            result.r_acceptances[i] = sample_r!(state, params).accept            # src/mcmc.jl:538 (host scalar)
-            sample_p!(state, params)                                             # src/mcmc.jl:539 (host scalar)
-            check(ctx, ccall((:rc_gibbs_sweep, LIB), Int32, (Ptr{Cvoid}, Cdouble, Cdouble, UInt64, UInt64),
-                             ctx, state.r, state.p, seed, i - 1))                # src/mcmc.jl:540 → :477
-            record = i > options.burnin && (i - options.burnin) % options.thin == 0   # src/mcmc.jl:546
-            # sizes and K for the next sample_r!/sample_p! come from the sweep's host-mapped summary (no device copy);
-            # the label vector itself is pulled only when a sample is recorded
-            check(ctx, ccall((:rc_get_state, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ref{Int64}),
-                             ctx, record ? pointer(state.clusts) : Ptr{Int64}(C_NULL), state.clustsizes, K))
-            state.K = K[]
-            if record
-                check(ctx, ccall((:rc_record_sample, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), ctx, result.clusts[j]))
-                result.K[j] = state.K; result.r[j] = state.r; result.p[j] = state.p
-                check(ctx, ccall((:rc_loglik, LIB), Int32, (Ptr{Cvoid}, Ref{Cdouble}), ctx, ll))
-                check(ctx, ccall((:rc_logprior, LIB), Int32, (Ptr{Cvoid}, Cdouble, Cdouble, Ref{Cdouble}),
-                                 ctx, state.r, state.p, lp))
-                result.loglik[j] = ll[]; result.logposterior[j] = ll[] + lp[]
-                j += 1
-            end
+        if options.numMH > 0
+            # the restricted scans of the split–merge proposals read the host matrices, as the reference's do
+            check(ctx, ccall((:rc_attach_host_matrices, LIB), Int32, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}),
+                             ctx, data.D, data.logD))
         end
+        clusts = Matrix{Int64}(undef, n, max(ns, 1))             # column j = sample j (row-major ns×n for the library)
+        racc = zeros(UInt8, options.numiters)
+        smacc = zeros(UInt8, max(options.numiters * options.numMH, 1))
+        smspl = zeros(UInt8, max(options.numiters * options.numMH, 1))
+        opt = RcChainOptions(options.numiters, options.burnin, options.thin, options.numGibbs, options.numMH,
+                             splitmerge == :intended ? 1 : 0, 0, seed % UInt64, 0, init.r, init.p, params.proposalsd_r,
+                             C_NULL, C_NULL, ns)
+        out = Ref(RcChainOutputs(pointer(clusts), pointer(result.K), pointer(result.r), pointer(result.p),
+                                 pointer(result.loglik), pointer(result.logposterior), pointer(racc), pointer(smacc),
+                                 pointer(smspl), C_NULL, C_NULL, 0, 0.0, 0.0, 0.0))
+        GC.@preserve data clusts racc smacc smspl result begin
+            check(ctx, ccall((:rc_run_chain, LIB), Int32, (Ptr{Cvoid}, Ref{RcChainOptions}, Ref{RcChainOutputs}),
+                             ctx, opt, out))
+        end
+        for j in 1:ns
+            result.clusts[j] .= view(clusts, :, j)
+        end
+        result.r_acceptances .= view(racc, 1:options.numiters) .!= 0
+        result.splitmerge_acceptances .= view(smacc, 1:options.numiters*options.numMH) .!= 0
+        result.splitmerge_splits .= view(smspl, 1:options.numiters*options.numMH) .!= 0
+        println(ostream, "Computing summary statistics and diagnostics.")
         # row-major n×n from the library == column-major because the matrix is symmetric (src/mcmc.jl:560)
         check(ctx, ccall((:rc_cocluster, LIB), Int32, (Ptr{Cvoid}, Ptr{Cdouble}, Int64),
-                         ctx, result.posterior_coclustering, max(options.numsamples, 1)))
-        result.K_iac, result.K_ess, result.K_acf = iac_ess_acf(result.K)        # src/mcmc.jl:564-573, unchanged
-        result.K_mean, result.K_variance = mean_and_var(result.K)
-        result.r_iac, result.r_ess, result.r_acf = iac_ess_acf(result.r)
-        result.r_mean, result.r_variance = mean_and_var(result.r)
-        result.p_iac, result.p_ess, result.p_acf = iac_ess_acf(result.p)
-        result.p_mean, result.p_variance = mean_and_var(result.p)
-        result.splitmerge_acceptance_rate = 0
-        result.r_acceptance_rate = mean(result.r_acceptances)
-        result.runtime = runtime
-        result.mean_iter_time = runtime / options.numiters
-        return result
+                         ctx, result.posterior_coclustering, max(ns, 1)))
+        return summarise!(result, options, params, out[].runtime_s)
     finally
         ccall((:rc_destroy, LIB), Int32, (Ptr{Cvoid},), ctx)
     end
 end
 
-# ---------------------------------------------------------------------------------------------------------------
-# The whole iteration loop in one call (rc_run_chain; src/mcmc.jl:533-556 incl. sample_r!/sample_p! on the library's
-# scalar stream and the split–merge step as written), and the point estimate afterwards.  Struct layouts mirror
-# rc_chain_options / rc_chain_outputs of include/redclust_hip.h.
-# ---------------------------------------------------------------------------------------------------------------
-struct RcChainOptions
-    numiters::Int64; burnin::Int64; thin::Int64; numGibbs::Int64; numMH::Int64
-    splitmerge_mode::Int32; pad_::Int32
-    seed::UInt64; first_iter::UInt64
-    r0::Cdouble; p0::Cdouble; proposalsd_r::Cdouble
-    r_trace::Ptr{Cdouble}; p_trace::Ptr{Cdouble}
-    max_samples::Int64
-end
-
-mutable struct RcChainOutputs
-    clusts::Ptr{Int64}; K::Ptr{Int64}; r::Ptr{Cdouble}; p::Ptr{Cdouble}; loglik::Ptr{Cdouble}; logposterior::Ptr{Cdouble}
-    r_acceptances::Ptr{UInt8}; splitmerge_acceptances::Ptr{UInt8}; splitmerge_splits::Ptr{UInt8}
-    r_all::Ptr{Cdouble}; p_all::Ptr{Cdouble}
-    num_samples::Int64; runtime_s::Cdouble; r_final::Cdouble; p_final::Cdouble
-end
-
 """
-    run_chain_hip!(ctx, result, data, options, params, init; seed)
+    runsampler_hip_chains(data, options, params, init; devices = [0], seed = rand(UInt64), kcap = 0)
+        -> (results::Vector{MCMCResult}, posterior_coclustering::Matrix{Float64}, total_samples::Int)
 
-Fills `result` (an `MCMCResult` allocated as `runsampler` does, src/mcmc.jl:515-531) from ONE call into the library.
-`ctx` must hold D (rc_create), the parameters (rc_set_params) and the initial labels (rc_set_state); for
-`options.numMH > 0` the host matrices are attached first (the proposal's scalar scans run on them, as in the reference).
+`length(devices)` independent chains, one per GPU, from one call into the library (rc_run_chains: a host thread and a
+context per device, chain c seeded `seed + c - 1`, then one RCCL all-reduce of the co-clustering counts).  Every chain
+starts from `init`; `results[c]` is the `MCMCResult` of chain c, the matrix is Σ counts / Σ numsamples over all chains.
 """
-function run_chain_hip!(ctx::Ptr{Cvoid}, result, data, options, params, init; seed::Integer = 0)
-    n = size(data.D, 1)
-    ns = options.numsamples
-    clusts = Matrix{Int64}(undef, n, ns)                       # column j = sample j (row-major ns×n for the library)
-    racc = zeros(UInt8, options.numiters)
-    smacc = zeros(UInt8, options.numiters * options.numMH)
-    smspl = zeros(UInt8, options.numiters * options.numMH)
-    if options.numMH > 0
-        check(ctx, ccall((:rc_attach_host_matrices, LIB), Int32, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), ctx, data.D, data.logD))
+function runsampler_hip_chains(data::MCMCData,
+    options::MCMCOptionsList=MCMCOptionsList(),
+    params::Union{PriorHyperparamsList,Nothing}=nothing,
+    init::Union{MCMCState,Nothing}=nothing;
+    devices::Vector{<:Integer}=[0], seed::Integer=rand(UInt64), kcap::Integer=0, verbose=true,
+    splitmerge::Symbol=:as_written)
+    params, init = default_params_init(data, params, init; verbose=verbose)
+    n = size(data.D, 1); ns = options.numsamples; nch = length(devices)
+    results = [MCMCResult(data, options, params) for _ in 1:nch]
+    clusts = [Matrix{Int64}(undef, n, max(ns, 1)) for _ in 1:nch]
+    racc = [zeros(UInt8, options.numiters) for _ in 1:nch]
+    smacc = [zeros(UInt8, max(options.numiters * options.numMH, 1)) for _ in 1:nch]
+    smspl = [zeros(UInt8, max(options.numiters * options.numMH, 1)) for _ in 1:nch]
+    outs = [RcChainOutputs(pointer(clusts[c]), pointer(results[c].K), pointer(results[c].r), pointer(results[c].p),
+                           pointer(results[c].loglik), pointer(results[c].logposterior), pointer(racc[c]),
+                           pointer(smacc[c]), pointer(smspl[c]), C_NULL, C_NULL, 0, 0.0, 0.0, 0.0) for c in 1:nch]
+    rcparams = Ref(RcParams(params))
+    devs = Int32.(devices)
+    opt = RcChainOptions(options.numiters, options.burnin, options.thin, options.numGibbs, options.numMH,
+                         splitmerge == :intended ? 1 : 0, 0, seed % UInt64, 0, init.r, init.p, params.proposalsd_r,
+                         C_NULL, C_NULL, ns)
+    post = zeros(n, n)
+    total = Ref{Int64}(0)
+    GC.@preserve data init rcparams clusts racc smacc smspl results outs begin
+        inp = RcChainsInput(n, pointer(data.D), pointer(data.logD), Ptr{Cdouble}(C_NULL), 0, 64, 0, kcap,
+                            Base.unsafe_convert(Ptr{RcParams}, rcparams), pointer(init.clusts))
+        rc = ccall((:rc_run_chains, LIB), Int32,
+                   (Int32, Ptr{Int32}, Ref{RcChainsInput}, Ref{RcChainOptions}, Ptr{RcChainOutputs}, Ptr{Cdouble},
+                    Ref{Int64}, Ptr{Cdouble}),
+                   nch, devs, inp, opt, outs, post, total, Ptr{Cdouble}(C_NULL))
+        check(Ptr{Cvoid}(C_NULL), rc)
     end
-    opt = RcChainOptions(options.numiters, options.burnin, options.thin, options.numGibbs, options.numMH, 0, 0,
-                         UInt64(seed), 0, init.r, init.p, params.proposalsd_r, C_NULL, C_NULL, ns)
-    out = RcChainOutputs(pointer(clusts), pointer(result.K), pointer(result.r), pointer(result.p), pointer(result.loglik),
-                         pointer(result.logposterior), pointer(racc), pointer(smacc), pointer(smspl), C_NULL, C_NULL, 0, 0.0, 0.0, 0.0)
-    GC.@preserve clusts racc smacc smspl result begin
-        check(ctx, ccall((:rc_run_chain, LIB), Int32, (Ptr{Cvoid}, Ref{RcChainOptions}, Ref{RcChainOutputs}), ctx, opt, out))
+    for c in 1:nch
+        runtime = outs[c].runtime_s
+        for j in 1:ns
+            results[c].clusts[j] .= view(clusts[c], :, j)
+        end
+        results[c].r_acceptances .= racc[c] .!= 0
+        results[c].splitmerge_acceptances .= view(smacc[c], 1:options.numiters*options.numMH) .!= 0
+        results[c].splitmerge_splits .= view(smspl[c], 1:options.numiters*options.numMH) .!= 0
+        results[c].posterior_coclustering .= post
+        summarise!(results[c], options, params, runtime)
     end
-    for j in 1:ns
-        result.clusts[j] .= view(clusts, :, j)
-    end
-    result.r_acceptances .= racc .!= 0
-    result.splitmerge_acceptances .= smacc .!= 0
-    result.splitmerge_splits .= smspl .!= 0
-    result.runtime = out.runtime_s
-    result.mean_iter_time = out.runtime_s / options.numiters
-    return result
+    return results, post, Int(total[])
 end
 
 """
@@ -178,7 +266,7 @@ function getpointestimate_hip(result; loss::String = "VI", device::Integer = 0)
     rc = ccall((:rc_loss_matrix, LIB), Int32,
                (Int32, Ptr{Int64}, Int64, Int64, Int32, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Int64}, Ptr{Cdouble}),
                device, samples, m, n, code[loss], C_NULL, C_NULL, best, C_NULL)
-    rc == 0 || error(unsafe_string(ccall((:rc_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))
+    check(Ptr{Cvoid}(C_NULL), rc)
     return (result.clusts[best[] + 1], Int(best[]) + 1)
 end
 

@@ -204,11 +204,13 @@ __global__ void k_make_log(const double *__restrict__ D, double *__restrict__ L,
     }
 }
 
-__global__ void k_maxabs(const double *__restrict__ X, size_t total, unsigned *flags, u64 *maxabs_bits)
+// flags: bit0 asymmetric (checked when n > 0: X is n×n), bit1 non-finite
+__global__ void k_maxabs(const double *__restrict__ X, size_t total, unsigned *flags, u64 *maxabs_bits, int n)
 {
     u64 m = 0;
     unsigned f = 0;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        if (n > 0 && X[t] != X[(t % (size_t)n) * (size_t)n + t / (size_t)n]) f |= 1u;
         const double x = fabs(X[t]);
         if (!(x <= 1.79769313486231570e308)) f |= 2u;
         const u64 b = (u64)__double_as_longlong(x);
@@ -2836,7 +2838,7 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
         } else {
             k_make_log<<<gb, 256, 0, s>>>(tmpD, tmpL, (int)n);
         }
-        k_maxabs<<<gb, 256, 0, s>>>(tmpL, nn, flags + 1, mx + 1);
+        k_maxabs<<<gb, 256, 0, s>>>(tmpL, nn, flags + 1, mx + 1, logD ? (int)n : 0);   // a caller's logD must be symmetric too
         return hipSuccess;
     };
     const bool log_staged = !derived;
@@ -2887,6 +2889,9 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
         HIPCHK2(hipStreamSynchronize(s));
     }
     if (hflags[1] & 2u) { cleanup(); return fail(c, RC_ERR_DOMAIN, "logD must be finite."); }
+    // the symmetric row-reduction kernels read the upper triangle only, the full-read kernel both: an asymmetric logD would
+    // make the two disagree (the reference derives logD from the symmetric D, types.jl:155, so it is symmetric there)
+    if (hflags[1] & 1u) { cleanup(); return fail(c, RC_ERR_DOMAIN, "logD must be symmetric."); }
     std::memcpy(&maxL, &hmx[1], 8);
     c->eL = quant_exponent(n, maxL, c->bits);
     if (derived && maxL > 0.0) {
@@ -3154,7 +3159,13 @@ static int32_t sync_and_check(rc_ctx *c, bool both = false)
     HIPCHK(c, hipGetLastError());
     c->last.K = c->hsum->K; c->last.n_changes = c->hsum->n_changes; c->last.n_rounds = c->hsum->n_rounds;
     c->last.err = c->hsum->err; c->last.slot_hi = c->hsum->slot_hi;
-    if (c->last.err & RC_DERR_BARRIER) return fail(c, RC_ERR_HIP, "grid barrier timed out inside the sweep kernel");
+    if (c->last.err & RC_DERR_BARRIER) {
+        // some blocks of the resolver gave up waiting for the others (another process holding part of the GPU?): the sweep is
+        // half-committed, so the state is void until rc_set_state installs labels again
+        c->have_state = false;
+        return fail(c, RC_ERR_HIP, "grid barrier timed out inside the sweep kernel (is another process using this GPU? one chain per "
+                                   "GPU); the label state is void: call rc_set_state before sweeping again");
+    }
     if (c->last.err & RC_DERR_CAPACITY)
         return fail(c, RC_ERR_CAPACITY, "number of clusters exceeded the slot capacity kcap=%d given to rc_create", c->kcap);
     return RC_OK;

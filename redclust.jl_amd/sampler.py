@@ -115,7 +115,12 @@ def runsampler(data: MCMCData, options: MCMCOptionsList | None = None, params: P
         ctx.cocluster_reset()
         numMH = options.numMH
         if numMH > 0:
-            ctx.attach_host_matrices(data.D, data.logD if host_logD is None else host_logD)
+            if data.points is not None and host_logD is None:
+                # MCMCData(points): the split–merge scans must see the SAME D and logD as the device's log-likelihoods —
+                # the matrix the device computed from the points, not a second evaluation by numpy
+                ctx.attach_host_matrices(ctx.get_matrix(0), ctx.get_matrix(1))
+            else:
+                ctx.attach_host_matrices(data.D, data.logD if host_logD is None else host_logD)
         result = MCMCResult.allocate(data, options, params)
         state = MCMCState(init.clusts, init.r, init.p)
         out("Run MCMC")

@@ -223,6 +223,10 @@ def test_edge_cases_and_errors():
     z = D.copy(); z[2, 3] = z[3, 2] = 0.0
     with pytest.raises(rc.RedClustHIPError, match="positive"):
         rc.Context(z)
+    # a caller's logD must be symmetric as well: the symmetric kernels read its upper triangle only
+    Lbad = np.log(D + np.eye(100)); Lbad[5, 6] += 1e-9
+    with pytest.raises(ValueError, match="logD must be symmetric"):
+        rc.Context(D, logD=Lbad)
     # the zero-distance decision (DESIGN.md "Zero distances"): a ValueError like the reference's ArgumentError class of
     # input errors, raised by the library for a matrix and for duplicate points alike, and by the MCMCData glue
     with pytest.raises(ValueError, match="jitter"):
