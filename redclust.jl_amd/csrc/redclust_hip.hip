@@ -2584,10 +2584,14 @@ struct rc_ctx {
     long long B_version = -2;
     // lgammal(alpha + delta1*pairs) - lgammal(alpha) and the zeta analogue, memoised by the integer pair count: between
     // consecutive rc_loglik calls cluster sizes rarely change, so nearly all of the K + K(K-1)/2 evaluations hit
-    std::unordered_map<long long, long double> lg_memo1, lg_memo2;
     struct LLTerm { long long e[4] = {0, 0, 0, 0}; int sk = -1, st = -1; long double term = 0; };
-    std::vector<LLTerm> ll_cache;        // loglik terms per slot pair ([t][k], ll_dim × ll_dim), see loglik_host
-    int ll_dim = 0;
+    struct LLCache {                     // memo of loglik_host: one per thread that evaluates log-likelihoods
+        std::unordered_map<long long, long double> lg_memo1, lg_memo2;
+        std::vector<LLTerm> ll_cache;    // loglik terms per slot pair ([t][k], ll_dim × ll_dim), see loglik_host
+        int ll_dim = 0;
+    };
+    LLCache llc;
+    long long params_version = 0;        // bumped by rc_set_params (worker-thread caches of the chain loop follow it)
     long long *pinB[RC_REC_SLOTS] = {};  // pinned staging: block sums / label snapshot / completion event per sample slot
     unsigned short *pinLab[RC_REC_SLOTS] = {};
     hipEvent_t pinEv[RC_REC_SLOTS] = {};
@@ -3108,10 +3112,8 @@ extern "C" int32_t rc_set_params(rc_ctx *c, const rc_params *P)
     HIPCHK(c, hipStreamSynchronize(c->sB));
     HIPCHK(c, hipStreamSynchronize(c->sB2));
     c->P = *P;
-    c->lg_memo1.clear();
-    c->lg_memo2.clear();
-    c->ll_cache.clear();
-    c->ll_dim = 0;
+    c->llc = rc_ctx::LLCache();
+    c->params_version++;
     c->ll_version = -1;   // cached log-likelihood / block sums belong to the old parameters
     c->B_version = -2;
     // size table (see DESIGN.md "Score arithmetic"): long double on the host, once per parameter set
@@ -3575,16 +3577,16 @@ extern "C" int32_t rc_get_state(rc_ctx *c, int64_t *clusts, int64_t *clustsizes,
 // two cluster sizes and its block sums, and most of them do not change from one recorded sample to the next, so the
 // terms are cached per slot pair and re-evaluated only when their (integer) inputs differ: the value — and the order
 // of the summation — is exactly that of evaluating every term afresh.
-static double loglik_host(rc_ctx *c, int hi, const int *ssize, const long long *B)
+static double loglik_host_c(const rc_ctx *c, rc_ctx::LLCache &cache, int hi, const int *ssize, const long long *B)
 {
     const rc_params &P = c->P;
     const long double d1 = P.delta1, d2 = P.delta2, al = P.alpha, be = P.beta, ze = P.zeta, ga = P.gamma;
     const long double lga = lgammal(al), lgz = lgammal(ze), lgd1 = lgammal(d1), lgd2 = lgammal(d2);
     const long double lb = logl(be), lg = logl(ga);
     const long double scD = ldexpl(1.0L, -c->eD), scL = ldexpl(1.0L, -c->eL);
-    if (hi > c->ll_dim) {
-        c->ll_dim = std::max(hi, std::min(c->kcap, 2 * hi));
-        c->ll_cache.assign((size_t)c->ll_dim * c->ll_dim, rc_ctx::LLTerm{});
+    if (hi > cache.ll_dim) {
+        cache.ll_dim = std::max(hi, std::min(c->kcap, 2 * hi));
+        cache.ll_cache.assign((size_t)cache.ll_dim * cache.ll_dim, rc_ctx::LLTerm{});
     }
     auto blk = [&](const long long *e, int which) -> long double {
         return ((long double)e[which ? 2 : 0] * (long double)(1ll << RC_LO_BITS) + (long double)e[which ? 3 : 1]) * (which ? scL : scD);
@@ -3595,36 +3597,36 @@ static double loglik_host(rc_ctx *c, int hi, const int *ssize, const long long *
     long double L1 = 0, L2 = 0;
     for (int k : act) {
         const long long *e = &B[((size_t)k * hi + k) * 4];
-        rc_ctx::LLTerm &T = c->ll_cache[(size_t)k * c->ll_dim + k];
+        rc_ctx::LLTerm &T = cache.ll_cache[(size_t)k * cache.ll_dim + k];
         if (!(T.sk == ssize[k] && T.e[0] == e[0] && T.e[1] == e[1] && T.e[2] == e[2] && T.e[3] == e[3])) {
             const long double sz = ssize[k];
             const long double pairs = sz * (sz - 1) / 2;  // binomial(sz_k, 2)
             const long double a = al + d1 * pairs;
             const long double bd = blk(e, 0) / 2, bl = blk(e, 1) / 2;
             const long long pk = (long long)pairs;
-            auto it = c->lg_memo1.find(pk);
-            if (it == c->lg_memo1.end()) it = c->lg_memo1.emplace(pk, lgammal(a) - lga).first;
+            auto it = cache.lg_memo1.find(pk);
+            if (it == cache.lg_memo1.end()) it = cache.lg_memo1.emplace(pk, lgammal(a) - lga).first;
             T.term = (d1 - 1) * bl - pairs * lgd1 + it->second - d1 * pairs * lb - a * log1pl(bd / be);
             T.sk = ssize[k]; T.st = ssize[k];
             std::memcpy(T.e, e, sizeof(T.e));
         }
         L1 += T.term;
     }
-    if (c->lg_memo1.size() > (1u << 20)) c->lg_memo1.clear();
-    if (c->lg_memo2.size() > (1u << 20)) c->lg_memo2.clear();
+    if (cache.lg_memo1.size() > (1u << 20)) cache.lg_memo1.clear();
+    if (cache.lg_memo2.size() > (1u << 20)) cache.lg_memo2.clear();
     if (P.repulsion)
         for (size_t x = 0; x < act.size(); ++x)
             for (size_t y = x + 1; y < act.size(); ++y) {
                 const int k = act[x], t = act[y];
                 const long long *e = &B[((size_t)t * hi + k) * 4];
-                rc_ctx::LLTerm &T = c->ll_cache[(size_t)t * c->ll_dim + k];
+                rc_ctx::LLTerm &T = cache.ll_cache[(size_t)t * cache.ll_dim + k];
                 if (!(T.sk == ssize[k] && T.st == ssize[t] && T.e[0] == e[0] && T.e[1] == e[1] && T.e[2] == e[2] && T.e[3] == e[3])) {
                     const long double pairs = (long double)ssize[k] * (long double)ssize[t];
                     const long double z = ze + d2 * pairs;
                     const long double bd = blk(e, 0), bl = blk(e, 1);
                     const long long pk = (long long)pairs;
-                    auto it = c->lg_memo2.find(pk);
-                    if (it == c->lg_memo2.end()) it = c->lg_memo2.emplace(pk, lgammal(z) - lgz).first;
+                    auto it = cache.lg_memo2.find(pk);
+                    if (it == cache.lg_memo2.end()) it = cache.lg_memo2.emplace(pk, lgammal(z) - lgz).first;
                     T.term = (d2 - 1) * bl - pairs * lgd2 + it->second - d2 * pairs * lg - z * log1pl(bd / ga);
                     T.sk = ssize[k]; T.st = ssize[t];
                     std::memcpy(T.e, e, sizeof(T.e));
@@ -3633,6 +3635,8 @@ static double loglik_host(rc_ctx *c, int hi, const int *ssize, const long long *
             }
     return (double)(L1 + L2);
 }
+
+static double loglik_host(rc_ctx *c, int hi, const int *ssize, const long long *B) { return loglik_host_c(c, c->llc, hi, ssize, B); }
 
 // enqueues the block sums of the current state on stream A and their copy into the pinned buffer `dst`
 // (hi·hi·4 int64); the caller synchronises (stream or event) before reading
@@ -4284,26 +4288,44 @@ struct Restricted {
 };
 }  // namespace
 
-// One proposal of the MH loop of sample_labels! (src/mcmc.jl:374-473) on the current device state.  On acceptance
-// the device state BECOMES the proposed state (what the reference's rebinding `state = finalstate`, mcmc.jl:470,
-// means for its caller is the host loop's business: rc_state_checkpoint / rc_state_restore).
-extern "C" int32_t rc_splitmerge(rc_ctx *c, double r, double p, int64_t numGibbs, uint64_t seed, uint64_t iter,
-                                 uint64_t mh_counter, uint8_t *accept_out, uint8_t *split_out)
-{
-    if (!c || !accept_out || !split_out) return fail(c, RC_ERR_ARG, "rc_splitmerge: NULL argument");
-    if (!c->have_params || !c->have_state) return fail(c, RC_ERR_STATE, "rc_splitmerge: params and state must be set");
-    if (!c->hostD || !c->hostL) return fail(c, RC_ERR_STATE, "rc_splitmerge: call rc_attach_host_matrices first");
-    if (!(r > 0.0) || !(p > 0.0 && p < 1.0) || numGibbs < 0) return fail(c, RC_ERR_ARG, "rc_splitmerge: need r > 0, 0 < p < 1, numGibbs >= 0");
-    if (c->n < 2) return fail(c, RC_ERR_ARG, "rc_splitmerge: needs n >= 2 (sample(1:n, 2, replace=false))");
-    HIPCHK(c, hipSetDevice(c->dev));
-    *accept_out = 0; *split_out = 0;
-    const int64_t n = c->n;
-    std::vector<int64_t> clusts, sizes;
+// The host part of one proposal of the MH loop of sample_labels! (src/mcmc.jl:374-473), as a pure function of a SNAPSHOT
+// of the state: labels, sizes by label, K, and the exact block sums B[t][k] of that state with the slot tables they are
+// indexed by.  Touches neither the device nor the context (only its parameters and the borrowed host matrices), so the
+// chain loop can run it on worker threads for several iterations at once (chain.inc.hip).  A merge is decided here
+// completely — block sums are additive: B'(m, l) = B(ci, l) + B(cj, l), B'(m, m) = B(ci,ci) + B(cj,cj) + 2 B(ci,cj), so the
+// merged state's log-likelihood follows from the snapshot's integers, the same ones k_blocksums would produce after
+// applying the merge.  A split needs the row sums of the two new clusters: needs_device is set and the caller applies
+// cfinal on the device, takes its log-likelihood and finishes the decision (finish_decision).
+struct ProposalSnapshot {
+    const int64_t *clusts, *sizes;   // n labels, n sizes by label
     int64_t K;
-    g_smprof.start();
-    int32_t rc = pull_labels(c, clusts, sizes, K);
-    if (rc != RC_OK) return rc;
-    g_smprof.lap(0);
+    int hi;                          // block sums: hi × hi × 4 int64, slot sizes and labels [hi]
+    const int *ssize, *slabel;
+    const long long *B;
+};
+struct ProposalResult {
+    bool accept = false, split = false, skipped = false, needs_device = false;
+    double log_prior_ratio = 0, log_proposal_ratio = 0, ll_cur = 0, ll_fin = 0;
+    std::vector<int64_t> cfinal;     // proposed labels (filled for splits and for accepted merges)
+    int32_t err = RC_OK;
+    const char *errmsg = nullptr;
+};
+
+static bool finish_decision(ProposalResult &R, uint64_t seed, uint64_t iter, uint64_t mh_counter)
+{
+    const double x = R.log_prior_ratio + (R.ll_fin - R.ll_cur) - R.log_proposal_ratio;
+    const double lar = (x != x) ? NAN : (x < 0 ? x : 0.0);                                // minimum([0, x]) propagates NaN
+    const double lu = std::log(rc_uniform_mh(seed, iter, mh_counter, 2));
+    R.accept = lu < lar;                                                                 // mcmc.jl:469-472
+    return R.accept;
+}
+
+static void proposal_core(const rc_ctx *c, rc_ctx::LLCache &cache, const ProposalSnapshot &S0, double r, double p, int64_t numGibbs,
+                          uint64_t seed, uint64_t iter, uint64_t mh_counter, ProposalResult &out, bool profile)
+{
+    const int64_t n = c->n;
+    const int64_t *clusts = S0.clusts, *sizes = S0.sizes;
+    const int64_t K = S0.K;
     // chaperones (mcmc.jl:379)
     int64_t i = (int64_t)std::floor(rc_uniform_mh(seed, iter, mh_counter, 0) * (double)n);
     int64_t j = (int64_t)std::floor(rc_uniform_mh(seed, iter, mh_counter, 1) * (double)(n - 1));
@@ -4311,25 +4333,24 @@ extern "C" int32_t rc_splitmerge(rc_ctx *c, double r, double p, int64_t numGibbs
     if (j >= n - 1) j = n - 2;
     if (j >= i) j += 1;
     const int64_t ci = clusts[(size_t)i], cj = clusts[(size_t)j];
-    if (c->P.maxK > 0 && ci == cj && K >= c->P.maxK) return RC_OK;                      // mcmc.jl:384-386
+    if (c->P.maxK > 0 && ci == cj && K >= c->P.maxK) { out.skipped = true; return; }      // mcmc.jl:384-386
     std::vector<int64_t> S, U;
     for (int64_t k = 0; k < n; ++k)
         if (clusts[(size_t)k] == ci || clusts[(size_t)k] == cj) {
             U.push_back(k);
             if (k != i && k != j) S.push_back(k);                                        // mcmc.jl:389-390
         }
-    if ((uint64_t)S.size() * (uint64_t)(2 * numGibbs + 4) + 8 > 0xFFFFFFFFull)
-        return fail(c, RC_ERR_ARG, "rc_splitmerge: uniform counter overflow (|S| * numGibbs too large)");
-    std::vector<int64_t> claunch = clusts, szlaunch = sizes;
-    int64_t Klaunch = K;
+    if ((uint64_t)S.size() * (uint64_t)(2 * numGibbs + 4) + 8 > 0xFFFFFFFFull) {
+        out.err = RC_ERR_ARG; out.errmsg = "rc_splitmerge: uniform counter overflow (|S| * numGibbs too large)"; return;
+    }
+    std::vector<int64_t> claunch(clusts, clusts + n), szlaunch(sizes, sizes + n);
     if (ci == cj) {                                                                      // mcmc.jl:396-401
         int64_t e = 0;
         while (e < n && sizes[(size_t)e] != 0) ++e;
-        if (e >= n) return fail(c, RC_ERR_STATE, "rc_splitmerge: no empty label for a split");
+        if (e >= n) { out.err = RC_ERR_STATE; out.errmsg = "rc_splitmerge: no empty label for a split"; return; }
         claunch[(size_t)i] = e + 1;
         szlaunch[(size_t)ci - 1] -= 1;
         szlaunch[(size_t)e] += 1;
-        Klaunch = K + 1;
     }
     const int64_t cand[2] = {claunch[(size_t)i], claunch[(size_t)j]};                    // mcmc.jl:402
     for (size_t q = 0; q < S.size(); ++q) {                                              // mcmc.jl:403-407
@@ -4345,97 +4366,118 @@ extern "C" int32_t rc_splitmerge(rc_ctx *c, double r, double p, int64_t numGibbs
     R.zgratio = P.zeta * std::log(P.gamma) - std::lgamma(P.zeta);
     R.lg_d1 = std::lgamma(P.delta1); R.lg_d2 = std::lgamma(P.delta2); R.logp = std::log(p);
     R.U = &U;
-    g_smprof.lap(1);
+    if (profile) g_smprof.lap(1);
     for (int64_t s = 0; s < numGibbs; ++s) R.scan(claunch, szlaunch, S, cand, nullptr, s);  // mcmc.jl:411-414
-    std::vector<int64_t> cfinal, szfinal;
-    double log_prior_ratio, log_proposal_ratio;
+    std::vector<int64_t> clusts_v;   // the merge's forced final scan wants the original labels as a vector
     if (ci == cj) {                                                                      // split, mcmc.jl:416-434
-        *split_out = 1;
+        out.split = true;
         const double ltp = R.scan(claunch, szlaunch, S, cand, nullptr, numGibbs);
-        cfinal = claunch; szfinal = szlaunch;
-        const double sfi = (double)szfinal[(size_t)cfinal[(size_t)i] - 1], sfj = (double)szfinal[(size_t)cfinal[(size_t)j] - 1];
+        out.cfinal = claunch;
+        const double sfi = (double)szlaunch[(size_t)claunch[(size_t)i] - 1], sfj = (double)szlaunch[(size_t)claunch[(size_t)j] - 1];
         const double sci = (double)sizes[(size_t)ci - 1];
-        log_prior_ratio = std::log((double)(K + 1)) + r * std::log(1 - p) - std::log(p) - std::lgamma(r) +
-                          std::lgamma(sfi - 1 + r) + std::lgamma(sfj - 1 + r) + std::log(sfi) + std::log(sfj) +
-                          -(std::lgamma(sci - 1 + r) + std::log(sci));
-        log_proposal_ratio = ltp;
+        out.log_prior_ratio = std::log((double)(K + 1)) + r * std::log(1 - p) - std::log(p) - std::lgamma(r) +
+                              std::lgamma(sfi - 1 + r) + std::lgamma(sfj - 1 + r) + std::log(sfi) + std::log(sfj) +
+                              -(std::lgamma(sci - 1 + r) + std::log(sci));
+        out.log_proposal_ratio = ltp;
     } else {                                                                             // merge, mcmc.jl:435-459
-        cfinal = claunch; szfinal = szlaunch;
+        std::vector<int64_t> szfinal = szlaunch;
+        out.cfinal = claunch;
         int64_t sz_clust_i = 0;
         for (int64_t k : U)
-            if (cfinal[(size_t)k] == ci) { cfinal[(size_t)k] = cj; ++sz_clust_i; }
+            if (out.cfinal[(size_t)k] == ci) { out.cfinal[(size_t)k] = cj; ++sz_clust_i; }
         szfinal[(size_t)ci - 1] = 0;
         szfinal[(size_t)cj - 1] += sz_clust_i;
         const double sfj = (double)szfinal[(size_t)cj - 1], sci = (double)sizes[(size_t)ci - 1], scj = (double)sizes[(size_t)cj - 1];
-        log_prior_ratio = -(std::log((double)K) + r * std::log(1 - p) - std::log(p) - std::lgamma(r)) +
-                          std::lgamma(sfj - 1 + r) + std::log(sfj) +
-                          -(std::lgamma(sci - 1 + r) + std::lgamma(scj - 1 + r) + std::log(sci) + std::log(scj));
-        const double ltp = R.scan(claunch, szlaunch, S, cand, &clusts, numGibbs);
-        log_proposal_ratio = -ltp;
+        out.log_prior_ratio = -(std::log((double)K) + r * std::log(1 - p) - std::log(p) - std::lgamma(r)) +
+                              std::lgamma(sfj - 1 + r) + std::log(sfj) +
+                              -(std::lgamma(sci - 1 + r) + std::lgamma(scj - 1 + r) + std::log(sci) + std::log(scj));
+        clusts_v.assign(clusts, clusts + n);
+        const double ltp = R.scan(claunch, szlaunch, S, cand, &clusts_v, numGibbs);
+        out.log_proposal_ratio = -ltp;
     }
-    (void)Klaunch;
-    g_smprof.lap(2);
-    // likelihood ratio (mcmc.jl:462-464): both states evaluated on the device from the exact S table
-    double ll_cur = 0, ll_fin = 0;
-    if (c->ll_version == c->state_version && c->B_version == c->state_version) {
-        ll_cur = c->ll_cached;  // same labels as at the last evaluation (e.g. the previous, rejected proposal)
-    } else {
-        rc = rc_loglik(c, &ll_cur);
+    if (profile) g_smprof.lap(2);
+    // likelihood ratio (mcmc.jl:462-464) from the exact block sums of the snapshot
+    out.ll_cur = loglik_host_c(c, cache, S0.hi, S0.ssize, S0.B);
+    if (profile) g_smprof.lap(3);
+    if (ci == cj) { out.needs_device = true; return; }
+    const int hi = S0.hi;
+    int si = -1, sj = -1;
+    for (int k = 0; k < hi; ++k) {
+        if (S0.ssize[k] > 0 && S0.slabel[k] == ci) si = k;
+        if (S0.ssize[k] > 0 && S0.slabel[k] == cj) sj = k;
+    }
+    if (si < 0 || sj < 0) { out.err = RC_ERR_STATE; out.errmsg = "rc_splitmerge: internal: slots of the merged clusters not found"; return; }
+    std::vector<long long> Bm(S0.B, S0.B + (size_t)hi * hi * 4);
+    std::vector<int> szm(S0.ssize, S0.ssize + hi);
+    for (int k = 0; k < hi; ++k)
+        for (int w = 0; w < 4; ++w) Bm[((size_t)sj * hi + k) * 4 + w] += Bm[((size_t)si * hi + k) * 4 + w];
+    for (int t = 0; t < hi; ++t)
+        for (int w = 0; w < 4; ++w) Bm[((size_t)t * hi + sj) * 4 + w] += Bm[((size_t)t * hi + si) * 4 + w];
+    szm[(size_t)sj] += szm[(size_t)si];
+    szm[(size_t)si] = 0;
+    out.ll_fin = loglik_host_c(c, cache, hi, szm.data(), Bm.data());
+    if (profile) g_smprof.lap(5);
+    finish_decision(out, seed, iter, mh_counter);
+    if (!out.accept) out.cfinal.clear();
+}
+
+// One proposal of the MH loop of sample_labels! (src/mcmc.jl:374-473) on the current device state.  On acceptance
+// the device state BECOMES the proposed state (what the reference's rebinding `state = finalstate`, mcmc.jl:470,
+// means for its caller is the host loop's business: rc_state_checkpoint / rc_state_restore).
+extern "C" int32_t rc_splitmerge(rc_ctx *c, double r, double p, int64_t numGibbs, uint64_t seed, uint64_t iter,
+                                 uint64_t mh_counter, uint8_t *accept_out, uint8_t *split_out)
+{
+    if (!c || !accept_out || !split_out) return fail(c, RC_ERR_ARG, "rc_splitmerge: NULL argument");
+    if (!c->have_params || !c->have_state) return fail(c, RC_ERR_STATE, "rc_splitmerge: params and state must be set");
+    if (!c->hostD || !c->hostL) return fail(c, RC_ERR_STATE, "rc_splitmerge: call rc_attach_host_matrices first");
+    if (!(r > 0.0) || !(p > 0.0 && p < 1.0) || numGibbs < 0) return fail(c, RC_ERR_ARG, "rc_splitmerge: need r > 0, 0 < p < 1, numGibbs >= 0");
+    if (c->n < 2) return fail(c, RC_ERR_ARG, "rc_splitmerge: needs n >= 2 (sample(1:n, 2, replace=false))");
+    HIPCHK(c, hipSetDevice(c->dev));
+    *accept_out = 0; *split_out = 0;
+    std::vector<int64_t> clusts, sizes;
+    int64_t K;
+    g_smprof.start();
+    int32_t rc = pull_labels(c, clusts, sizes, K);
+    if (rc != RC_OK) return rc;
+    g_smprof.lap(0);
+    // block sums of the current state (kept from the last evaluation when the labels have not changed since)
+    if (!(c->ll_version == c->state_version && c->B_version == c->state_version)) {
+        double ll_tmp = 0;
+        rc = rc_loglik(c, &ll_tmp);
         if (rc != RC_OK) return rc;
     }
-    const long long version_cur = c->state_version;
-    g_smprof.lap(3);
-    bool applied = false;
-    if (ci != cj) {
-        // Merge: block sums are additive — B'(m, l) = B(ci, l) + B(cj, l), B'(m, m) = B(ci,ci) + B(cj,cj) + 2 B(ci,cj) —
-        // so the merged state's log-likelihood is evaluated on the host from the current state's exact integer block
-        // sums: the same integers k_blocksums would produce after applying the merge, hence the same value, with no
-        // device work and nothing to revert when the proposal is rejected (the common case).
-        const int hi = c->B_hi;
-        int si = -1, sj = -1;
-        for (int k = 0; k < hi; ++k) {
-            if (c->B_ssize[(size_t)k] > 0 && c->B_slabel[(size_t)k] == ci) si = k;
-            if (c->B_ssize[(size_t)k] > 0 && c->B_slabel[(size_t)k] == cj) sj = k;
-        }
-        if (si < 0 || sj < 0) return fail(c, RC_ERR_STATE, "rc_splitmerge: internal: slots of the merged clusters not found");
-        std::vector<long long> Bm = c->B_cur;
-        std::vector<int> szm(c->B_ssize.begin(), c->B_ssize.begin() + hi);
-        for (int k = 0; k < hi; ++k)
-            for (int w = 0; w < 4; ++w) Bm[((size_t)sj * hi + k) * 4 + w] += Bm[((size_t)si * hi + k) * 4 + w];
-        for (int t = 0; t < hi; ++t)
-            for (int w = 0; w < 4; ++w) Bm[((size_t)t * hi + sj) * 4 + w] += Bm[((size_t)t * hi + si) * 4 + w];
-        szm[(size_t)sj] += szm[(size_t)si];
-        szm[(size_t)si] = 0;
-        ll_fin = loglik_host(c, hi, szm.data(), Bm.data());
-        g_smprof.lap(5);
-    } else {
-        rc = apply_labels(c, clusts, cfinal);
-        if (rc != RC_OK) return rc;
-        applied = true;
-        g_smprof.lap(4);
-        rc = rc_loglik(c, &ll_fin);
-        if (rc != RC_OK) return rc;
-        g_smprof.lap(5);
-    }
-    const double x = log_prior_ratio + (ll_fin - ll_cur) - log_proposal_ratio;
-    const double lar = (x != x) ? NAN : (x < 0 ? x : 0.0);                                // minimum([0, x]) propagates NaN
-    const double lu = std::log(rc_uniform_mh(seed, iter, mh_counter, 2));
-    if (lu < lar) {                                                                      // mcmc.jl:469-472
-        *accept_out = 1;  // the proposed state stays on the device (tables and perm generations follow it)
-        if (!applied) {
-            rc = apply_labels(c, clusts, cfinal);
+    ProposalSnapshot S0{clusts.data(), sizes.data(), K, c->B_hi, c->B_ssize.data(), c->B_slabel.data(), c->B_cur.data()};
+    ProposalResult R;
+    proposal_core(c, c->llc, S0, r, p, numGibbs, seed, iter, mh_counter, R, true);
+    if (R.err != RC_OK) return fail(c, R.err, "%s", R.errmsg);
+    if (R.skipped) return RC_OK;
+    *split_out = R.split ? 1 : 0;
+    if (!R.needs_device) {                                                               // merge: decided on the host
+        if (R.accept) {
+            *accept_out = 1;  // the proposed state goes to the device (tables and perm generations follow it)
+            rc = apply_labels(c, clusts, R.cfinal);
             if (rc != RC_OK) return rc;
             g_smprof.lap(4);
+            c->ll_cached = R.ll_fin; c->ll_version = c->state_version;
         }
-        c->ll_cached = ll_fin; c->ll_version = c->state_version;
         return RC_OK;
     }
-    if (!applied) return RC_OK;                                                          // nothing was touched
-    rc = apply_labels(c, cfinal, clusts);                                                // rejected: revert, bit-exactly
+    // split: the proposed state is applied on the device for its log-likelihood
+    rc = apply_labels(c, clusts, R.cfinal);
+    if (rc != RC_OK) return rc;
+    g_smprof.lap(4);
+    rc = rc_loglik(c, &R.ll_fin);
+    if (rc != RC_OK) return rc;
+    g_smprof.lap(5);
+    if (finish_decision(R, seed, iter, mh_counter)) {
+        *accept_out = 1;
+        c->ll_cached = R.ll_fin; c->ll_version = c->state_version;
+        return RC_OK;
+    }
+    rc = apply_labels(c, R.cfinal, clusts);                                              // rejected: revert, bit-exactly
     if (rc != RC_OK) return rc;
     g_smprof.lap(6);
-    (void)version_cur;
-    c->ll_cached = ll_cur; c->ll_version = c->state_version;                             // the reverted state is the evaluated one
+    c->ll_cached = R.ll_cur; c->ll_version = c->state_version;                           // the reverted state is the evaluated one
     return RC_OK;
 }
 
