@@ -173,6 +173,448 @@ static int32_t record_finish(rc_ctx *c, Pending &R, rc_chain_outputs *out)
     return RC_OK;
 }
 
+// ---- speculative pipeline for numMH > 0 --------------------------------------------------------------------------
+// A split–merge proposal is 0.8 ms of sequential host work (the restricted scans, mcmc.jl:259-354) against a 0.09 ms
+// sweep, and it is almost always rejected.  A rejected proposal leaves the state untouched, so the loop SPECULATES that
+// every proposal of an iteration is rejected: it takes a snapshot of the state an iteration starts from (labels, slot
+// tables, block sums), launches the sweep at once and hands the proposals to a worker thread, which decides them on the
+// snapshot alone (proposal_core: no device, no context state).  Several iterations are in flight.  Iterations are
+// confirmed in order; a sample is recorded only from confirmed iterations (labels and block sums of the following
+// snapshot).  When a proposal turns out to be accepted — or is a split, whose likelihood needs the device — the loop rolls
+// back: workers are drained, the device returns to the snapshot's labels (exact integer corrections, as
+// rc_state_restore), that iteration is redone by the synchronous path, and speculation restarts behind it.  The
+// speculation depth halves on a rollback and doubles again after 16 clean iterations, so a regime in which most
+// proposals are splits degrades to the synchronous loop instead of thrashing.  Results are those of the synchronous loop
+// bit for bit: every draw is a function of (seed, iteration, state) only.
+struct SpecSlot {
+    int64_t it = 0;                          // 1-based iteration whose initial state this is
+    double r = 0, p = 0;
+    int hi = 0, K = 0, capB = 0;
+    std::vector<int> ssize, slabel;
+    unsigned short *dev_row = nullptr, *pin_lab = nullptr;
+    long long *pin_B = nullptr;
+    hipEvent_t ev = nullptr;
+    std::vector<int64_t> labels, sizes;      // by point, by label (the proposal's view of the state)
+    std::vector<uint8_t> acc, spl;
+    bool clean = false;                      // every proposal decided on the host and rejected (or skipped)
+    bool split_pending = false;              // proposal number pend_mh is a split: the host part is in pend, the decision needs ll_fin
+    int64_t pend_mh = 0;
+    ProposalResult pend;
+    int32_t err = RC_OK;
+    const char *errmsg = nullptr;
+    int state = 0;                           // 0 idle, 1 queued / running, 2 done   (guarded by SpecPool::m)
+};
+
+struct SpecPool {
+    rc_ctx *c;
+    const rc_chain_options *o;
+    std::vector<SpecSlot> slots;
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    std::deque<int> queue;
+    bool stop = false;
+
+    SpecPool(rc_ctx *c_, const rc_chain_options *o_, int nslots) : c(c_), o(o_), slots((size_t)nslots) {}
+    void start(int nworkers)
+    {
+        for (int w = 0; w < nworkers; ++w) threads.emplace_back([this] { run(); });
+    }
+    void run()
+    {
+        rc_ctx::LLCache cache;
+        for (;;) {
+            int si;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv_work.wait(lk, [&] { return stop || !queue.empty(); });
+                if (stop) return;
+                si = queue.front(); queue.pop_front();
+            }
+            SpecSlot &s = slots[(size_t)si];
+            bool clean = true;
+            for (int64_t mh = 0; mh < o->numMH && clean; ++mh) {
+                ProposalSnapshot S0{s.labels.data(), s.sizes.data(), (int64_t)s.K, s.hi, s.ssize.data(), s.slabel.data(), s.pin_B};
+                ProposalResult R;
+                proposal_core(c, cache, S0, s.r, s.p, o->numGibbs, o->seed, o->first_iter + (uint64_t)(s.it - 1), (uint64_t)mh, R, false);
+                if (R.err != RC_OK) { s.err = R.err; s.errmsg = R.errmsg; clean = false; break; }
+                s.acc[(size_t)mh] = 0; s.spl[(size_t)mh] = R.split ? 1 : 0;
+                if (R.needs_device) { s.split_pending = true; s.pend_mh = mh; s.pend = std::move(R); clean = false; }
+                else if (R.accept) clean = false;
+            }
+            s.clean = clean;
+            {
+                std::lock_guard<std::mutex> lk(m);
+                s.state = 2;
+            }
+            cv_done.notify_all();
+        }
+    }
+    void submit(int si)
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            slots[(size_t)si].state = 1;
+            queue.push_back(si);
+        }
+        cv_work.notify_one();
+    }
+    bool done(int si) { std::lock_guard<std::mutex> lk(m); return slots[(size_t)si].state == 2; }
+    void wait(int si) { std::unique_lock<std::mutex> lk(m); cv_done.wait(lk, [&] { return slots[(size_t)si].state == 2; }); }
+    void drain()   // nothing queued or running afterwards; every slot idle
+    {
+        std::unique_lock<std::mutex> lk(m);
+        for (int si : queue) slots[(size_t)si].state = 0;      // never started
+        queue.clear();
+        cv_done.wait(lk, [&] { for (auto &s : slots) if (s.state == 1) return false; return true; });   // running ones finish
+        for (auto &s : slots) s.state = 0;
+    }
+    ~SpecPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv_work.notify_all();
+        for (auto &t : threads) t.join();
+        for (auto &s : slots) {
+            if (s.dev_row) (void)hipFree(s.dev_row);
+            if (s.pin_lab) (void)hipHostFree(s.pin_lab);
+            if (s.pin_B) (void)hipHostFree(s.pin_B);
+            if (s.ev) (void)hipEventDestroy(s.ev);
+        }
+    }
+};
+
+// snapshot of the state on the device (complete: the caller has synchronised) into slot s, asynchronously on stream A
+// (prev != nullptr: the sweep that produced this state changed no label and prev is the snapshot of the state before it —
+// the two states are identical, so the host copies are duplicated and only the device label row is copied, with no wait)
+static int32_t spec_snapshot(rc_ctx *c, SpecSlot &s, const SpecSlot *prev, bool *need_wait)
+{
+    *need_wait = true;
+    if (prev && prev->pin_B && prev->dev_row && s.dev_row && s.capB >= prev->hi) {
+        s.hi = prev->hi; s.K = prev->K; s.ssize = prev->ssize; s.slabel = prev->slabel;
+        std::memcpy(s.pin_lab, prev->pin_lab, (size_t)c->n * sizeof(unsigned short));
+        std::memcpy(s.pin_B, prev->pin_B, (size_t)prev->hi * prev->hi * 4 * sizeof(long long));
+        HIPCHK(c, hipMemcpyAsync(s.dev_row, prev->dev_row, (size_t)c->ldc * sizeof(unsigned short), hipMemcpyDeviceToDevice, c->sA));
+        *need_wait = false;
+        return RC_OK;
+    }
+    s.hi = std::max(1, std::min(c->kcap, c->hsum->slot_hi));
+    s.K = c->hsum->K;
+    s.ssize.resize((size_t)c->kcap); s.slabel.resize((size_t)c->kcap);
+    for (int k = 0; k < c->kcap; ++k) { s.ssize[(size_t)k] = c->hsum->size_label[2 * k]; s.slabel[(size_t)k] = c->hsum->size_label[2 * k + 1]; }
+    if (!s.dev_row) {
+        HIPCHK(c, hipMalloc((void **)&s.dev_row, (size_t)c->ldc * sizeof(unsigned short)));
+        HIPCHK(c, hipHostMalloc((void **)&s.pin_lab, (size_t)(c->n + 8) * sizeof(unsigned short), hipHostMallocDefault));
+        HIPCHK(c, hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+    }
+    if (s.hi > s.capB) {
+        if (s.pin_B) (void)hipHostFree(s.pin_B);
+        s.pin_B = nullptr;
+        s.capB = std::min(c->kcap, std::max(64, 2 * s.hi));
+        HIPCHK(c, hipHostMalloc((void **)&s.pin_B, (size_t)s.capB * s.capB * 4 * sizeof(long long), hipHostMallocDefault));
+    }
+    int32_t rc = order_A_after_sweeps(c);
+    if (rc != RC_OK) return rc;
+    k_snapshot<<<(c->ldc + 255) / 256, 256, 0, c->sA>>>(c->slot_of, c->pi, c->n, c->ldc, s.dev_row);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(s.pin_lab, s.dev_row, (size_t)c->n * sizeof(unsigned short), hipMemcpyDeviceToHost, c->sA));
+    rc = loglik_enqueue(c, s.hi, s.pin_B);
+    if (rc != RC_OK) return rc;
+    HIPCHK(c, hipEventRecord(s.ev, c->sA));
+    return RC_OK;
+}
+
+// the recorded sample of an iteration (mcmc.jl:546-553) from the snapshot of the state it ended in
+static int32_t spec_record(rc_ctx *c, SpecSlot &after, int64_t j, double r, double p, rc_chain_outputs *out)
+{
+    int32_t rc = ensure_counts(c);
+    if (rc != RC_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->snap + (size_t)c->snap_cnt * c->ldc, after.dev_row, (size_t)c->ldc * sizeof(unsigned short),
+                             hipMemcpyDeviceToDevice, c->sA));
+    if (++c->snap_cnt == RC_CC_BATCH) {
+        rc = flush_counts(c);
+        if (rc != RC_OK) return rc;
+    }
+    if (out->clusts) {   // sortlabels (utils.jl:69-74): relabel by order of first appearance
+        int64_t *dst = out->clusts + (size_t)j * c->n;
+        std::vector<int> map((size_t)c->kcap, 0);
+        int next = 0;
+        for (int i = 0; i < c->n; ++i) {
+            int &m = map[(size_t)after.pin_lab[i]];
+            if (m == 0) m = ++next;
+            dst[i] = m;
+        }
+    }
+    const double ll = loglik_host(c, after.hi, after.ssize.data(), after.pin_B);                 // mcmc.jl:551
+    const double lp = logprior_host(c, after.ssize.data(), after.slabel.data(), r, p);
+    if (out->K) out->K[j] = after.K;
+    if (out->r) out->r[j] = r;
+    if (out->p) out->p[j] = p;
+    if (out->loglik) out->loglik[j] = ll;
+    if (out->logposterior) out->logposterior[j] = ll + lp;                                       // mcmc.jl:552
+    return RC_OK;
+}
+
+// Log-likelihood of the state a SPLIT proposal leads to, evaluated against the snapshot the proposal was made on and
+// without touching the live device state: the block sums of the new cluster c0 (the points labelled R.cfinal[i] ≠ their
+// snapshot label) against every cluster come from k_split_eval on the matrices, those of the remainder c1 by exact
+// subtraction from the snapshot's block sums.  The new cluster takes the lowest free slot of the snapshot's table, as
+// apply_labels would give it, so the terms are summed in the same order and the value is the one the synchronous path
+// computes after applying the proposal.  Returns RC_ERR_CAPACITY (no error text) when there is no free slot: the caller
+// falls back to the synchronous path.
+struct SplitScratch { unsigned short *d_bucket = nullptr; int *d_rows = nullptr; long long *d_out = nullptr, *h_out = nullptr; std::vector<unsigned short> bucket; std::vector<int> rows; };
+
+static int32_t spec_eval_split(rc_ctx *c, rc_ctx::LLCache &cache, SplitScratch &X, const SpecSlot &s, ProposalResult &R)
+{
+    const int n = c->n, hi = s.hi;
+    int f = -1;
+    for (int k = 0; k < c->kcap; ++k)
+        if (s.slabel[(size_t)k] == 0) { f = k; break; }
+    if (f < 0) return RC_ERR_CAPACITY;
+    const int h2 = std::max(hi, f + 1);
+    if ((size_t)h2 * 4 * sizeof(u64) > 48 * 1024) return RC_ERR_CAPACITY;   // LDS bins of k_split_eval (beyond: synchronous path)
+    if (!X.d_bucket) {
+        HIPCHK(c, hipMalloc((void **)&X.d_bucket, (size_t)c->ld * sizeof(unsigned short)));
+        HIPCHK(c, hipMalloc((void **)&X.d_rows, (size_t)n * sizeof(int)));
+        HIPCHK(c, hipMalloc((void **)&X.d_out, (size_t)(c->kcap + 1) * 4 * sizeof(long long)));
+        HIPCHK(c, hipHostMalloc((void **)&X.h_out, (size_t)(c->kcap + 1) * 4 * sizeof(long long), hipHostMallocDefault));
+        X.bucket.resize((size_t)c->ld); X.rows.resize((size_t)n);
+    }
+    // buckets in the internal point order: the snapshot's slot, except that the points moved to the new label go to f
+    int si = -1, nrows = 0;
+    std::fill(X.bucket.begin(), X.bucket.end(), (unsigned short)0);
+    for (int q = 0; q < n; ++q) {
+        const int u = c->h_pi[(size_t)q];
+        int b = s.pin_lab[q];
+        if (R.cfinal[(size_t)q] != s.labels[(size_t)q]) { si = b; b = f; X.rows[(size_t)nrows++] = u; }
+        X.bucket[(size_t)u] = (unsigned short)b;
+    }
+    if (nrows == 0 || si < 0) return fail(c, RC_ERR_STATE, "split evaluation: the proposal moves no point");
+    HIPCHK(c, hipMemcpyAsync(X.d_bucket, X.bucket.data(), (size_t)c->ld * sizeof(unsigned short), hipMemcpyHostToDevice, c->sA));
+    HIPCHK(c, hipMemcpyAsync(X.d_rows, X.rows.data(), (size_t)nrows * sizeof(int), hipMemcpyHostToDevice, c->sA));
+    HIPCHK(c, hipMemsetAsync(X.d_out, 0, (size_t)h2 * 4 * sizeof(long long), c->sA));
+    View V = make_view(c);
+    k_split_eval<<<nrows, 256, (size_t)h2 * 4 * sizeof(u64), c->sA>>>(V, X.d_bucket, X.d_rows, h2, X.d_out);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(X.h_out, X.d_out, (size_t)h2 * 4 * sizeof(long long), hipMemcpyDeviceToHost, c->sA));
+    HIPCHK(c, hipStreamSynchronize(c->sA));
+    // proposed block sums (h2 × h2 × 4) and sizes
+    std::vector<long long> B2((size_t)h2 * h2 * 4, 0);
+    std::vector<int> sz2((size_t)h2, 0);
+    for (int t = 0; t < hi; ++t) {
+        sz2[(size_t)t] = s.ssize[(size_t)t];
+        for (int k = 0; k < hi; ++k)
+            for (int w = 0; w < 4; ++w) B2[((size_t)t * h2 + k) * 4 + w] = s.pin_B[((size_t)t * hi + k) * 4 + w];
+    }
+    const long long *T = X.h_out;
+    auto at = [&](int t, int k, int w) -> long long & { return B2[((size_t)t * h2 + k) * 4 + w]; };
+    for (int w = 0; w < 4; ++w) {
+        for (int k = 0; k < h2; ++k) {
+            if (k == f || k == si) continue;
+            at(f, k, w) = T[k * 4 + w]; at(k, f, w) = T[k * 4 + w];
+            at(si, k, w) -= T[k * 4 + w]; at(k, si, w) -= T[k * 4 + w];
+        }
+        const long long t00 = T[f * 4 + w], t01 = T[si * 4 + w];
+        at(si, si, w) -= t00 + 2 * t01;
+        at(f, f, w) = t00;
+        at(f, si, w) = t01; at(si, f, w) = t01;
+    }
+    sz2[(size_t)f] = nrows;
+    sz2[(size_t)si] -= nrows;
+    R.ll_fin = loglik_host_c(c, cache, h2, sz2.data(), B2.data());
+    return RC_OK;
+}
+
+static int32_t run_chain_speculative(rc_ctx *c, const rc_chain_options *o, rc_chain_outputs *out)
+{
+    const int n = c->n;
+    const rc_params &P = c->P;
+    const int Dmax = std::max(1, std::min(64, getenv("RC_CHAIN_DEPTH") ? atoi(getenv("RC_CHAIN_DEPTH")) : 12));
+    int nw = getenv("RC_CHAIN_WORKERS") ? atoi(getenv("RC_CHAIN_WORKERS")) : (int)std::min<unsigned>(12u, std::max(2u, std::thread::hardware_concurrency()) - 1u);
+    nw = std::max(1, std::min(nw, Dmax));
+    const int Rn = Dmax + 2;
+    SpecPool pool(c, o, Rn);
+    pool.start(nw);
+    auto slot_of_it = [&](int64_t it) -> int { return (int)(it % Rn); };
+    int32_t rc = sync_and_check(c, true);
+    if (rc != RC_OK) return rc;
+    double r_prev = o->r0, p_prev = o->p0;   // r, p of the last started iteration
+    std::vector<int64_t> C;
+    int64_t j = 0, conf = 1, i = 1, prev_it = -1;   // prev_it: iteration of the last snapshot taken with the device untouched since
+    int D = Dmax, clean_run = 0;
+    SplitScratch scratch;
+    long long n_rollbacks = 0, n_split_evals = 0; double t_rollback = 0, t_sync = 0, t_snap = 0, t_evwait = 0, t_build = 0, t_confirm = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    const int64_t N = o->numiters;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto recording = [&](int64_t it) { return it > o->burnin && (it - o->burnin) % o->thin == 0; };
+    while (conf <= N) {
+        // 1. start iteration i (i == N + 1: only the closing snapshot, the state the last iteration ended in)
+        if (i <= N + 1 && i - conf <= D) {
+            const auto ta = now();
+            rc = sync_and_check(c);                        // the state iteration i starts from is complete; K and sizes visible
+            if (rc != RC_OK) return rc;
+            const auto tb = now(); t_sync += secs(ta, tb);
+            SpecSlot &s = pool.slots[(size_t)slot_of_it(i)];
+            s.it = i;
+            if (i <= N) {
+                const uint64_t it = o->first_iter + (uint64_t)(i - 1);
+                double r = r_prev, p = p_prev;
+                if (o->r_trace) {
+                    r = o->r_trace[i - 1]; p = o->p_trace[i - 1];
+                    if (!(r > 0.0) || !(p > 0.0 && p < 1.0)) return fail(c, RC_ERR_ARG, "rc_run_chain: r_trace/p_trace entry %lld out of range", (long long)i);
+                } else {
+                    sizes_by_label(c, C);
+                    bool acc = false;
+                    r = sample_r(o->seed, it, r, p, C, P.eta, P.sigma, o->proposalsd_r, &acc);            // mcmc.jl:538
+                    if (out->r_acceptances) out->r_acceptances[i - 1] = acc;
+                    p = sample_p(o->seed, it, (int64_t)C.size(), n, r, P.u, P.v);                        // mcmc.jl:539
+                }
+                if (out->r_all) out->r_all[i - 1] = r;
+                if (out->p_all) out->p_all[i - 1] = p;
+                s.r = r; s.p = p;
+                r_prev = r; p_prev = p;
+            }
+            // an unchanged state (the last sweep moved no label, nothing else touched the device) shares the previous snapshot
+            const SpecSlot *prev = (prev_it == i - 1 && c->hsum->n_changes == 0) ? &pool.slots[(size_t)slot_of_it(i - 1)] : nullptr;
+            bool need_wait = true;
+            rc = spec_snapshot(c, s, prev, &need_wait);
+            if (rc != RC_OK) return rc;
+            prev_it = i;
+            if (i <= N) {
+                rc = rc_gibbs_sweep_async(c, s.r, s.p, o->seed, o->first_iter + (uint64_t)(i - 1));     // mcmc.jl:477, speculatively
+                if (rc != RC_OK) return rc;
+            }
+            const auto tc = now(); t_snap += secs(tb, tc);
+            if (need_wait) HIPCHK(c, hipEventSynchronize(s.ev));
+            const auto td = now(); t_evwait += secs(tc, td);
+            if (i <= N) {
+                s.labels.resize((size_t)n); s.sizes.assign((size_t)n, 0);
+                for (int q = 0; q < n; ++q) s.labels[(size_t)q] = s.slabel[(size_t)s.pin_lab[q]];
+                for (int k = 0; k < c->kcap; ++k)
+                    if (s.slabel[(size_t)k] > 0) s.sizes[(size_t)s.slabel[(size_t)k] - 1] = s.ssize[(size_t)k];
+                s.acc.assign((size_t)o->numMH, 0); s.spl.assign((size_t)o->numMH, 0);
+                s.clean = false; s.err = RC_OK; s.split_pending = false;
+                pool.submit(slot_of_it(i));
+            }
+            t_build += secs(td, now());
+            ++i;
+        }
+        // 2. confirm finished iterations in order
+        while (conf <= N && conf < i) {
+            const int si = slot_of_it(conf);
+            SpecSlot &s = pool.slots[(size_t)si];
+            const bool can_start_more = (i <= N + 1 && i - conf <= D);
+            if (!pool.done(si)) {
+                if (can_start_more) break;
+                pool.wait(si);
+            }
+            if (s.err != RC_OK) return fail(c, s.err, "%s", s.errmsg ? s.errmsg : "split-merge proposal failed");
+            if (s.clean) {
+                if (recording(conf) && conf + 1 >= i) break;                  // the snapshot this sample is read from comes next
+                for (int64_t mh = 0; mh < o->numMH; ++mh) {
+                    if (out->splitmerge_acceptances) out->splitmerge_acceptances[(conf - 1) * o->numMH + mh] = 0;
+                    if (out->splitmerge_splits) out->splitmerge_splits[(conf - 1) * o->numMH + mh] = s.spl[(size_t)mh];
+                }
+                if (recording(conf)) {
+                    if (j >= o->max_samples) return fail(c, RC_ERR_ARG, "rc_run_chain: more samples than max_samples=%lld", (long long)o->max_samples);
+                    rc = spec_record(c, pool.slots[(size_t)slot_of_it(conf + 1)], j++, s.r, s.p, out);
+                    if (rc != RC_OK) return rc;
+                }
+                { std::lock_guard<std::mutex> lk(pool.m); s.state = 0; }
+                ++conf;
+                if (++clean_run >= 16 && D < Dmax) { D = std::min(Dmax, 2 * D); clean_run = 0; }
+                continue;
+            }
+            if (s.split_pending) {
+                // split proposals: the worker did the scans; the likelihood of the proposed state is evaluated here against the
+                // snapshot, off the live state.  A rejected split (the usual case) costs no rollback.
+                bool resolved = true;
+                int64_t mh = s.pend_mh;
+                ProposalResult *R = &s.pend;
+                ProposalResult Rtmp;
+                for (;;) {
+                    if (R->needs_device) {
+                        const int32_t erc = spec_eval_split(c, c->llc, scratch, s, *R);
+                        if (erc == RC_ERR_CAPACITY) { resolved = false; break; }
+                        if (erc != RC_OK) return erc;
+                        ++n_split_evals;
+                        if (finish_decision(*R, o->seed, o->first_iter + (uint64_t)(conf - 1), (uint64_t)mh)) { resolved = false; break; }
+                    } else if (R->accept) { resolved = false; break; }
+                    s.acc[(size_t)mh] = 0; s.spl[(size_t)mh] = R->split ? 1 : 0;
+                    if (++mh >= o->numMH) break;
+                    // the remaining proposals of the iteration see the same (unchanged) state
+                    ProposalSnapshot S0{s.labels.data(), s.sizes.data(), (int64_t)s.K, s.hi, s.ssize.data(), s.slabel.data(), s.pin_B};
+                    Rtmp = ProposalResult();
+                    proposal_core(c, c->llc, S0, s.r, s.p, o->numGibbs, o->seed, o->first_iter + (uint64_t)(conf - 1), (uint64_t)mh, Rtmp, false);
+                    if (Rtmp.err != RC_OK) return fail(c, Rtmp.err, "%s", Rtmp.errmsg);
+                    R = &Rtmp;
+                }
+                s.split_pending = false;
+                if (resolved) { s.clean = true; continue; }          // confirmed by the clean branch on the next pass
+            }
+            // rollback: a proposal of iteration `conf` is accepted (or could not be evaluated off-line).  Everything started after it is void.
+            const auto tr0 = now(); ++n_rollbacks;
+            pool.drain();
+            rc = sync_and_check(c, true);
+            if (rc != RC_OK) return rc;
+            c->checkpoint = s.labels;                                          // the state iteration conf started from
+            rc = rc_state_restore(c);
+            if (rc != RC_OK) return rc;
+            const uint64_t it = o->first_iter + (uint64_t)(conf - 1);
+            bool accepted_any = false;
+            for (int64_t mh = 0; mh < o->numMH; ++mh) {                        // the synchronous path, mcmc.jl:372-474
+                uint8_t a = 0, sp = 0;
+                rc = rc_splitmerge(c, s.r, s.p, o->numGibbs, o->seed, it, (uint64_t)mh, &a, &sp);
+                if (rc != RC_OK) return rc;
+                if (out->splitmerge_acceptances) out->splitmerge_acceptances[(conf - 1) * o->numMH + mh] = a;
+                if (out->splitmerge_splits) out->splitmerge_splits[(conf - 1) * o->numMH + mh] = sp;
+                accepted_any |= a != 0;
+            }
+            if (accepted_any && o->splitmerge_mode == RC_SM_AS_WRITTEN) {
+                rc = rc_state_restore(c);                                      // Q1: the caller never sees the accepted proposal
+                if (rc != RC_OK) return rc;
+            } else {
+                rc = rc_gibbs_sweep_async(c, s.r, s.p, o->seed, it);
+                if (rc != RC_OK) return rc;
+            }
+            rc = sync_and_check(c);
+            if (rc != RC_OK) return rc;
+            if (recording(conf)) {
+                if (j >= o->max_samples) return fail(c, RC_ERR_ARG, "rc_run_chain: more samples than max_samples=%lld", (long long)o->max_samples);
+                Pending pend;
+                pend.active = true; pend.j = j++; pend.r = s.r; pend.p = s.p;
+                rc = record_enqueue(c, pend, out->clusts != nullptr);
+                if (rc != RC_OK) return rc;
+                rc = record_finish(c, pend, out);
+                if (rc != RC_OK) return rc;
+            }
+            r_prev = s.r; p_prev = s.p;
+            ++conf;
+            i = conf;
+            prev_it = -1;
+            D = std::max(1, D / 2); clean_run = 0;
+            t_rollback += secs(tr0, now());
+        }
+    }
+    pool.drain();
+    rc = sync_and_check(c, true);
+    if (rc != RC_OK) return rc;
+    out->num_samples = j;
+    out->runtime_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (getenv("RC_SM_PROFILE"))
+        fprintf(stderr, "[rc_run_chain speculative] %lld iterations %.3f s: %lld rollbacks %.3f s, %lld splits evaluated off-line; wait for sweep %.3f s, snapshot + launch %.3f s, wait for snapshot %.3f s, job build %.3f s; %d workers depth %d\n",
+                (long long)N, out->runtime_s, n_rollbacks, t_rollback, n_split_evals, t_sync, t_snap, t_evwait, t_build, nw, Dmax);
+    (void)t_confirm;
+    out->r_final = r_prev;
+    out->p_final = p_prev;
+    if (scratch.d_bucket) { (void)hipFree(scratch.d_bucket); (void)hipFree(scratch.d_rows); (void)hipFree(scratch.d_out); (void)hipHostFree(scratch.h_out); }
+    return RC_OK;
+}
+
 }  // namespace chain
 
 extern "C" int32_t rc_scalar_updates(uint64_t seed, uint64_t iter, double r, double p, const int64_t *sizes, int64_t K,
@@ -200,6 +642,8 @@ extern "C" int32_t rc_run_chain(rc_ctx *c, const rc_chain_options *o, rc_chain_o
     if (o->numMH > 0 && (!c->hostD || !c->hostL)) return fail(c, RC_ERR_STATE, "rc_run_chain: numMH > 0 needs rc_attach_host_matrices");
     if ((o->r_trace == nullptr) != (o->p_trace == nullptr)) return fail(c, RC_ERR_ARG, "rc_run_chain: give both r_trace and p_trace or neither");
     HIPCHK(c, hipSetDevice(c->dev));
+    if (o->numMH > 0 && o->numiters > 0 && !(getenv("RC_CHAIN_PIPELINE") && atoi(getenv("RC_CHAIN_PIPELINE")) == 0))
+        return chain::run_chain_speculative(c, o, out);
     const int n = c->n;
     const rc_params &P = c->P;
     int32_t rc = sync_and_check(c, true);

@@ -48,8 +48,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <unordered_map>
 #include <vector>
@@ -2427,6 +2430,34 @@ __global__ __launch_bounds__(256) void k_blocksums(View V, int gen, int hi, long
     }
     __syncthreads();
     for (int q = threadIdx.x; q < hi * 4; q += blockDim.x) out[(size_t)t * hi * 4 + q] = (long long)bins[q];
+}
+
+// Block sums of ONE would-be cluster against a bucketing of all points, straight from the matrices:
+// out[b] = Σ_{y in rows} Σ_{x: bucket[x] = b} X[y][x] for X = D and logD, as (hi, lo) halves like k_blocksums.  The chain
+// loop evaluates split proposals with it on a SNAPSHOT of the labels (bucket = snapshot slot, the members of the split
+// cluster bucketed by their proposed side) without touching the live state.  One block per row; indices are internal.
+__global__ __launch_bounds__(256) void k_split_eval(View V, const unsigned short *__restrict__ bucket, const int *__restrict__ rows,
+                                                    int nbuckets, long long *out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64 *bins = (u64 *)smem;  // [nbuckets][4]
+    for (int q = threadIdx.x; q < nbuckets * 4; q += blockDim.x) bins[q] = 0;
+    __syncthreads();
+    const int u = rows[blockIdx.x];
+    const long long mask = ((long long)1 << RC_LO_BITS) - 1;
+    for (int x = threadIdx.x; x < V.n; x += blockDim.x) {
+        const size_t e = (size_t)u * V.ld + x;
+        const long long d = (V.bits == 64) ? ((const long long *)V.Dq)[e] : (long long)((const int *)V.Dq)[e];
+        const long long l = rc_load_L(V, u, x, d);
+        const int b = bucket[x];
+        atomicAdd(&bins[b * 4 + 0], (u64)(d >> RC_LO_BITS));
+        atomicAdd(&bins[b * 4 + 1], (u64)(d & mask));
+        atomicAdd(&bins[b * 4 + 2], (u64)(l >> RC_LO_BITS));
+        atomicAdd(&bins[b * 4 + 3], (u64)(l & mask));
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < nbuckets * 4; q += blockDim.x)
+        if (bins[q]) atomicAdd((u64 *)out + q, bins[q]);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -161,3 +161,36 @@ def test_run_chains_in_the_library_one_chain_over_a_real_rccl_communicator():
                                                    rc.MCMCState(np.arange(60) % 4 + 1, 1.0, 0.5), [0], base_seed=3)
     assert tot == 8 and merged.shape == (60, 60) and np.all(np.diag(merged) == 1.0) and np.array_equal(merged, merged.T)
     ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["as_written", "intended"])
+def test_speculative_loop_equals_the_synchronous_loop(mode):
+    """rc_run_chain with numMH > 0 speculates that every split-merge proposal is rejected (proposals decided by worker
+    threads on state snapshots, several iterations in flight, splits evaluated off the live state, rollback on acceptance).
+    It must reproduce the synchronous loop (RC_CHAIN_PIPELINE=0) bit for bit — here on a chain that moves, with few large
+    clusters (many split proposals) and several accepted proposals, at every speculation depth."""
+    D, truth = paper(2)
+    P = T.likelihood_hyperparams(D, truth)
+    init = np.random.default_rng(11).integers(1, 4, 100).astype(np.int64)     # three clusters: P(split proposal) ~ 1/3
+    L = np.log(D + np.eye(100))
+    runs = {}
+    for tag, env in (("sync", {"RC_CHAIN_PIPELINE": "0"}), ("spec", {}), ("spec_shallow", {"RC_CHAIN_DEPTH": "2", "RC_CHAIN_WORKERS": "1"}),
+                     ("spec_deep", {"RC_CHAIN_DEPTH": "40", "RC_CHAIN_WORKERS": "6"})):
+        for k in ("RC_CHAIN_PIPELINE", "RC_CHAIN_DEPTH", "RC_CHAIN_WORKERS"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        ctx = rc.Context(D, logD=L); ctx.set_params(**P); ctx.set_state(init); ctx.cocluster_reset()
+        ctx.attach_host_matrices(D, L)
+        ch = ctx.run_chain(120, 20, 3, 5, 2, 77, 1.0, 0.5, 0.7, splitmerge=mode)
+        ch["cocluster"] = ctx.cocluster(max(ch["num_samples"], 1)); ch["final"] = ctx.get_state()[0]
+        runs[tag] = ch
+        ctx.close()
+    for k in ("RC_CHAIN_PIPELINE", "RC_CHAIN_DEPTH", "RC_CHAIN_WORKERS"):
+        os.environ.pop(k, None)
+    ref = runs["sync"]
+    assert ref["splitmerge_acceptances"].sum() >= 2 and ref["splitmerge_splits"].sum() >= 10 and ref["num_samples"] == 33
+    assert len(np.unique(ref["K"])) > 1                                           # the chain moves
+    for tag in ("spec", "spec_shallow", "spec_deep"):
+        for f in ("clusts", "K", "r", "p", "loglik", "logposterior", "r_acceptances", "splitmerge_acceptances", "splitmerge_splits",
+                  "r_all", "p_all", "cocluster", "final", "r_final", "p_final", "num_samples"):
+            assert np.array_equal(runs[tag][f], ref[f]), (tag, f)
