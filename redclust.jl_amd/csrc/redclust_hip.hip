@@ -1497,9 +1497,11 @@ struct Tab {
     int *bse;                 // [RC_MAXB] smallest empty label after the entry
     unsigned char *bflag;     // [RC_MAXB] RC_BF_* bits
     short *birth;             // [RC_MAXB] the entries that create a cluster, ascending
-    short *nexta, *nextb;     // [RC_MAXB] next entry (ascending) that touches the same source / target slot, -1 = none
-    short *head;              // [kcap] first entry that touches the slot, -1 = none
+    short *pairs;             // [2·RC_MAXB] the entries that touch each slot, grouped by slot, ascending within a slot
+    short *pairs_tmp;         // [2·RC_MAXB] the same groups before they are ordered
+    int *seg;                 // [kcap+1] before / during batch_sim: entries leaving the slot; afterwards seg[k] = end of slot k's group
     unsigned char *joined;    // [kcap] some entry of the batch moves a point INTO the slot
+    unsigned char *candie;    // [kcap] the slot could become empty inside the batch (size − leavers < 1): its size is simulated
     int *ccnt;                // [nchunks + 1] scratch: changers per chunk / exclusive offsets
 };
 #define RC_BF_DEATH 1   // the source cluster becomes empty
@@ -1508,7 +1510,7 @@ struct Tab {
 #define RC_BF_NOOP 8    // a singleton that draws "new cluster" and keeps its label: nothing changes
 
 #define RC_A16(x) (((x) + 15) & ~(size_t)15)
-#define RC_TAB_NOFF 28
+#define RC_TAB_NOFF 30
 __host__ __device__ inline size_t tab_layout(int kcap, int n, int nw, size_t *off /*RC_TAB_NOFF*/)
 {
     size_t o = 0;
@@ -1527,7 +1529,7 @@ __host__ __device__ inline size_t tab_layout(int kcap, int n, int nw, size_t *of
     off[12] = o; o = RC_A16(o + sizeof(int) * RC_MAXB);         // bx
     off[13] = o; o = RC_A16(o + sizeof(short) * RC_MAXB);       // ba
     off[14] = o; o = RC_A16(o + sizeof(short) * RC_MAXB);       // bb
-    off[15] = o; o = RC_A16(o + sizeof(short) * kcap);          // head
+    off[15] = o; o = RC_A16(o + sizeof(int) * (kcap + 1));      // seg
     off[16] = o; o = RC_A16(o + sizeof(int) * ((n + RC_PTS - 1) / RC_PTS + 1));  // ccnt
     off[17] = o; o = RC_A16(o + sizeof(int) * RC_MAXB);         // bu
     off[18] = o; o = RC_A16(o + sizeof(int) * RC_MAXB);         // blab
@@ -1535,11 +1537,13 @@ __host__ __device__ inline size_t tab_layout(int kcap, int n, int nw, size_t *of
     off[20] = o; o = RC_A16(o + sizeof(short) * RC_MAXB);       // bK
     off[21] = o; o = RC_A16(o + (size_t)RC_MAXB);               // bflag
     off[22] = o; o = RC_A16(o + sizeof(short) * RC_MAXB);       // birth
-    off[23] = o; o = RC_A16(o + sizeof(short) * RC_MAXB);       // nexta
-    off[24] = o; o = RC_A16(o + sizeof(short) * RC_MAXB);       // nextb
+    off[23] = o; o = RC_A16(o + sizeof(short) * 2 * RC_MAXB);   // pairs
+    off[24] = o; o = RC_A16(o + (size_t)kcap);                  // candie
     off[25] = o; o = RC_A16(o + sizeof(int) * RC_MAXB);         // bse
     off[26] = o; o = RC_A16(o + (size_t)kcap);                  // joined
-    off[27] = o;
+    off[27] = o; o = RC_A16(o + sizeof(short) * 2 * RC_MAXB);   // pairs_tmp
+    off[28] = o;
+    off[29] = o;
     return o;
 }
 
@@ -1553,11 +1557,11 @@ __device__ Tab tab_carve(char *smem, int kcap, int n, int nw)
     T.red_pos = (int *)(smem + off[6]); T.red_slot = (int *)(smem + off[7]); T.used = (unsigned *)(smem + off[8]);
     T.misc = (int *)(smem + off[9]); T.pos = (short *)(smem + off[10]); T.act = (short *)(smem + off[11]);
     T.bx = (int *)(smem + off[12]); T.ba = (short *)(smem + off[13]); T.bb = (short *)(smem + off[14]);
-    T.head = (short *)(smem + off[15]); T.ccnt = (int *)(smem + off[16]); T.bu = (int *)(smem + off[17]);
+    T.seg = (int *)(smem + off[15]); T.ccnt = (int *)(smem + off[16]); T.bu = (int *)(smem + off[17]);
     T.blab = (int *)(smem + off[18]); T.bold = (int *)(smem + off[19]); T.bK = (short *)(smem + off[20]);
     T.bflag = (unsigned char *)(smem + off[21]); T.birth = (short *)(smem + off[22]);
-    T.nexta = (short *)(smem + off[23]); T.nextb = (short *)(smem + off[24]); T.bse = (int *)(smem + off[25]);
-    T.joined = (unsigned char *)(smem + off[26]);
+    T.pairs = (short *)(smem + off[23]); T.candie = (unsigned char *)(smem + off[24]); T.bse = (int *)(smem + off[25]);
+    T.joined = (unsigned char *)(smem + off[26]); T.pairs_tmp = (short *)(smem + off[27]);
     return T;
 }
 
@@ -1777,7 +1781,6 @@ __device__ __forceinline__ void best_merge(double &bv, int &bp, int &bs, double 
 //   that differs from the tentative one is a violation (block-local minimum in T.blk_key).  Points outside (lo, hi] are
 //   skipped.
 #define RC_NEWKEY 0x7ffffffe   // order key of the new-cluster candidate: after every label (utils.jl:5 first-index rule)
-__device__ __forceinline__ int batch_next(const Tab &T, int q, int k) { return (T.ba[q] == k) ? T.nexta[q] : T.nextb[q]; }
 
 __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long long *SD, const long long *SL,
                            int chunk, int lo, int hi, int mode, int nb, u64 *cword, unsigned *rec, unsigned stamp)
@@ -1803,7 +1806,11 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
         }
         int so = T.size[own];
         if (mode == 1)
-            for (int q = T.head[own]; q >= 0 && q < j; q = batch_next(T, q, own)) so += (T.bb[q] == own) - (T.ba[q] == own);
+            for (int e = own ? T.seg[own - 1] : 0, e1 = T.seg[own]; e < e1; ++e) {
+                const int q = T.pairs[e];
+                if (q >= j) break;
+                so += (T.bb[q] == own) - (T.ba[q] == own);
+            }
         const int single = (so == 1);
         const int Ki = ((mode == 1 && j > 0) ? (int)T.bK[j - 1] : K) - single;
         const long long dg = V.diagq[u];
@@ -1814,7 +1821,9 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
             long long sd = SD[(size_t)k * ld + u], sl = SL[(size_t)k * ld + u];
             bool touched = false;
             if (mode == 1) {
-                for (int q = T.head[k]; q >= 0 && q < j; q = batch_next(T, q, k)) {
+                for (int e = k ? T.seg[k - 1] : 0, e1 = T.seg[k]; e < e1; ++e) {
+                    const int q = T.pairs[e];
+                    if (q >= j) break;
                     const int qa = T.ba[q], qb = T.bb[q];
                     if (qa != qb) {
                         const size_t e = (size_t)T.bu[q] * ld + u;
@@ -1965,11 +1974,12 @@ __device__ int next_empty_label(const Tab &T, int n, int lab)
 // What every changer of the batch does when the batch is applied in order (identical in every block): moves between
 // clusters, deaths, births (slot = next free slot of the committed table, label = smallest empty label at that moment,
 // mcmc.jl:199), singletons that take a smaller label or keep theirs.  Fills bb (real target slot), blab / bold / bflag /
-// bK / bse, the list of births and the per-slot entry lists (newest entry first); the batch is cut before an entry whose
-// target cluster an earlier entry emptied (that point has to be drawn again) or that finds no free slot.
+// bK / bse and the list of births; the batch is cut before an entry whose target cluster an earlier entry emptied (that
+// point has to be drawn again) or that finds no free slot.
 // Run by wave 0 with all lanes in step: 64 entries at a time are fetched lane-parallel (source, target, the source's
-// label) and then applied one after the other from registers, so that an entry costs one LDS round trip (the current sizes
-// and list heads of its two slots) instead of the ten of a plain one-thread loop (60 -> 12 µs for 165 entries).
+// label, whether either cluster can become empty inside the batch) and only the entries that need the running state —
+// births, deaths, singletons, anything touching a cluster that could die — are visited one after the other, from
+// registers plus one LDS round trip for the current sizes of their two slots.
 // T.size is used in place (the caller restores it from the entries), T.used is scratch (the caller builds it).
 // misc: [3] entries kept, [4] last point covered, [5] capacity failure, [8] births, [9] entries that change something,
 // [10] index of the first of them.
@@ -1978,21 +1988,30 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
     const int lane = threadIdx.x & 63;
     const int nb0 = min(total, cap);
     int K = T.misc[0], se = T.misc[1], fcur = 0, nbirth = 0, neff = 0, first_eff = -1;
-    int nb = nb0, hi = (total > cap) ? T.misc[2] - 1 : V.n - 1, fail = 0;
+    int nb = nb0, hi = (total > cap) ? T.misc[2] - 1 : V.n - 1, fail = 0, nvisited = 0;
     bool stop = false;
     for (int q0 = 0; q0 < nb0 && !stop; q0 += 64) {
         int va = 0, vt = -1, vla = 0;
-        bool vfast = false;
+        bool vfast = false, vsafe = false;
         if (q0 + lane < nb0) {
             va = T.ba[q0 + lane]; vt = T.bb[q0 + lane]; vla = T.label[va];
             // a singleton nobody in the batch joins, drawing "new cluster": alone at its turn whatever happened before
             vfast = vt < 0 && T.size[va] == 1 && !T.joined[va];
+            // a move between two clusters neither of which can become empty inside the batch: a plain move whatever the
+            // order, nothing to simulate (the sizes of such clusters are not tracked here at all)
+            vsafe = vt >= 0 && !T.candie[va] && !T.candie[vt];
         }
-        const u64 fastmask = __ballot(vfast);
-        int ob = 0, olab = 0, oold = 0, oflag = 0, oK = 0, ose = 0;   // results of entry q0 + lane (stored after the chunk)
+        const u64 fastmask = __ballot(vfast), safemask = __ballot(vsafe);
+        // results of entry q0 + lane (stored after the chunk).  The plain moves are not visited at all: their target is the
+        // tentative one, and cluster count / smallest empty label are those left by the last visited entry before them
+        int ob = vt, olab = 0, oold = 0, oflag = 0, oK = K, ose = se;
         const int cnt = min(64, nb0 - q0);
         int done = cnt;
-        for (int e = 0; e < cnt; ++e) {
+        u64 todo = ~safemask & (cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull));
+        while (todo) {
+            const int e = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            ++nvisited;
             const int q = q0 + e;
             const int a = __builtin_amdgcn_readlane(va, e), la = __builtin_amdgcn_readlane(vla, e);
             int b, flag = 0, lab = 0, old = 0;
@@ -2002,10 +2021,11 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
                 const int tgt = __builtin_amdgcn_readlane(vt, e);
                 const int sza = T.size[a], szt = T.size[tgt >= 0 ? tgt : a];
                 b = tgt;
+                const bool cda = T.candie[a] != 0, cdt = tgt >= 0 && T.candie[tgt] != 0;   // (sizes of the other slots are not simulated)
                 if (tgt >= 0) {
-                    if (szt == 0) { nb = q; hi = T.bx[q] - 1; stop = true; done = e; break; }
-                    if (sza == 1) { flag = RC_BF_DEATH; old = la; K -= 1; }
-                } else if (sza == 1) {
+                    if (cdt && szt == 0) { nb = q; hi = T.bx[q] - 1; stop = true; done = e; break; }
+                    if (cda && sza == 1) { flag = RC_BF_DEATH; old = la; K -= 1; }
+                } else if (cda && sza == 1) {
                     b = a;
                     if (se < la) { flag = RC_BF_RENAME; lab = se; old = la; }
                     else flag = RC_BF_NOOP;
@@ -2030,37 +2050,32 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
                 if (lab) se = next_empty_label(T, V.n, lab);
                 else if (old && old < se) se = old;
                 if (lane == 0) {
-                    if (a != b) { T.size[a] = sza - 1; T.size[b] = ((flag & RC_BF_BIRTH) ? 0 : szt) + 1; }
+                    if (a != b) {
+                        if (cda) T.size[a] = sza - 1;
+                        if (flag & RC_BF_BIRTH) T.size[b] = 1; else if (cdt) T.size[b] = szt + 1;
+                    }
                     if (flag & RC_BF_BIRTH) T.birth[nbirth] = (short)q;
                 }
                 if (flag & RC_BF_BIRTH) ++nbirth;
                 if (!(flag & RC_BF_NOOP)) { if (first_eff < 0) first_eff = q; ++neff; }
             }
-            if (lane == e) { ob = b; olab = lab; oold = old; oflag = flag; oK = K; ose = se; }
+            if (lane == e) { ob = b; olab = lab; oold = old; oflag = flag; }
+            if (lane >= e) { oK = K; ose = se; }
+        }
+        {   // the plain moves before the cut count as effective entries
+            const u64 kept = safemask & (done == 64 ? ~0ull : ((1ull << done) - 1ull));
+            if (kept) {
+                const int fs = q0 + __ffsll((long long)kept) - 1;
+                if (first_eff < 0 || fs < first_eff) first_eff = fs;
+                neff += __popcll(kept);
+            }
         }
         if (lane < done) {
             const int q = q0 + lane;
             T.bb[q] = (short)ob; T.blab[q] = olab; T.bold[q] = oold; T.bflag[q] = (unsigned char)oflag; T.bK[q] = (short)oK; T.bse[q] = ose;
         }
     }
-    // per-slot lists of the entries that change something, ascending (threaded back to front)
-    for (int q1 = ((nb + 63) & ~63); q1 > 0; q1 -= 64) {
-        const int q0 = q1 - 64;
-        int va = 0, vb = 0, vf = RC_BF_NOOP;
-        if (q0 + lane < nb) { va = T.ba[q0 + lane]; vb = T.bb[q0 + lane]; vf = T.bflag[q0 + lane]; }
-        u64 todo = __ballot(!(vf & RC_BF_NOOP));
-        while (todo) {
-            const int e = 63 - __clzll((long long)todo);
-            todo &= ~(1ull << e);
-            const int a = __builtin_amdgcn_readlane(va, e), b = __builtin_amdgcn_readlane(vb, e), q = q0 + e;
-            const int hda = T.head[a], hdb = T.head[b];
-            if (lane == 0) {
-                T.nexta[q] = (short)hda; T.head[a] = (short)q;
-                if (b != a) { T.nextb[q] = (short)hdb; T.head[b] = (short)q; }
-            }
-        }
-    }
-    if (lane == 0) { T.misc[3] = nb; T.misc[4] = hi; T.misc[5] = fail; T.misc[8] = nbirth; T.misc[9] = neff; T.misc[10] = first_eff; }
+    if (lane == 0) { T.misc[3] = nb; T.misc[4] = hi; T.misc[5] = fail; T.misc[8] = nbirth; T.misc[9] = neff; T.misc[10] = first_eff; T.misc[13] = nvisited; }
 }
 
 // Commit of the first `nc` batch changers: sizes, labels, cluster count, per-slot constants, slot_of, and the S
@@ -2219,7 +2234,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
             T.ccnt[c] = cnt;
             any |= cnt;
         }
-        for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) { T.head[k] = -1; T.joined[k] = 0; }
+        for (int k = threadIdx.x; k <= V.kcap; k += blockDim.x) { T.seg[k] = 0; if (k < V.kcap) T.joined[k] = 0; }
         if (threadIdx.x == 0) T.misc[2] = 0;
         __syncthreads();
         if (any) T.misc[2] = 1;
@@ -2256,6 +2271,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
                         const unsigned rc = __hip_atomic_load(rec + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         T.bx[o] = x; T.bu[o] = V.pi[x]; T.ba[o] = (short)(rc >> 16); T.bb[o] = (short)((int)(rc & 0xFFFFu) - 1);
                         if (rc & 0xFFFFu) T.joined[(rc & 0xFFFFu) - 1] = 1;
+                        atomicAdd(&T.seg[rc >> 16], 1);   // leaves its cluster
                     } else {
                         T.misc[2] = x;  // first changer that does not fit into the batch
                     }
@@ -2277,13 +2293,65 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
             __syncthreads();
         }
         RC_PHASE(8)
+        // clusters that could become empty inside the batch (more leavers than would leave one member): only their sizes matter
+        for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) T.candie[k] = (T.size[k] - T.seg[k] < 1);
+        __syncthreads();
         if (threadIdx.x < 64) batch_sim(V, T, total, cap);
         if (threadIdx.x == 0) *T.blk_key = RC_KEY_NONE;
         __syncthreads();
-        // the simulated sizes back to the committed ones
-        for (int q = threadIdx.x; q < T.misc[3]; q += blockDim.x) {
-            const int a_ = T.ba[q], b_ = T.bb[q];
-            if (a_ != b_) { atomicAdd(&T.size[a_], 1); atomicSub(&T.size[b_], 1); }
+        RC_PHASE(14)
+        RC_PF(ps[15] += T.misc[13];)
+        // the simulated sizes back to the committed ones (only clusters that could die, and new ones, were simulated), and
+        // the entries that touch each slot, grouped by slot: count, offsets, scatter, sort within a slot
+        {
+            const int nbk = T.misc[3];
+            for (int k = threadIdx.x; k <= V.kcap; k += blockDim.x) T.seg[k] = 0;
+            __syncthreads();
+            for (int q = threadIdx.x; q < nbk; q += blockDim.x) {
+                const int a_ = T.ba[q], b_ = T.bb[q], fl = T.bflag[q];
+                if (a_ != b_) {
+                    if (T.candie[a_]) atomicAdd(&T.size[a_], 1);
+                    if ((fl & RC_BF_BIRTH) || T.candie[b_]) atomicSub(&T.size[b_], 1);
+                }
+                if (!(fl & RC_BF_NOOP)) { atomicAdd(&T.seg[a_], 1); if (b_ != a_) atomicAdd(&T.seg[b_], 1); }
+            }
+            __syncthreads();
+            if (threadIdx.x < 64) {   // exclusive offsets over the slots (wave 0: per-lane runs + shuffle scan)
+                const int per = (V.kcap + 1 + 63) / 64, c0_ = (int)threadIdx.x * per, c1_ = min(c0_ + per, V.kcap + 1);
+                int sum = 0;
+                for (int k = c0_; k < c1_; ++k) sum += T.seg[k];
+                int incl = sum;
+#pragma unroll
+                for (int d_ = 1; d_ < 64; d_ <<= 1) {
+                    const int up = __shfl_up(incl, d_);
+                    if ((int)threadIdx.x >= d_) incl += up;
+                }
+                int o = incl - sum;
+                for (int k = c0_; k < c1_; ++k) { const int x = T.seg[k]; T.seg[k] = o; o += x; }
+            }
+            __syncthreads();
+            for (int q = threadIdx.x; q < nbk; q += blockDim.x) {
+                const int a_ = T.ba[q], b_ = T.bb[q];
+                if (!(T.bflag[q] & RC_BF_NOOP)) {
+                    T.pairs_tmp[atomicAdd(&T.seg[a_], 1)] = (short)q;
+                    if (b_ != a_) T.pairs_tmp[atomicAdd(&T.seg[b_], 1)] = (short)q;
+                }
+            }
+            __syncthreads();   // now seg[k] = end of slot k's group, seg[k-1] (0 for k = 0) its begin
+            // order every group by entry index: each entry ranks itself inside the groups of its two slots (a group can hold
+            // hundreds of entries when the changers of a batch share a cluster: a one-thread-per-slot sort took 335 µs there)
+            for (int q = threadIdx.x; q < nbk; q += blockDim.x) {
+                if (T.bflag[q] & RC_BF_NOOP) continue;
+                const int a_ = T.ba[q], b_ = T.bb[q];
+                for (int side = 0; side < 2; ++side) {
+                    const int k = side ? b_ : a_;
+                    if (side && b_ == a_) break;
+                    const int e0 = k ? T.seg[k - 1] : 0, e1 = T.seg[k];
+                    int rank = 0;
+                    for (int e = e0; e < e1; ++e) rank += (T.pairs_tmp[e] < q);
+                    T.pairs[e0 + rank] = (short)q;
+                }
+            }
         }
         __syncthreads();
         const int nb = T.misc[3], hi = T.misc[4];
