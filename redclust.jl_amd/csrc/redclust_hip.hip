@@ -1039,7 +1039,11 @@ __device__ __forceinline__ void syml_units(const View &V, long long (*tt)[RC_SL_
     const int qeD = V.qeD;
     const double qsL = V.qsL;
     const int tr = lane >> 4, tq = lane & 15;   // transposed role: tile row, column octet
+#ifdef RC_EXP_NO_FLUSH   // timing experiment (profiles/r02): every flush computed, none issued
+    auto add64 = [](long long *p, long long v) { if (v == 0x7fffffffffffffffll) __hip_atomic_fetch_add((u64 *)p, (u64)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+#else
     auto add64 = [](long long *p, long long v) { __hip_atomic_fetch_add((u64 *)p, (u64)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+#endif
     RC_PF(long long pf_wait = 0; long long pf_tiles = 0; long long pf_setup = 0; long long pf_log = 0; long long pf_d2 = 0; long long pf_issue = 0; long long pf_ldsw = 0; long long pf_d1 = 0;)
     RC_PF(const long long pf_t0 = __builtin_amdgcn_s_memtime(); const long long pf_r0 = __builtin_amdgcn_s_memrealtime();)
     (void)pf_out;

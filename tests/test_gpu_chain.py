@@ -160,6 +160,12 @@ def test_run_chains_in_the_library_one_chain_over_a_real_rccl_communicator():
     ch, merged, tot = rc.run_chains_single_process(data, rc.MCMCOptionsList(numiters=20, burnin=4, thin=2, numMH=0), params,
                                                    rc.MCMCState(np.arange(60) % 4 + 1, 1.0, 0.5), [0], base_seed=3)
     assert tot == 8 and merged.shape == (60, 60) and np.all(np.diag(merged) == 1.0) and np.array_equal(merged, merged.T)
+    # chains.run_chains — the one-process-per-GPU caller (here a world of one, no process group): runsampler on the rank's
+    # context, the merge through the library's communicator, rc_cocluster of the merged counts
+    res, merged1, traces = rc.run_chains(data, rc.MCMCOptionsList(numiters=20, burnin=4, thin=2, numMH=0), params,
+                                         rc.MCMCState(np.arange(60) % 4 + 1, 1.0, 0.5), base_seed=3)
+    assert len(traces) == 1 and traces[0]["rank"] == 0 and np.array_equal(merged1, res.posterior_coclustering)
+    assert np.array_equal(merged1, merged)             # same data, init, seed and options as chain 0 above
     ctx.close()
 
 
