@@ -234,6 +234,24 @@ def main():
         cm.close()
         del Dm
 
+    # Third figure: the whole iteration of the reference with its DEFAULT options (MCMCOptionsList(): numMH = 1, numGibbs = 5,
+    # src/types.jl:3-43) — sample_r, sample_p, one split-merge proposal, the Gibbs sweep — through rc_run_chain
+    defaults = None
+    if rank == 0 and not os.environ.get("RC_BENCH_NO_DEFAULTS"):
+        cd = rc.Context(D, device=local_rank, kcap=max(128, 2 * K), storage_bits=BITS)
+        cd.set_params(**P); cd.set_state(truth); cd.cocluster_reset()
+        cd.attach_host_matrices(D)                        # the proposals' restricted scans read the host matrix (logD derived by the library)
+        cd.run_chain(40, 0, 10, 5, 1, 1, r, p, 1.0)
+        its = max(200, min(5 * args.steps, 1000))
+        t1 = time.perf_counter()
+        chd = cd.run_chain(its, 0, 10, 5, 1, 1, r, p, 1.0, first_iter=40)
+        t_def = time.perf_counter() - t1
+        defaults = {"numMH": 1, "numGibbs": 5, "iterations": its, "iterations_per_s": its / t_def, "ms_per_iteration": t_def / its * 1e3,
+                    "splitmerge_acceptances": int(chd["splitmerge_acceptances"].sum()), "splitmerge_splits": int(chd["splitmerge_splits"].sum()),
+                    "note": "rc_run_chain, speculative split-merge pipeline (proposals of several iterations decided concurrently on host "
+                            "threads; bit-identical to the sequential loop)"}
+        cd.close()
+
     if rank == 0:
         # bytes of matrix data the selected row-reduction kernel has to read per sweep: k_bulk reads every entry of D
         # and logD (2·n²·sizeof); k_bulk_sym exploits symmetry and reads the upper triangle only
@@ -276,6 +294,7 @@ def main():
             "sweep_GBps_vs_reference_dataflow": value / world * full_bytes / 1e9,  # 2·n²·sizeof per sweep, what the reference reads
             "label_changes_last_sweep": stats["n_changes"], "K_final": stats["K"],
             "moving_regime": moving,
+            "reference_default_options": defaults,
             "incremental_mode_sweeps_per_s_rank0": inc_sweeps_per_s,
             "coclustering_allreduce_ms": allreduce_ms, "coclustering_merge_path": merge_path, "coclustering_diag_ok": diag_ok,
             # roofline of the dominant kernel.  `achieved` / `frac` use the algorithmic bytes SURVEY.md §8(d) prescribes
