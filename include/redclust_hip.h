@@ -65,7 +65,9 @@ typedef struct rc_sweep_stats {
  * storage_bits: 64 (int64 fixed point; the Float64 path) or 32 (int32 fixed point: every entry rounded to
  * 2^-30 of the largest magnitude, half the HBM traffic; all sums stay exact 64-bit integers and scores stay f64
  * — the counterpart of BASELINE config 5's Float32 storage, which the reference itself does not have).
- * kcap: slot capacity = most clusters the state may hold at once (0 = default min(n, 1024); at most 4096).
+ * kcap: slot capacity = most clusters the state may hold at once (0 = default min(n, 512); at most 4096; RC_ERR_CAPACITY
+ * when a sweep would need more — up to 512 the resolver's tables fit beside the row reduction on a CU, beyond it a sweep is
+ * ≈15 % slower at n = 8192).
  * device_id: HIP device ordinal. */
 int32_t rc_create(int64_t n, const double *D, const double *logD_or_null, int32_t storage_bits,
                   int32_t device_id, int64_t kcap, rc_ctx **out);

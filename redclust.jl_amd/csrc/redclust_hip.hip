@@ -1484,8 +1484,7 @@ __global__ __launch_bounds__(256) void k_bulk_sym32(View V, int wgen, int zgen, 
 struct Tab {
     int *size;       // [kcap]
     int *label;      // [kcap] 0 = free
-    short *pos;      // [kcap] rank of the slot's label among active labels (candidate order, mcmc.jl:195)
-    short *act;      // [kcap] act[pos] = slot
+    short *act;      // [kcap] the active slots, in ascending label order (candidate order, mcmc.jl:195)
     double *base_o;  // [kcap] A[s] + log p + log(s-1+r), s = size          (candidate cluster of another point)
     double *base_s;  // [kcap] same with s = size-1                          (the point's own cluster, itself removed)
     unsigned *used;  // [(n+31)/32] label occupancy bitset, bit (label-1); built when a round has changers
@@ -1496,9 +1495,8 @@ struct Tab {
     // batch of tentative changers of the current round (identical in every block), ascending in point index
     int *bx, *bu;             // [RC_MAXB] point (original index), its internal index
     short *ba, *bb;           // [RC_MAXB] source slot; target slot (after batch_sim: the slot it really goes to)
-    int *blab, *bold;         // [RC_MAXB] label the entry takes (birth / rename) and label it frees (death / rename), 0 = none
+    int *blab;                // [RC_MAXB] label the entry takes (birth / rename), 0 = none
     short *bK;                // [RC_MAXB] number of clusters after the entry
-    int *bse;                 // [RC_MAXB] smallest empty label after the entry
     unsigned char *bflag;     // [RC_MAXB] RC_BF_* bits
     short *birth;             // [RC_MAXB] the entries that create a cluster, ascending
     short *pairs;             // [2·RC_MAXB] the entries that touch each slot, grouped by slot, ascending within a slot
@@ -1528,7 +1526,7 @@ __host__ __device__ inline size_t tab_layout(int kcap, int n, int nw, size_t *of
     off[7] = o; o = RC_A16(o + sizeof(int) * nw * RC_PTS);      // red_slot
     off[8] = o; o = RC_A16(o + sizeof(unsigned) * ((n + 31) / 32));  // used
     off[9] = o; o = RC_A16(o + sizeof(int) * 16);               // misc
-    off[10] = o; o = RC_A16(o + sizeof(short) * kcap);          // pos
+    off[10] = o;                                                // (unused)
     off[11] = o; o = RC_A16(o + sizeof(short) * kcap);          // act
     off[12] = o; o = RC_A16(o + sizeof(int) * RC_MAXB);         // bx
     off[13] = o; o = RC_A16(o + sizeof(short) * RC_MAXB);       // ba
@@ -1537,13 +1535,13 @@ __host__ __device__ inline size_t tab_layout(int kcap, int n, int nw, size_t *of
     off[16] = o; o = RC_A16(o + sizeof(int) * ((n + RC_PTS - 1) / RC_PTS + 1));  // ccnt
     off[17] = o; o = RC_A16(o + sizeof(int) * RC_MAXB);         // bu
     off[18] = o; o = RC_A16(o + sizeof(int) * RC_MAXB);         // blab
-    off[19] = o; o = RC_A16(o + sizeof(int) * RC_MAXB);         // bold
+    off[19] = o;                                                // (unused)
     off[20] = o; o = RC_A16(o + sizeof(short) * RC_MAXB);       // bK
     off[21] = o; o = RC_A16(o + (size_t)RC_MAXB);               // bflag
     off[22] = o; o = RC_A16(o + sizeof(short) * RC_MAXB);       // birth
     off[23] = o; o = RC_A16(o + sizeof(short) * 2 * RC_MAXB);   // pairs
     off[24] = o; o = RC_A16(o + (size_t)kcap);                  // candie
-    off[25] = o; o = RC_A16(o + sizeof(int) * RC_MAXB);         // bse
+    off[25] = o;                                                // (unused)
     off[26] = o; o = RC_A16(o + (size_t)kcap);                  // joined
     off[27] = o; o = RC_A16(o + sizeof(short) * 2 * RC_MAXB);   // pairs_tmp
     off[28] = o;
@@ -1559,12 +1557,12 @@ __device__ Tab tab_carve(char *smem, int kcap, int n, int nw)
     T.base_o = (double *)(smem + off[0]); T.base_s = (double *)(smem + off[1]); T.red_v = (double *)(smem + off[2]);
     T.blk_key = (u64 *)(smem + off[3]); T.size = (int *)(smem + off[4]); T.label = (int *)(smem + off[5]);
     T.red_pos = (int *)(smem + off[6]); T.red_slot = (int *)(smem + off[7]); T.used = (unsigned *)(smem + off[8]);
-    T.misc = (int *)(smem + off[9]); T.pos = (short *)(smem + off[10]); T.act = (short *)(smem + off[11]);
+    T.misc = (int *)(smem + off[9]); T.act = (short *)(smem + off[11]);
     T.bx = (int *)(smem + off[12]); T.ba = (short *)(smem + off[13]); T.bb = (short *)(smem + off[14]);
     T.seg = (int *)(smem + off[15]); T.ccnt = (int *)(smem + off[16]); T.bu = (int *)(smem + off[17]);
-    T.blab = (int *)(smem + off[18]); T.bold = (int *)(smem + off[19]); T.bK = (short *)(smem + off[20]);
+    T.blab = (int *)(smem + off[18]); T.bK = (short *)(smem + off[20]);
     T.bflag = (unsigned char *)(smem + off[21]); T.birth = (short *)(smem + off[22]);
-    T.pairs = (short *)(smem + off[23]); T.candie = (unsigned char *)(smem + off[24]); T.bse = (int *)(smem + off[25]);
+    T.pairs = (short *)(smem + off[23]); T.candie = (unsigned char *)(smem + off[24]);
     T.joined = (unsigned char *)(smem + off[26]); T.pairs_tmp = (short *)(smem + off[27]);
     return T;
 }
@@ -1627,7 +1625,6 @@ __device__ void tab_structural(const View &V, Tab &T)
                 const int lq = T.label[q];
                 c += (lq > 0 && lq < lab);
             }
-            T.pos[k] = (short)c;
             T.act[c] = (short)k;
         }
     }
@@ -1641,7 +1638,6 @@ __device__ void tab_load(const View &V, Tab &T)
     for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) {
         T.size[k] = V.slot_size[k];
         T.label[k] = V.slot_label[k];
-        T.pos[k] = V.slot_pos[k];
         T.act[k] = V.slot_act[k];
     }
     if (threadIdx.x == 0) {
@@ -1658,7 +1654,6 @@ __device__ void tab_store(const View &V, const Tab &T)
     for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) {
         V.slot_size[k] = T.size[k];
         V.slot_label[k] = T.label[k];
-        V.slot_pos[k] = T.pos[k];
         V.slot_act[k] = T.act[k];
     }
     if (threadIdx.x == 0) {
@@ -1744,7 +1739,7 @@ __global__ __launch_bounds__(1024) void k_derive(View V, int rebuild_perm)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Tab T = tab_carve(smem, V.kcap, V.n, 1);
-    for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) { T.size[k] = V.slot_size[k]; T.label[k] = V.slot_label[k]; T.pos[k] = 0; T.act[k] = 0; }
+    for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) { T.size[k] = V.slot_size[k]; T.label[k] = V.slot_label[k]; T.act[k] = 0; }
     if (threadIdx.x == 0) { T.misc[0] = V.sc->K; T.misc[7] = V.sc->slot_hi; }
     __syncthreads();
     tab_structural(V, T);
@@ -1977,8 +1972,8 @@ __device__ int next_empty_label(const Tab &T, int n, int lab)
 
 // What every changer of the batch does when the batch is applied in order (identical in every block): moves between
 // clusters, deaths, births (slot = next free slot of the committed table, label = smallest empty label at that moment,
-// mcmc.jl:199), singletons that take a smaller label or keep theirs.  Fills bb (real target slot), blab / bold / bflag /
-// bK / bse and the list of births; the batch is cut before an entry whose target cluster an earlier entry emptied (that
+// mcmc.jl:199), singletons that take a smaller label or keep theirs.  Fills bb (real target slot), blab / bflag /
+// bK and the list of births; the batch is cut before an entry whose target cluster an earlier entry emptied (that
 // point has to be drawn again) or that finds no free slot.
 // Run by wave 0 with all lanes in step: 64 entries at a time are fetched lane-parallel (source, target, the source's
 // label, whether either cluster can become empty inside the batch) and only the entries that need the running state —
@@ -2008,7 +2003,7 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
         const u64 fastmask = __ballot(vfast), safemask = __ballot(vsafe);
         // results of entry q0 + lane (stored after the chunk).  The plain moves are not visited at all: their target is the
         // tentative one, and cluster count / smallest empty label are those left by the last visited entry before them
-        int ob = vt, olab = 0, oold = 0, oflag = 0, oK = K, ose = se;
+        int ob = vt, olab = 0, oflag = 0, oK = K;
         const int cnt = min(64, nb0 - q0);
         int done = cnt;
         u64 todo = ~safemask & (cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull));
@@ -2063,8 +2058,8 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
                 if (flag & RC_BF_BIRTH) ++nbirth;
                 if (!(flag & RC_BF_NOOP)) { if (first_eff < 0) first_eff = q; ++neff; }
             }
-            if (lane == e) { ob = b; olab = lab; oold = old; oflag = flag; }
-            if (lane >= e) { oK = K; ose = se; }
+            if (lane == e) { ob = b; olab = lab; oflag = flag; }
+            if (lane >= e) oK = K;
         }
         {   // the plain moves before the cut count as effective entries
             const u64 kept = safemask & (done == 64 ? ~0ull : ((1ull << done) - 1ull));
@@ -2076,7 +2071,7 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
         }
         if (lane < done) {
             const int q = q0 + lane;
-            T.bb[q] = (short)ob; T.blab[q] = olab; T.bold[q] = oold; T.bflag[q] = (unsigned char)oflag; T.bK[q] = (short)oK; T.bse[q] = ose;
+            T.bb[q] = (short)ob; T.blab[q] = olab; T.bflag[q] = (unsigned char)oflag; T.bK[q] = (short)oK;
         }
     }
     if (lane == 0) { T.misc[3] = nb; T.misc[4] = hi; T.misc[5] = fail; T.misc[8] = nbirth; T.misc[9] = neff; T.misc[10] = first_eff; T.misc[13] = nvisited; }
@@ -3042,7 +3037,7 @@ static int32_t alloc_ctx(int64_t n, int32_t storage_bits, int32_t device_id, int
 {
     if (n < 1 || n > (1 << 20)) return fail(nullptr, RC_ERR_ARG, "rc_create: n must be in 1..2^20 (got %lld)", (long long)n);
     if (storage_bits != 64 && storage_bits != 32) return fail(nullptr, RC_ERR_ARG, "rc_create: storage_bits must be 64 or 32");
-    if (kcap == 0) kcap = std::min<int64_t>(n, 1024);
+    if (kcap == 0) kcap = std::min<int64_t>(n, 512);   // up to 512 the resolver's tables leave room for it beside the row reduction
     if (kcap < 1 || kcap > RC_MAX_KCAP) return fail(nullptr, RC_ERR_ARG, "rc_create: kcap must be in 1..%d", RC_MAX_KCAP);
     if (kcap > n) kcap = n;
     int ndev = 0;
