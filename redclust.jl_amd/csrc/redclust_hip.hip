@@ -1,6 +1,7 @@
 // redclust_hip.hip — MI355X (gfx950 / CDNA4) implementation of RedClust.jl's Gibbs label sweep and its
-// observables behind the C ABI of include/redclust_hip.h.  Written for gfx950 only.  (pointestimate.inc.hip and
-// chain.inc.hip — the MPEL loss matrix and the native iteration loop — are included at the end of this file.)
+// observables behind the C ABI of include/redclust_hip.h.  Written for gfx950 only.  (pointestimate.inc.hip,
+// chain.inc.hip and chains.inc.hip — the MPEL loss matrix, the native iteration loop and the chain-parallel driver — are
+// included at the end of this file.)
 //
 // Reference path (RedClust.jl v1.2.2, paths under the reference checkout):
 //   sample_labels_Gibbs!  src/mcmc.jl:158-256     loglik  src/mcmc.jl:1-56     logprior  src/mcmc.jl:58-78
@@ -23,18 +24,23 @@
 //                    (rc_qlog), so this kernel reads only D's upper triangle, n²/2·8 B.
 //     Points are kept in an internal cluster-contiguous order (pi / ipi), invisible through the ABI.
 //   * The sequential dependence of the sweep is resolved exactly by speculation: every point is scored
-//     and drawn in parallel under "no earlier point of this sweep has changed"; the first point whose
-//     draw differs from its label is the true first change of the sequential sweep; it is committed,
-//     S is corrected for the two clusters involved (exactly — integers), and the points after it are
-//     re-drawn.  Draws are deterministic functions of (state, counter-based uniforms), so the result
-//     is identical to the sequential loop.  k_resolve runs this loop inside ONE persistent launch (two
-//     grid barriers per batch of independent changes); at stationarity it is a single scoring pass.
-//   * Sweeps are software-pipelined over three streams: k_resolve of sweep t runs concurrently with the
-//     row reduction of sweep t+1, which reduces the rows under the labels known before sweep t; the label
-//     changes of sweep t are added to that table by k_resolve with the same commutative integer atomics,
-//     so the table k_resolve(t+1) reads is exactly the row sums under the labels after sweep t.  Row
-//     reductions of consecutive sweeps alternate between two streams and overlap (k_resolve clears the
-//     generation two sweeps ahead).
+//     and drawn in parallel under the committed state; the ordered batch of points whose draw differs from their
+//     label is simulated in order (moves, births, deaths, relabelings), every later point is drawn again under
+//     the batch entries that precede it, and the entries before the first point whose draw changes are
+//     committed together (S corrected exactly — integers).  The Gumbel noise of a candidate is keyed by
+//     (sweep, point, cluster LABEL), so births and deaths leave the other candidates' noise alone and batch
+//     like plain moves.  Draws are deterministic functions of (state, counter-based uniforms), so the result
+//     is identical to the sequential loop.  k_resolve runs this inside ONE persistent launch (two grid
+//     barriers per batch); at stationarity it is a single scoring pass.
+//   * Sweeps are software-pipelined: sweep t (row reduction, then k_resolve) lives on one stream per sweep
+//     parity; the row reduction of sweep t+1 runs on the other stream concurrently with k_resolve(t) — three
+//     reduction blocks and one resolver block per CU — under the labels known before sweep t; the label changes
+//     of sweep t are added to that table by k_resolve with the same commutative integer atomics, so the table
+//     k_resolve(t+1) reads is exactly the row sums under the labels after sweep t (k_resolve clears the
+//     generation two sweeps ahead).  A third stream carries the observables.
+//   * The iteration loop (chain.inc.hip) speculates that split–merge proposals are rejected: proposals are
+//     decided by worker threads on state snapshots while the sweeps run on; chains.inc.hip runs one chain per
+//     GPU and merges the co-clustering counts over RCCL.
 //   * Scores use the regrouped arithmetic of SURVEY.md §7 H2 (size-only lgamma terms tabulated on the
 //     host in long double; log(β+S) = log β + log1p(S/β)); terms common to all candidates (L2_i, the
 //     subtracted minimum) are dropped — they cannot change the Gumbel-max argmax.
