@@ -229,3 +229,32 @@ def test_config5_against_table_oracle():
         assert np.array_equal(c1, c2) and K1 == K2 and ctx.loglik() == ll1, name
     assert total_moved > 100
     ctx.close()
+
+
+def test_maximum_slot_capacity_and_many_clusters():
+    """kcap at its maximum (4096: the resolver's slot tables take ≈150 KiB of LDS) and a state with more than a thousand
+    clusters (every fourth point a singleton): exact against the oracle from a moving start, resolver alone on the CU."""
+    n, K = 4200, 30
+    data = rc.generatemixture(n, K, seed=9, sigma=0.15)
+    D, truth = data["distancematrix"], data["clusts"]
+    P = rc.likelihood_hyperparams(D, truth)
+    ctx = rc.Context(D, kcap=4096)
+    ctx.set_params(**P)
+    init = truth.copy()
+    init[::4] = K + 1 + np.arange(len(init[::4]))             # 1050 singletons with labels 31..1080
+    ctx.set_state(init)
+    L = ctx.get_matrix(1)
+    eD, eL = ctx.debug_rowsums(1)[2:4]
+    orc = O.Oracle(D, P, logD=L, eL=eL, eD=eD)
+    orc.set_state(init)
+    assert ctx.get_state()[2] == K + 1050
+    for t in range(3):
+        r, p = rp_schedule(t)
+        ctx.gibbs_sweep(r, p, 77, t)
+        orc.sweep_stable(r, p, 77, t)
+        lab, sizes, Kc = ctx.get_state()
+        st = ctx.sweep_stats()
+        assert np.array_equal(lab, orc.clusts) and np.array_equal(sizes, orc.sizes) and Kc == orc.K, (t, st)
+        assert st["n_changes"] == orc.last_changes
+    assert abs(ctx.loglik() - orc.loglik_stable()) <= 1e-9 * abs(orc.loglik_stable())
+    ctx.close()
