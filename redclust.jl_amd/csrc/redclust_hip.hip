@@ -88,6 +88,7 @@ typedef unsigned long long u64;
 #define RC_RES_THREADS 512  // k_resolve block: 32 points x 16 candidate streams; 2 waves/SIMD so it co-resides with k_bulk
 #define RC_PTS 32           // points per chunk (lanes of a half wave)
 #define RC_MAX_KCAP 4096
+#define RC_RES_ONE_STREAM_MAX_N 1024   // up to this size the in-order resolver chain wins (n = 1000: 26 k -> 32 k sweeps/s; n >= 2000: even or worse)
 #define RC_MAXB 512          // tentative changers validated per resolve round
 #define RC_SPIN_LIMIT (1u << 23)
 #if defined(RC_PROF_SYML) || defined(RC_TRACE_RESOLVE)   // profiling / diagnostic builds: records behind the work counter
@@ -2653,6 +2654,7 @@ struct rc_ctx {
     int rows_per_split = 256;
     int num_cus = 256;
     // software pipeline
+    bool res_one_stream = false;      // small problems: every resolver on stream B (in order, no event between consecutive resolvers), every row reduction on B2
     hipStream_t s_res_last = nullptr; // stream of the last resolver launch (sB / sB2 by sweep parity, sA in incremental mode)
     hipEvent_t ev_a = nullptr;        // marker on stream A: work that reads the state and must precede the next resolver
     bool sA_dirty = false;
@@ -3060,6 +3062,7 @@ static int32_t alloc_ctx(int64_t n, int32_t storage_bits, int32_t device_id, int
     c->dbg = getenv("RC_DEBUG_FLAGS") ? atoi(getenv("RC_DEBUG_FLAGS")) : 0;
     c->prefetch = !(getenv("RC_NO_PREFETCH") && atoi(getenv("RC_NO_PREFETCH")));
     c->relayout = !(getenv("RC_NO_RELAYOUT") && atoi(getenv("RC_NO_RELAYOUT")));
+    c->res_one_stream = getenv("RC_RES_ONE_STREAM") ? atoi(getenv("RC_RES_ONE_STREAM")) != 0 : (n <= RC_RES_ONE_STREAM_MAX_N);
     if (getenv("RC_SYM_VARIANT")) c->sym_variant = atoi(getenv("RC_SYM_VARIANT"));
     if (getenv("RC_SYMW_PER_CU")) c->symw_per_cu = std::max(1, atoi(getenv("RC_SYMW_PER_CU")));
     if (getenv("RC_SYML_PAD")) c->syml_pad = (size_t)std::max(0, atoi(getenv("RC_SYML_PAD")));
@@ -3084,7 +3087,11 @@ static int32_t finish_create(rc_ctx *c)
         c->rows_per_split = std::max(16, std::min(512, (c->n + splits_target - 1) / splits_target));
         if (getenv("RC_BULK_ROWS")) c->rows_per_split = std::max(1, atoi(getenv("RC_BULK_ROWS")));
         const int per_cu = getenv("RC_BULK_PER_CU") ? atoi(getenv("RC_BULK_PER_CU")) : 2;
-        c->bulk_lds = per_cu > 0 ? (size_t)((150 * 1024 / per_cu) & ~1023) : 0;
+        // ... and the LDS the resolver's tables need must stay free beside them (160 KiB per CU): with the tables at 25-35 KiB
+        // a fixed 150 KiB for the reduction left the resolver waiting for reduction blocks to retire
+        const size_t lds_res = std::max(tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64), 2 * sizeof(int) * (size_t)c->kcap);
+        const size_t avail = lds_res + 4096 < 150 * 1024 ? std::min<size_t>(150 * 1024, 160 * 1024 - lds_res - 2048) : 16 * 1024;
+        c->bulk_lds = per_cu > 0 ? (size_t)((avail / per_cu) & ~(size_t)1023) : 0;
         if (c->bulk_lds > 64 * 1024) {
             (void)hipFuncSetAttribute(c->bits == 64 ? (const void *)k_bulk<long long> : (const void *)k_bulk<int>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->bulk_lds);
@@ -3405,7 +3412,7 @@ static void syml_geometry(const rc_ctx *c, int cap_blocks, int *gc_out, int *nit
 // clears generation (t+1)%3.  Needs k_resolve(t-2) (perm, and the last reader of the generation being cleared).
 static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
 {
-    const hipStream_t sb = (t & 1) ? c->sB2 : c->sB;
+    const hipStream_t sb = c->res_one_stream ? c->sB2 : ((t & 1) ? c->sB2 : c->sB);
     if (t >= 2) HIPCHK(c, hipStreamWaitEvent(sb, c->ev_res[(t - 2) & 3], 0));
     const int splits = (c->n + c->rows_per_split - 1) / c->rows_per_split;
     dim3 gb((unsigned)(c->ld / (c->bits == 64 ? 512 : 1024)), (unsigned)splits);
@@ -3606,7 +3613,11 @@ extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t 
         rc = enqueue_bulk(c, V, t);
         if (rc != RC_OK) return rc;
     }
-    const hipStream_t sx = (t & 1) ? c->sB2 : c->sB;            // the stream of sweep t: its row reduction is already on it
+    // the stream of sweep t: its row reduction is already on it — except for small problems, where the chain that bounds the
+    // sweep rate is resolver(t) -> resolver(t+1) (a cross-stream event costs more than the resolver itself): all resolvers
+    // then run in order on stream B and the (short) row reductions on B2, each resolver waiting for its reduction's event
+    const hipStream_t sx = c->res_one_stream ? c->sB : ((t & 1) ? c->sB2 : c->sB);
+    if (c->res_one_stream) HIPCHK(c, hipStreamWaitEvent(sx, c->ev_bulk[t & 3], 0));
     rc = launch_resolve(c, V, sa, res_threads, lds, sx);
     if (rc != RC_OK) return rc;
     c->t_next = t + 1;

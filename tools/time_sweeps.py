@@ -16,6 +16,7 @@ for t in range(10): ctx.gibbs_sweep(1.0, 0.5, 1, t, blocking=False)
 ctx.synchronize()
 t0 = time.perf_counter()
 for t in range(10, 10 + steps): ctx.gibbs_sweep(1.0, 0.5, 1, t, blocking=False)
+t_enq = time.perf_counter() - t0
 ctx.synchronize()
 dt = time.perf_counter() - t0
-print(f"n={n} K={K} bits={bits}: {steps / dt:.1f} sweeps/s ({dt / steps * 1e3:.3f} ms/sweep) changes {ctx.sweep_stats()}")
+print(f"n={n} K={K} bits={bits}: {steps / dt:.1f} sweeps/s ({dt / steps * 1e3:.3f} ms/sweep; host enqueue {t_enq / steps * 1e6:.1f} us/sweep) changes {ctx.sweep_stats()}")
