@@ -2654,6 +2654,7 @@ struct rc_ctx {
     int rows_per_split = 256;
     int num_cus = 256;
     // software pipeline
+    bool registered = false;          // counted in g_res_contexts
     bool res_one_stream = false;      // small problems: every resolver on stream B (in order, no event between consecutive resolvers), every row reduction on B2
     hipStream_t s_res_last = nullptr; // stream of the last resolver launch (sB / sB2 by sweep parity, sA in incremental mode)
     hipEvent_t ev_a = nullptr;        // marker on stream A: work that reads the state and must precede the next resolver
@@ -2814,11 +2815,38 @@ struct SmProfile {
 static SmProfile g_smprof;
 static void smprof_report() { g_smprof.report(); }
 
+// Resolver launches of different contexts on one device must not overlap (launch_resolve).  A device that only ever holds
+// one context at a time — the normal case — skips the chain and its two barrier packets per sweep; the first time a second
+// context appears the device is drained once and the chain is used from then on.
+static std::mutex g_res_mutex;
+static hipEvent_t g_res_event[64] = {};
+static int g_res_contexts[64] = {};   // live contexts per device
+static bool g_res_multi[64] = {};
+
+static void res_register(rc_ctx *c)
+{
+    bool drain = false;
+    {
+        std::lock_guard<std::mutex> lock(g_res_mutex);
+        const int d = c->dev & 63;
+        if (++g_res_contexts[d] > 1 && !g_res_multi[d]) { g_res_multi[d] = true; drain = true; }
+    }
+    if (drain) (void)hipDeviceSynchronize();   // launches made without the chain are complete before the newcomer's first one
+}
+
+static void res_unregister(rc_ctx *c)
+{
+    std::lock_guard<std::mutex> lock(g_res_mutex);
+    const int d = c->dev & 63;
+    if (g_res_contexts[d] > 0) --g_res_contexts[d];
+}
+
 extern "C" int32_t rc_destroy(rc_ctx *ctx)
 {
     smprof_report();
     if (!ctx) return RC_OK;
     (void)hipSetDevice(ctx->dev);
+    if (ctx->registered) { res_unregister(ctx); ctx->registered = false; }
     if (ctx->sA) (void)hipStreamSynchronize(ctx->sA);
     if (ctx->sB) (void)hipStreamSynchronize(ctx->sB);
     if (ctx->sB2) (void)hipStreamSynchronize(ctx->sB2);
@@ -3077,6 +3105,7 @@ static int32_t alloc_ctx(int64_t n, int32_t storage_bits, int32_t device_id, int
 // launch geometry and LDS attributes that depend on (n, kcap, bits)
 static int32_t finish_create(rc_ctx *c)
 {
+    if (!c->registered) { res_register(c); c->registered = true; }
     const int nchunks = (c->n + RC_PTS - 1) / RC_PTS;
     c->G = std::max(1, std::min(nchunks, c->num_cus));
     {
@@ -3125,6 +3154,7 @@ extern "C" int32_t rc_create(int64_t n, const double *D, const double *logD_or_n
     if (rc == RC_OK) rc = finish_create(c);
     if (rc != RC_OK) {
         snprintf(g_err, sizeof(g_err), "%s", c->err);
+        if (c->registered) { res_unregister(c); c->registered = false; }
         free_all(c);
         return rc;
     }
@@ -3148,6 +3178,7 @@ extern "C" int32_t rc_create_from_points(int64_t n, int64_t dim, const double *p
     if (rc == RC_OK) rc = finish_create(c);
     if (rc != RC_OK) {
         snprintf(g_err, sizeof(g_err), "%s", c->err);
+        if (c->registered) { res_unregister(c); c->registered = false; }
         free_all(c);
         return rc;
     }
@@ -3413,7 +3444,10 @@ static void syml_geometry(const rc_ctx *c, int cap_blocks, int *gc_out, int *nit
 static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
 {
     const hipStream_t sb = c->res_one_stream ? c->sB2 : ((t & 1) ? c->sB2 : c->sB);
-    if (t >= 2) HIPCHK(c, hipStreamWaitEvent(sb, c->ev_res[(t - 2) & 3], 0));
+    // resolver(t-2) — the last reader of the generation being filled and the writer of the labels read here.  With the sweep's
+    // parity streams it ran on this very stream: in order already, and every event wait is a barrier packet the command
+    // processor works through on the critical path (12-19 µs between two kernels of one stream with five of them, ~4 without)
+    if (t >= 2 && (c->res_one_stream || c->incremental)) HIPCHK(c, hipStreamWaitEvent(sb, c->ev_res[(t - 2) & 3], 0));
     const int splits = (c->n + c->rows_per_split - 1) / c->rows_per_split;
     dim3 gb((unsigned)(c->ld / (c->bits == 64 ? 512 : 1024)), (unsigned)splits);
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
@@ -3473,7 +3507,7 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
         HIPCHK(c, hipEventRecord(ev.second, sb));
         c->ev_pending.push_back(ev);
     }
-    HIPCHK(c, hipEventRecord(c->ev_bulk[t & 3], sb));
+    if (t == 0 || c->res_one_stream) HIPCHK(c, hipEventRecord(c->ev_bulk[t & 3], sb));   // (read by ensure_S for sweep 0 and by the one-stream mode)
     c->bulk_enq = t;
     return RC_OK;
 }
@@ -3520,8 +3554,6 @@ static int32_t ensure_S(rc_ctx *c, int *gen)
 // fits (G <= number of CUs), but two launches from different contexts of this process could each hold part of the
 // chip and wait for the rest for ever (until the bounded spin reports RC_DERR_BARRIER).  Resolver launches on one
 // device are therefore chained: each waits for the completion of the previous one, whichever context it came from.
-static std::mutex g_res_mutex;
-static hipEvent_t g_res_event[64] = {};
 
 static int32_t launch_resolve(rc_ctx *c, const View &V, const SweepArgs &sa, int res_threads, size_t lds, hipStream_t sx)
 {
@@ -3533,12 +3565,15 @@ static int32_t launch_resolve(rc_ctx *c, const View &V, const SweepArgs &sa, int
     if (sa.t >= 1 && c->s_res_last && c->s_res_last != sx) HIPCHK(c, hipStreamWaitEvent(sx, c->ev_res[(sa.t - 1) & 3], 0));
     std::lock_guard<std::mutex> lock(g_res_mutex);
     const int d = c->dev & 63;
-    if (g_res_event[d]) HIPCHK(c, hipStreamWaitEvent(sx, g_res_event[d], 0));
-    else HIPCHK(c, hipEventCreateWithFlags(&g_res_event[d], hipEventDisableTiming));
+    const bool chain = g_res_multi[d];   // several contexts on this device: their resolvers must not overlap (see above)
+    if (chain) {
+        if (g_res_event[d]) HIPCHK(c, hipStreamWaitEvent(sx, g_res_event[d], 0));
+        else HIPCHK(c, hipEventCreateWithFlags(&g_res_event[d], hipEventDisableTiming));
+    }
     k_resolve<<<c->G, res_threads, lds, sx>>>(V, sa, c->G);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(c, RC_ERR_HIP, "k_resolve launch failed: %s", hipGetErrorString(e));
-    HIPCHK(c, hipEventRecord(g_res_event[d], sx));
+    if (chain) HIPCHK(c, hipEventRecord(g_res_event[d], sx));
     HIPCHK(c, hipEventRecord(c->ev_res[sa.t & 3], sx));
     c->s_res_last = sx;
     return RC_OK;
