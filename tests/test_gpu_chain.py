@@ -200,3 +200,26 @@ def test_speculative_loop_equals_the_synchronous_loop(mode):
         for f in ("clusts", "K", "r", "p", "loglik", "logposterior", "r_acceptances", "splitmerge_acceptances", "splitmerge_splits",
                   "r_all", "p_all", "cocluster", "final", "r_final", "p_final", "num_samples"):
             assert np.array_equal(runs[tag][f], ref[f]), (tag, f)
+
+
+def test_parameters_changed_between_proposals_invalidate_the_cached_likelihood():
+    """rc_set_params between two rc_splitmerge calls with unchanged labels (allowed by the C ABI): the second proposal must
+    use block sums / log-likelihood terms of the NEW parameters — it equals the proposal of a fresh context that only ever
+    saw the new parameters."""
+    D, truth = paper(1)
+    P1 = T.likelihood_hyperparams(D, truth)
+    P2 = dict(P1, delta1=P1["delta1"] * 1.7, alpha=P1["alpha"] * 0.6, zeta=P1["zeta"] * 1.3)
+    init = truth.copy(); init[init == 2] = 1; init[init == 4] = 3
+    L = np.log(D + np.eye(100))
+    a = rc.Context(D, logD=L); a.set_params(**P1); a.set_state(init); a.attach_host_matrices(D, L)
+    b = rc.Context(D, logD=L); b.set_params(**P2); b.set_state(init); b.attach_host_matrices(D, L)
+    first = a.splitmerge(1.0, 0.5, 5, 21, 0, 0)          # fills a's caches under P1
+    a.set_state(init)                                    # same labels again, whatever the first proposal did
+    ll1 = a.loglik()
+    a.set_params(**P2)
+    assert a.loglik() == b.loglik() != ll1
+    for it in range(1, 6):
+        ra, rb = a.splitmerge(1.0, 0.5, 5, 21, it, 0), b.splitmerge(1.0, 0.5, 5, 21, it, 0)
+        assert ra == rb, (it, ra, rb, first)
+        assert np.array_equal(a.get_state()[0], b.get_state()[0]) and a.loglik() == b.loglik()
+    a.close(); b.close()
