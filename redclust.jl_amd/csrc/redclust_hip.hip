@@ -89,6 +89,7 @@ typedef unsigned long long u64;
 #define RC_PTS 32           // points per chunk (lanes of a half wave)
 #define RC_MAX_KCAP 4096
 #define RC_RES_ONE_STREAM_MAX_N 1024   // up to this size the in-order resolver chain wins (n = 1000: 26 k -> 32 k sweeps/s; n >= 2000: even or worse)
+#define RC_USED_LDS_MAX_N 16384   // up to this n the label-occupancy bitset of the resolver lives in LDS (n/8 bytes)
 #define RC_MAXB 512          // tentative changers validated per resolve round
 #define RC_SPIN_LIMIT (1u << 23)
 #if defined(RC_PROF_SYML) || defined(RC_TRACE_RESOLVE)   // profiling / diagnostic builds: records behind the work counter
@@ -125,6 +126,8 @@ struct HostSummary {
 // Everything a kernel needs, passed by value.
 struct View {
     int n, ld, kcap;
+    unsigned *used_scratch;    // [G][(n+31)/32] label bitsets of the resolver blocks when n > RC_USED_LDS_MAX_N
+    int maxb;                  // batch capacity of the resolver (<= RC_MAXB; smaller when that makes its LDS fit beside the row reduction)
     const void *Dq, *Lq;       // [n][ld] fixed point: int64 (bits = 64) or int32 (bits = 32); rows/columns in INTERNAL order
     int bits;
     const long long *diagq;    // [n] Dq[i][i]
@@ -1494,7 +1497,7 @@ struct Tab {
     short *act;      // [kcap] the active slots, in ascending label order (candidate order, mcmc.jl:195)
     double *base_o;  // [kcap] A[s] + log p + log(s-1+r), s = size          (candidate cluster of another point)
     double *base_s;  // [kcap] same with s = size-1                          (the point's own cluster, itself removed)
-    unsigned *used;  // [(n+31)/32] label occupancy bitset, bit (label-1); built when a round has changers
+    unsigned *used;  // [(n+31)/32] label occupancy bitset, bit (label-1); built when a round has changers (LDS, or V.used_scratch for large n)
     double *red_v;   // [NW][32] reduction scratch (NW = waves per block)
     int *red_pos, *red_slot;
     int *misc;       // [0]=K [1]=smallest_empty [2]=scratch [3]=nb [4]=hi [5]=fail [6]=barrier ok [7]=slot_hi [8]=#births [9]=#effective
@@ -1511,7 +1514,7 @@ struct Tab {
     int *seg;                 // [kcap+1] before / during batch_sim: entries leaving the slot; afterwards seg[k] = end of slot k's group
     unsigned char *joined;    // [kcap] some entry of the batch moves a point INTO the slot
     unsigned char *candie;    // [kcap] the slot could become empty inside the batch (size − leavers < 1): its size is simulated
-    int *ccnt;                // [nchunks + 1] scratch: changers per chunk / exclusive offsets
+    unsigned short *ccnt;     // [nchunks + 1] scratch: changers per chunk / exclusive offsets, saturating at 65535 (only offsets <= batch capacity matter)
 };
 #define RC_BF_DEATH 1   // the source cluster becomes empty
 #define RC_BF_BIRTH 2   // the target is a new cluster (slot bb, label blab)
@@ -1520,7 +1523,7 @@ struct Tab {
 
 #define RC_A16(x) (((x) + 15) & ~(size_t)15)
 #define RC_TAB_NOFF 30
-__host__ __device__ inline size_t tab_layout(int kcap, int n, int nw, size_t *off /*RC_TAB_NOFF*/)
+__host__ __device__ inline size_t tab_layout(int kcap, int n, int nw, size_t *off /*RC_TAB_NOFF*/, int maxb = RC_MAXB)
 {
     size_t o = 0;
     off[0] = o; o = RC_A16(o + sizeof(double) * kcap);          // base_o
@@ -1531,42 +1534,42 @@ __host__ __device__ inline size_t tab_layout(int kcap, int n, int nw, size_t *of
     off[5] = o; o = RC_A16(o + sizeof(int) * kcap);             // label
     off[6] = o; o = RC_A16(o + sizeof(int) * nw * RC_PTS);      // red_pos
     off[7] = o; o = RC_A16(o + sizeof(int) * nw * RC_PTS);      // red_slot
-    off[8] = o; o = RC_A16(o + sizeof(unsigned) * ((n + 31) / 32));  // used
+    off[8] = o; o = RC_A16(o + (n <= RC_USED_LDS_MAX_N ? sizeof(unsigned) * ((n + 31) / 32) : 0));  // used (beyond: per-block global scratch)
     off[9] = o; o = RC_A16(o + sizeof(int) * 16);               // misc
     off[10] = o;                                                // (unused)
     off[11] = o; o = RC_A16(o + sizeof(short) * kcap);          // act
-    off[12] = o; o = RC_A16(o + sizeof(int) * RC_MAXB);         // bx
-    off[13] = o; o = RC_A16(o + sizeof(short) * RC_MAXB);       // ba
-    off[14] = o; o = RC_A16(o + sizeof(short) * RC_MAXB);       // bb
+    off[12] = o; o = RC_A16(o + sizeof(int) * maxb);         // bx
+    off[13] = o; o = RC_A16(o + sizeof(short) * maxb);       // ba
+    off[14] = o; o = RC_A16(o + sizeof(short) * maxb);       // bb
     off[15] = o; o = RC_A16(o + sizeof(int) * (kcap + 1));      // seg
-    off[16] = o; o = RC_A16(o + sizeof(int) * ((n + RC_PTS - 1) / RC_PTS + 1));  // ccnt
-    off[17] = o; o = RC_A16(o + sizeof(int) * RC_MAXB);         // bu
-    off[18] = o; o = RC_A16(o + sizeof(int) * RC_MAXB);         // blab
+    off[16] = o; o = RC_A16(o + sizeof(unsigned short) * ((n + RC_PTS - 1) / RC_PTS + 1));  // ccnt
+    off[17] = o; o = RC_A16(o + sizeof(int) * maxb);         // bu
+    off[18] = o; o = RC_A16(o + sizeof(int) * maxb);         // blab
     off[19] = o;                                                // (unused)
-    off[20] = o; o = RC_A16(o + sizeof(short) * RC_MAXB);       // bK
-    off[21] = o; o = RC_A16(o + (size_t)RC_MAXB);               // bflag
-    off[22] = o; o = RC_A16(o + sizeof(short) * RC_MAXB);       // birth
-    off[23] = o; o = RC_A16(o + sizeof(short) * 2 * RC_MAXB);   // pairs
+    off[20] = o; o = RC_A16(o + sizeof(short) * maxb);       // bK
+    off[21] = o; o = RC_A16(o + (size_t)maxb);               // bflag
+    off[22] = o; o = RC_A16(o + sizeof(short) * maxb);       // birth
+    off[23] = o; o = RC_A16(o + sizeof(short) * 2 * maxb);   // pairs
     off[24] = o; o = RC_A16(o + (size_t)kcap);                  // candie
     off[25] = o;                                                // (unused)
     off[26] = o; o = RC_A16(o + (size_t)kcap);                  // joined
-    off[27] = o; o = RC_A16(o + sizeof(short) * 2 * RC_MAXB);   // pairs_tmp
+    off[27] = o; o = RC_A16(o + sizeof(short) * 2 * maxb);   // pairs_tmp
     off[28] = o;
     off[29] = o;
     return o;
 }
 
-__device__ Tab tab_carve(char *smem, int kcap, int n, int nw)
+__device__ Tab tab_carve(char *smem, int kcap, int n, int nw, int maxb = RC_MAXB)
 {
     size_t off[RC_TAB_NOFF];
-    tab_layout(kcap, n, nw, off);
+    tab_layout(kcap, n, nw, off, maxb);
     Tab T;
     T.base_o = (double *)(smem + off[0]); T.base_s = (double *)(smem + off[1]); T.red_v = (double *)(smem + off[2]);
     T.blk_key = (u64 *)(smem + off[3]); T.size = (int *)(smem + off[4]); T.label = (int *)(smem + off[5]);
     T.red_pos = (int *)(smem + off[6]); T.red_slot = (int *)(smem + off[7]); T.used = (unsigned *)(smem + off[8]);
     T.misc = (int *)(smem + off[9]); T.act = (short *)(smem + off[11]);
     T.bx = (int *)(smem + off[12]); T.ba = (short *)(smem + off[13]); T.bb = (short *)(smem + off[14]);
-    T.seg = (int *)(smem + off[15]); T.ccnt = (int *)(smem + off[16]); T.bu = (int *)(smem + off[17]);
+    T.seg = (int *)(smem + off[15]); T.ccnt = (unsigned short *)(smem + off[16]); T.bu = (int *)(smem + off[17]);
     T.blab = (int *)(smem + off[18]); T.bK = (short *)(smem + off[20]);
     T.bflag = (unsigned char *)(smem + off[21]); T.birth = (short *)(smem + off[22]);
     T.pairs = (short *)(smem + off[23]); T.candie = (unsigned char *)(smem + off[24]);
@@ -1574,16 +1577,16 @@ __device__ Tab tab_carve(char *smem, int kcap, int n, int nw)
     return T;
 }
 
-__device__ inline size_t tab_bytes_dev(int kcap, int n, int nw)
+__device__ inline size_t tab_bytes_dev(int kcap, int n, int nw, int maxb = RC_MAXB)
 {
     size_t off[RC_TAB_NOFF];
-    return tab_layout(kcap, n, nw, off);
+    return tab_layout(kcap, n, nw, off, maxb);
 }
 
-static size_t tab_bytes(int kcap, int n, int nw)
+static size_t tab_bytes(int kcap, int n, int nw, int maxb = RC_MAXB)
 {
     size_t off[RC_TAB_NOFF];
-    return tab_layout(kcap, n, nw, off);
+    return tab_layout(kcap, n, nw, off, maxb);
 }
 
 __device__ __forceinline__ double tab_base(const View &V, const SweepArgs &a, int s)
@@ -1746,6 +1749,7 @@ __global__ __launch_bounds__(1024) void k_derive(View V, int rebuild_perm)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Tab T = tab_carve(smem, V.kcap, V.n, 1);
+    if (V.n > RC_USED_LDS_MAX_N) T.used = V.used_scratch;   // one block
     for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) { T.size[k] = V.slot_size[k]; T.label[k] = V.slot_label[k]; T.act[k] = 0; }
     if (threadIdx.x == 0) { T.misc[0] = V.sc->K; T.misc[7] = V.sc->slot_hi; }
     __syncthreads();
@@ -2195,7 +2199,8 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
 #endif
     RC_PF(long long ps[16]; for (int q_ = 0; q_ < 16; ++q_) ps[q_] = 0; ps[0] = __builtin_amdgcn_s_memrealtime(); long long pt_ = ps[0];)
 #define RC_PHASE(k) RC_PF({ const long long now_ = __builtin_amdgcn_s_memrealtime(); ps[k] += now_ - pt_; pt_ = now_; })
-    Tab T = tab_carve(smem, V.kcap, V.n, blockDim.x >> 6);
+    Tab T = tab_carve(smem, V.kcap, V.n, blockDim.x >> 6, V.maxb);
+    if (V.n > RC_USED_LDS_MAX_N) T.used = V.used_scratch + (size_t)blockIdx.x * (size_t)((V.n + 31) / 32);
     const int t = sa.t, own_gen = sa.own_gen, next_gen = sa.next_gen, kg = t & 1;
     const long long *SD = V.SD[own_gen], *SL = V.SL[own_gen];
     u64 *keys = V.keys[kg];
@@ -2206,7 +2211,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
     RC_PF(ps[1] = __builtin_amdgcn_s_memrealtime();)
     const int nchunks = (V.n + RC_PTS - 1) / RC_PTS;
     int after = -1, round = 0, changes = 0, nbar = 0;
-    int cap = RC_MAXB;   // changers taken into the next batch (adaptive, identical in every block)
+    int cap = V.maxb;    // changers taken into the next batch (adaptive, identical in every block)
     bool ok = true;
     for (;;) {
         const unsigned stamp = (unsigned)round + 1u;
@@ -2237,7 +2242,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
                 const u64 w = __hip_atomic_load(cword + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((unsigned)(w >> 32) == stamp) cnt = __popc((unsigned)w);
             }
-            T.ccnt[c] = cnt;
+            T.ccnt[c] = (unsigned short)cnt;
             any |= cnt;
         }
         for (int k = threadIdx.x; k <= V.kcap; k += blockDim.x) { T.seg[k] = 0; if (k < V.kcap) T.joined[k] = 0; }
@@ -2261,7 +2266,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
                 if ((int)threadIdx.x >= d_) incl += up;
             }
             int o = incl - sum;
-            for (int c = c0_; c < c1_; ++c) { const int x = T.ccnt[c]; T.ccnt[c] = o; o += x; }
+            for (int c = c0_; c < c1_; ++c) { const int x = T.ccnt[c]; T.ccnt[c] = (unsigned short)min(o, 65535); o += x; }
         }
         __syncthreads();
         const int total = T.ccnt[nchunks];
@@ -2365,7 +2370,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         RC_CHAOS_AT(2);
 #ifdef RC_TRACE_RESOLVE   // diagnostic builds: per-round record of block RC_TRACE_BLOCK (default 0) behind the work counter
         if ((int)blockIdx.x == (sa.dbg >> 8) && threadIdx.x == 0 && round < 120) {   // kept in LDS until the sweep is over
-            int *tr = (int *)(smem + tab_bytes_dev(V.kcap, V.n, blockDim.x >> 6)) + (size_t)round * 8;
+            int *tr = (int *)(smem + tab_bytes_dev(V.kcap, V.n, blockDim.x >> 6, V.maxb)) + (size_t)round * 8;
             tr[0] = round; tr[1] = total; tr[2] = nb; tr[3] = hi; tr[4] = T.bx[0]; tr[5] = after; tr[6] = T.misc[9]; tr[7] = T.misc[8];
         }
 #endif
@@ -2407,7 +2412,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         // Validation costs (points covered) x (changers before them); everything behind the first violation is wasted.
         // When less than a third of a batch could be committed the next one is cut to three times what was (at least 64),
         // otherwise it doubles.
-        cap = (3 * nc < nb) ? max(64, 3 * nc) : min(RC_MAXB, 2 * cap);
+        cap = (3 * nc < nb) ? min(V.maxb, max(64, 3 * nc)) : min(V.maxb, 2 * cap);
         after = limit - 1;
         ++round;
         if (round > V.n) break;  // cannot happen: every round finalises at least the first changer
@@ -2415,7 +2420,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
 #ifdef RC_TRACE_RESOLVE
     __syncthreads();
     if ((int)blockIdx.x == (sa.dbg >> 8)) {
-        const int *tr = (const int *)(smem + tab_bytes_dev(V.kcap, V.n, blockDim.x >> 6));
+        const int *tr = (const int *)(smem + tab_bytes_dev(V.kcap, V.n, blockDim.x >> 6, V.maxb));
         long long *out = (long long *)((char *)V.work[kg] + 64);
         for (int q = threadIdx.x; q < 120 * 8; q += blockDim.x) out[q] = (q / 8 <= round) ? tr[q] : -7;
     }
@@ -2655,6 +2660,8 @@ struct rc_ctx {
     int num_cus = 256;
     // software pipeline
     bool registered = false;          // counted in g_res_contexts
+    unsigned *used_scratch = nullptr; // label bitsets of the resolver blocks for large n
+    int maxb = RC_MAXB;               // resolver batch capacity (finish_create: the largest that lets the resolver's LDS fit beside the row reduction)
     bool res_one_stream = false;      // small problems: every resolver on stream B (in order, no event between consecutive resolvers), every row reduction on B2
     hipStream_t s_res_last = nullptr; // stream of the last resolver launch (sB / sB2 by sweep parity, sA in incremental mode)
     hipEvent_t ev_a = nullptr;        // marker on stream A: work that reads the state and must precede the next resolver
@@ -2730,7 +2737,7 @@ static int32_t fail(rc_ctx *c, int32_t code, const char *fmt, ...)
 static View make_view(const rc_ctx *c)
 {
     View V{};
-    V.n = c->n; V.ld = c->ld; V.kcap = c->kcap;
+    V.n = c->n; V.ld = c->ld; V.kcap = c->kcap; V.maxb = c->maxb; V.used_scratch = c->used_scratch;
     V.Dq = c->Dq; V.Lq = c->Lq; V.bits = c->bits; V.diagq = c->diagq; V.pi = c->pi;
     V.derived = c->derived ? 1 : 0; V.qsD = std::ldexp(1.0, -c->eD); V.qsL = std::ldexp(1.0, c->eL); V.ltab = c->ltab; V.qeD = c->eD;
     for (int g = 0; g < 3; ++g) { V.SD[g] = c->SD[g]; V.SL[g] = c->SL[g]; }
@@ -2773,7 +2780,7 @@ static void free_all(rc_ctx *c)
     void *ptrs[] = {c->ltab, c->Dq, c->Lq, c->Dq_src, c->Lq_src, c->diag_src, c->pi, c->ipi, c->diagq, c->SD[0], c->SD[1], c->SD[2], c->SL[0], c->SL[1], c->SL[2], c->slot_of,
                     c->slot_size, c->slot_label, c->slot_pos, c->slot_act, c->perm[0], c->perm[1], c->pslot[0],
                     c->pslot[1], c->lsnap[0], c->lsnap[1], c->work[0], c->work[1], c->cword[0], c->cword[1], c->rec, c->tent, c->A, c->keys[0], c->keys[1], c->arrive[0], c->arrive[1], c->sc, c->blocks,
-                    c->counts, c->cc_out, c->snap, c->d_moves};
+                    c->counts, c->cc_out, c->snap, c->d_moves, c->used_scratch};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->hsum) (void)hipHostFree(c->hsum);
@@ -2944,6 +2951,7 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     HIPCHK2(hipMalloc(&c->slot_label, (size_t)c->kcap * sizeof(int)));
     HIPCHK2(hipMalloc(&c->slot_pos, (size_t)c->kcap * sizeof(short)));
     HIPCHK2(hipMalloc(&c->slot_act, (size_t)c->kcap * sizeof(short)));
+    if (c->n > RC_USED_LDS_MAX_N) HIPCHK2(hipMalloc((void **)&c->used_scratch, (size_t)std::max(c->num_cus, 256) * (size_t)((c->n + 31) / 32) * sizeof(unsigned)));
     HIPCHK2(hipMalloc(&c->A, (size_t)(n + 1) * sizeof(double)));
     HIPCHK2(hipMalloc(&c->sc, sizeof(DevScalars)));
     HIPCHK2(hipHostMalloc((void **)&c->hsum, sizeof(HostSummary), hipHostMallocMapped));
@@ -3106,6 +3114,25 @@ static int32_t alloc_ctx(int64_t n, int32_t storage_bits, int32_t device_id, int
 static int32_t finish_create(rc_ctx *c)
 {
     if (!c->registered) { res_register(c); c->registered = true; }
+    {
+        // Resolver batch capacity.  The resolver of sweep t has to be resident beside the row-reduction blocks of sweep t+1
+        // (its grid barrier needs every block at once; behind persistent reduction blocks it would wait for the whole
+        // reduction — config 5: 1.34 ms per resolver instead of 0.3).  LDS beside the reduction: three 40 KiB blocks of the
+        // wave-autonomous kernel (64-bit, logD derived), two 65 KiB blocks of the block-tiled kernels otherwise; the
+        // full-read kernel of small problems sizes itself around the resolver.  Largest capacity whose tables fit.
+        const bool syml = (c->bits == 64 && c->derived);
+        const size_t beside = syml ? (size_t)c->symw_per_cu * 40960 : (size_t)2 * 69632;   // (k_bulk_sym32: 67,864 B per block, k_bulk_sym: 67,288 B; measured: beside two of them 24.6 KB of tables become resident, 26.5 KB do not — 4 KiB allocation granules)
+        const size_t avail = 160 * 1024 > beside + 1024 ? 160 * 1024 - beside - 1024 : 0;
+        c->maxb = RC_MAXB;
+        if (getenv("RC_RES_MAXB")) c->maxb = std::max(16, std::min(RC_MAXB, atoi(getenv("RC_RES_MAXB"))));
+        else if (c->n > 4096 && tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, RC_MAXB) > avail)
+            for (int mb : {384, 256, 192, 128, 96, 64})
+                if (tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, mb) <= avail) { c->maxb = mb; break; }
+        if (getenv("RC_SM_PROFILE"))
+            fprintf(stderr, "[rc_create] resolver batch capacity %d: tables %zu B (512: %zu, 256: %zu, 128: %zu, 64: %zu), %zu B free beside the row reduction\n", c->maxb,
+                    tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, c->maxb), tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, 512), tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, 256),
+                    tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, 128), tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, 64), avail);
+    }
     const int nchunks = (c->n + RC_PTS - 1) / RC_PTS;
     c->G = std::max(1, std::min(nchunks, c->num_cus));
     {
@@ -3118,7 +3145,7 @@ static int32_t finish_create(rc_ctx *c)
         const int per_cu = getenv("RC_BULK_PER_CU") ? atoi(getenv("RC_BULK_PER_CU")) : 2;
         // ... and the LDS the resolver's tables need must stay free beside them (160 KiB per CU): with the tables at 25-35 KiB
         // a fixed 150 KiB for the reduction left the resolver waiting for reduction blocks to retire
-        const size_t lds_res = std::max(tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64), 2 * sizeof(int) * (size_t)c->kcap);
+        const size_t lds_res = std::max(tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, c->maxb), 2 * sizeof(int) * (size_t)c->kcap);
         const size_t avail = lds_res + 4096 < 150 * 1024 ? std::min<size_t>(150 * 1024, 160 * 1024 - lds_res - 2048) : 16 * 1024;
         c->bulk_lds = per_cu > 0 ? (size_t)((avail / per_cu) & ~(size_t)1023) : 0;
         if (c->bulk_lds > 64 * 1024) {
@@ -3128,7 +3155,7 @@ static int32_t finish_create(rc_ctx *c)
         }
     }
     // kernels whose dynamic LDS can exceed the 64 KiB default (large kcap)
-    const size_t lds_r = std::max(tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64), 2 * sizeof(int) * (size_t)c->kcap);
+    const size_t lds_r = std::max(tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, c->maxb), 2 * sizeof(int) * (size_t)c->kcap);
     const size_t lds_d = std::max(tab_bytes(c->kcap, c->n, 1), 2 * sizeof(int) * (size_t)c->kcap);
     const size_t lds_b = (size_t)c->kcap * 4 * sizeof(u64);
     hipError_t e1 = hipFuncSetAttribute((const void *)k_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
@@ -3613,9 +3640,9 @@ extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t 
     sa.t = (int)t;
     sa.dbg = c->dbg;
 #ifdef RC_TRACE_RESOLVE
-    const size_t lds = std::max(tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64), 2 * sizeof(int) * (size_t)c->kcap) + 4096;
+    const size_t lds = std::max(tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, c->maxb), 2 * sizeof(int) * (size_t)c->kcap) + 4096;
 #else
-    const size_t lds = std::max(tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64), 2 * sizeof(int) * (size_t)c->kcap);
+    const size_t lds = std::max(tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, c->maxb), 2 * sizeof(int) * (size_t)c->kcap);
 #endif
     // Resolver block size.  With 256 threads (one wave per SIMD, 112 VGPRs) a k_resolve block fits on a CU beside two
     // k_bulk_sym blocks, so the resolver of sweep t really overlaps the row reduction of sweep t+1 (config 5:
