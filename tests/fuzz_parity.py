@@ -1,0 +1,67 @@
+"""Randomised differential check of the sweep against the oracle: random sizes, cluster counts, overlaps, capacities, batch
+capacities, storage widths, stored / derived logD, maxK and repulsion, from random labels (births, deaths, relabelings).
+usage: python3 tests/fuzz_parity.py [cases] [first_seed]   (test_gpu_fuzz.py runs a short batch in the suite)"""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import redclust_amd as rc
+import oracle_lib as O
+def run(cases, first):
+    saved = {k: os.environ.get(k) for k in ("RC_RES_MAXB", "RC_RES_ONE_STREAM")}
+    bad = 0
+    for seed in range(first, first + cases):
+        g = np.random.default_rng(seed)
+        n = int(g.integers(40, 1500)); K = int(g.integers(2, 25)); dim = int(g.integers(max(2, K), K + 6))
+        sigma = float(g.uniform(0.15, 0.9))
+        data = rc.generatemixture(n, K, seed=seed, sigma=sigma, dim=dim)
+        sh = g.permutation(n)
+        D = np.ascontiguousarray(data["distancematrix"][np.ix_(sh, sh)]); truth = data["clusts"][sh]
+        P = dict(rc.likelihood_hyperparams(D, truth), repulsion=bool(g.random() < 0.8), maxK=int(g.choice([0, 0, K + 3, 2 * K])))
+        bits = int(g.choice([64, 64, 32])); stored = bool(g.random() < 0.4) or bits == 32
+        os.environ["RC_RES_MAXB"] = str(int(g.choice([512, 512, 64, 16])))
+        os.environ["RC_RES_ONE_STREAM"] = str(int(g.integers(0, 2)))
+        kcap = int(g.choice([n, min(n, 4 * K + 64)]))
+        orc0 = O.Oracle(D, P)
+        ctx = rc.Context(D, logD=orc0.logD if stored else None, kcap=kcap, storage_bits=bits)
+        ctx.set_params(**P)
+        L = ctx.get_matrix(1); Dd = ctx.get_matrix(0)
+        eD, eL = ctx.debug_rowsums(1)[2:4] if False else (None, None)
+        init = g.integers(1, int(g.integers(1, min(n, 3 * K) + 1)) + 1, n).astype(np.int64)
+        if P["maxK"]: init = (init - 1) % P["maxK"] + 1
+        ctx.set_state(init)
+        eD, eL = ctx.debug_rowsums(int(init[0]))[2:4]
+        orc = O.Oracle(Dd, P, logD=L, eL=eL, eD=eD)
+        orc.set_state(init)
+        mode = "incremental" if g.random() < 0.3 else "full"
+        ctx.set_mode(mode)
+        ok = True
+        try:
+            for t in range(5):
+                r, p = float(g.uniform(0.3, 3.0)), float(g.uniform(0.05, 0.95))
+                ctx.gibbs_sweep(r, p, seed, t, blocking=bool(t & 1))
+                orc.sweep_stable(r, p, seed, t)
+                lab, sizes, Kc = ctx.get_state()
+                if not (np.array_equal(lab, orc.clusts) and np.array_equal(sizes, orc.sizes) and Kc == orc.K and ctx.sweep_stats()["n_changes"] == orc.last_changes):
+                    ok = False
+                    print(f"MISMATCH seed {seed} sweep {t}: n={n} K={K} sigma={sigma:.2f} bits={bits} stored={stored} kcap={kcap} maxK={P['maxK']} rep={P['repulsion']} mode={mode} env={os.environ['RC_RES_MAXB']},{os.environ['RC_RES_ONE_STREAM']} differing {int(np.sum(lab != orc.clusts))} stats {ctx.sweep_stats()} oracle changes {orc.last_changes}")
+                    break
+        except rc.RedClustHIPError as e:
+            if "RC_ERR_CAPACITY" not in str(e):
+                ok = False; print(f"ERROR seed {seed}: {e}")
+        bad += not ok
+        ctx.close()
+
+    for k, v in saved.items():
+        if v is None: os.environ.pop(k, None)
+        else: os.environ[k] = v
+    return bad
+
+
+if __name__ == "__main__":
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    bad = run(cases, first)
+    print(f"fuzz: {cases} cases from seed {first}, {bad} bad")
+    sys.exit(1 if bad else 0)
