@@ -162,7 +162,7 @@ static int32_t record_finish(rc_ctx *c, Pending &R, rc_chain_outputs *out)
             dst[i] = m;
         }
     }
-    const double ll = loglik_host(c, R.hi, R.ssize.data(), c->pinB[REC_SLOT]);                    // mcmc.jl:551
+    const double ll = loglik_host(c, R.hi, R.ssize.data(), c->pinB[REC_SLOT], R.slabel.data());                    // mcmc.jl:551
     const double lp = logprior_host(c, R.ssize.data(), R.slabel.data(), R.r, R.p);
     if (out->K) out->K[j] = R.K;
     if (out->r) out->r[j] = R.r;
@@ -347,7 +347,7 @@ static int32_t spec_record(rc_ctx *c, SpecSlot &after, int64_t j, double r, doub
             dst[i] = m;
         }
     }
-    const double ll = loglik_host(c, after.hi, after.ssize.data(), after.pin_B);                 // mcmc.jl:551
+    const double ll = loglik_host(c, after.hi, after.ssize.data(), after.pin_B, after.slabel.data());                 // mcmc.jl:551
     const double lp = logprior_host(c, after.ssize.data(), after.slabel.data(), r, p);
     if (out->K) out->K[j] = after.K;
     if (out->r) out->r[j] = r;
@@ -383,12 +383,12 @@ static int32_t spec_eval_split(rc_ctx *c, rc_ctx::LLCache &cache, SplitScratch &
         X.bucket.resize((size_t)c->ld); X.rows.resize((size_t)n);
     }
     // buckets in the internal point order: the snapshot's slot, except that the points moved to the new label go to f
-    int si = -1, nrows = 0;
+    int si = -1, nrows = 0, new_label = 0;
     std::fill(X.bucket.begin(), X.bucket.end(), (unsigned short)0);
     for (int q = 0; q < n; ++q) {
         const int u = c->h_pi[(size_t)q];
         int b = s.pin_lab[q];
-        if (R.cfinal[(size_t)q] != s.labels[(size_t)q]) { si = b; b = f; X.rows[(size_t)nrows++] = u; }
+        if (R.cfinal[(size_t)q] != s.labels[(size_t)q]) { si = b; b = f; X.rows[(size_t)nrows++] = u; new_label = (int)R.cfinal[(size_t)q]; }
         X.bucket[(size_t)u] = (unsigned short)b;
     }
     if (nrows == 0 || si < 0) return fail(c, RC_ERR_STATE, "split evaluation: the proposal moves no point");
@@ -423,7 +423,10 @@ static int32_t spec_eval_split(rc_ctx *c, rc_ctx::LLCache &cache, SplitScratch &
     }
     sz2[(size_t)f] = nrows;
     sz2[(size_t)si] -= nrows;
-    R.ll_fin = loglik_host_c(c, cache, h2, sz2.data(), B2.data());
+    std::vector<int> lab2(s.slabel.begin(), s.slabel.begin() + std::min<size_t>(s.slabel.size(), (size_t)h2));
+    lab2.resize((size_t)h2, 0);
+    lab2[(size_t)f] = new_label;
+    R.ll_fin = loglik_host_c(c, cache, h2, sz2.data(), B2.data(), lab2.data());
     return RC_OK;
 }
 

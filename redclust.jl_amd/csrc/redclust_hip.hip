@@ -3754,7 +3754,11 @@ extern "C" int32_t rc_get_state(rc_ctx *c, int64_t *clusts, int64_t *clustsizes,
 // two cluster sizes and its block sums, and most of them do not change from one recorded sample to the next, so the
 // terms are cached per slot pair and re-evaluated only when their (integer) inputs differ: the value — and the order
 // of the summation — is exactly that of evaluating every term afresh.
-static double loglik_host_c(const rc_ctx *c, rc_ctx::LLCache &cache, int hi, const int *ssize, const long long *B)
+// The terms are summed in ascending LABEL order (slabel: the label of every slot), the order of the reference's loops over
+// findall(clustsizes .> 0) (mcmc.jl:13-53) — not in slot order: slot numbers depend on the history of births and deaths (and
+// differ between the speculative and the synchronous chain loop after a rollback), labels do not, so the value is a function of
+// the partition alone, bit for bit.
+static double loglik_host_c(const rc_ctx *c, rc_ctx::LLCache &cache, int hi, const int *ssize, const long long *B, const int *slabel)
 {
     const rc_params &P = c->P;
     const long double d1 = P.delta1, d2 = P.delta2, al = P.alpha, be = P.beta, ze = P.zeta, ga = P.gamma;
@@ -3771,6 +3775,7 @@ static double loglik_host_c(const rc_ctx *c, rc_ctx::LLCache &cache, int hi, con
     std::vector<int> act;
     for (int k = 0; k < hi; ++k)
         if (ssize[k] > 0) act.push_back(k);
+    std::sort(act.begin(), act.end(), [&](int x, int y) { return slabel[x] < slabel[y]; });
     long double L1 = 0, L2 = 0;
     for (int k : act) {
         const long long *e = &B[((size_t)k * hi + k) * 4];
@@ -3813,7 +3818,7 @@ static double loglik_host_c(const rc_ctx *c, rc_ctx::LLCache &cache, int hi, con
     return (double)(L1 + L2);
 }
 
-static double loglik_host(rc_ctx *c, int hi, const int *ssize, const long long *B) { return loglik_host_c(c, c->llc, hi, ssize, B); }
+static double loglik_host(rc_ctx *c, int hi, const int *ssize, const long long *B, const int *slabel) { return loglik_host_c(c, c->llc, hi, ssize, B, slabel); }
 
 // enqueues the block sums of the current state on stream A and their copy into the pinned buffer `dst`
 // (hi·hi·4 int64); the caller synchronises (stream or event) before reading
@@ -3863,7 +3868,7 @@ extern "C" int32_t rc_loglik(rc_ctx *c, double *out)
     rc = loglik_enqueue(c, hi, c->pinB[0]);
     if (rc != RC_OK) return rc;
     HIPCHK(c, hipStreamSynchronize(c->sA));
-    *out = loglik_host(c, hi, ssize.data(), c->pinB[0]);
+    *out = loglik_host(c, hi, ssize.data(), c->pinB[0], slabel.data());
     // keep the block sums: a merge proposal's log-likelihood follows from them without touching the device
     c->B_cur.assign(c->pinB[0], c->pinB[0] + (size_t)hi * hi * 4);
     c->B_ssize = ssize; c->B_slabel = slabel;
@@ -4574,7 +4579,7 @@ static void proposal_core(const rc_ctx *c, rc_ctx::LLCache &cache, const Proposa
     }
     if (profile) g_smprof.lap(2);
     // likelihood ratio (mcmc.jl:462-464) from the exact block sums of the snapshot
-    out.ll_cur = loglik_host_c(c, cache, S0.hi, S0.ssize, S0.B);
+    out.ll_cur = loglik_host_c(c, cache, S0.hi, S0.ssize, S0.B, S0.slabel);
     if (profile) g_smprof.lap(3);
     if (ci == cj) { out.needs_device = true; return; }
     const int hi = S0.hi;
@@ -4592,7 +4597,7 @@ static void proposal_core(const rc_ctx *c, rc_ctx::LLCache &cache, const Proposa
         for (int w = 0; w < 4; ++w) Bm[((size_t)t * hi + sj) * 4 + w] += Bm[((size_t)t * hi + si) * 4 + w];
     szm[(size_t)sj] += szm[(size_t)si];
     szm[(size_t)si] = 0;
-    out.ll_fin = loglik_host_c(c, cache, hi, szm.data(), Bm.data());
+    out.ll_fin = loglik_host_c(c, cache, hi, szm.data(), Bm.data(), S0.slabel);   // the merged cluster keeps cj's slot and label
     if (profile) g_smprof.lap(5);
     finish_decision(out, seed, iter, mh_counter);
     if (!out.accept) out.cfinal.clear();

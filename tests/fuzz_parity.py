@@ -59,9 +59,55 @@ def run(cases, first):
     return bad
 
 
+def run_chains(cases, first):
+    """rc_run_chain with split-merge proposals: the speculative pipeline at a random depth / worker count against the synchronous
+    loop (RC_CHAIN_PIPELINE=0) on random small problems — every output array and the final state must be identical."""
+    keys = ("RC_CHAIN_PIPELINE", "RC_CHAIN_DEPTH", "RC_CHAIN_WORKERS")
+    saved = {k: os.environ.get(k) for k in keys}
+    bad = 0
+    for seed in range(first, first + cases):
+        g = np.random.default_rng(seed)
+        n = int(g.integers(30, 400)); K = int(g.integers(2, 12)); dim = int(g.integers(max(2, K), K + 4))
+        data = rc.generatemixture(n, K, seed=seed, sigma=float(g.uniform(0.3, 0.9)), dim=dim)
+        D, truth = data["distancematrix"], data["clusts"]
+        P = dict(rc.likelihood_hyperparams(D, truth), maxK=int(g.choice([0, 0, 2 * K])))
+        L = np.log(D + np.eye(n))
+        init = g.integers(1, int(g.integers(1, 2 * K + 1)) + 1, n).astype(np.int64)
+        if P["maxK"]: init = (init - 1) % P["maxK"] + 1
+        iters, burn, thin = int(g.integers(5, 60)), int(g.integers(0, 5)), int(g.integers(1, 4))
+        numGibbs, numMH = int(g.integers(0, 6)), int(g.integers(1, 4))
+        mode = str(g.choice(["as_written", "intended"])); stored = bool(g.random() < 0.5)
+        outs = []
+        for env in ({"RC_CHAIN_PIPELINE": "0"}, {"RC_CHAIN_DEPTH": str(int(g.integers(1, 30))), "RC_CHAIN_WORKERS": str(int(g.integers(1, 9)))}):
+            for k in keys: os.environ.pop(k, None)
+            os.environ.update(env)
+            ctx = rc.Context(D, logD=L if stored else None, kcap=n); ctx.set_params(**P); ctx.set_state(init); ctx.cocluster_reset()
+            ctx.attach_host_matrices(D, L)
+            ch = ctx.run_chain(iters, burn, thin, numGibbs, numMH, seed, 1.0, 0.5, 0.8, splitmerge=mode)
+            ch["final"] = ctx.get_state()[0]; ch["cocluster"] = ctx.cocluster(max(ch["num_samples"], 1))
+            outs.append(ch); ctx.close()
+        a, b = outs
+        same = all(np.array_equal(a[f], b[f]) for f in ("clusts", "K", "r", "p", "loglik", "logposterior", "r_acceptances", "splitmerge_acceptances",
+                                                         "splitmerge_splits", "r_all", "p_all", "final", "cocluster", "r_final", "p_final", "num_samples"))
+        if not same:
+            bad += 1
+            print("   differing fields:", [f for f in ("clusts", "K", "r", "p", "loglik", "logposterior", "r_acceptances", "splitmerge_acceptances", "splitmerge_splits",
+                                                       "r_all", "p_all", "final", "cocluster", "r_final", "p_final", "num_samples") if not np.array_equal(a[f], b[f])],
+                  "env", env, "max |dloglik|", float(np.max(np.abs(a["loglik"] - b["loglik"]))) if len(a["loglik"]) else None)
+            print(f"CHAIN MISMATCH seed {seed}: n={n} K={K} iters={iters} burn={burn} thin={thin} numGibbs={numGibbs} numMH={numMH} mode={mode} stored={stored} "
+                  f"acc {int(a['splitmerge_acceptances'].sum())}/{int(b['splitmerge_acceptances'].sum())} splits {int(a['splitmerge_splits'].sum())}")
+    for k, v in saved.items():
+        if v is None: os.environ.pop(k, None)
+        else: os.environ[k] = v
+    return bad
+
+
 if __name__ == "__main__":
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    bad = run(cases, first)
+    if len(sys.argv) > 3 and sys.argv[3] == "chains":
+        bad = run_chains(cases, first)
+    else:
+        bad = run(cases, first)
     print(f"fuzz: {cases} cases from seed {first}, {bad} bad")
     sys.exit(1 if bad else 0)

@@ -9,3 +9,8 @@ pytestmark = pytest.mark.gpu
 def test_randomised_sweeps_against_the_oracle():
     import fuzz_parity
     assert fuzz_parity.run(40, 5000) == 0
+
+
+def test_randomised_chains_speculative_against_synchronous():
+    import fuzz_parity
+    assert fuzz_parity.run_chains(8, 9000) == 0
