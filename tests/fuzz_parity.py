@@ -8,12 +8,12 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import redclust_amd as rc
 import oracle_lib as O
-def run(cases, first):
+def run(cases, first, nlo=40, nhi=1500, kmax=25):
     saved = {k: os.environ.get(k) for k in ("RC_RES_MAXB", "RC_RES_ONE_STREAM")}
     bad = 0
     for seed in range(first, first + cases):
         g = np.random.default_rng(seed)
-        n = int(g.integers(40, 1500)); K = int(g.integers(2, 25)); dim = int(g.integers(max(2, K), K + 6))
+        n = int(g.integers(nlo, nhi)); K = int(g.integers(2, kmax)); dim = int(g.integers(max(2, K), K + 6))
         sigma = float(g.uniform(0.15, 0.9))
         data = rc.generatemixture(n, K, seed=seed, sigma=sigma, dim=dim)
         sh = g.permutation(n)
@@ -22,13 +22,15 @@ def run(cases, first):
         bits = int(g.choice([64, 64, 32])); stored = bool(g.random() < 0.4) or bits == 32
         os.environ["RC_RES_MAXB"] = str(int(g.choice([512, 512, 64, 16])))
         os.environ["RC_RES_ONE_STREAM"] = str(int(g.integers(0, 2)))
-        kcap = int(g.choice([n, min(n, 4 * K + 64)]))
+        kcap = int(g.choice([min(n, 4096), min(n, 4 * K + 64)]))
         orc0 = O.Oracle(D, P)
         ctx = rc.Context(D, logD=orc0.logD if stored else None, kcap=kcap, storage_bits=bits)
         ctx.set_params(**P)
         L = ctx.get_matrix(1); Dd = ctx.get_matrix(0)
         eD, eL = ctx.debug_rowsums(1)[2:4] if False else (None, None)
         init = g.integers(1, int(g.integers(1, min(n, 3 * K) + 1)) + 1, n).astype(np.int64)
+        if g.random() < 0.5:      # a few percent of the labels re-drawn around the generating partition: the symmetric kernels' regime
+            init = truth.copy(); idx = g.choice(n, max(1, int(n * g.uniform(0.0, 0.05))), replace=False); init[idx] = g.integers(1, K + 1, len(idx))
         if P["maxK"]: init = (init - 1) % P["maxK"] + 1
         ctx.set_state(init)
         eD, eL = ctx.debug_rowsums(int(init[0]))[2:4]
@@ -107,6 +109,8 @@ if __name__ == "__main__":
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     if len(sys.argv) > 3 and sys.argv[3] == "chains":
         bad = run_chains(cases, first)
+    elif len(sys.argv) > 3 and sys.argv[3] == "large":     # beyond the kernel-choice threshold: symmetric kernels, re-layouts
+        bad = run(cases, first, 4100, 7000, 60)
     else:
         bad = run(cases, first)
     print(f"fuzz: {cases} cases from seed {first}, {bad} bad")

@@ -1,6 +1,8 @@
 """A short batch of the randomised differential check (tests/fuzz_parity.py: random sizes, overlaps, capacities, batch capacities,
 storage widths, stored / derived logD, maxK, repulsion, stream arrangement, modes; five sweeps from random labels against the
-oracle).  1350 further cases were run once by hand with no mismatch."""
+oracle; speculative against synchronous chain loop).  By hand, once: 1750 small and 90 large (4100 ≤ n < 7000: symmetric kernels,
+re-layouts) sweep cases and 1150 chain cases without a mismatch — after the chain comparison had found last-bit differences of
+loglik in 6 of 1000 chains (slot-order summation, fixed)."""
 import pytest
 
 pytestmark = pytest.mark.gpu
