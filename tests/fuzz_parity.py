@@ -104,14 +104,54 @@ def run_chains(cases, first):
     return bad
 
 
+def run_chains_oracle(cases, first):
+    """rc_run_chain (free-running r / p, split-merge proposals, both modes) against the oracle's loop on random small problems:
+    scalar draws, labels, K, split-merge decisions exactly; log-likelihood / log-posterior to 1e-9 relative."""
+    bad = 0
+    for seed in range(first, first + cases):
+        g = np.random.default_rng(seed)
+        n = int(g.integers(25, 160)); K = int(g.integers(2, 9)); dim = int(g.integers(max(2, K), K + 4))
+        data = rc.generatemixture(n, K, seed=seed, sigma=float(g.uniform(0.3, 0.9)), dim=dim)
+        D, truth = data["distancematrix"], data["clusts"]
+        P = dict(rc.likelihood_hyperparams(D, truth), maxK=int(g.choice([0, 0, 2 * K])))
+        orc = O.Oracle(D, P)
+        init = g.integers(1, int(g.integers(1, 2 * K + 1)) + 1, n).astype(np.int64)
+        if P["maxK"]: init = (init - 1) % P["maxK"] + 1
+        iters, burn, thin = int(g.integers(5, 40)), int(g.integers(0, 5)), int(g.integers(1, 4))
+        numGibbs, numMH = int(g.integers(0, 6)), int(g.integers(0, 4))
+        intended = bool(g.random() < 0.5); sd = float(g.uniform(0.3, 1.5))
+        ctx = rc.Context(D, logD=orc.logD, kcap=n); ctx.set_params(**P); ctx.set_state(init); ctx.cocluster_reset()
+        if numMH: ctx.attach_host_matrices(D, orc.logD)
+        ch = ctx.run_chain(iters, burn, thin, numGibbs, numMH, seed, 1.0, 0.5, sd, splitmerge="intended" if intended else "as_written")
+        ref = O.run_chain(orc, init, 1.0, 0.5, iters, burn, thin, numGibbs, numMH, seed, proposalsd_r=sd, stable=True, intended=intended)
+        ok = all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in ((ch["r_all"], ref["r_all"]), (ch["p_all"], ref["p_all"]), (ch["K"], ref["K"]),
+                                                                             (ch["r_acceptances"], ref["r_acc"])))
+        ok = ok and (len(ref["clusts"]) == 0 or np.array_equal(ch["clusts"], ref["clusts"]))
+        if numMH:
+            ok = ok and np.array_equal(ch["splitmerge_acceptances"], ref["sm_acc"]) and np.array_equal(ch["splitmerge_splits"], ref["sm_split"])
+        if len(ref["loglik"]):
+            ok = ok and np.allclose(ch["loglik"], ref["loglik"], rtol=1e-9, atol=0) and np.allclose(ch["logposterior"], ref["logposterior"], rtol=1e-8, atol=0)
+        lab = ctx.get_state()[0]
+        ok = ok and np.array_equal(lab, orc.clusts)
+        if not ok:
+            bad += 1
+            print(f"ORACLE CHAIN MISMATCH seed {seed}: n={n} K={K} iters={iters} burn={burn} thin={thin} numGibbs={numGibbs} numMH={numMH} intended={intended}")
+        ctx.close()
+    return bad
+
+
 if __name__ == "__main__":
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     if len(sys.argv) > 3 and sys.argv[3] == "chains":
         bad = run_chains(cases, first)
+    elif len(sys.argv) > 3 and sys.argv[3] == "oracle_chains":
+        bad = run_chains_oracle(cases, first)
     elif len(sys.argv) > 3 and sys.argv[3] == "large":     # beyond the kernel-choice threshold: symmetric kernels, re-layouts
         bad = run(cases, first, 4100, 7000, 60)
     else:
         bad = run(cases, first)
     print(f"fuzz: {cases} cases from seed {first}, {bad} bad")
     sys.exit(1 if bad else 0)
+
+

@@ -1,7 +1,7 @@
 """A short batch of the randomised differential check (tests/fuzz_parity.py: random sizes, overlaps, capacities, batch capacities,
 storage widths, stored / derived logD, maxK, repulsion, stream arrangement, modes; five sweeps from random labels against the
 oracle; speculative against synchronous chain loop).  By hand, once: 1750 small and 90 large (4100 ≤ n < 7000: symmetric kernels,
-re-layouts) sweep cases and 1150 chain cases without a mismatch — after the chain comparison had found last-bit differences of
+re-layouts) sweep cases, 1150 speculative-vs-synchronous chain cases and 2300 chain-vs-oracle-loop cases without a mismatch — after the chain comparison had found last-bit differences of
 loglik in 6 of 1000 chains (slot-order summation, fixed)."""
 import pytest
 
@@ -16,3 +16,8 @@ def test_randomised_sweeps_against_the_oracle():
 def test_randomised_chains_speculative_against_synchronous():
     import fuzz_parity
     assert fuzz_parity.run_chains(8, 9000) == 0
+
+
+def test_randomised_chains_against_the_oracle_loop():
+    import fuzz_parity
+    assert fuzz_parity.run_chains_oracle(12, 11000) == 0
