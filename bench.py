@@ -241,10 +241,10 @@ def main():
         cd = rc.Context(D, device=local_rank, kcap=max(128, 2 * K), storage_bits=BITS)
         cd.set_params(**P); cd.set_state(truth); cd.cocluster_reset()
         cd.attach_host_matrices(D)                        # the proposals' restricted scans read the host matrix (logD derived by the library)
-        cd.run_chain(40, 0, 10, 5, 1, 1, r, p, 1.0)
-        its = max(200, min(5 * args.steps, 1000))
+        cd.run_chain(100, 0, 10, 5, 1, 1, r, p, 1.0)               # warm-up (worker threads, pinned buffers, caches)
+        its = 1000
         t1 = time.perf_counter()
-        chd = cd.run_chain(its, 0, 10, 5, 1, 1, r, p, 1.0, first_iter=40)
+        chd = cd.run_chain(its, 0, 10, 5, 1, 1, r, p, 1.0, first_iter=100)
         t_def = time.perf_counter() - t1
         defaults = {"numMH": 1, "numGibbs": 5, "iterations": its, "iterations_per_s": its / t_def, "ms_per_iteration": t_def / its * 1e3,
                     "splitmerge_acceptances": int(chd["splitmerge_acceptances"].sum()), "splitmerge_splits": int(chd["splitmerge_splits"].sum()),
