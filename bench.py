@@ -279,6 +279,11 @@ def main():
                 if traffic is None and os.path.exists(f) and BITS == 64 and (name.endswith(f"{tag}.json") or not derived):
                     traffic = json.load(open(f))["k_bulk_hbm_bytes_per_launch"]
                     traffic_source = f"profiles/{rnd}/{name} (rocprofv3 --pmc, collected offline with the same command)"
+        ceiling = None
+        try:   # the fraction is also reported against a streaming-read ceiling measured on this box, now
+            ceiling = rc.measure_read_ceiling(local_rank, 2048, 5)
+        except Exception:   # noqa: BLE001
+            pass
         out = {
             "metric": "Gibbs sweeps/sec (n×n distM)", "value": value, "unit": "sweeps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -302,6 +307,8 @@ def main():
             # symmetric matrix — so the physical figures (bytes it must read ÷ time) are given beside them, and
             # `traffic` is the HBM bytes per launch measured with the PMC counters.
             "roofline": {"kernel": kernel_name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "measured_streaming_read_GBps": ceiling, "frac_of_measured_streaming_read": (achieved / ceiling) if achieved and ceiling else None,
+                         "frac_on_bytes_read_of_measured_streaming_read": (achieved_read / ceiling) if achieved_read and ceiling else None,
                          "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic, "traffic_source": traffic_source,
                          "pricing": "achieved / frac: SURVEY.md §8(d) algorithmic bytes per sweep (n²·sizeof when logD is derived on the fly, "
                                     "2·n²·sizeof when stored) ÷ mean launch duration; *_on_bytes_read: the bytes this kernel has to read "

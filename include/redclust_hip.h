@@ -277,6 +277,11 @@ int32_t rc_run_chains(int32_t n_chains, const int32_t *device_ids, const rc_chai
                       rc_chain_outputs *outs /* n_chains */, double *posterior_coclustering, int64_t *total_samples,
                       double *allreduce_ms);
 
+/* Measured streaming-read ceiling of a device in GB/s (SURVEY.md §8d asks for the roofline fraction against it as well as
+ * against the nominal 8 TB/s): `mib` MiB — use far more than the 256 MiB Infinity Cache — read once per launch with the access
+ * pattern of the row reductions, best of `reps` launches.  No context needed. */
+int32_t rc_measure_read_ceiling(int32_t device, int64_t mib, int32_t reps, double *gbps_out);
+
 /* One sample_r + sample_p pair exactly as rc_run_chain draws them (tests; host only, no GPU needed).  sizes: the K
  * non-empty cluster sizes in ascending label order. */
 int32_t rc_scalar_updates(uint64_t seed, uint64_t iter, double r, double p, const int64_t *sizes, int64_t K, int64_t n,

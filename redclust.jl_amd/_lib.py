@@ -131,6 +131,7 @@ SIGNATURES = {
                                              C.POINTER(C.c_double)]),
     "rc_run_chains": (C.c_int32, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(RcChainsInput), C.POINTER(RcChainOptions),
                                   C.POINTER(RcChainOutputs), C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "rc_measure_read_ceiling": (C.c_int32, [C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_double)]),
     "rc_scalar_updates": (C.c_int32, [C.c_uint64, C.c_uint64, C.c_double, C.c_double, _ip, C.c_int64, C.c_int64, C.c_double,
                                       C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), C.POINTER(C.c_uint8)]),
@@ -496,6 +497,16 @@ def run_chains(device_ids, params: dict, init_clusts, numiters, burnin, thin, nu
             res[k] = res[k].astype(bool)
     del keep
     return ress, post, int(tot.value), float(ms.value)
+
+
+def measure_read_ceiling(device: int = 0, mib: int = 2048, reps: int = 5) -> float:
+    """rc_measure_read_ceiling: the device's streaming-read rate in GB/s as measured now (buffer >> Infinity Cache)."""
+    L = lib()
+    out = C.c_double(0)
+    rc = L.rc_measure_read_ceiling(int(device), int(mib), int(reps), C.byref(out))
+    if rc != RC_OK:
+        raise _error(rc, L.rc_last_error(None).decode())
+    return float(out.value)
 
 
 def loss_matrix(samples, loss: int, device: int = 0, want_matrix: bool = True):

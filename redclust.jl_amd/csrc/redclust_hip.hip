@@ -4782,6 +4782,50 @@ extern "C" int32_t rc_debug_prof(rc_ctx *c, int32_t gen, long long *out /* 8192 
 }
 #endif
 
+// Streaming-read ceiling of the device as this box delivers it ("also report against a measured
+// device-to-device streaming-read ceiling"): a buffer far larger than the 256 MiB Infinity Cache read once per launch with
+// 16-byte-per-lane non-temporal loads — the access pattern of the row reductions — timed with HIP events; the best of
+// `reps` launches.  Independent of any context.
+__global__ __launch_bounds__(256) void k_read_ceiling(const ll2 *__restrict__ p, size_t n16, long long *out)
+{
+    long long acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        const ll2 v = __builtin_nontemporal_load(p + i);
+        acc += v.x + v.y;
+    }
+    if (acc == 0x7fffffffffffffffll) out[0] = acc;
+}
+
+extern "C" int32_t rc_measure_read_ceiling(int32_t device, int64_t mib, int32_t reps, double *gbps_out)
+{
+    if (!gbps_out || mib < 64 || mib > 65536 || reps < 1) return fail(nullptr, RC_ERR_ARG, "rc_measure_read_ceiling: need 64 <= mib <= 65536, reps >= 1 and an output");
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, RC_ERR_HIP, "rc_measure_read_ceiling: device %d: %s", device, hipGetErrorString(hipGetLastError()));
+    const size_t bytes = (size_t)mib << 20;
+    void *buf = nullptr;
+    long long *out = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&]() { if (buf) (void)hipFree(buf); if (out) (void)hipFree(out); if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); };
+    if (hipMalloc(&buf, bytes) != hipSuccess || hipMalloc((void **)&out, 64) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess ||
+        hipMemset(buf, 1, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        const hipError_t e = hipGetLastError();
+        cleanup();
+        return fail(nullptr, RC_ERR_HIP, "rc_measure_read_ceiling: %s", hipGetErrorString(e));
+    }
+    double best = 0;
+    for (int it = 0; it < reps + 1; ++it) {   // the first launch is a warm-up
+        (void)hipEventRecord(e0, 0);
+        k_read_ceiling<<<8192, 256>>>((const ll2 *)buf, bytes / 16, out);
+        (void)hipEventRecord(e1, 0);
+        if (hipEventSynchronize(e1) != hipSuccess) { const hipError_t e = hipGetLastError(); cleanup(); return fail(nullptr, RC_ERR_HIP, "rc_measure_read_ceiling: %s", hipGetErrorString(e)); }
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (it > 0 && ms > 0) best = std::max(best, (double)bytes / (ms * 1e-3) / 1e9);
+    }
+    cleanup();
+    *gbps_out = best;
+    return RC_OK;
+}
+
 #include "pointestimate.inc.hip"
 #include "chain.inc.hip"
 #include "chains.inc.hip"
