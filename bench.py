@@ -61,8 +61,11 @@ def cpu_baseline(D, P, labels, r, p, max_seconds=20.0):
     t0 = time.perf_counter()
     orc.sweep_literal_range(r, p, 1, 0, 0, 0, n)
     dt_sp = time.perf_counter() - t0
+    import shutil
     return {"value": sweeps_per_s, "unit": "sweeps/s", "cores": 1, "kind": "port",
             "single_pass_variant_sweeps_per_s": 1.0 / dt_sp,
+            # time the Julia package itself if the box has it — it does not (probed, nothing installed)
+            "julia_on_this_box": shutil.which("julia") is not None,
             "sample": f"first {want} of {n} points of one sweep (faithful-cost literal C restatement of "
                       f"mcmc.jl:158-256, single thread, {dt:.1f} s), scaled to a full sweep; host has {os.cpu_count()} cores"}
 
