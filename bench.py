@@ -230,7 +230,18 @@ def main():
             cm.gibbs_sweep(r, p, 7, sw, blocking=False); sw += 1
         cm.synchronize()
         t_async = time.perf_counter() - t1
-        moving = {"sigma": sig, "sweeps_per_s": msteps / t_async, "ms_per_sweep": t_async / msteps * 1e3,
+        # SURVEY.md §8(d)'s other movement workload: labels uniform on 1..K from a fixed seed on the headline data — the first sweeps
+        # relabel nearly every point (a one-off transient: thousands of changes resolved in batches)
+        uni = np.random.default_rng(13).integers(1, K + 1, size=n).astype(np.int64)
+        cu = rc.Context(D, device=local_rank, kcap=max(512, 8 * K), storage_bits=BITS)
+        cu.set_params(**P); cu.set_state(uni); cu.synchronize()
+        uniform_init = []
+        for q in range(3):
+            t1 = time.perf_counter(); cu.gibbs_sweep(r, p, 7, q, blocking=True); t_q = time.perf_counter() - t1
+            st = cu.sweep_stats()
+            uniform_init.append({"sweep": q, "ms": t_q * 1e3, "label_changes": st["n_changes"], "resolve_rounds": st["n_rounds"], "K": st["K"]})
+        cu.close()
+        moving = {"sigma": sig, "uniform_init_first_sweeps": uniform_init, "sweeps_per_s": msteps / t_async, "ms_per_sweep": t_async / msteps * 1e3,
                   "sweeps_per_s_blocking": msteps / t_block, "label_changes_per_sweep": ch / msteps,
                   "resolve_rounds_per_sweep": rounds / msteps, "K": cm.sweep_stats()["K"], "steps": msteps,
                   "note": "overlapping clusters, equilibrium after 60 burn-in sweeps from the generating labels"}

@@ -1792,6 +1792,45 @@ __device__ __forceinline__ void best_merge(double &bv, int &bp, int &bs, double 
 //   skipped.
 #define RC_NEWKEY 0x7ffffffe   // order key of the new-cluster candidate: after every label (utils.jl:5 first-index rule)
 
+// Net effect on slot k, as seen from point u, of the batch entries < limit that touch the slot (its group in T.pairs,
+// ascending): the exact integer corrections ±Dq[x_q][u], ±Lq[x_q][u] of its two row sums, its size, its label after a
+// relabelling.  The matrix entries are fetched four entries at a time — the loads of a group are independent of each other,
+// but one load per loop turn costs a memory round trip per entry, and the changers of a batch can crowd into one cluster
+// (first sweep from random labels: groups of 100+ entries, 115 µs of skew at the barrier while one thread per point walked them).
+__device__ __forceinline__ bool batch_corr(const View &V, const Tab &T, int k, int u, int limit, long long &sd, long long &sl, int &sz, int &lab)
+{
+    bool touched = false;
+    const size_t ld = (size_t)V.ld;
+    int e = k ? T.seg[k - 1] : 0;
+    const int e1 = T.seg[k];
+    while (e < e1) {
+        int qq[4], sgn[4], cnt = 0;
+        for (; cnt < 4 && e < e1; ++e) {
+            const int q = T.pairs[e];
+            if (q >= limit) { e = e1; break; }
+            const int qa = T.ba[q], qb = T.bb[q];
+            if (qa != qb) { qq[cnt] = T.bu[q]; sgn[cnt] = (qb == k) - (qa == k); ++cnt; }
+            else lab = T.blab[q];   // the singleton took a new label
+        }
+        long long xd[4], xl[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (t < cnt) {
+                const size_t ee = (size_t)qq[t] * ld + u;
+                xd[t] = (V.bits == 64) ? ((const long long *)V.Dq)[ee] : (long long)((const int *)V.Dq)[ee];
+                xl[t] = (V.derived && !V.Lq) ? 0 : ((V.bits == 64) ? ((const long long *)V.Lq)[ee] : (long long)((const int *)V.Lq)[ee]);
+            }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (t < cnt) {
+                if (V.derived && !V.Lq) xl[t] = rc_load_L(V, qq[t], u, xd[t]);
+                sd += sgn[t] * xd[t]; sl += sgn[t] * xl[t]; sz += sgn[t];
+                touched = true;
+            }
+    }
+    return touched;
+}
+
 __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long long *SD, const long long *SL,
                            int chunk, int lo, int hi, int mode, int nb, u64 *cword, unsigned *rec, unsigned stamp)
 {
@@ -1829,24 +1868,7 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
             const int isown = (k == own);
             int sz = T.size[k], lab = T.label[k];
             long long sd = SD[(size_t)k * ld + u], sl = SL[(size_t)k * ld + u];
-            bool touched = false;
-            if (mode == 1) {
-                for (int e = k ? T.seg[k - 1] : 0, e1 = T.seg[k]; e < e1; ++e) {
-                    const int q = T.pairs[e];
-                    if (q >= j) break;
-                    const int qa = T.ba[q], qb = T.bb[q];
-                    if (qa != qb) {
-                        const size_t e = (size_t)T.bu[q] * ld + u;
-                        const long long xd = (V.bits == 64) ? ((const long long *)V.Dq)[e] : (long long)((const int *)V.Dq)[e];
-                        const long long xl = rc_load_L(V, T.bu[q], u, xd);
-                        const int sg = (qb == k) - (qa == k);
-                        sd += sg * xd; sl += sg * xl; sz += sg;
-                        touched = true;
-                    } else {
-                        lab = T.blab[q];   // the singleton took a new label
-                    }
-                }
-            }
+            const bool touched = (mode == 1) && batch_corr(V, T, k, u, j, sd, sl, sz, lab);
             const int s = sz - isown;
             if (s == 0) continue;  // empty once i is removed (its own singleton cluster, mcmc.jl:193-196) or emptied by the batch
             sd -= (isown ? dg : 0);                                              // i itself excluded (clusts[i] = -1)
@@ -2117,36 +2139,24 @@ __device__ int commit_batch(const View &V, const SweepArgs &sa, Tab &T, int nc, 
     const int pt = threadIdx.x & (RC_PTS - 1), st = threadIdx.x >> 5, NS = blockDim.x >> 5;
     long long *SDo = V.SD[own_gen], *SLo = V.SL[own_gen];
     long long *SDn = next_gen >= 0 ? V.SD[next_gen] : nullptr, *SLn = next_gen >= 0 ? V.SL[next_gen] : nullptr;
+    const int hi_slots = T.misc[7];   // slots in use, births of this batch included
     for (int c = blockIdx.x; c < nchunks; c += G) {
         const int io = c * RC_PTS + pt;
         if (io >= V.n) continue;
         const int i = V.pi[io];
-        // Own generation: plain read-modify-write (this block reads these rows again next round, through its L1), so
-        // every (slot row, point) is touched by exactly one thread — stream (slot mod NS).  Next generation: atomics,
-        // because the row reduction of the following sweep is adding to it concurrently.
-        for (int q = 0; q < nc; ++q) {
-            const int a = T.ba[q], b = T.bb[q];
-            if (a == b) continue;
-            const bool da = (a % NS) == st, db = (b % NS) == st;
-            if (!da && !db) continue;
-            const size_t e = (size_t)T.bu[q] * V.ld + i;
-            const long long xd = (V.bits == 64) ? ((const long long *)V.Dq)[e] : (long long)((const int *)V.Dq)[e];
-            const long long xl = rc_load_L(V, T.bu[q], i, xd);
-            const size_t ia = (size_t)a * V.ld + i, ib = (size_t)b * V.ld + i;
-            if (da) {
-                SDo[ia] -= xd; SLo[ia] -= xl;
-                if (SDn) {
-                    __hip_atomic_fetch_add((u64 *)(SDn + ia), (u64)(-xd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_fetch_add((u64 *)(SLn + ia), (u64)(-xl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            if (db) {
-                SDo[ib] += xd; SLo[ib] += xl;
-                if (SDn) {
-                    __hip_atomic_fetch_add((u64 *)(SDn + ib), (u64)xd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_fetch_add((u64 *)(SLn + ib), (u64)xl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
+        // Slot by slot (the groups of T.pairs): the net correction of the first nc entries, then ONE read-modify-write of the
+        // generation being read (plain: every (slot row, point) belongs to one thread — stream slot mod NS — and this block
+        // reads these rows again next round through its L1) and one atomic pair on the next generation, which the row reduction
+        // of the following sweep is adding to concurrently.  (Entry by entry this was a chain of dependent round trips per
+        // entry: 118 µs per round when a hundred changers joined one cluster.)
+        for (int k = st; k < hi_slots; k += NS) {
+            if ((k ? T.seg[k - 1] : 0) == T.seg[k]) continue;
+            long long dD = 0, dL = 0;
+            int sz_ = 0, lab_ = 0;
+            if (!batch_corr(V, T, k, i, nc, dD, dL, sz_, lab_)) continue;
+            const size_t ik = (size_t)k * V.ld + i;
+            if (dD) { SDo[ik] += dD; if (SDn) __hip_atomic_fetch_add((u64 *)(SDn + ik), (u64)dD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            if (dL) { SLo[ik] += dL; if (SLn) __hip_atomic_fetch_add((u64 *)(SLn + ik), (u64)dL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         }
     }
     for (int q = threadIdx.x; q < nc; q += blockDim.x)
@@ -2198,7 +2208,11 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
     __builtin_amdgcn_s_setprio(3);
 #endif
     RC_PF(long long ps[16]; for (int q_ = 0; q_ < 16; ++q_) ps[q_] = 0; ps[0] = __builtin_amdgcn_s_memrealtime(); long long pt_ = ps[0];)
+#ifdef RC_PROF_ROUND   // absolute stamps of ONE round (number RC_PROF_ROUND) instead of per-phase sums over all rounds
+#define RC_PHASE(k) RC_PF({ if (round == RC_PROF_ROUND) ps[k] = __builtin_amdgcn_s_memrealtime(); })
+#else
 #define RC_PHASE(k) RC_PF({ const long long now_ = __builtin_amdgcn_s_memrealtime(); ps[k] += now_ - pt_; pt_ = now_; })
+#endif
     Tab T = tab_carve(smem, V.kcap, V.n, blockDim.x >> 6, V.maxb);
     if (V.n > RC_USED_LDS_MAX_N) T.used = V.used_scratch + (size_t)blockIdx.x * (size_t)((V.n + 31) / 32);
     const int t = sa.t, own_gen = sa.own_gen, next_gen = sa.next_gen, kg = t & 1;
