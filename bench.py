@@ -233,7 +233,7 @@ def main():
         # SURVEY.md §8(d)'s other movement workload: labels uniform on 1..K from a fixed seed on the headline data — the first sweeps
         # relabel nearly every point (a one-off transient: thousands of changes resolved in batches)
         uni = np.random.default_rng(13).integers(1, K + 1, size=n).astype(np.int64)
-        cu = rc.Context(D, device=local_rank, kcap=max(512, 8 * K), storage_bits=BITS)
+        cu = rc.Context(D, device=local_rank, kcap=max(256, 4 * K), storage_bits=BITS)
         cu.set_params(**P); cu.set_state(uni); cu.synchronize()
         uniform_init = []
         for q in range(3):

@@ -2426,7 +2426,10 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         // Validation costs (points covered) x (changers before them); everything behind the first violation is wasted.
         // When less than a third of a batch could be committed the next one is cut to three times what was (at least 64),
         // otherwise it doubles.
-        cap = (3 * nc < nb) ? min(V.maxb, max(64, 3 * nc)) : min(V.maxb, 2 * cap);
+#ifndef RC_CAP_FLOOR
+#define RC_CAP_FLOOR 128
+#endif
+        cap = (nc < nb) ? min(V.maxb, max(RC_CAP_FLOOR, nc + nc / 2)) : min(V.maxb, 2 * cap);
         after = limit - 1;
         ++round;
         if (round > V.n) break;  // cannot happen: every round finalises at least the first changer

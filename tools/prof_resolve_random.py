@@ -6,7 +6,7 @@ import redclust_amd as rc
 n, K = 8192, 50
 d = rc.generatemixture(n, K, seed=1); D, truth = d["distancematrix"], d["clusts"]
 P = rc.likelihood_hyperparams(D, truth)
-ctx = rc.Context(D, kcap=256); ctx.set_params(**P)
+ctx = rc.Context(D, kcap=int(os.environ.get("KCAP", 256))); ctx.set_params(**P)
 lab = np.random.default_rng(5).integers(1, K + 1, n)
 ctx.set_state(lab); ctx.set_mode("incremental"); ctx.synchronize()
 L = rc.lib()
