@@ -128,6 +128,9 @@ struct HostSummary {
 struct View {
     int n, ld, kcap;
     unsigned *used_scratch;    // [G][(n+31)/32] label bitsets of the resolver blocks when n > RC_USED_LDS_MAX_N
+    double *wc;                // [kcap][ldw] score cache of the resolver (eval_chunk), valid inside one launch; null = off
+    int ldw;                   // n rounded up to whole chunks
+    int wc_always;             // 1: fill the cache in every sweep; 0: only when the previous sweep changed labels
     int maxb;                  // batch capacity of the resolver (<= RC_MAXB; smaller when that makes its LDS fit beside the row reduction)
     const void *Dq, *Lq;       // [n][ld] fixed point: int64 (bits = 64) or int32 (bits = 32); rows/columns in INTERNAL order
     int bits;
@@ -1501,7 +1504,7 @@ struct Tab {
     unsigned *used;  // [(n+31)/32] label occupancy bitset, bit (label-1); built when a round has changers (LDS, or V.used_scratch for large n)
     double *red_v;   // [NW][32] reduction scratch (NW = waves per block)
     int *red_pos, *red_slot;
-    int *misc;       // [0]=K [1]=smallest_empty [2]=scratch [3]=nb [4]=hi [5]=fail [6]=barrier ok [7]=slot_hi [8]=#births [9]=#effective
+    int *misc;       // [0]=K [1]=smallest_empty [2]=scratch [3]=nb [4]=hi [5]=fail [6]=barrier ok [7]=slot_hi [8]=#births [9]=#effective [13]=visited [14]=#clean slots (tab_partition) [15]=#dirty
     u64 *blk_key;    // block-local minimum (first violation)
     // batch of tentative changers of the current round (identical in every block), ascending in point index
     int *bx, *bu;             // [RC_MAXB] point (original index), its internal index
@@ -1515,6 +1518,8 @@ struct Tab {
     int *seg;                 // [kcap+1] before / during batch_sim: entries leaving the slot; afterwards seg[k] = end of slot k's group
     unsigned char *joined;    // [kcap] some entry of the batch moves a point INTO the slot
     unsigned char *candie;    // [kcap] the slot could become empty inside the batch (size − leavers < 1): its size is simulated
+    short *act2;              // [kcap] the active slots again, those whose cached scores are valid first (tab_partition)
+    unsigned char *dirty;     // [kcap] a committed change of this sweep touched the slot: its cached scores are void
     unsigned short *ccnt;     // [nchunks + 1] scratch: changers per chunk / exclusive offsets, saturating at 65535 (only offsets <= batch capacity matter)
 };
 #define RC_BF_DEATH 1   // the source cluster becomes empty
@@ -1537,7 +1542,7 @@ __host__ __device__ inline size_t tab_layout(int kcap, int n, int nw, size_t *of
     off[7] = o; o = RC_A16(o + sizeof(int) * nw * RC_PTS);      // red_slot
     off[8] = o; o = RC_A16(o + (n <= RC_USED_LDS_MAX_N ? sizeof(unsigned) * ((n + 31) / 32) : 0));  // used (beyond: per-block global scratch)
     off[9] = o; o = RC_A16(o + sizeof(int) * 16);               // misc
-    off[10] = o;                                                // (unused)
+    off[10] = o; o = RC_A16(o + sizeof(short) * kcap);         // act2
     off[11] = o; o = RC_A16(o + sizeof(short) * kcap);          // act
     off[12] = o; o = RC_A16(o + sizeof(int) * maxb);         // bx
     off[13] = o; o = RC_A16(o + sizeof(short) * maxb);       // ba
@@ -1546,7 +1551,7 @@ __host__ __device__ inline size_t tab_layout(int kcap, int n, int nw, size_t *of
     off[16] = o; o = RC_A16(o + sizeof(unsigned short) * ((n + RC_PTS - 1) / RC_PTS + 1));  // ccnt
     off[17] = o; o = RC_A16(o + sizeof(int) * maxb);         // bu
     off[18] = o; o = RC_A16(o + sizeof(int) * maxb);         // blab
-    off[19] = o;                                                // (unused)
+    off[19] = o; o = RC_A16(o + (size_t)kcap);                  // dirty
     off[20] = o; o = RC_A16(o + sizeof(short) * maxb);       // bK
     off[21] = o; o = RC_A16(o + (size_t)maxb);               // bflag
     off[22] = o; o = RC_A16(o + sizeof(short) * maxb);       // birth
@@ -1575,6 +1580,7 @@ __device__ Tab tab_carve(char *smem, int kcap, int n, int nw, int maxb = RC_MAXB
     T.bflag = (unsigned char *)(smem + off[21]); T.birth = (short *)(smem + off[22]);
     T.pairs = (short *)(smem + off[23]); T.candie = (unsigned char *)(smem + off[24]);
     T.joined = (unsigned char *)(smem + off[26]); T.pairs_tmp = (short *)(smem + off[27]);
+    T.act2 = (short *)(smem + off[10]); T.dirty = (unsigned char *)(smem + off[19]);
     return T;
 }
 
@@ -1832,8 +1838,16 @@ __device__ __forceinline__ bool batch_corr(const View &V, const Tab &T, int k, i
     return touched;
 }
 
+// Score cache (cmode; V.wc).  The score of (point i, cluster k ≠ i's own) — size term, likelihood, noise of (sweep, i, label) —
+// changes inside a sweep only when a committed change touches slot k (size, row sums or label) or, under validation, when a
+// batch entry before i does.  The first tentative pass of a sweep evaluates every point against every cluster and stores the
+// scores (cmode 1: W[k][i], i in sweep order, 8 B per pair); later passes (cmode 2) read them back for the slots that are
+// still clean — T.act2 lists those first (tab_partition) — and compute only the slots a change touched, the point's own
+// cluster (its score excludes the point itself), the clusters born in the batch and the new-cluster candidate.  The cached
+// value is the very double the computation would produce again, so decisions are unchanged; a pass costs ~330 VALU
+// instructions per computed candidate and one load per cached one (moving regime, K = 206: eight passes per sweep).
 __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long long *SD, const long long *SL,
-                           int chunk, int lo, int hi, int mode, int nb, u64 *cword, unsigned *rec, unsigned stamp)
+                           int chunk, int lo, int hi, int mode, int nb, u64 *cword, unsigned *rec, unsigned stamp, int cmode)
 {
     const int pt = threadIdx.x & (RC_PTS - 1), st = threadIdx.x >> 5, NS = blockDim.x >> 5;
     const int wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
@@ -1864,14 +1878,14 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
         const int single = (so == 1);
         const int Ki = ((mode == 1 && j > 0) ? (int)T.bK[j - 1] : K) - single;
         const long long dg = V.diagq[u];
-        for (int pos = st; pos < ((a.dbg & 1) ? 0 : K); pos += NS) {
-            const int k = T.act[pos];
+        double *const wrow = V.wc + i;   // column i of the score cache (used only when cmode != 0)
+        auto consider = [&](const int k) {
             const int isown = (k == own);
             int sz = T.size[k], lab = T.label[k];
             long long sd = SD[(size_t)k * ld + u], sl = SL[(size_t)k * ld + u];
             const bool touched = (mode == 1) && batch_corr(V, T, k, u, j, sd, sl, sz, lab);
             const int s = sz - isown;
-            if (s == 0) continue;  // empty once i is removed (its own singleton cluster, mcmc.jl:193-196) or emptied by the batch
+            if (s == 0) return;  // empty once i is removed (its own singleton cluster, mcmc.jl:193-196) or emptied by the batch
             sd -= (isown ? dg : 0);                                              // i itself excluded (clusts[i] = -1)
             const double SDr = (double)sd * V.scD, SLr = (double)sl * V.scL;      // logD diagonal is 0 (types.jl:155)
             const double base = touched ? tab_base(V, a, s) : (isown ? T.base_s[k] : T.base_o[k]);
@@ -1882,7 +1896,25 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
                 const double un = rc_uniform(a, (unsigned)i, (unsigned)lab);
                 v = v + (-log(-log(un)));
             }
+            if (cmode == 1 && !isown) wrow[(size_t)k * V.ldw] = v;
             if (bestslot == -2 || v > bestv || (v == bestv && lab < bestpos)) { bestv = v; bestpos = lab; bestslot = k; }
+        };
+        if (cmode != 2) {
+            for (int pos = st; pos < ((a.dbg & 1) ? 0 : K); pos += NS) consider(T.act[pos]);
+        } else {
+            const int Kc = T.misc[14];
+            for (int pos = st; pos < Kc; pos += NS) {          // clean slots: the stored score
+                const int k = T.act2[pos];
+                if (k == own) continue;
+                const double v = wrow[(size_t)k * V.ldw];
+                const int lab = T.label[k];
+                if (bestslot == -2 || v > bestv || (v == bestv && lab < bestpos)) { bestv = v; bestpos = lab; bestslot = k; }
+            }
+            for (int pos = Kc + st; pos < K; pos += NS) {      // slots a change touched
+                const int k = T.act2[pos];
+                if (k != own) consider(k);
+            }
+            if (st == ((K + 1) % NS)) consider(own);            // the point's own cluster, itself removed
         }
         // clusters created by the changers before i: singletons {x_q}, row sums = row x_q of the matrices
         if (mode == 1 && j > 0) {
@@ -1989,6 +2021,23 @@ __device__ bool grid_barrier(const View &V, Tab &T, unsigned *arrive, unsigned t
     return sh_ok != 0;
 }
 
+// T.act2 = the active slots with those whose cached scores are still valid first (T.misc[14] of them): not touched by a
+// committed change of this sweep nor — with_batch, for the validation pass — by an entry of the current batch.  The order
+// inside the two parts is arbitrary (ties between candidates are broken by label, not by position).  Ends synchronised.
+__device__ void tab_partition(const View &V, Tab &T, bool with_batch)
+{
+    if (threadIdx.x == 0) { T.misc[14] = 0; T.misc[15] = 0; }
+    __syncthreads();
+    const int K = T.misc[0];
+    for (int pos = threadIdx.x; pos < K; pos += blockDim.x) {
+        const int k = T.act[pos];
+        const bool d = T.dirty[k] || (with_batch && (k ? T.seg[k - 1] : 0) != T.seg[k]);
+        if (d) T.act2[K - 1 - atomicAdd(&T.misc[15], 1)] = (short)k;
+        else T.act2[atomicAdd(&T.misc[14], 1)] = (short)k;
+    }
+    __syncthreads();
+}
+
 // smallest label > lab (1-based) whose bit is clear in the occupancy bitset; n + 1 if none
 __device__ int next_empty_label(const Tab &T, int n, int lab)
 {
@@ -2034,7 +2083,7 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
             // order, nothing to simulate (the sizes of such clusters are not tracked here at all)
             vsafe = vt >= 0 && !T.candie[va] && !T.candie[vt];
         }
-        const u64 fastmask = __ballot(vfast), safemask = __ballot(vsafe);
+        const u64 safemask = __ballot(vsafe);
         // results of entry q0 + lane (stored after the chunk).  The plain moves are not visited at all: their target is the
         // tentative one, and cluster count / smallest empty label are those left by the last visited entry before them
         int ob = vt, olab = 0, oflag = 0, oK = K;
@@ -2042,15 +2091,23 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
         int done = cnt;
         u64 todo = ~safemask & (cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull));
         while (todo) {
-            const int e = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
+            // the lone singletons that keep their label under the current smallest empty label change nothing: all of them up to
+            // the next entry that needs the serial path are settled at once (a hundred of them per round in the moving regime)
+            const u64 ser = todo & ~__ballot(vfast && se >= vla);
+            const u64 nop = todo & (ser ? ((ser & (0ull - ser)) - 1ull) : ~0ull);
+            if (nop) {
+                if ((nop >> lane) & 1) { ob = va; oflag = RC_BF_NOOP; oK = K; }
+                nvisited += __popcll(nop);
+                todo &= ~nop;
+            }
+            if (!ser) break;
+            const int e = __ffsll((long long)ser) - 1;
+            todo &= ~(1ull << e);
             ++nvisited;
             const int q = q0 + e;
             const int a = __builtin_amdgcn_readlane(va, e), la = __builtin_amdgcn_readlane(vla, e);
             int b, flag = 0, lab = 0, old = 0;
-            if (((fastmask >> e) & 1) && se >= la) {
-                b = a; flag = RC_BF_NOOP;                               // keeps its label: registers only
-            } else {
+            {
                 const int tgt = __builtin_amdgcn_readlane(vt, e);
                 const int sza = T.size[a], szt = T.size[tgt >= 0 ? tgt : a];
                 b = tgt;
@@ -2134,7 +2191,7 @@ __device__ int commit_batch(const View &V, const SweepArgs &sa, Tab &T, int nc, 
         if (flag & RC_BF_BIRTH) { T.label[b] = T.blab[q]; atomicMax(&T.misc[7], b + 1); }
         if (flag & RC_BF_RENAME) T.label[a] = T.blab[q];
         if (flag & (RC_BF_DEATH | RC_BF_BIRTH | RC_BF_RENAME)) T.misc[11] = 1;
-        if (!(flag & RC_BF_NOOP)) atomicAdd(&T.misc[12], 1);
+        if (!(flag & RC_BF_NOOP)) { atomicAdd(&T.misc[12], 1); T.dirty[a] = 1; T.dirty[b] = 1; }
     }
     __syncthreads();
     if (T.misc[11]) tab_structural(V, T);
@@ -2225,7 +2282,12 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
     u64 *const cword_gen = V.cword[kg];
     unsigned *arrive = V.arrive[kg];
     tab_load(V, T);
+    for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) T.dirty[k] = 0;
     tab_bases(V, sa, T);
+    // Score cache: filling it costs 8 B per (point, cluster) in the first pass — 1.5 % of a stationary sweep at n = 8192, which
+    // has no later pass to profit from it — so it is filled only when the previous sweep changed labels (read before the first
+    // grid barrier; block 0 rewrites the count in its epilogue).  Same results either way.
+    const bool use_wc = V.wc != nullptr && sa.dbg == 0 && (V.wc_always || V.sc->n_changes > 0);
     RC_PF(ps[1] = __builtin_amdgcn_s_memrealtime();)
     const int nchunks = (V.n + RC_PTS - 1) / RC_PTS;
     int after = -1, round = 0, changes = 0, nbar = 0;
@@ -2242,8 +2304,9 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         RC_CHAOS_AT(0);
         RC_PF(pt_ = __builtin_amdgcn_s_memrealtime(); ps[13] += 1;)
         // 1. tentative decisions of the points after `after`
+        if (use_wc && round > 0) tab_partition(V, T, false);
         for (int c = blockIdx.x; c < nchunks; c += G)
-            if (c * RC_PTS + RC_PTS - 1 > after) eval_chunk(V, sa, T, SD, SL, c, after, V.n, 0, 0, cword, rec, stamp);
+            if (c * RC_PTS + RC_PTS - 1 > after) eval_chunk(V, sa, T, SD, SL, c, after, V.n, 0, 0, cword, rec, stamp, use_wc ? (round > 0 ? 2 : 1) : 0);
         if (sa.dbg & 2) break;
         RC_PHASE(6)
         RC_PF(if (round == 0) ps[2] = __builtin_amdgcn_s_memrealtime();)
@@ -2407,8 +2470,9 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         }
         // 3. validation of the points after the first changer, each under the changers that precede it
         const int first = T.bx[T.misc[10]];   // the points up to the first effective changer saw no change at all
+        if (use_wc) tab_partition(V, T, true);
         for (int c = blockIdx.x; c < nchunks; c += G)
-            if (c * RC_PTS + RC_PTS - 1 > first && c * RC_PTS <= hi) eval_chunk(V, sa, T, SD, SL, c, first, hi, 1, nb, cword, rec, stamp);
+            if (c * RC_PTS + RC_PTS - 1 > first && c * RC_PTS <= hi) eval_chunk(V, sa, T, SD, SL, c, first, hi, 1, nb, cword, rec, stamp, use_wc ? 2 : 0);
         __syncthreads();
         RC_PHASE(10)
         const u64 mine = *T.blk_key;
@@ -2682,6 +2746,8 @@ struct rc_ctx {
     // software pipeline
     bool registered = false;          // counted in g_res_contexts
     unsigned *used_scratch = nullptr; // label bitsets of the resolver blocks for large n
+    double *wc = nullptr;             // score cache of the resolver, kcap x ldw (RC_SCORE_CACHE=0: none, =1: filled in every sweep)
+    int wc_always = 0;
     int maxb = RC_MAXB;               // resolver batch capacity (finish_create: the largest that lets the resolver's LDS fit beside the row reduction)
     bool res_one_stream = false;      // small problems: every resolver on stream B (in order, no event between consecutive resolvers), every row reduction on B2
     hipStream_t s_res_last = nullptr; // stream of the last resolver launch (sB / sB2 by sweep parity, sA in incremental mode)
@@ -2759,6 +2825,7 @@ static View make_view(const rc_ctx *c)
 {
     View V{};
     V.n = c->n; V.ld = c->ld; V.kcap = c->kcap; V.maxb = c->maxb; V.used_scratch = c->used_scratch;
+    V.wc = c->wc; V.wc_always = c->wc_always; V.ldw = (c->n + RC_PTS - 1) / RC_PTS * RC_PTS;
     V.Dq = c->Dq; V.Lq = c->Lq; V.bits = c->bits; V.diagq = c->diagq; V.pi = c->pi;
     V.derived = c->derived ? 1 : 0; V.qsD = std::ldexp(1.0, -c->eD); V.qsL = std::ldexp(1.0, c->eL); V.ltab = c->ltab; V.qeD = c->eD;
     for (int g = 0; g < 3; ++g) { V.SD[g] = c->SD[g]; V.SL[g] = c->SL[g]; }
@@ -2801,7 +2868,7 @@ static void free_all(rc_ctx *c)
     void *ptrs[] = {c->ltab, c->Dq, c->Lq, c->Dq_src, c->Lq_src, c->diag_src, c->pi, c->ipi, c->diagq, c->SD[0], c->SD[1], c->SD[2], c->SL[0], c->SL[1], c->SL[2], c->slot_of,
                     c->slot_size, c->slot_label, c->slot_pos, c->slot_act, c->perm[0], c->perm[1], c->pslot[0],
                     c->pslot[1], c->lsnap[0], c->lsnap[1], c->work[0], c->work[1], c->cword[0], c->cword[1], c->rec, c->tent, c->A, c->keys[0], c->keys[1], c->arrive[0], c->arrive[1], c->sc, c->blocks,
-                    c->counts, c->cc_out, c->snap, c->d_moves, c->used_scratch};
+                    c->counts, c->cc_out, c->snap, c->d_moves, c->used_scratch, c->wc};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->hsum) (void)hipHostFree(c->hsum);
@@ -2972,6 +3039,8 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     HIPCHK2(hipMalloc(&c->slot_label, (size_t)c->kcap * sizeof(int)));
     HIPCHK2(hipMalloc(&c->slot_pos, (size_t)c->kcap * sizeof(short)));
     HIPCHK2(hipMalloc(&c->slot_act, (size_t)c->kcap * sizeof(short)));
+    c->wc_always = getenv("RC_SCORE_CACHE") && atoi(getenv("RC_SCORE_CACHE")) == 1;
+    if (!getenv("RC_SCORE_CACHE") || atoi(getenv("RC_SCORE_CACHE")) != 0) HIPCHK2(hipMalloc((void **)&c->wc, (size_t)c->kcap * (size_t)((c->n + RC_PTS - 1) / RC_PTS * RC_PTS) * sizeof(double)));
     if (c->n > RC_USED_LDS_MAX_N) HIPCHK2(hipMalloc((void **)&c->used_scratch, (size_t)std::max(c->num_cus, 256) * (size_t)((c->n + 31) / 32) * sizeof(unsigned)));
     HIPCHK2(hipMalloc(&c->A, (size_t)(n + 1) * sizeof(double)));
     HIPCHK2(hipMalloc(&c->sc, sizeof(DevScalars)));

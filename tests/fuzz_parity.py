@@ -9,10 +9,14 @@ import numpy as np
 import redclust_amd as rc
 import oracle_lib as O
 def run(cases, first, nlo=40, nhi=1500, kmax=25):
-    saved = {k: os.environ.get(k) for k in ("RC_RES_MAXB", "RC_RES_ONE_STREAM")}
+    saved = {k: os.environ.get(k) for k in ("RC_RES_MAXB", "RC_RES_ONE_STREAM", "RC_SCORE_CACHE")}
     bad = 0
     for seed in range(first, first + cases):
         g = np.random.default_rng(seed)
+        # resolver score cache: off / filled in every sweep / adaptive (the default) — a separate generator keeps the cases of a seed what they were
+        sc = ["0", "1", "1", None][int(np.random.default_rng(seed + 77777).integers(0, 4))]
+        if sc is None: os.environ.pop("RC_SCORE_CACHE", None)
+        else: os.environ["RC_SCORE_CACHE"] = sc
         n = int(g.integers(nlo, nhi)); K = int(g.integers(2, kmax)); dim = int(g.integers(max(2, K), K + 6))
         sigma = float(g.uniform(0.15, 0.9))
         data = rc.generatemixture(n, K, seed=seed, sigma=sigma, dim=dim)
@@ -47,7 +51,7 @@ def run(cases, first, nlo=40, nhi=1500, kmax=25):
                 lab, sizes, Kc = ctx.get_state()
                 if not (np.array_equal(lab, orc.clusts) and np.array_equal(sizes, orc.sizes) and Kc == orc.K and ctx.sweep_stats()["n_changes"] == orc.last_changes):
                     ok = False
-                    print(f"MISMATCH seed {seed} sweep {t}: n={n} K={K} sigma={sigma:.2f} bits={bits} stored={stored} kcap={kcap} maxK={P['maxK']} rep={P['repulsion']} mode={mode} env={os.environ['RC_RES_MAXB']},{os.environ['RC_RES_ONE_STREAM']} differing {int(np.sum(lab != orc.clusts))} stats {ctx.sweep_stats()} oracle changes {orc.last_changes}")
+                    print(f"MISMATCH seed {seed} sweep {t}: n={n} K={K} sigma={sigma:.2f} bits={bits} stored={stored} kcap={kcap} maxK={P['maxK']} rep={P['repulsion']} mode={mode} env={os.environ['RC_RES_MAXB']},{os.environ['RC_RES_ONE_STREAM']},cache={os.environ.get('RC_SCORE_CACHE')} differing {int(np.sum(lab != orc.clusts))} stats {ctx.sweep_stats()} oracle changes {orc.last_changes}")
                     break
         except rc.RedClustHIPError as e:
             if "RC_ERR_CAPACITY" not in str(e):
