@@ -1498,7 +1498,7 @@ __global__ __launch_bounds__(256) void k_bulk_sym32(View V, int wgen, int zgen, 
 struct Tab {
     int *size;       // [kcap]
     int *label;      // [kcap] 0 = free
-    short *act;      // [kcap] the active slots, in ascending label order (candidate order, mcmc.jl:195)
+    short *act;      // [kcap] the active slots (the candidates of mcmc.jl:195; in slot order — the order does not matter, see tab_structural)
     double *base_o;  // [kcap] A[s] + log p + log(s-1+r), s = size          (candidate cluster of another point)
     double *base_s;  // [kcap] same with s = size-1                          (the point's own cluster, itself removed)
     unsigned *used;  // [(n+31)/32] label occupancy bitset, bit (label-1); built when a round has changers (LDS, or V.used_scratch for large n)
@@ -1634,18 +1634,25 @@ __device__ void tab_structural(const View &V, Tab &T)
             if (lab <= V.n) atomicMin(&T.misc[2], lab);
         }
     }
-    for (int k = threadIdx.x; k < hi; k += blockDim.x) {
-        const int lab = T.label[k];
-        if (lab > 0) {
-            int c = 0;
-            for (int q = 0; q < hi; ++q) {
-                const int lq = T.label[q];
-                c += (lq > 0 && lq < lab);
-            }
-            T.act[c] = (short)k;
+    // the active slots, in slot order (ballot compaction; wave totals through the reduction scratch).  The candidate order is
+    // immaterial: the noise is keyed by label and ties between scores go to the smaller label (eval_chunk), so the label-rank
+    // order of round 1 — a pass over all slots per slot — is not needed.
+    {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, NW = blockDim.x >> 6;
+        int base = 0;
+        for (int k0 = 0; k0 < hi; k0 += blockDim.x) {
+            const int k = k0 + threadIdx.x;
+            const bool f = k < hi && T.label[k] > 0;
+            const u64 m = __ballot(f);
+            if (lane == 0) T.red_pos[wave] = __popcll(m);
+            __syncthreads();
+            int before = 0, tot = 0;
+            for (int w = 0; w < NW; ++w) { const int x = T.red_pos[w]; tot += x; before += (w < wave) ? x : 0; }
+            if (f) T.act[base + before + __popcll(m & ((1ull << lane) - 1ull))] = (short)k;
+            base += tot;
+            __syncthreads();
         }
     }
-    __syncthreads();
     if (threadIdx.x == 0) T.misc[1] = T.misc[2];
     __syncthreads();
 }
@@ -1998,7 +2005,14 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
 // (s_waitcnt lgkmcnt(0); global accesses of one CU are kept in order by its L1, which is all a workgroup barrier needs),
 // so every wave first waits for its own outstanding global stores: without this another block could see the arrival
 // before a record and assemble a different batch (observed as diverging chains once the timing changed).
-__device__ bool grid_barrier(const View &V, Tab &T, unsigned *arrive, unsigned target, u64 my_key, u64 *key_word)
+// Two-level arrival (RC_BAR_* words of the arrival buffer, each on its own 128-byte line): the blocks arrive on one of eight
+// group counters (blockIdx & 7), the last of a group on the top counter, the last of all publishes the barrier number in
+// the eight release words the groups poll.  Returning atomics on one address serialise at ≈25 ns each — 256 blocks on one
+// counter were 5-6 µs per barrier, twice per round; now 32 + 8 in sequence, and the polls no longer queue behind the arrivals.
+#define RC_BAR_GROUPS 8
+#define RC_BAR_STRIDE 32                      // unsigneds per line
+#define RC_BAR_WORDS ((2 * RC_BAR_GROUPS + 1) * RC_BAR_STRIDE)
+__device__ bool grid_barrier(const View &V, Tab &T, unsigned *arrive, int G, unsigned nbar, u64 my_key, u64 *key_word)
 {
     int &sh_ok = T.misc[6];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2008,10 +2022,16 @@ __device__ bool grid_barrier(const View &V, Tab &T, unsigned *arrive, unsigned t
             const u64 old = atomicMin(key_word, my_key);
             asm volatile("" ::"v"((unsigned)old));  // data dependence: the min has been performed before we arrive
         }
-        __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int ngroups = min(G, RC_BAR_GROUPS), g = (int)blockIdx.x & (RC_BAR_GROUPS - 1);
+        const unsigned members = (unsigned)((G - g + RC_BAR_GROUPS - 1) / RC_BAR_GROUPS);   // blocks b < G with b % 8 == g
+        unsigned *grp = arrive + g * RC_BAR_STRIDE, *top = arrive + RC_BAR_GROUPS * RC_BAR_STRIDE;
+        unsigned *rel = arrive + (RC_BAR_GROUPS + 1) * RC_BAR_STRIDE;
+        if (__hip_atomic_fetch_add(grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == members * nbar)
+            if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == (unsigned)ngroups * nbar)
+                for (int q = 0; q < ngroups; ++q) __hip_atomic_store(rel + q * RC_BAR_STRIDE, nbar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
         int ok = 1;
-        while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        while (__hip_atomic_load(rel + g * RC_BAR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nbar) {
             __builtin_amdgcn_s_sleep(2);
             if (++spins > RC_SPIN_LIMIT) { ok = 0; atomicOr(&V.sc->err, RC_DERR_BARRIER); break; }
         }
@@ -2090,6 +2110,9 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
         const int cnt = min(64, nb0 - q0);
         int done = cnt;
         u64 todo = ~safemask & (cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull));
+#ifdef RC_PROF_SIM
+        const long long psim0_ = __builtin_amdgcn_s_memrealtime();
+#endif
         while (todo) {
             // the lone singletons that keep their label under the current smallest empty label change nothing: all of them up to
             // the next entry that needs the serial path are settled at once (a hundred of them per round in the moving regime)
@@ -2155,6 +2178,9 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
             if (lane == e) { ob = b; olab = lab; oflag = flag; }
             if (lane >= e) oK = K;
         }
+#ifdef RC_PROF_SIM
+        nvisited = nvisited % 1000 + 1000 * (nvisited / 1000 + (int)(__builtin_amdgcn_s_memrealtime() - psim0_));
+#endif
         {   // the plain moves before the cut count as effective entries
             const u64 kept = safemask & (done == 64 ? ~0ull : ((1ull << done) - 1ull));
             if (kept) {
@@ -2194,8 +2220,14 @@ __device__ int commit_batch(const View &V, const SweepArgs &sa, Tab &T, int nc, 
         if (!(flag & RC_BF_NOOP)) { atomicAdd(&T.misc[12], 1); T.dirty[a] = 1; T.dirty[b] = 1; }
     }
     __syncthreads();
+#ifdef RC_PROF_COMMIT
+    const long long pc0_ = __builtin_amdgcn_s_memrealtime();
+#endif
     if (T.misc[11]) tab_structural(V, T);
     tab_bases(V, sa, T);
+#ifdef RC_PROF_COMMIT
+    if (threadIdx.x == 0) T.misc[13] = (int)(__builtin_amdgcn_s_memrealtime() - pc0_);
+#endif
     const int nchunks = (V.n + RC_PTS - 1) / RC_PTS;
     const int pt = threadIdx.x & (RC_PTS - 1), st = threadIdx.x >> 5, NS = blockDim.x >> 5;
     long long *SDo = V.SD[own_gen], *SLo = V.SL[own_gen];
@@ -2309,8 +2341,10 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
             if (c * RC_PTS + RC_PTS - 1 > after) eval_chunk(V, sa, T, SD, SL, c, after, V.n, 0, 0, cword, rec, stamp, use_wc ? (round > 0 ? 2 : 1) : 0);
         if (sa.dbg & 2) break;
         RC_PHASE(6)
+#ifndef RC_PROF_COMMIT
         RC_PF(if (round == 0) ps[2] = __builtin_amdgcn_s_memrealtime();)
-        ok = grid_barrier(V, T, arrive, (unsigned)G * (unsigned)(++nbar), RC_KEY_NONE, keys + round);
+#endif
+        ok = grid_barrier(V, T, arrive, G, (unsigned)(++nbar), RC_KEY_NONE, keys + round);
         RC_PF(if (round == 0) ps[3] = __builtin_amdgcn_s_memrealtime();)
         RC_PHASE(7)
         if (!ok) break;
@@ -2476,7 +2510,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         __syncthreads();
         RC_PHASE(10)
         const u64 mine = *T.blk_key;
-        ok = grid_barrier(V, T, arrive, (unsigned)G * (unsigned)(++nbar), mine, keys + round);
+        ok = grid_barrier(V, T, arrive, G, (unsigned)(++nbar), mine, keys + round);
         RC_PHASE(11)
         if (!ok) break;
         RC_CHAOS_AT(3);
@@ -2491,6 +2525,9 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         }
         changes += commit_batch(V, sa, T, nc, G, own_gen, next_gen);
         RC_PHASE(12)
+#ifdef RC_PROF_COMMIT
+        RC_PF(ps[2] += T.misc[13];)
+#endif
         // Validation costs (points covered) x (changers before them); everything behind the first violation is wasted.
         // When less than a third of a batch could be committed the next one is cut to three times what was (at least 64),
         // otherwise it doubles.
@@ -2530,7 +2567,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         // re-arm the other key / chunk-word / barrier generation for the next sweep (its last user, sweep t-1, is done)
         for (int q = threadIdx.x; q < V.n + 2; q += blockDim.x) V.keys[kg ^ 1][q] = RC_KEY_NONE;
         for (int q = threadIdx.x; q < 2 * (nchunks + 1); q += blockDim.x) V.cword[kg ^ 1][q] = 0;
-        if (threadIdx.x == 0) *V.arrive[kg ^ 1] = 0u;
+        for (int q = threadIdx.x; q < RC_BAR_WORDS; q += blockDim.x) V.arrive[kg ^ 1][q] = 0u;
         tab_store(V, T);
         const int last = V.sc->last_change_sweep;
         __syncthreads();
@@ -3030,7 +3067,7 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
         HIPCHK2(hipMalloc(&c->cword[g], 2 * ((size_t)(n + RC_PTS - 1) / RC_PTS + 1) * sizeof(u64)));
         HIPCHK2(hipMemsetAsync(c->cword[g], 0, 2 * ((size_t)(n + RC_PTS - 1) / RC_PTS + 1) * sizeof(u64), s));
         HIPCHK2(hipMalloc(&c->keys[g], (size_t)(n + 2) * sizeof(u64)));
-        HIPCHK2(hipMalloc(&c->arrive[g], 64));
+        HIPCHK2(hipMalloc(&c->arrive[g], RC_BAR_WORDS * sizeof(unsigned)));
     }
     HIPCHK2(hipMalloc(&c->slot_of, (size_t)n * sizeof(int)));
     HIPCHK2(hipMalloc(&c->rec, 2 * (size_t)n * sizeof(unsigned)));
@@ -3506,7 +3543,7 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
     for (int g = 0; g < 2; ++g) {
         HIPCHK(c, hipMemsetAsync(c->keys[g], 0xFF, (size_t)(n + 2) * sizeof(u64), c->sA));
         HIPCHK(c, hipMemsetAsync(c->cword[g], 0, 2 * ((size_t)(n + RC_PTS - 1) / RC_PTS + 1) * sizeof(u64), c->sA));
-        HIPCHK(c, hipMemsetAsync(c->arrive[g], 0, 64, c->sA));
+        HIPCHK(c, hipMemsetAsync(c->arrive[g], 0, RC_BAR_WORDS * sizeof(unsigned), c->sA));
         HIPCHK(c, hipMemsetAsync(c->work[g], 0, 64, c->sA));
     }
     View V = make_view(c);
@@ -4787,7 +4824,7 @@ extern "C" int32_t rc_set_mode(rc_ctx *c, int32_t mode)
         for (int g = 0; g < 2; ++g) {
             HIPCHK(c, hipMemsetAsync(c->keys[g], 0xFF, (size_t)(c->n + 2) * sizeof(u64), c->sA));
             HIPCHK(c, hipMemsetAsync(c->cword[g], 0, 2 * ((size_t)(c->n + RC_PTS - 1) / RC_PTS + 1) * sizeof(u64), c->sA));
-            HIPCHK(c, hipMemsetAsync(c->arrive[g], 0, 64, c->sA));
+            HIPCHK(c, hipMemsetAsync(c->arrive[g], 0, RC_BAR_WORDS * sizeof(unsigned), c->sA));
             HIPCHK(c, hipMemsetAsync(c->work[g], 0, 64, c->sA));
         }
         const int minus1 = -1;

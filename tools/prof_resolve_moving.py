@@ -17,7 +17,7 @@ ctx.synchronize()
 L = rc.lib()
 out = np.zeros((8192, 16), np.int64)
 L.rc_debug_prof.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
-names = {6: "eval tentative", 7: "barrier 1", 8: "assemble batch", 14: "batch_sim", 9: "restore + lists", 10: "eval validate", 11: "barrier 2", 12: "commit"}
+names = {2: "(commit: tables)", 6: "eval tentative", 7: "barrier 1", 8: "assemble batch", 14: "batch_sim", 9: "restore + lists", 10: "eval validate", 11: "barrier 2", 12: "commit"}
 acc = {k: [] for k in names}; mx = {k: [] for k in names}; mn = {k: [] for k in names}; rounds = []; tot = []
 for t in range(60, 80):
     ctx.gibbs_sweep(1.0, 0.5, 7, t, blocking=True)
@@ -29,3 +29,6 @@ for t in range(60, 80):
     rounds.append(st["n_rounds"]); tot.append(np.median(o[:, 4] - o[:, 0]))
 print(f"sigma {sig} kcap {kcap} K {st['K']} rounds/sweep {np.mean(rounds):.1f}  loop total {np.mean(tot):.1f} us (median block)")
 for k, nm in names.items(): print(f"   {nm:16s} {np.mean(acc[k]):8.1f} us per sweep   {np.mean(acc[k]) / np.mean(rounds):7.1f} per round   (blocks: min {np.mean(mn[k]):7.1f} max {np.mean(mx[k]):7.1f} per sweep)")
+if os.environ.get("RC_PROF_SIM"):   # -DRC_PROF_SIM build: column 15 = 1000 * (ticks inside the serial loop of batch_sim) + entries visited, summed over the rounds
+    v = out[8192 - 256, 15]
+    print(f"   last sweep, block 0: serial loop of batch_sim {v // 1000 / 100.0:.1f} us, entries visited {v % 1000}")
