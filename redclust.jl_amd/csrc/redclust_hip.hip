@@ -468,6 +468,41 @@ __device__ void build_perm_block(const View &V, int gen, int *lds_off /*kcap*/, 
     __syncthreads();
 }
 
+// The same order built by all G blocks of the resolver at the end of a sweep: the slot offsets are the running sums of the
+// slot sizes (every block holds them), block b places the points of its share of the slots — one pass over slot_of per block,
+// positions inside a slot from LDS counters (the order inside a cluster is arbitrary here as above).  lds: 2·kcap + 1 ints.
+__device__ void build_perm_grid(const View &V, int gen, const int *size /*LDS, [hi]*/, int hi, int G, int *lds)
+{
+    int *off = lds, *cur = lds + V.kcap + 1;
+    for (int k = threadIdx.x; k <= V.kcap; k += blockDim.x) { off[k] = (k < hi) ? size[k] : 0; if (k < V.kcap) cur[k] = 0; }
+    __syncthreads();
+    if (threadIdx.x < 64) {   // exclusive offsets (wave 0: per-lane runs + shuffle scan)
+        const int per = (hi + 63) / 64, c0 = (int)threadIdx.x * per, c1 = min(c0 + per, hi);
+        int sum = 0;
+        for (int k = c0; k < c1; ++k) sum += off[k];
+        int incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if ((int)threadIdx.x >= d) incl += up;
+        }
+        int o = incl - sum;
+        for (int k = c0; k < c1; ++k) { const int x = off[k]; off[k] = o; o += x; }
+    }
+    __syncthreads();
+    const int k0 = (int)((long long)hi * blockIdx.x / G), k1 = (int)((long long)hi * (blockIdx.x + 1) / G);
+    if (k0 == k1) return;
+    int *perm = V.perm[gen], *pslot = V.pslot[gen];
+    for (int i = threadIdx.x; i < V.n; i += blockDim.x) {
+        const int s = V.slot_of[i];
+        if (s >= k0 && s < k1) {
+            const int p = off[s] + atomicAdd(&cur[s], 1);
+            perm[p] = i;
+            pslot[p] = s;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // k_bulk — THE HBM-BOUND KERNEL.  Row-bucket reduction of D and logD into S (matsum(D,[i],clust_k) and
 // matsum(logD,[i],clust_k), src/mcmc.jl:210-213, for all i and k).  Algorithmic traffic 2·n²·8 bytes.
@@ -1688,6 +1723,23 @@ __device__ void tab_store(const View &V, const Tab &T)
 }
 
 // label snapshot of generation g and the run count of the labels in natural point order.  One block.
+// the two halves of snapshot_labels for the resolver's epilogue: the copy by all blocks, the run count by one
+__device__ void snapshot_copy_grid(const View &V, int g, int G)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V.n; i += G * blockDim.x) V.snap[g][i] = V.slot_of[i];
+}
+__device__ void snapshot_runs(const View &V, int *lds_cnt)
+{
+    if (threadIdx.x == 0) *lds_cnt = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int i = threadIdx.x; i < V.n; i += blockDim.x) mine += (i == 0) || (V.slot_of[i] != V.slot_of[i - 1]);
+    atomicAdd(lds_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) { V.sc->runs = *lds_cnt; V.hsum->runs = *lds_cnt; }
+    __syncthreads();
+}
+
 __device__ void snapshot_labels(const View &V, int g, int *lds_cnt)
 {
     if (threadIdx.x == 0) *lds_cnt = 0;
@@ -1700,7 +1752,7 @@ __device__ void snapshot_labels(const View &V, int g, int *lds_cnt)
     }
     atomicAdd(lds_cnt, mine);
     __syncthreads();
-    if (threadIdx.x == 0) V.sc->runs = *lds_cnt;
+    if (threadIdx.x == 0) { V.sc->runs = *lds_cnt; V.hsum->runs = *lds_cnt; }
     __syncthreads();
 }
 
@@ -1715,7 +1767,6 @@ __device__ void write_summary(const View &V, int n_changes, int n_rounds)
         V.hsum->n_changes = n_changes;
         V.hsum->n_rounds = n_rounds;
         V.hsum->slot_hi = V.sc->slot_hi;
-        V.hsum->runs = V.sc->runs;
         V.hsum->err = __hip_atomic_load(&V.sc->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         V.hsum->seq += 1;
     }
@@ -2320,6 +2371,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
     // has no later pass to profit from it — so it is filled only when the previous sweep changed labels (read before the first
     // grid barrier; block 0 rewrites the count in its epilogue).  Same results either way.
     const bool use_wc = V.wc != nullptr && sa.dbg == 0 && (V.wc_always || V.sc->n_changes > 0);
+    const int last = V.sc->last_change_sweep;   // (read before the first barrier as well: the epilogue rewrites it)
     RC_PF(ps[1] = __builtin_amdgcn_s_memrealtime();)
     const int nchunks = (V.n + RC_PTS - 1) / RC_PTS;
     int after = -1, round = 0, changes = 0, nbar = 0;
@@ -2560,34 +2612,41 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         const ll2 z = {0, 0};
         for (size_t q = me; q < total2; q += nthreads) { zd[q] = z; zl[q] = z; }
     }
-    if (blockIdx.x == 0) {
-        __syncthreads();
+    // Epilogue.  Every block holds the same tables and has written the same slot_of, so the jobs are spread: re-arming, the
+    // slot tables with the host summary, and the run count go to three different blocks, the label snapshot and the point
+    // order of the next layout are built by all blocks together (one block doing everything in turn was a 42 µs tail on
+    // every sweep that changed labels, 32 of them the order build).
+    const int b_rearm = G > 1 ? 1 : 0, b_snap = G > 2 ? 2 : 0;
+    __syncthreads();
+    if ((int)blockIdx.x == b_rearm) {
         // the row reduction of this sweep is complete (stream order): re-arm its work counter for sweep t+2
         if (threadIdx.x == 0) *V.work[kg] = 0;
         // re-arm the other key / chunk-word / barrier generation for the next sweep (its last user, sweep t-1, is done)
         for (int q = threadIdx.x; q < V.n + 2; q += blockDim.x) V.keys[kg ^ 1][q] = RC_KEY_NONE;
         for (int q = threadIdx.x; q < 2 * (nchunks + 1); q += blockDim.x) V.cword[kg ^ 1][q] = 0;
         for (int q = threadIdx.x; q < RC_BAR_WORDS; q += blockDim.x) V.arrive[kg ^ 1][q] = 0u;
+    }
+    if (blockIdx.x == 0) {
         tab_store(V, T);
-        const int last = V.sc->last_change_sweep;
-        __syncthreads();
         if (threadIdx.x == 0) {
             V.sc->n_changes = changes;
             V.sc->n_rounds = round + 1;
             if (changes) V.sc->last_change_sweep = t;
         }
         __syncthreads();
-        // label snapshot of this generation: k_bulk_sym of sweep t+2 reads it (as the perm generation below)
-        if (changes || last == t - 1 || t < 2) snapshot_labels(V, kg, &T.misc[2]);
-        write_summary(V, changes, round + 1);
-        // perm generation t%2 must describe the labels after this sweep (k_bulk of sweep t+2 reads it)
-        if (changes && ok) {
-            int *off = (int *)smem, *cur = off + V.kcap;  // LDS tables are no longer needed
-            __syncthreads();
-            build_perm_block(V, kg, off, cur);
-        } else if (last == t - 1 && t >= 1) {
-            for (int p = threadIdx.x; p < V.n; p += blockDim.x) { V.perm[kg][p] = V.perm[kg ^ 1][p]; V.pslot[kg][p] = V.pslot[kg ^ 1][p]; }
-        }
+    }
+    // label snapshot of this generation: k_bulk_sym of sweep t+2 reads it (as the perm generation below)
+    if (changes || last == t - 1 || t < 2) {
+        snapshot_copy_grid(V, kg, G);
+        if ((int)blockIdx.x == b_snap) snapshot_runs(V, &T.misc[2]);
+    }
+    if (blockIdx.x == 0) write_summary(V, changes, round + 1);
+    // perm generation t%2 must describe the labels after this sweep (k_bulk of sweep t+2 reads it): all blocks
+    if (changes && ok) {
+        __syncthreads();
+        build_perm_grid(V, kg, T.size, T.misc[7], G, (int *)smem);   // (the tables in LDS are no longer needed: T.size lies behind the 16·kcap bytes this uses)
+    } else if (last == t - 1 && t >= 1) {
+        for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < V.n; p += G * blockDim.x) { V.perm[kg][p] = V.perm[kg ^ 1][p]; V.pslot[kg][p] = V.pslot[kg ^ 1][p]; }
     }
     RC_PF(if (threadIdx.x == 0 && blockIdx.x < 256) { long long *o = (long long *)((char *)V.work[kg] + 64) + (size_t)(8192 - 256 + blockIdx.x) * 16;
                                                        ps[5] = __builtin_amdgcn_s_memrealtime(); for (int q = 0; q < 16; ++q) o[q] = ps[q]; })

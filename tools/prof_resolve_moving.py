@@ -27,7 +27,9 @@ for t in range(60, 80):
     o = o[o[:, 0] > 0]
     for k in names: acc[k].append(np.median(o[:, k])); mx[k].append(o[:, k].max()); mn[k].append(o[:, k].min())
     rounds.append(st["n_rounds"]); tot.append(np.median(o[:, 4] - o[:, 0]))
+    pro = np.median(o[:, 1] - o[:, 0]); epi0 = [round(float(o[b, 5] - o[b, 4]), 1) for b in range(4)]; epi = np.median(o[4:, 5] - o[4:, 4]); span = o[:, 5].max() - o[:, 0].min()
 print(f"sigma {sig} kcap {kcap} K {st['K']} rounds/sweep {np.mean(rounds):.1f}  loop total {np.mean(tot):.1f} us (median block)")
+print(f"   last sweep: prologue (tables) {pro:.1f} us, epilogue of blocks 0-3 {epi0} us (other blocks {epi:.1f}), first start to last end {span:.1f} us")
 for k, nm in names.items(): print(f"   {nm:16s} {np.mean(acc[k]):8.1f} us per sweep   {np.mean(acc[k]) / np.mean(rounds):7.1f} per round   (blocks: min {np.mean(mn[k]):7.1f} max {np.mean(mx[k]):7.1f} per sweep)")
 if os.environ.get("RC_PROF_SIM"):   # -DRC_PROF_SIM build: column 15 = 1000 * (ticks inside the serial loop of batch_sim) + entries visited, summed over the rounds
     v = out[8192 - 256, 15]
