@@ -1899,11 +1899,13 @@ __device__ __forceinline__ bool batch_corr(const View &V, const Tab &T, int k, i
 // Score cache (cmode; V.wc).  The score of (point i, cluster k ≠ i's own) — size term, likelihood, noise of (sweep, i, label) —
 // changes inside a sweep only when a committed change touches slot k (size, row sums or label) or, under validation, when a
 // batch entry before i does.  The first tentative pass of a sweep evaluates every point against every cluster and stores the
-// scores (cmode 1: W[k][i], i in sweep order, 8 B per pair); later passes (cmode 2) read them back for the slots that are
-// still clean — T.act2 lists those first (tab_partition) — and compute only the slots a change touched, the point's own
-// cluster (its score excludes the point itself), the clusters born in the batch and the new-cluster candidate.  The cached
-// value is the very double the computation would produce again, so decisions are unchanged; a pass costs ~330 VALU
-// instructions per computed candidate and one load per cached one (moving regime, K = 206: eight passes per sweep).
+// scores (cmode 1: W[k][i], i in sweep order, 8 B per pair).  A later tentative pass (cmode 2, mode 0) reads them back for the
+// slots that are still clean — T.act2 lists those first (tab_partition) — computes the slots the last commit touched and stores
+// their new scores, so that after it the cache is current again for every open point and the dirty flags are cleared.  A
+// validation pass (cmode 2, mode 1) computes a slot of the batch only for the points that have one of its entries before them.
+// Always computed: the point's own cluster (its score excludes the point itself), the clusters born in the batch, the
+// new-cluster candidate.  The cached value is the very double the computation would produce again, so decisions are
+// unchanged; a computed candidate costs ~330 VALU instructions, a cached one a load (moving regime, K = 206: eight passes per sweep).
 __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long long *SD, const long long *SL,
                            int chunk, int lo, int hi, int mode, int nb, u64 *cword, unsigned *rec, unsigned stamp, int cmode)
 {
@@ -1954,7 +1956,7 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
                 const double un = rc_uniform(a, (unsigned)i, (unsigned)lab);
                 v = v + (-log(-log(un)));
             }
-            if (cmode == 1 && !isown) wrow[(size_t)k * V.ldw] = v;
+            if (cmode != 0 && mode == 0 && !isown) wrow[(size_t)k * V.ldw] = v;   // tentative passes keep the cache current
             if (bestslot == -2 || v > bestv || (v == bestv && lab < bestpos)) { bestv = v; bestpos = lab; bestslot = k; }
         };
         if (cmode != 2) {
@@ -1970,7 +1972,17 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
             }
             for (int pos = Kc + st; pos < K; pos += NS) {      // slots a change touched
                 const int k = T.act2[pos];
-                if (k != own) consider(k);
+                if (k == own) continue;
+                if (mode == 1 && !T.dirty[k]) {                // a slot of the batch: untouched for this point if no entry of its group precedes it
+                    const int e0 = k ? T.seg[k - 1] : 0;
+                    if (e0 == T.seg[k] || T.pairs[e0] >= j) {
+                        const double v = wrow[(size_t)k * V.ldw];
+                        const int lab = T.label[k];
+                        if (bestslot == -2 || v > bestv || (v == bestv && lab < bestpos)) { bestv = v; bestpos = lab; bestslot = k; }
+                        continue;
+                    }
+                }
+                consider(k);
             }
             if (st == ((K + 1) % NS)) consider(own);            // the point's own cluster, itself removed
         }
@@ -2143,16 +2155,34 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
     int K = T.misc[0], se = T.misc[1], fcur = 0, nbirth = 0, neff = 0, first_eff = -1;
     int nb = nb0, hi = (total > cap) ? T.misc[2] - 1 : V.n - 1, fail = 0, nvisited = 0;
     bool stop = false;
+    // Register-held running state (kcap < 2048: some label <= 2048 is always empty, so the smallest empty one lies in the
+    // first 64 words of the bitset): lane w holds word w of the label bitset and the free-slot mask of slots 64w..64w+63.
+    // The entries that need it are applied by ONE wave, one after the other: what counts is the number of dependent
+    // instructions per entry, and a label taken or freed is two instructions here against LDS round trips (a birth cost
+    // ~1.2 µs: up to four 64-slot steps to the first free slot, two read-modify-writes of the bitset and a word-by-word
+    // walk to the next empty label).
+    const bool regs = V.kcap < 2048;
+    unsigned U = 0xffffffffu;
+    u64 myfree = 0;
+    if (regs) {
+        if (lane < (V.n + 31) / 32) U = T.used[lane];
+        for (int w = 0; w * 64 < V.kcap; ++w) {
+            const int k = w * 64 + lane;
+            const u64 m = __ballot(k < V.kcap && T.label[k] == 0);
+            if (lane == w) myfree = m;
+        }
+    }
     for (int q0 = 0; q0 < nb0 && !stop; q0 += 64) {
-        int va = 0, vt = -1, vla = 0;
+        int va = 0, vt = -1, vla = 0, vcda = 0, vcdt = 0;
         bool vfast = false, vsafe = false;
         if (q0 + lane < nb0) {
             va = T.ba[q0 + lane]; vt = T.bb[q0 + lane]; vla = T.label[va];
+            vcda = T.candie[va]; vcdt = vt >= 0 ? (int)T.candie[vt] : 0;
             // a singleton nobody in the batch joins, drawing "new cluster": alone at its turn whatever happened before
             vfast = vt < 0 && T.size[va] == 1 && !T.joined[va];
             // a move between two clusters neither of which can become empty inside the batch: a plain move whatever the
             // order, nothing to simulate (the sizes of such clusters are not tracked here at all)
-            vsafe = vt >= 0 && !T.candie[va] && !T.candie[vt];
+            vsafe = vt >= 0 && !vcda && !vcdt;
         }
         const u64 safemask = __ballot(vsafe);
         // results of entry q0 + lane (stored after the chunk).  The plain moves are not visited at all: their target is the
@@ -2171,7 +2201,9 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
             const u64 nop = todo & (ser ? ((ser & (0ull - ser)) - 1ull) : ~0ull);
             if (nop) {
                 if ((nop >> lane) & 1) { ob = va; oflag = RC_BF_NOOP; oK = K; }
+#ifndef RC_PROF_SIM
                 nvisited += __popcll(nop);
+#endif
                 todo &= ~nop;
             }
             if (!ser) break;
@@ -2181,11 +2213,26 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
             const int q = q0 + e;
             const int a = __builtin_amdgcn_readlane(va, e), la = __builtin_amdgcn_readlane(vla, e);
             int b, flag = 0, lab = 0, old = 0;
+#ifdef RC_PROF_SIM
+            const long long pq0_ = __builtin_amdgcn_s_memtime();
+            long long pq1_ = pq0_, pq2_ = pq0_, pq3_ = pq0_;
+#endif
             {
                 const int tgt = __builtin_amdgcn_readlane(vt, e);
-                const int sza = T.size[a], szt = T.size[tgt >= 0 ? tgt : a];
+                // (everything here is the same in every lane; saying so — readfirstlane — turns the decisions below into scalar
+                // branches instead of compares, exec masks and their restores: the loop is bound by its instruction count)
+                // The could-die flags come from the chunk's prefetch; the running sizes — kept only for slots that could die — are
+                // the one LDS round trip of an entry, and only if one of its two slots is such a slot.
+                const bool cda = __builtin_amdgcn_readlane(vcda, e) != 0, cdt = __builtin_amdgcn_readlane(vcdt, e) != 0;
+                int sza = 0, szt = 0;
+                if (cda || cdt) {
+                    const int x_ = T.size[a], y_ = T.size[tgt >= 0 ? tgt : a];   // (both issued before either is waited for)
+                    sza = __builtin_amdgcn_readfirstlane(x_); szt = __builtin_amdgcn_readfirstlane(y_);
+                }
                 b = tgt;
-                const bool cda = T.candie[a] != 0, cdt = tgt >= 0 && T.candie[tgt] != 0;   // (sizes of the other slots are not simulated)
+#ifdef RC_PROF_SIM
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pq1_ = __builtin_amdgcn_s_memtime();
+#endif
                 if (tgt >= 0) {
                     if (cdt && szt == 0) { nb = q; hi = T.bx[q] - 1; stop = true; done = e; break; }
                     if (cda && sza == 1) { flag = RC_BF_DEATH; old = la; K -= 1; }
@@ -2194,13 +2241,24 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
                     if (se < la) { flag = RC_BF_RENAME; lab = se; old = la; }
                     else flag = RC_BF_NOOP;
                 } else {
-                    // next free slot of the committed table, 64 slots per step
+                    // next free slot of the committed table (none is reused inside a batch)
                     int f = -1;
-                    while (fcur < V.kcap) {
-                        const int k = fcur + lane;
-                        const u64 fr = __ballot(k < V.kcap && T.label[k] == 0);
-                        if (fr) { f = fcur + __ffsll((long long)fr) - 1; break; }
-                        fcur += 64;
+                    if (regs) {
+                        const u64 anyfree = __ballot(myfree != 0ull);
+                        if (anyfree) {
+                            const int fw = __ffsll((long long)anyfree) - 1;
+                            const u64 word = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myfree >> 32), fw) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)myfree, fw);
+                            const int bitpos = __ffsll((long long)word) - 1;
+                            f = fw * 64 + bitpos;
+                            if (lane == fw) myfree &= ~(1ull << bitpos);
+                        }
+                    } else {
+                        while (fcur < V.kcap) {   // 64 slots per step
+                            const int k = fcur + lane;
+                            const u64 fr = __ballot(k < V.kcap && T.label[k] == 0);
+                            if (fr) { f = fcur + __ffsll((long long)fr) - 1; break; }
+                            fcur += 64;
+                        }
                     }
                     if (f < 0) { fail = (q == 0); nb = q; hi = T.bx[q] - 1; stop = true; done = e; break; }
                     // births are the expensive entries of the simulation and a batch with dozens of them rarely survives validation
@@ -2209,13 +2267,36 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
                     fcur = f + 1;   // (a partial step is re-read from f + 1 on: harmless)
                     b = f; flag = RC_BF_BIRTH; lab = se; K += 1;
                 }
-                // (one lane writes: 64 lanes storing to one LDS address are serialised)
-                if (lane == 0) {
-                    if (lab) T.used[(lab - 1) >> 5] |= 1u << ((lab - 1) & 31);
-                    if (old) T.used[(old - 1) >> 5] &= ~(1u << ((old - 1) & 31));
+#ifdef RC_PROF_SIM
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pq2_ = __builtin_amdgcn_s_memtime();
+#endif
+                if (regs) {
+                    if (lab && lane == ((lab - 1) >> 5)) U |= 1u << ((lab - 1) & 31);
+                    if (old && lane == ((old - 1) >> 5)) U &= ~(1u << ((old - 1) & 31));   // (a label beyond 2048 has no lane: never the smallest empty one)
+                    if (lab) {   // smallest empty label above lab: its bit index is >= lab
+                        const int w0 = lab >> 5;
+                        unsigned inv = (lane >= w0) ? ~U : 0u;
+                        if (lane == w0) inv &= ~((1u << (lab & 31)) - 1u);
+                        const u64 anyw = __ballot(inv != 0u);
+                        se = V.n + 1;
+                        if (anyw) {
+                            const int fl = __ffsll((long long)anyw) - 1;
+                            const int r = fl * 32 + __ffs(__builtin_amdgcn_readlane((int)inv, fl));   // 1-based label
+                            if (r <= V.n) se = r;
+                        }
+                    } else if (old && old < se) se = old;
+                } else {
+                    // (one lane writes: 64 lanes storing to one LDS address are serialised)
+                    if (lane == 0) {
+                        if (lab) T.used[(lab - 1) >> 5] |= 1u << ((lab - 1) & 31);
+                        if (old) T.used[(old - 1) >> 5] &= ~(1u << ((old - 1) & 31));
+                    }
+                    if (lab) se = next_empty_label(T, V.n, lab);
+                    else if (old && old < se) se = old;
                 }
-                if (lab) se = next_empty_label(T, V.n, lab);
-                else if (old && old < se) se = old;
+#ifdef RC_PROF_SIM
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pq3_ = __builtin_amdgcn_s_memtime();
+#endif
                 if (lane == 0) {
                     if (a != b) {
                         if (cda) T.size[a] = sza - 1;
@@ -2228,6 +2309,14 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
             }
             if (lane == e) { ob = b; olab = lab; oflag = flag; }
             if (lane >= e) oK = K;
+#ifdef RC_PROF_SIM
+            if (blockIdx.x == 0 && lane == 0) {
+                long long *dbg_ = (long long *)((char *)V.work[0] + 64);
+                const long long pq4_ = __builtin_amdgcn_s_memtime();
+                dbg_[0] += 1; dbg_[1] += pq1_ - pq0_; dbg_[2] += pq2_ - pq1_; dbg_[3] += pq3_ - pq2_; dbg_[4] += pq4_ - pq3_;
+                dbg_[5] += (flag & RC_BF_BIRTH) ? 1 : 0; dbg_[6] += (flag & RC_BF_DEATH) ? 1 : 0; dbg_[7] += (flag & RC_BF_RENAME) ? 1 : 0; dbg_[8] += (flag & RC_BF_NOOP) ? 1 : 0;
+            }
+#endif
         }
 #ifdef RC_PROF_SIM
         nvisited = nvisited % 1000 + 1000 * (nvisited / 1000 + (int)(__builtin_amdgcn_s_memrealtime() - psim0_));
@@ -2391,6 +2480,8 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         if (use_wc && round > 0) tab_partition(V, T, false);
         for (int c = blockIdx.x; c < nchunks; c += G)
             if (c * RC_PTS + RC_PTS - 1 > after) eval_chunk(V, sa, T, SD, SL, c, after, V.n, 0, 0, cword, rec, stamp, use_wc ? (round > 0 ? 2 : 1) : 0);
+        // the pass has stored the new scores of the slots the last commit touched, for every point that is still open: clean again
+        if (use_wc && round > 0) { for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) T.dirty[k] = 0; }
         if (sa.dbg & 2) break;
         RC_PHASE(6)
 #ifndef RC_PROF_COMMIT

@@ -34,3 +34,6 @@ for k, nm in names.items(): print(f"   {nm:16s} {np.mean(acc[k]):8.1f} us per sw
 if os.environ.get("RC_PROF_SIM"):   # -DRC_PROF_SIM build: column 15 = 1000 * (ticks inside the serial loop of batch_sim) + entries visited, summed over the rounds
     v = out[8192 - 256, 15]
     print(f"   last sweep, block 0: serial loop of batch_sim {v // 1000 / 100.0:.1f} us, entries visited {v % 1000}")
+    L.rc_debug_prof(ctx.h, 0, out.ctypes.data_as(C.c_void_p))
+    r = out[0, :9].astype(np.float64)   # cumulative over all sweeps (s_memtime ticks at 100 MHz): per serial entry
+    print(f"   serial entries {int(r[0])}: per entry (s_memtime ticks = 10 ns) size/flag reads {r[1] / r[0]:.1f}, decision + free slot {r[2] / r[0]:.1f}, bitset + next empty label {r[3] / r[0]:.1f}, stores + bookkeeping {r[4] / r[0]:.1f}; births {int(r[5])} deaths {int(r[6])} renames {int(r[7])} no-ops {int(r[8])}")
