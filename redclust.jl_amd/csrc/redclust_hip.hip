@@ -2161,6 +2161,10 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
     // instructions per entry, and a label taken or freed is two instructions here against LDS round trips (a birth cost
     // ~1.2 µs: up to four 64-slot steps to the first free slot, two read-modify-writes of the bitset and a word-by-word
     // walk to the next empty label).
+#ifdef RC_PROF_SIM
+    const long long pf0_ = __builtin_amdgcn_s_memrealtime();
+    long long pf_pro_ = 0, pf_loop_ = 0, pf_epi_ = 0, pf_init_ = 0, pf_ser_ = 0, pf_b_ = 0, pf_d_ = 0, pf_ch_ = 0;
+#endif
     const bool regs = V.kcap < 2048;
     unsigned U = 0xffffffffu;
     u64 myfree = 0;
@@ -2172,7 +2176,13 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
             if (lane == w) myfree = m;
         }
     }
+#ifdef RC_PROF_SIM
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pf_init_ = __builtin_amdgcn_s_memrealtime() - pf0_;
+#endif
     for (int q0 = 0; q0 < nb0 && !stop; q0 += 64) {
+#ifdef RC_PROF_SIM
+        const long long pc0_ = __builtin_amdgcn_s_memrealtime(); ++pf_ch_;
+#endif
         int va = 0, vt = -1, vla = 0, vcda = 0, vcdt = 0;
         bool vfast = false, vsafe = false;
         if (q0 + lane < nb0) {
@@ -2192,7 +2202,8 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
         int done = cnt;
         u64 todo = ~safemask & (cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull));
 #ifdef RC_PROF_SIM
-        const long long psim0_ = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const long long psim0_ = __builtin_amdgcn_s_memrealtime(); pf_pro_ += psim0_ - pc0_;
 #endif
         while (todo) {
             // the lone singletons that keep their label under the current smallest empty label change nothing: all of them up to
@@ -2212,11 +2223,12 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
             ++nvisited;
             const int q = q0 + e;
             const int a = __builtin_amdgcn_readlane(va, e), la = __builtin_amdgcn_readlane(vla, e);
+            // the running state is the same in every lane: keep it in scalar registers (one wave applies these entries one after
+            // the other, ~10 cycles per dependent instruction; with the state in vector registers every decision below was a
+            // compare + exec-mask save / restore: 150 instructions and 0.7 µs per entry)
+            se = __builtin_amdgcn_readfirstlane(se); K = __builtin_amdgcn_readfirstlane(K); fcur = __builtin_amdgcn_readfirstlane(fcur);
+            nbirth = __builtin_amdgcn_readfirstlane(nbirth); neff = __builtin_amdgcn_readfirstlane(neff); first_eff = __builtin_amdgcn_readfirstlane(first_eff);
             int b, flag = 0, lab = 0, old = 0;
-#ifdef RC_PROF_SIM
-            const long long pq0_ = __builtin_amdgcn_s_memtime();
-            long long pq1_ = pq0_, pq2_ = pq0_, pq3_ = pq0_;
-#endif
             {
                 const int tgt = __builtin_amdgcn_readlane(vt, e);
                 // (everything here is the same in every lane; saying so — readfirstlane — turns the decisions below into scalar
@@ -2230,9 +2242,6 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
                     sza = __builtin_amdgcn_readfirstlane(x_); szt = __builtin_amdgcn_readfirstlane(y_);
                 }
                 b = tgt;
-#ifdef RC_PROF_SIM
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pq1_ = __builtin_amdgcn_s_memtime();
-#endif
                 if (tgt >= 0) {
                     if (cdt && szt == 0) { nb = q; hi = T.bx[q] - 1; stop = true; done = e; break; }
                     if (cda && sza == 1) { flag = RC_BF_DEATH; old = la; K -= 1; }
@@ -2267,9 +2276,6 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
                     fcur = f + 1;   // (a partial step is re-read from f + 1 on: harmless)
                     b = f; flag = RC_BF_BIRTH; lab = se; K += 1;
                 }
-#ifdef RC_PROF_SIM
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pq2_ = __builtin_amdgcn_s_memtime();
-#endif
                 if (regs) {
                     if (lab && lane == ((lab - 1) >> 5)) U |= 1u << ((lab - 1) & 31);
                     if (old && lane == ((old - 1) >> 5)) U &= ~(1u << ((old - 1) & 31));   // (a label beyond 2048 has no lane: never the smallest empty one)
@@ -2291,12 +2297,9 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
                         if (lab) T.used[(lab - 1) >> 5] |= 1u << ((lab - 1) & 31);
                         if (old) T.used[(old - 1) >> 5] &= ~(1u << ((old - 1) & 31));
                     }
-                    if (lab) se = next_empty_label(T, V.n, lab);
+                    if (lab) se = __builtin_amdgcn_readfirstlane(next_empty_label(T, V.n, lab));
                     else if (old && old < se) se = old;
                 }
-#ifdef RC_PROF_SIM
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pq3_ = __builtin_amdgcn_s_memtime();
-#endif
                 if (lane == 0) {
                     if (a != b) {
                         if (cda) T.size[a] = sza - 1;
@@ -2310,16 +2313,11 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
             if (lane == e) { ob = b; olab = lab; oflag = flag; }
             if (lane >= e) oK = K;
 #ifdef RC_PROF_SIM
-            if (blockIdx.x == 0 && lane == 0) {
-                long long *dbg_ = (long long *)((char *)V.work[0] + 64);
-                const long long pq4_ = __builtin_amdgcn_s_memtime();
-                dbg_[0] += 1; dbg_[1] += pq1_ - pq0_; dbg_[2] += pq2_ - pq1_; dbg_[3] += pq3_ - pq2_; dbg_[4] += pq4_ - pq3_;
-                dbg_[5] += (flag & RC_BF_BIRTH) ? 1 : 0; dbg_[6] += (flag & RC_BF_DEATH) ? 1 : 0; dbg_[7] += (flag & RC_BF_RENAME) ? 1 : 0; dbg_[8] += (flag & RC_BF_NOOP) ? 1 : 0;
-            }
+            ++pf_ser_; pf_b_ += (flag & RC_BF_BIRTH) ? 1 : 0; pf_d_ += (flag & RC_BF_DEATH) ? 1 : 0;
 #endif
         }
 #ifdef RC_PROF_SIM
-        nvisited = nvisited % 1000 + 1000 * (nvisited / 1000 + (int)(__builtin_amdgcn_s_memrealtime() - psim0_));
+        const long long psim1_ = __builtin_amdgcn_s_memrealtime(); pf_loop_ += psim1_ - psim0_;
 #endif
         {   // the plain moves before the cut count as effective entries
             const u64 kept = safemask & (done == 64 ? ~0ull : ((1ull << done) - 1ull));
@@ -2333,7 +2331,17 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
             const int q = q0 + lane;
             T.bb[q] = (short)ob; T.blab[q] = olab; T.bflag[q] = (unsigned char)oflag; T.bK[q] = (short)oK;
         }
+#ifdef RC_PROF_SIM
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pf_epi_ += __builtin_amdgcn_s_memrealtime() - psim1_;
+#endif
     }
+#ifdef RC_PROF_SIM
+    if (blockIdx.x == 0 && lane == 0) {
+        long long *dbg_ = (long long *)((char *)V.work[0] + 64);
+        dbg_[0] += 1; dbg_[1] += pf_init_; dbg_[2] += pf_pro_; dbg_[3] += pf_loop_; dbg_[4] += pf_epi_; dbg_[5] += pf_ser_; dbg_[6] += pf_b_; dbg_[7] += pf_d_; dbg_[8] += pf_ch_;
+        dbg_[9] += nb0; dbg_[10] += __builtin_amdgcn_s_memrealtime() - pf0_;
+    }
+#endif
     if (lane == 0) { T.misc[3] = nb; T.misc[4] = hi; T.misc[5] = fail; T.misc[8] = nbirth; T.misc[9] = neff; T.misc[10] = first_eff; T.misc[13] = nvisited; }
 }
 

@@ -18,6 +18,9 @@ L = rc.lib()
 out = np.zeros((8192, 16), np.int64)
 L.rc_debug_prof.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
 names = {2: "(commit: tables)", 6: "eval tentative", 7: "barrier 1", 8: "assemble batch", 14: "batch_sim", 9: "restore + lists", 10: "eval validate", 11: "barrier 2", 12: "commit"}
+base0 = None
+if os.environ.get("RC_PROF_SIM"):
+    L.rc_debug_prof(ctx.h, 0, out.ctypes.data_as(C.c_void_p)); base0 = out[0, :11].astype(np.float64).copy()
 acc = {k: [] for k in names}; mx = {k: [] for k in names}; mn = {k: [] for k in names}; rounds = []; tot = []
 for t in range(60, 80):
     ctx.gibbs_sweep(1.0, 0.5, 7, t, blocking=True)
@@ -31,9 +34,8 @@ for t in range(60, 80):
 print(f"sigma {sig} kcap {kcap} K {st['K']} rounds/sweep {np.mean(rounds):.1f}  loop total {np.mean(tot):.1f} us (median block)")
 print(f"   last sweep: prologue (tables) {pro:.1f} us, epilogue of blocks 0-3 {epi0} us (other blocks {epi:.1f}), first start to last end {span:.1f} us")
 for k, nm in names.items(): print(f"   {nm:16s} {np.mean(acc[k]):8.1f} us per sweep   {np.mean(acc[k]) / np.mean(rounds):7.1f} per round   (blocks: min {np.mean(mn[k]):7.1f} max {np.mean(mx[k]):7.1f} per sweep)")
-if os.environ.get("RC_PROF_SIM"):   # -DRC_PROF_SIM build: column 15 = 1000 * (ticks inside the serial loop of batch_sim) + entries visited, summed over the rounds
-    v = out[8192 - 256, 15]
-    print(f"   last sweep, block 0: serial loop of batch_sim {v // 1000 / 100.0:.1f} us, entries visited {v % 1000}")
+if os.environ.get("RC_PROF_SIM"):   # -DRC_PROF_SIM build: block 0's batch_sim accumulators (cumulative over all sweeps; 10 ns ticks) in row 0 of parity 0
     L.rc_debug_prof(ctx.h, 0, out.ctypes.data_as(C.c_void_p))
-    r = out[0, :9].astype(np.float64)   # cumulative over all sweeps (s_memtime ticks at 100 MHz): per serial entry
-    print(f"   serial entries {int(r[0])}: per entry (s_memtime ticks = 10 ns) size/flag reads {r[1] / r[0]:.1f}, decision + free slot {r[2] / r[0]:.1f}, bitset + next empty label {r[3] / r[0]:.1f}, stores + bookkeeping {r[4] / r[0]:.1f}; births {int(r[5])} deaths {int(r[6])} renames {int(r[7])} no-ops {int(r[8])}")
+    r = out[0, :11].astype(np.float64) - base0; c = r[0]
+    print(f"   batch_sim calls {int(c)}: per call {r[10] / c / 100:.1f} us = state set-up {r[1] / c / 100:.1f} + chunk prefetch {r[2] / c / 100:.1f} + entry loop {r[3] / c / 100:.1f} + chunk write-back {r[4] / c / 100:.1f};"
+          f" per call {r[9] / c:.0f} entries in {r[8] / c:.1f} chunks, {r[5] / c:.1f} applied one by one ({r[6] / c:.1f} births, {r[7] / c:.1f} deaths): {r[3] / max(r[5], 1) * 10:.0f} ns each")
