@@ -156,12 +156,12 @@ int32_t rc_debug_rowsums(rc_ctx *ctx, int64_t label, int64_t *sumD_q /* n */, in
 
 /* Timing of the dominant kernel (row-bucket reduction) measured with HIP events on the stream it is launched
  * on: accumulated milliseconds and number of timed launches since the last reset.  enable: 0 = off, 1 = time
- * every launch, N > 1 = time every N-th launch (each timed launch costs a few microseconds of stream time),
- * negative = just read the counters. */
+ * every launch, N > 1 = time every N-th launch, negative = just read the counters.  The two events of a timed
+ * launch ride in its dispatch (hipExtLaunchKernelGGL) and report the kernel's own start and stop on that stream;
+ * no marker packets are added around the kernel. */
 int32_t rc_kernel_timing(rc_ctx *ctx, int32_t enable, double *bulk_ms_total, int64_t *bulk_launches);
-/* An event pair also measures the marker / dispatch latency around the kernel (several microseconds that a kernel
- * trace does not include).  It is calibrated with an empty kernel when timing is enabled and subtracted from the
- * totals above; this returns the calibrated value. */
+/* What is subtracted from every timed launch: 0 (round 1 recorded marker pairs around the launch and subtracted
+ * what such a pair reports around an empty kernel; kept so that the bench line can say so). */
 int32_t rc_event_overhead_ms(rc_ctx *ctx, double *out);
 
 /* Which row-reduction kernel the last enqueued sweep used — 0: k_bulk (reads every entry of D and logD, any point
