@@ -258,3 +258,49 @@ def test_maximum_slot_capacity_and_many_clusters():
         assert st["n_changes"] == orc.last_changes
     assert abs(ctx.loglik() - orc.loglik_stable()) <= 1e-9 * abs(orc.loglik_stable())
     ctx.close()
+
+
+def test_moving_regime_at_headline_size_with_and_without_score_cache():
+    """N = 8192 on overlapping clusters (sigma = 0.2: the moving regime of bench.py — dozens to hundreds of label changes per
+    sweep with births, deaths and relabelings, several resolver rounds): three sweeps from the generating labels against the
+    oracle, once with the resolver's score cache off and once with it filled in every sweep (RC_SCORE_CACHE, read when the
+    context is created; the default fills it only after a sweep that changed labels) — labels, sizes, K and change counts exact."""
+    import os
+    n, K = 8192, 50
+    data = rc.generatemixture(n, K, seed=2, sigma=0.2)
+    D, truth = data["distancematrix"], data["clusts"]
+    P = rc.likelihood_hyperparams(D, truth)
+    saved = os.environ.get("RC_SCORE_CACHE")
+    ref = None
+    try:
+        for mode in ("0", "1"):
+            os.environ["RC_SCORE_CACHE"] = mode
+            ctx = rc.Context(D, kcap=512)
+            ctx.set_params(**P)
+            ctx.set_state(truth)
+            if ref is None:                                   # the oracle's three sweeps, once
+                L = ctx.get_matrix(1)
+                eD, eL = ctx.debug_rowsums(1)[2:4]
+                orc = O.Oracle(D, P, logD=L, eL=eL, eD=eD)
+                orc.set_state(truth)
+                ref = []
+                for t in range(3):
+                    r, p = rp_schedule(t)
+                    orc.sweep_stable(r, p, 77, t)
+                    ref.append((orc.clusts.copy(), orc.sizes.copy(), orc.K, orc.last_changes))
+                del orc, L
+                assert sum(x[3] for x in ref) > 100 and ref[-1][2] > K     # it moves, and clusters are born
+            rounds = 0
+            for t in range(3):
+                r, p = rp_schedule(t)
+                ctx.gibbs_sweep(r, p, 77, t, blocking=bool(t & 1))
+                lab, sizes, Kc = ctx.get_state()
+                st = ctx.sweep_stats()
+                assert np.array_equal(lab, ref[t][0]), (mode, t, int(np.sum(lab != ref[t][0])))
+                assert np.array_equal(sizes, ref[t][1]) and Kc == ref[t][2] and st["n_changes"] == ref[t][3], (mode, t, st)
+                rounds += st["n_rounds"]
+            assert rounds > 3                                  # more than one resolver round somewhere: the cached passes ran
+            ctx.close()
+    finally:
+        if saved is None: os.environ.pop("RC_SCORE_CACHE", None)
+        else: os.environ["RC_SCORE_CACHE"] = saved
