@@ -1074,14 +1074,20 @@ __device__ __forceinline__ void row16_sum4_dpp(long long &a, long long &b, long 
 //   rows are already in flight (a unit's set-up otherwise costs a full memory round trip, ~20 % of a 64-row unit).
 //   A unit's column set-up (the two clusters that own its 128 columns, per-lane class masks) is done once; its rows are
 //   taken in 64-row halves (direction-2 totals live one row per lane).
-template <bool DERIVED>
+// T: storage type of the matrices — long long, or int for 32-bit storage (logD stored): a lane then loads 8 instead of 16 bytes
+// per row and matrix and widens its two entries on use; everything behind the load is the same 64-bit pipeline.
+template <typename T> struct SymlRaw;
+template <> struct SymlRaw<long long> { typedef ll2 vec; };
+template <> struct SymlRaw<int> { typedef int vec __attribute__((ext_vector_type(2))); };
+template <bool DERIVED, typename T = long long>
 __device__ __forceinline__ void syml_units(const View &V, long long (*tt)[RC_SL_R][RC_SL_P], int wgen, int sgen, int nitems,
                                            int jsplit, int gfine, int gcoarse, int first_unit, int nwaves, long long *pf_out)
 {
+    typedef typename SymlRaw<T>::vec rawvec;
     const int lane = threadIdx.x & 63;
     const size_t ld = (size_t)V.ld;
-    const long long *__restrict__ Dq = (const long long *)V.Dq + 2 * lane;
-    const long long *__restrict__ Lq = (const long long *)V.Lq + 2 * lane;
+    const T *__restrict__ Dq = (const T *)V.Dq + 2 * lane;
+    const T *__restrict__ Lq = (const T *)V.Lq + 2 * lane;
     const int *__restrict__ slot = V.snap[sgen];
     long long *SD = V.SD[wgen], *SL = V.SL[wgen];
     const int n = V.n;
@@ -1110,13 +1116,13 @@ __device__ __forceinline__ void syml_units(const View &V, long long (*tt)[RC_SL_
         oc0 = J * RC_SW_COLS; oa0 = it * g; oitem = it;
         oa1 = min(oa0 + g, min(oc0 + RC_SW_COLS, n));                  // rows a >= c0+128 have no column b > a here
     };
-    ll2 d[RC_SL_R], l[RC_SL_R];
+    rawvec d[RC_SL_R], l[RC_SL_R];
     auto issue = [&](int a, int cb0) {
 #pragma unroll
         for (int u = 0; u < RC_SL_R; ++u) {
             const int r = min(a + u, n - 1);
-            d[u] = __builtin_nontemporal_load((const ll2 *)(Dq + (size_t)r * ld + cb0));
-            if (!DERIVED) l[u] = __builtin_nontemporal_load((const ll2 *)(Lq + (size_t)r * ld + cb0));
+            d[u] = __builtin_nontemporal_load((const rawvec *)(Dq + (size_t)r * ld + cb0));
+            if (!DERIVED) l[u] = __builtin_nontemporal_load((const rawvec *)(Lq + (size_t)r * ld + cb0));
         }
     };
     int unit = first_unit;
@@ -1205,8 +1211,8 @@ __device__ __forceinline__ void syml_units(const View &V, long long (*tt)[RC_SL_
             RC_PF({ const long long w0 = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pf_wait += __builtin_amdgcn_s_memtime() - w0; pf_tiles += 1; })
 #pragma unroll
             for (int u = 0; u < RC_SL_R; ++u) {
-                x[u] = d[u];
-                if (!DERIVED) y[u] = l[u];
+                x[u].x = d[u].x; x[u].y = d[u].y;
+                if (!DERIVED) { y[u].x = l[u].x; y[u].y = l[u].y; }
             }
             RC_PF(const long long pi0 = __builtin_amdgcn_s_memtime();)
             if (a + RC_SL_R < a1) issue(a + RC_SL_R, c0);               // next tile in flight under this one's work
@@ -1344,7 +1350,7 @@ __device__ __forceinline__ void syml_load_table(const View &V, long long (*tl)[2
 #ifndef RC_SYML_MINWAVES
 #define RC_SYML_MINWAVES 4
 #endif
-template <bool DERIVED>
+template <bool DERIVED, typename T = long long>
 __global__ __launch_bounds__(256, RC_SYML_MINWAVES) void k_bulk_syml(View V, int wgen, int zgen, int sgen, int cgen, int nitems, int jsplit, int gfine, int gcoarse)
 {
     // [wave][matrix][row][octet-padded col]: 10 KiB per wave, 40 KiB per block = four blocks (16 waves) per CU exactly.
@@ -1358,7 +1364,7 @@ __global__ __launch_bounds__(256, RC_SYML_MINWAVES) void k_bulk_syml(View V, int
     long long *pf = nullptr;
     RC_PF(if (w < 8192) pf = (long long *)((char *)V.work[cgen] + 64) + (size_t)w * 16;)
     (void)cgen;
-    syml_units<DERIVED>(V, tl[threadIdx.x >> 6], wgen, sgen, nitems, jsplit, gfine, gcoarse, w, (int)gridDim.x * 4, pf);
+    syml_units<DERIVED, T>(V, tl[threadIdx.x >> 6], wgen, sgen, nitems, jsplit, gfine, gcoarse, w, (int)gridDim.x * 4, pf);
 }
 
 
@@ -3396,6 +3402,12 @@ static int32_t alloc_ctx(int64_t n, int32_t storage_bits, int32_t device_id, int
     return RC_OK;
 }
 
+// Symmetric-kernel variant of a context: RC_SYM_VARIANT, else the wave-autonomous kernel when logD is derived and the block-tiled
+// ones when it is stored.
+static int sym_variant_of(const rc_ctx *c) { return c->sym_variant >= 0 ? c->sym_variant : (c->derived ? 2 : 0); }
+// the wave-autonomous kernel (three 40 KiB blocks per CU) is the symmetric kernel of this context
+static bool uses_syml(const rc_ctx *c) { return sym_variant_of(c) == 2; }
+
 // launch geometry and LDS attributes that depend on (n, kcap, bits)
 static int32_t finish_create(rc_ctx *c)
 {
@@ -3406,7 +3418,7 @@ static int32_t finish_create(rc_ctx *c)
         // reduction — config 5: 1.34 ms per resolver instead of 0.3).  LDS beside the reduction: three 40 KiB blocks of the
         // wave-autonomous kernel (64-bit, logD derived), two 65 KiB blocks of the block-tiled kernels otherwise; the
         // full-read kernel of small problems sizes itself around the resolver.  Largest capacity whose tables fit.
-        const bool syml = (c->bits == 64 && c->derived);
+        const bool syml = uses_syml(c);
         const size_t beside = syml ? (size_t)c->symw_per_cu * 40960 : (size_t)2 * 69632;   // (k_bulk_sym32: 67,864 B per block, k_bulk_sym: 67,288 B; measured: beside two of them 24.6 KB of tables become resident, 26.5 KB do not — 4 KiB allocation granules)
         const size_t avail = 160 * 1024 > beside + 1024 ? 160 * 1024 - beside - 1024 : 0;
         c->maxb = RC_MAXB;
@@ -3729,7 +3741,6 @@ static bool choose_sym(const rc_ctx *c)
     return c->bulk_kernel == 1 || (c->bulk_kernel < 0 && (long long)c->hsum->runs * 32 <= (long long)c->n &&
                                    !(c->derived && c->n <= 4096));
 }
-static int sym_variant_of(const rc_ctx *c) { return c->sym_variant >= 0 ? c->sym_variant : (c->derived ? 2 : 0); }
 
 // Static unit list of the wave-autonomous symmetric reduction for `cap_blocks` resident 4-wave blocks.  Every column block
 // is cut into units of gc rows, gc chosen so that the list is a whole number of rounds over the resident waves with the
@@ -3780,7 +3791,13 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
     const bool use_sym = choose_sym(c);
     c->last_bulk_kernel = use_sym ? 1 : 0;
     const int sym_variant = sym_variant_of(c);
-    if (use_sym && c->bits == 64 && sym_variant >= 1) {
+    if (use_sym && c->bits == 32 && sym_variant == 2) {
+        int gc = 0, nitems = 0;
+        syml_geometry(c, c->symw_per_cu * c->num_cus, &gc, &nitems);
+        const int nblocks = std::max(1, std::min((nitems + 3) / 4, c->symw_per_cu * c->num_cus));
+        auto kf_ = k_bulk_syml<false, int>;
+        RC_BULK_LAUNCH(kf_, nblocks, 256, c->syml_pad, V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems, 0, 8, gc);
+    } else if (use_sym && c->bits == 64 && sym_variant >= 1) {
         const int ncb = (c->n + RC_SW_COLS - 1) / RC_SW_COLS;
         const int cap_blocks = c->symw_per_cu * c->num_cus;          // resident 4-wave blocks
         auto rows_of = [&](int J) { return std::min(RC_SW_COLS * J + RC_SW_COLS, c->n); };
@@ -5008,7 +5025,7 @@ extern "C" const char *rc_bulk_kernel_name(rc_ctx *c)
 {
     if (!c) return "";
     if (!c->last_bulk_kernel) return c->derived ? "k_bulk<long long, true>" : (c->bits == 64 ? "k_bulk<long long, false>" : "k_bulk<int, false>");
-    if (c->bits != 64) return "k_bulk_sym32";
+    if (c->bits != 64) return sym_variant_of(c) == 2 ? "k_bulk_syml<false, int>" : "k_bulk_sym32";
     const int v = c->sym_variant >= 0 ? c->sym_variant : (c->derived ? 2 : 0);
     if (v == 2) return c->derived ? "k_bulk_syml<true>" : "k_bulk_syml<false>";
     if (v == 1) return c->derived ? "k_bulk_symw<true>" : "k_bulk_symw<false>";
