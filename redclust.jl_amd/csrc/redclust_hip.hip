@@ -2543,24 +2543,24 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         }
         __syncthreads();
         const int total = T.ccnt[nchunks];
-        for (int c = threadIdx.x; c < nchunks; c += blockDim.x) {
-            int o = T.ccnt[c];
-            if (T.ccnt[c + 1] > o && o < cap + 1) {
-                unsigned m = (unsigned)__hip_atomic_load(cword + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                while (m && o <= cap) {
-                    const int bit = __ffs((int)m) - 1;
-                    m &= m - 1;
-                    const int x = c * RC_PTS + bit;
-                    if (o < cap) {
-                        const unsigned rc = __hip_atomic_load(rec + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        T.bx[o] = x; T.bu[o] = V.pi[x]; T.ba[o] = (short)(rc >> 16); T.bb[o] = (short)((int)(rc & 0xFFFFu) - 1);
-                        if (rc & 0xFFFFu) T.joined[(rc & 0xFFFFu) - 1] = 1;
-                        atomicAdd(&T.seg[rc >> 16], 1);   // leaves its cluster
-                    } else {
-                        T.misc[2] = x;  // first changer that does not fit into the batch
-                    }
-                    ++o;
-                }
+        // one thread per batch entry (and one for the first changer that does not fit): its chunk by bisection of the offsets, its
+        // point from the rank of its bit in the chunk's mask, then ONE record load — all loads of a batch in flight together (a
+        // thread per chunk fetched the records of its up to 32 changers one after the other: 4.6 µs per round in the moving
+        // regime, 11.5 when every point moves)
+        for (int o = threadIdx.x; o < min(total, cap + 1); o += blockDim.x) {
+            int lo_ = 0, hi_ = nchunks;                      // the largest c with ccnt[c] <= o (then ccnt[c + 1] > o)
+            while (hi_ - lo_ > 1) { const int mid = (lo_ + hi_) >> 1; if ((int)T.ccnt[mid] <= o) lo_ = mid; else hi_ = mid; }
+            const int c = lo_;
+            unsigned m = (unsigned)__hip_atomic_load(cword + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int r_ = o - (int)T.ccnt[c]; r_ > 0; --r_) m &= m - 1;
+            const int x = c * RC_PTS + __ffs((int)m) - 1;
+            if (o < cap) {
+                const unsigned rc = __hip_atomic_load(rec + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                T.bx[o] = x; T.bu[o] = V.pi[x]; T.ba[o] = (short)(rc >> 16); T.bb[o] = (short)((int)(rc & 0xFFFFu) - 1);
+                if (rc & 0xFFFFu) T.joined[(rc & 0xFFFFu) - 1] = 1;
+                atomicAdd(&T.seg[rc >> 16], 1);   // leaves its cluster
+            } else {
+                T.misc[2] = x;  // first changer that does not fit into the batch
             }
         }
         __syncthreads();
