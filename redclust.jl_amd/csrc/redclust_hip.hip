@@ -1546,7 +1546,7 @@ struct Tab {
     unsigned *used;  // [(n+31)/32] label occupancy bitset, bit (label-1); built when a round has changers (LDS, or V.used_scratch for large n)
     double *red_v;   // [NW][32] reduction scratch (NW = waves per block)
     int *red_pos, *red_slot;
-    int *misc;       // [0]=K [1]=smallest_empty [2]=scratch [3]=nb [4]=hi [5]=fail [6]=barrier ok [7]=slot_hi [8]=#births [9]=#effective [13]=visited [14]=#clean slots (tab_partition) [15]=#dirty
+    int *misc;       // [0]=K [1]=smallest_empty [2]=scratch [3]=nb [4]=hi [5]=fail [6]=barrier ok [7]=slot_hi [8]=#births [9]=#effective [13]=visited [14]=#clean slots (tab_partition) [15]=#dirty [16]=hot slot of the batch (-1: none) [17]=scratch
     u64 *blk_key;    // block-local minimum (first violation)
     // batch of tentative changers of the current round (identical in every block), ascending in point index
     int *bx, *bu;             // [RC_MAXB] point (original index), its internal index
@@ -1583,7 +1583,7 @@ __host__ __device__ inline size_t tab_layout(int kcap, int n, int nw, size_t *of
     off[6] = o; o = RC_A16(o + sizeof(int) * nw * RC_PTS);      // red_pos
     off[7] = o; o = RC_A16(o + sizeof(int) * nw * RC_PTS);      // red_slot
     off[8] = o; o = RC_A16(o + (n <= RC_USED_LDS_MAX_N ? sizeof(unsigned) * ((n + 31) / 32) : 0));  // used (beyond: per-block global scratch)
-    off[9] = o; o = RC_A16(o + sizeof(int) * 16);               // misc
+    off[9] = o; o = RC_A16(o + sizeof(int) * 24);               // misc
     off[10] = o; o = RC_A16(o + sizeof(short) * kcap);         // act2
     off[11] = o; o = RC_A16(o + sizeof(short) * kcap);          // act
     off[12] = o; o = RC_A16(o + sizeof(int) * maxb);         // bx
@@ -1903,6 +1903,42 @@ __device__ __forceinline__ bool batch_corr(const View &V, const Tab &T, int k, i
     return touched;
 }
 
+// The batch's largest group.  When the changers of a batch crowd into one cluster (first sweeps from a poor labelling: a hundred
+// entries join the same cluster), that slot's group is walked — one matrix row entry per batch entry — by the ONE candidate stream
+// that scores the slot for a point (validation) or owns its correction (commit), while the other streams of the point have a
+// handful of entries each: 80 µs of validation per round on the four blocks that hold the batch, everyone else at the barrier.
+// For that slot (T.misc[16], groups of RC_HOT_MIN entries or more) the NS streams of a point share the entries — stream st takes
+// entries st, st + NS, ... before `limit` — and add their exact integer partial sums into the point's record in LDS
+// (aliasing the argmax scratch T.red_v: 32 B per point — sum D, sum L, size change, contributing entries, new label).
+#define RC_HOT_MIN 24
+__device__ __forceinline__ void hot_accumulate(const View &V, const Tab &T, int h, int u, int limit, int st, int NS, long long *acc)
+{
+    const size_t ld = (size_t)V.ld;
+    const int e1 = T.seg[h];
+    long long sd = 0, sl = 0;
+    int sz = 0, cnt = 0;
+    for (int e = (h ? T.seg[h - 1] : 0) + st; e < e1; e += NS) {
+        const int q = T.pairs[e];
+        if (q >= limit) break;   // ascending within the group: the later entries of this stream are beyond the limit too
+        const int qa = T.ba[q], qb = T.bb[q];
+        if (qa != qb) {
+            const int sgn = (qb == h) - (qa == h), x = T.bu[q];
+            const size_t ee = (size_t)x * ld + u;
+            const long long xd = (V.bits == 64) ? ((const long long *)V.Dq)[ee] : (long long)((const int *)V.Dq)[ee];
+            const long long xl = rc_load_L(V, x, u, xd);
+            sd += sgn * xd; sl += sgn * xl; sz += sgn; ++cnt;
+        } else {
+            ((int *)acc)[6] = T.blab[q];   // the singleton took a new label (at most one such entry per slot and batch)
+        }
+    }
+    if (cnt) {
+        atomicAdd((unsigned long long *)&acc[0], (unsigned long long)sd);
+        atomicAdd((unsigned long long *)&acc[1], (unsigned long long)sl);
+        atomicAdd(&((int *)acc)[4], sz);
+        atomicAdd(&((int *)acc)[5], cnt);
+    }
+}
+
 // Score cache (cmode; V.wc).  The score of (point i, cluster k ≠ i's own) — size term, likelihood, noise of (sweep, i, label) —
 // changes inside a sweep only when a committed change touches slot k (size, row sums or label) or, under validation, when a
 // batch entry before i does.  The first tentative pass of a sweep evaluates every point against every cluster and stores the
@@ -1923,20 +1959,31 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
     const int K = T.misc[0];
     double bestv = -INFINITY;
     int bestpos = 0x7fffffff, bestslot = -2;
-    int own = 0;
+    int own = 0, u = 0, j = 0;
     if (valid) {
-        const int u = V.pi[i];  // matrices, S and slot_of are stored in the internal (cluster-contiguous) point order
+        u = V.pi[i];  // matrices, S and slot_of are stored in the internal (cluster-contiguous) point order
         own = V.slot_of[u];
-        const size_t ld = (size_t)V.ld;
         // number of batch changers before i (bx ascending)
-        int j = 0;
         if (mode == 1) {
             int lo_ = 0, hi_ = nb;
             while (lo_ < hi_) { const int mid = (lo_ + hi_) >> 1; if (T.bx[mid] < i) lo_ = mid + 1; else hi_ = mid; }
             j = lo_;
         }
+    }
+    // the batch's largest group, shared by the candidate streams of every point (see hot_accumulate)
+    const int hot = (mode == 1) ? T.misc[16] : -1;
+    long long *const hotacc = (long long *)T.red_v + 4 * pt;
+    if (hot >= 0) {
+        if (threadIdx.x < 4 * RC_PTS) ((long long *)T.red_v)[threadIdx.x] = 0;
+        __syncthreads();
+        if (valid && j > 0) hot_accumulate(V, T, hot, u, j, st, NS, hotacc);
+        __syncthreads();
+    }
+    if (valid) {
+        const size_t ld = (size_t)V.ld;
         int so = T.size[own];
-        if (mode == 1)
+        if (mode == 1 && own == hot) so += ((const int *)hotacc)[4];
+        else if (mode == 1)
             for (int e = own ? T.seg[own - 1] : 0, e1 = T.seg[own]; e < e1; ++e) {
                 const int q = T.pairs[e];
                 if (q >= j) break;
@@ -1950,7 +1997,15 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
             const int isown = (k == own);
             int sz = T.size[k], lab = T.label[k];
             long long sd = SD[(size_t)k * ld + u], sl = SL[(size_t)k * ld + u];
-            const bool touched = (mode == 1) && batch_corr(V, T, k, u, j, sd, sl, sz, lab);
+            bool touched;
+            if (mode == 1 && k == hot) {
+                const int *hi_ = (const int *)hotacc;
+                touched = hi_[5] > 0;
+                sd += hotacc[0]; sl += hotacc[1]; sz += hi_[4];
+                if (hi_[6]) lab = hi_[6];
+            } else {
+                touched = (mode == 1) && batch_corr(V, T, k, u, j, sd, sl, sz, lab);
+            }
             const int s = sz - isown;
             if (s == 0) return;  // empty once i is removed (its own singleton cluster, mcmc.jl:193-196) or emptied by the batch
             sd -= (isown ? dg : 0);                                              // i itself excluded (clusts[i] = -1)
@@ -2020,6 +2075,7 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
             if (v > bestv || bestslot == -2) { bestv = v; bestpos = RC_NEWKEY; bestslot = -1; }
         }
     }
+    if (hot >= 0) __syncthreads();   // (the records of the hot slot alias the reduction scratch)
     // reduce over the candidate streams: the two halves of each wave by shuffle, then the waves through LDS
     {
         const double ov = __shfl_xor(bestv, 32);
@@ -2388,24 +2444,34 @@ __device__ int commit_batch(const View &V, const SweepArgs &sa, Tab &T, int nc, 
     long long *SDo = V.SD[own_gen], *SLo = V.SL[own_gen];
     long long *SDn = next_gen >= 0 ? V.SD[next_gen] : nullptr, *SLn = next_gen >= 0 ? V.SL[next_gen] : nullptr;
     const int hi_slots = T.misc[7];   // slots in use, births of this batch included
+    const int hot = T.misc[16];        // the batch's largest group: its correction is shared by the streams of a point (hot_accumulate)
+    long long *const hotacc = (long long *)T.red_v + 4 * pt;
     for (int c = blockIdx.x; c < nchunks; c += G) {
         const int io = c * RC_PTS + pt;
-        if (io >= V.n) continue;
-        const int i = V.pi[io];
+        const bool act = io < V.n;
+        const int i = act ? V.pi[io] : 0;
+        if (hot >= 0) {
+            if (threadIdx.x < 4 * RC_PTS) ((long long *)T.red_v)[threadIdx.x] = 0;
+            __syncthreads();
+            if (act) hot_accumulate(V, T, hot, i, nc, st, NS, hotacc);
+            __syncthreads();
+        }
         // Slot by slot (the groups of T.pairs): the net correction of the first nc entries, then ONE read-modify-write of the
         // generation being read (plain: every (slot row, point) belongs to one thread — stream slot mod NS — and this block
         // reads these rows again next round through its L1) and one atomic pair on the next generation, which the row reduction
         // of the following sweep is adding to concurrently.  (Entry by entry this was a chain of dependent round trips per
         // entry: 118 µs per round when a hundred changers joined one cluster.)
-        for (int k = st; k < hi_slots; k += NS) {
+        for (int k = st; act && k < hi_slots; k += NS) {
             if ((k ? T.seg[k - 1] : 0) == T.seg[k]) continue;
             long long dD = 0, dL = 0;
             int sz_ = 0, lab_ = 0;
-            if (!batch_corr(V, T, k, i, nc, dD, dL, sz_, lab_)) continue;
+            if (k == hot) { if (((const int *)hotacc)[5] == 0) continue; dD = hotacc[0]; dL = hotacc[1]; }
+            else if (!batch_corr(V, T, k, i, nc, dD, dL, sz_, lab_)) continue;
             const size_t ik = (size_t)k * V.ld + i;
             if (dD) { SDo[ik] += dD; if (SDn) __hip_atomic_fetch_add((u64 *)(SDn + ik), (u64)dD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             if (dL) { SLo[ik] += dL; if (SLn) __hip_atomic_fetch_add((u64 *)(SLn + ik), (u64)dL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         }
+        if (hot >= 0) __syncthreads();
     }
     for (int q = threadIdx.x; q < nc; q += blockDim.x)
         if (T.ba[q] != T.bb[q]) V.slot_of[T.bu[q]] = T.bb[q];  // same values from every block
@@ -2621,7 +2687,14 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
                     if (b_ != a_) T.pairs_tmp[atomicAdd(&T.seg[b_], 1)] = (short)q;
                 }
             }
+            if (threadIdx.x == 0) T.misc[17] = 0;
             __syncthreads();   // now seg[k] = end of slot k's group, seg[k-1] (0 for k = 0) its begin
+            for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) {   // the largest group, if it is worth sharing (hot_accumulate)
+                const int sz_ = T.seg[k] - (k ? T.seg[k - 1] : 0);
+                if (sz_ >= RC_HOT_MIN) atomicMax(&T.misc[17], (sz_ << 16) | k);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) T.misc[16] = T.misc[17] ? (T.misc[17] & 0xFFFF) : -1;
             // order every group by entry index: each entry ranks itself inside the groups of its two slots (a group can hold
             // hundreds of entries when the changers of a batch share a cluster: a one-thread-per-slot sort took 335 µs there)
             for (int q = threadIdx.x; q < nbk; q += blockDim.x) {
