@@ -1350,8 +1350,8 @@ __device__ __forceinline__ void syml_load_table(const View &V, long long (*tl)[2
 #ifndef RC_SYML_MINWAVES
 #define RC_SYML_MINWAVES 4
 #endif
-template <bool DERIVED, typename T = long long>
-__global__ __launch_bounds__(256, RC_SYML_MINWAVES) void k_bulk_syml(View V, int wgen, int zgen, int sgen, int cgen, int nitems, int jsplit, int gfine, int gcoarse)
+template <bool DERIVED, typename T>
+__device__ __forceinline__ void syml_kernel_body(const View &V, int wgen, int zgen, int sgen, int cgen, int nitems, int jsplit, int gfine, int gcoarse)
 {
     // [wave][matrix][row][octet-padded col]: 10 KiB per wave, 40 KiB per block = four blocks (16 waves) per CU exactly.
     // The log table of the derived mode (128 × 16 B) lives in the padding: entry j of a wave's private copy sits in
@@ -1365,6 +1365,16 @@ __global__ __launch_bounds__(256, RC_SYML_MINWAVES) void k_bulk_syml(View V, int
     RC_PF(if (w < 8192) pf = (long long *)((char *)V.work[cgen] + 64) + (size_t)w * 16;)
     (void)cgen;
     syml_units<DERIVED, T>(V, tl[threadIdx.x >> 6], wgen, sgen, nitems, jsplit, gfine, gcoarse, w, (int)gridDim.x * 4, pf);
+}
+template <bool DERIVED>
+__global__ __launch_bounds__(256, RC_SYML_MINWAVES) void k_bulk_syml(View V, int wgen, int zgen, int sgen, int cgen, int nitems, int jsplit, int gfine, int gcoarse)
+{
+    syml_kernel_body<DERIVED, long long>(V, wgen, zgen, sgen, cgen, nitems, jsplit, gfine, gcoarse);
+}
+// the same for 32-bit storage (logD stored): RC_SYM_VARIANT=2 on a 32-bit context
+__global__ __launch_bounds__(256, RC_SYML_MINWAVES) void k_bulk_syml32(View V, int wgen, int zgen, int sgen, int cgen, int nitems, int jsplit, int gfine, int gcoarse)
+{
+    syml_kernel_body<false, int>(V, wgen, zgen, sgen, cgen, nitems, jsplit, gfine, gcoarse);
 }
 
 
@@ -3868,7 +3878,7 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
         int gc = 0, nitems = 0;
         syml_geometry(c, c->symw_per_cu * c->num_cus, &gc, &nitems);
         const int nblocks = std::max(1, std::min((nitems + 3) / 4, c->symw_per_cu * c->num_cus));
-        auto kf_ = k_bulk_syml<false, int>;
+        auto kf_ = k_bulk_syml32;
         RC_BULK_LAUNCH(kf_, nblocks, 256, c->syml_pad, V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), nitems, 0, 8, gc);
     } else if (use_sym && c->bits == 64 && sym_variant >= 1) {
         const int ncb = (c->n + RC_SW_COLS - 1) / RC_SW_COLS;
@@ -5098,7 +5108,7 @@ extern "C" const char *rc_bulk_kernel_name(rc_ctx *c)
 {
     if (!c) return "";
     if (!c->last_bulk_kernel) return c->derived ? "k_bulk<long long, true>" : (c->bits == 64 ? "k_bulk<long long, false>" : "k_bulk<int, false>");
-    if (c->bits != 64) return sym_variant_of(c) == 2 ? "k_bulk_syml<false, int>" : "k_bulk_sym32";
+    if (c->bits != 64) return sym_variant_of(c) == 2 ? "k_bulk_syml32" : "k_bulk_sym32";
     const int v = c->sym_variant >= 0 ? c->sym_variant : (c->derived ? 2 : 0);
     if (v == 2) return c->derived ? "k_bulk_syml<true>" : "k_bulk_syml<false>";
     if (v == 1) return c->derived ? "k_bulk_symw<true>" : "k_bulk_symw<false>";
