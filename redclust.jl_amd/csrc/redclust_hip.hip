@@ -32,6 +32,9 @@
 //     like plain moves.  Draws are deterministic functions of (state, counter-based uniforms), so the result
 //     is identical to the sequential loop.  k_resolve runs this inside ONE persistent launch (two grid
 //     barriers per batch); at stationarity it is a single scoring pass.
+//     Inside a sweep the scores of (point, cluster) pairs that no change has touched are kept (score cache), the batch's
+//     largest group of corrections is shared by all candidate streams of a point, the grid barrier is two-level, and the
+//     epilogue (label snapshot, point order of the next layout) is built by all blocks.
 //   * Sweeps are software-pipelined: sweep t (row reduction, then k_resolve) lives on one stream per sweep
 //     parity; the row reduction of sweep t+1 runs on the other stream concurrently with k_resolve(t) — three
 //     reduction blocks and one resolver block per CU — under the labels known before sweep t; the label changes
