@@ -1776,12 +1776,15 @@ __device__ void snapshot_labels(const View &V, int g, int *lds_cnt)
     __syncthreads();
 }
 
-__device__ void write_summary(const View &V, int n_changes, int n_rounds)
+// tables = false: the slot sizes and labels in the record are still right (a sweep that changed nothing) — 2·kcap stores to
+// host memory less in the tail of block 0, which is the end of the launch in the stationary regime
+__device__ void write_summary(const View &V, int n_changes, int n_rounds, bool tables = true)
 {
-    for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) {
-        V.hsum->size_label[2 * k] = V.slot_size[k];
-        V.hsum->size_label[2 * k + 1] = V.slot_label[k];
-    }
+    if (tables)
+        for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) {
+            V.hsum->size_label[2 * k] = V.slot_size[k];
+            V.hsum->size_label[2 * k + 1] = V.slot_label[k];
+        }
     if (threadIdx.x == 0) {
         V.hsum->K = V.sc->K;
         V.hsum->n_changes = n_changes;
@@ -2819,7 +2822,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         for (int q = threadIdx.x; q < RC_BAR_WORDS; q += blockDim.x) V.arrive[kg ^ 1][q] = 0u;
     }
     if (blockIdx.x == 0) {
-        tab_store(V, T);
+        if (changes || t < 2) tab_store(V, T);   // (nothing committed: the tables in global memory are the ones that were loaded)
         if (threadIdx.x == 0) {
             V.sc->n_changes = changes;
             V.sc->n_rounds = round + 1;
@@ -2832,7 +2835,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         snapshot_copy_grid(V, kg, G);
         if ((int)blockIdx.x == b_snap) snapshot_runs(V, &T.misc[2]);
     }
-    if (blockIdx.x == 0) write_summary(V, changes, round + 1);
+    if (blockIdx.x == 0) write_summary(V, changes, round + 1, changes != 0 || t < 2);
     // perm generation t%2 must describe the labels after this sweep (k_bulk of sweep t+2 reads it): all blocks
     if (changes && ok) {
         __syncthreads();
