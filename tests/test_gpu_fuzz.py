@@ -1,7 +1,7 @@
 """A short batch of the randomised differential check (tests/fuzz_parity.py: random sizes, overlaps, capacities, batch capacities,
 storage widths, stored / derived logD, maxK, repulsion, stream arrangement, modes; five sweeps from random labels against the
-oracle; speculative against synchronous chain loop).  By hand over round 2: 5400 small and 330 large (4100 ≤ n < 7000: symmetric kernels,
-re-layouts) sweep cases — the later 3700 with the resolver's score cache off / always on / adaptive at random —, 1370 speculative-vs-synchronous chain cases and 2450 chain-vs-oracle-loop cases without a mismatch — after the chain comparison had found last-bit differences of
+oracle; speculative against synchronous chain loop).  By hand over round 2: 7100 small and 450 large (4100 ≤ n < 7000: symmetric kernels,
+re-layouts) sweep cases — the later 5400 with the resolver's score cache off / always on / adaptive at random, 400 of them on the chaos build (block-dependent random delays inside the resolver's rounds) —, 1370 speculative-vs-synchronous chain cases and 2450 chain-vs-oracle-loop cases without a mismatch — after the chain comparison had found last-bit differences of
 loglik in 6 of 1000 chains (slot-order summation, fixed)."""
 import pytest
 
