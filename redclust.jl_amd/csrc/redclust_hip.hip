@@ -3515,6 +3515,11 @@ static int32_t finish_create(rc_ctx *c)
         else if (c->n > 4096 && tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, RC_MAXB) > avail)
             for (int mb : {384, 256, 192, 128, 96, 64})
                 if (tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, mb) <= avail) { c->maxb = mb; break; }
+        // a slot capacity whose tables cannot sit beside the reduction at any batch capacity (kcap >= 1024) must at least fit the CU:
+        // kcap = 4096 needs 160 KiB at 512 entries per batch for n >= 8192, 149 KiB at 128
+        if (!getenv("RC_RES_MAXB") && tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, c->maxb) > 160 * 1024)
+            for (int mb : {384, 256, 192, 128, 96, 64})
+                if (tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, mb) <= 160 * 1024) { c->maxb = mb; break; }
         if (getenv("RC_SM_PROFILE"))
             fprintf(stderr, "[rc_create] resolver batch capacity %d: tables %zu B (512: %zu, 256: %zu, 128: %zu, 64: %zu), %zu B free beside the row reduction\n", c->maxb,
                     tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, c->maxb), tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, 512), tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, 256),

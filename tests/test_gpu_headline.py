@@ -304,3 +304,22 @@ def test_moving_regime_at_headline_size_with_and_without_score_cache():
     finally:
         if saved is None: os.environ.pop("RC_SCORE_CACHE", None)
         else: os.environ["RC_SCORE_CACHE"] = saved
+
+
+def test_maximum_slot_capacity_at_headline_size(headline):
+    """kcap = 4096 at n = 8192: the resolver's tables fill the CU's 160 KiB only with a smaller batch capacity, which the library
+    picks by itself (512 entries per batch would need 164 KiB); two sweeps from a 2 %-perturbed start agree with the default context."""
+    h = headline
+    init = _init("perturbed", h["truth"], h["K"])
+    big = rc.Context(h["D"], kcap=4096)
+    big.set_params(**h["P"])
+    out = []
+    for ctx in (h["ctx"], big):
+        ctx.set_state(init)
+        for t in range(2):
+            r, p = rp_schedule(t)
+            ctx.gibbs_sweep(r, p, 4096, t)
+        out.append((ctx.get_state(), ctx.sweep_stats()["n_changes"], ctx.loglik()))
+    big.close()
+    (a, ca, la), (b, cb, lb) = out
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] and ca == cb and la == lb
