@@ -135,7 +135,18 @@ def main():
     # 14.3 k once a second of sweeps had run (tools/ramp_test.py) — so the same workload runs for RC_BENCH_SETTLE_MS (default 400,
     # 0 = off; reported as config.settle_ms) before the warm-up and the timed steps.
     settle_ms = float(os.environ.get("RC_BENCH_SETTLE_MS", 400))
+    unsettled = None
     if settle_ms > 0:
+        # the same W + K steps once BEFORE the settle phase (no event timing), reported beside the headline as
+        # config.sweeps_per_s_before_settle: what the window measures straight after the idle set-up phase
+        for _ in range(args.warmup):
+            ctx.gibbs_sweep(r, p, chain_seed, sweep, blocking=False); sweep += 1
+        ctx.synchronize()
+        t_u = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.gibbs_sweep(r, p, chain_seed, sweep, blocking=False); sweep += 1
+        ctx.synchronize()
+        unsettled = args.steps / (time.perf_counter() - t_u)
         t_s = time.perf_counter()
         while (time.perf_counter() - t_s) * 1e3 < settle_ms:
             for _ in range(256):
@@ -318,7 +329,7 @@ def main():
             "config": {"workload": f"generatemixture N={n} K={K} dim={K} sigma=0.1 dense Float64 distM ({BITS}-bit fixed-point storage), 1 chain per GPU, "
                                    "numMH=0 Gibbs sweep, init = generating labels (stationary), r=1 p=0.5",
                        "chains": world, "n": n, "K": K, "parallelism": f"chains x{world}",
-                       "settle_ms": settle_ms, "settle_note": "untimed sweeps of the same workload before the warm-up steps (device clocks of a running chain; RC_BENCH_SETTLE_MS=0 disables)"},
+                       "settle_ms": settle_ms, "sweeps_per_s_before_settle": unsettled, "settle_note": "untimed sweeps of the same workload before the warm-up steps (device clocks of a running chain; RC_BENCH_SETTLE_MS=0 disables)"},
             "logD": "derived on the fly (table log of the fixed-point D)" if derived else "stored",
             "sweep_GBps_algorithmic": value / world * survey_bytes / 1e9,          # whole sweep (not just the kernel) at §8(d) bytes
             "sweep_frac_of_hbm_peak": value / world * survey_bytes / 1e9 / HBM_PEAK_GBPS,
