@@ -17,10 +17,11 @@ ctx.synchronize()
 L = rc.lib()
 out = np.zeros((8192, 16), np.int64)
 L.rc_debug_prof.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
-names = {2: "(commit: tables)", 6: "eval tentative", 7: "barrier 1", 8: "assemble batch", 14: "batch_sim", 9: "restore + lists", 10: "eval validate", 11: "barrier 2", 12: "commit"}
+names = {6: "eval tentative", 7: "barrier 1", 8: "assemble batch", 14: "batch_sim", 9: "restore + lists", 10: "eval validate", 11: "barrier 2", 12: "commit"}
 base0 = None
 if os.environ.get("RC_PROF_SIM"):
     L.rc_debug_prof(ctx.h, 0, out.ctypes.data_as(C.c_void_p)); base0 = out[0, :11].astype(np.float64).copy()
+if os.environ.get("RC_PROF_COMMIT"): names = {2: "(commit: tables)", **names}   # -DRC_PROF_COMMIT build: column 2 = table rebuild inside the commit
 acc = {k: [] for k in names}; mx = {k: [] for k in names}; mn = {k: [] for k in names}; rounds = []; tot = []
 for t in range(60, 80):
     ctx.gibbs_sweep(1.0, 0.5, 7, t, blocking=True)
