@@ -132,7 +132,7 @@ def main():
     sweep = 0
     # Device settle (untimed, before the W warm-up steps): a short window right after the idle set-up phase does not see the clocks
     # of a running chain — 20 timed sweeps measured 13.2 k sweeps/s after a host-side pause, 12.1 k over the following 200 sweeps and
-    # 14.3 k once a second of sweeps had run (tools/ramp_test.py) — so the same workload runs for RC_BENCH_SETTLE_MS (default 400,
+    # 14.3 k once a second of sweeps had run (tools/ramp_probe.py) — so the same workload runs for RC_BENCH_SETTLE_MS (default 400,
     # 0 = off; reported as config.settle_ms) before the warm-up and the timed steps.
     settle_ms = float(os.environ.get("RC_BENCH_SETTLE_MS", 400))
     unsettled = None

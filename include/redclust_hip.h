@@ -65,9 +65,13 @@ typedef struct rc_sweep_stats {
  * storage_bits: 64 (int64 fixed point; the Float64 path) or 32 (int32 fixed point: every entry rounded to
  * 2^-30 of the largest magnitude, half the HBM traffic; all sums stay exact 64-bit integers and scores stay f64
  * — the counterpart of BASELINE config 5's Float32 storage, which the reference itself does not have).
- * kcap: slot capacity = most clusters the state may hold at once (0 = default min(n, 512); at most 4096; RC_ERR_CAPACITY
- * when a sweep would need more — up to 512 the resolver's tables fit beside the row reduction on a CU, beyond it a sweep is
- * ≈15 % slower at n = 8192).
+ * kcap: INITIAL slot capacity (clusters the sweep kernel's tables hold).  It grows on demand — rc_set_state with more
+ * clusters, a sweep or a split–merge proposal that needs one more slot: the tables are doubled, the sweep is resumed at the
+ * point that needed the slot and the sweeps enqueued behind it are replayed; the chain is exactly the one a larger capacity
+ * would have produced — up to min(n, 4096), the most the kernel's LDS-resident tables hold (the reference's clustsizes has
+ * length n, src/types.jl:131-137, src/mcmc.jl:198-199: any n <= 4096 is unrestricted; beyond, more than 4096 simultaneous
+ * clusters is RC_ERR_CAPACITY).  0 = automatic: sized from the first state (twice its cluster count, at least 128).  Small
+ * capacities are faster (the tables sit beside more row-reduction blocks on a CU); rc_capacity_info reports the current one.
  * device_id: HIP device ordinal. */
 int32_t rc_create(int64_t n, const double *D, const double *logD_or_null, int32_t storage_bits,
                   int32_t device_id, int64_t kcap, rc_ctx **out);
@@ -99,6 +103,9 @@ int32_t rc_get_state(rc_ctx *ctx, int64_t *clusts /* n */, int64_t *clustsizes /
  * would under the uniform stream (seed, sweep_index).  Blocking. */
 int32_t rc_gibbs_sweep(rc_ctx *ctx, double r, double p, uint64_t seed, uint64_t sweep_index);
 int32_t rc_last_sweep_stats(rc_ctx *ctx, rc_sweep_stats *out);
+/* Current slot capacity, its ceiling min(n, 4096), the number of growths so far and the resolver's batch capacity (each
+ * pointer may be NULL).  Diagnostics; no reference counterpart. */
+int32_t rc_capacity_info(rc_ctx *ctx, int64_t *kcap, int64_t *kcap_max, int64_t *n_grows, int64_t *batch_capacity);
 
 /* Data flow of the sweep.  RC_MODE_FULL (default) recomputes the row-sum table S[k][i] = Σ_j D[i,j]·[c_j = k] from
  * the matrices in every sweep — what the reference does (src/mcmc.jl:206-214) and what the HBM roofline metric
@@ -231,6 +238,10 @@ typedef struct rc_chain_outputs {
 } rc_chain_outputs;
 
 int32_t rc_run_chain(rc_ctx *ctx, const rc_chain_options *opt, rc_chain_outputs *out);
+/* Counters of the last rc_run_chain on this context (each pointer may be NULL): rollbacks of the speculative split–merge
+ * pipeline (an accepted proposal voids the iterations launched behind it), split proposals evaluated off the live state,
+ * host worker threads used, capacity growths during the run.  Diagnostics; no reference counterpart. */
+int32_t rc_chain_stats(rc_ctx *ctx, int64_t *rollbacks, int64_t *split_evals, int64_t *workers, int64_t *grows);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Chain-parallel execution: independent chains, one per GPU; the single exchange step is the SUM
@@ -265,7 +276,7 @@ typedef struct rc_chains_input {
     int64_t dim;
     int32_t storage_bits;        /* 64 or 32 */
     int32_t pad_;
-    int64_t kcap;                /* 0 = default */
+    int64_t kcap;                /* initial slot capacity as rc_create, 0 = automatic */
     const rc_params *params;
     const int64_t *init_clusts;  /* n labels: every chain starts from them (MCMCState.clusts) */
 } rc_chains_input;

@@ -9,6 +9,6 @@ from ._lib import Context, Comm, measure_read_ceiling, RedClustHIPError, RedClus
 from .types import MCMCData, MCMCOptionsList, MCMCResult, MCMCState, PriorHyperparamsList  # noqa: F401
 from .sampler import runsampler, sample_r, sample_p, iac_ess_acf  # noqa: F401
 from .datagen import generatemixture, likelihood_hyperparams, likelihood_hyperparams_device  # noqa: F401
-from .chains import chain_seed, merge_chains, run_chains, run_chains_single_process, library_merge, device_counts_tensor  # noqa: F401
+from .chains import chain_seed, merge_chains, run_chains, run_chains_single_process, library_merge, agreed_merge, device_counts_tensor  # noqa: F401
 from .pointestimate import (getpointestimate, lossmatrix, binderloss, infodist, varinfo, evaluateclustering,  # noqa: F401
                             summarise)

@@ -141,6 +141,8 @@ SIGNATURES = {
     "rc_layout_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rc_event_overhead_ms": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double)]),
     "rc_kernel_timing": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "rc_capacity_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "rc_chain_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 }
 
 _lib = None
@@ -370,6 +372,19 @@ class Context:
         for k in ("r_acceptances", "splitmerge_acceptances", "splitmerge_splits"):
             res[k] = res[k].astype(bool)
         return res
+
+    def capacity_info(self) -> dict:
+        """Slot capacity now, its ceiling min(n, 4096), growths so far, the resolver's batch capacity."""
+        v = [C.c_int64(0) for _ in range(4)]
+        self._chk(self.L.rc_capacity_info(self.h, *[C.byref(x) for x in v]))
+        return dict(kcap=int(v[0].value), kcap_max=int(v[1].value), n_grows=int(v[2].value), batch_capacity=int(v[3].value))
+
+    def chain_stats(self) -> dict:
+        """Counters of the last run_chain: rollbacks of the speculative pipeline, off-line split evaluations, worker threads,
+        capacity growths."""
+        v = [C.c_int64(0) for _ in range(4)]
+        self._chk(self.L.rc_chain_stats(self.h, *[C.byref(x) for x in v]))
+        return dict(rollbacks=int(v[0].value), split_evals=int(v[1].value), workers=int(v[2].value), grows=int(v[3].value))
 
     def within_between(self) -> dict:
         """rc_within_between: |A|, ΣA, Σlog A and |B|, ΣB, Σlog B of fitprior's split under the current labels."""

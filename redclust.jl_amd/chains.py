@@ -63,11 +63,49 @@ def library_merge(ctx, local_device: int, num_samples: int, group=None):
         comm.close()
 
 
+def agreed_merge(ctx, local_device: int, num_samples: int, group=None, *, probe=None, lib_merge=None, fallback=None):
+    """The exchange step with the path AGREED by all ranks before anyone enters a collective.  Every rank probes the
+    library's RCCL (opening librccl, `Comm.unique_id()`) inside try; the ok flags are MIN-all-reduced; if every rank can use
+    the library the counts are merged by rc_comm_allreduce_counts (`library_merge`), otherwise every rank falls back to a
+    torch.distributed all-reduce of the library's device count buffer (`merge_chains`).  A rank that alone failed to open
+    librccl would otherwise raise while the others block in broadcast_object_list / ncclCommInitRank for ever.
+    Returns (total_samples, allreduce_ms, path).  probe / lib_merge / fallback are injection points of the CPU tests."""
+    import time
+    import torch
+    import torch.distributed as dist
+    from ._lib import Comm
+    probe = probe or Comm.unique_id
+    ok, why = 1, ""
+    try:
+        probe()
+    except Exception as e:   # noqa: BLE001
+        ok, why = 0, str(e)
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if distributed:
+        on_gpu = dist.get_backend(group) == "nccl"
+        flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", local_device) if on_gpu else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        ok = int(flag.item())
+    if ok:
+        total, ms = (lib_merge or library_merge)(ctx, local_device, num_samples, group)
+        return total, ms, "libredclust_hip.so rc_comm_allreduce_counts (RCCL ncclAllReduce sum uint32, in place)"
+    t0 = time.perf_counter()
+    if fallback is not None:
+        total = fallback(ctx, local_device, num_samples, group)
+    else:
+        counts = device_counts_tensor(ctx, local_device)     # zero-copy view: the reduction lands in the library's buffer
+        _c, total, _tr = merge_chains(counts, num_samples, {}, group)
+        torch.cuda.synchronize(local_device)
+    ms = (time.perf_counter() - t0) * 1e3
+    return total, ms, f"torch.distributed all_reduce (library RCCL unavailable on some rank{': ' + why if why else ''})"
+
+
 def run_chains(data, options, params, init, *, base_seed: int = 1, verbose: bool = False, kcap: int = 0):
     """One chain per rank on its own GPU (LOCAL_RANK): a thin caller of the library — the chain runs through
-    runsampler(ctx=...), the counts are merged by rc_comm_allreduce_counts (RCCL inside libredclust_hip.so) and the
-    merged matrix is rc_cocluster of the merged counts.  Returns (local MCMCResult, merged posterior_coclustering
-    (n×n float64), per-chain traces)."""
+    runsampler(ctx=...), the counts are merged by rc_comm_allreduce_counts (RCCL inside libredclust_hip.so; all ranks agree
+    on that path first and fall back to a torch.distributed all-reduce together, `agreed_merge`) and the merged matrix is
+    rc_cocluster of the merged counts.  Returns (local MCMCResult, merged posterior_coclustering (n×n float64), per-chain
+    traces)."""
     import os
     import torch
     import torch.distributed as dist
@@ -79,13 +117,14 @@ def run_chains(data, options, params, init, *, base_seed: int = 1, verbose: bool
     ndev = torch.cuda.device_count()
     if local >= ndev:
         raise RuntimeError(f"run_chains: LOCAL_RANK={local} but only {ndev} GPU(s) are visible — launch one process per GPU")
+    torch.cuda.set_device(local)      # the object collectives below stage through the current device under nccl
     ctx = (Context.from_points(data.points, device=local, kcap=kcap) if data.points is not None
            else Context(data.D, device=local, kcap=kcap))
     try:
         res = runsampler(data, options, params, init, verbose=verbose and rank == 0,
                          seed=chain_seed(base_seed, rank), ctx=ctx)
         traces = dict(rank=rank, K=res.K, r=res.r, p=res.p, loglik=res.loglik, logposterior=res.logposterior)
-        total, _ms = library_merge(ctx, local, options.numsamples)
+        total, _ms, _path = agreed_merge(ctx, local, options.numsamples)
         merged = ctx.cocluster(max(total, 1))
         chains = [traces]
         if dist.is_initialized() and dist.get_world_size() > 1:

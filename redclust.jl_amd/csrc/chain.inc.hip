@@ -12,6 +12,10 @@
 // Beta = Gamma ratio.  (The reference samples through Distributions.jl on Julia's global RNG — same distributions,
 // irreproducible stream.)
 
+// chains running rc_run_chain in this process right now (rc_run_chains announces all of its chains before any starts)
+static std::atomic<int> g_chains_running{0};
+static thread_local bool t_counted_by_driver = false;
+
 namespace chain {
 
 struct Stream {
@@ -364,13 +368,19 @@ static int32_t spec_record(rc_ctx *c, SpecSlot &after, int64_t j, double r, doub
 // apply_labels would give it, so the terms are summed in the same order and the value is the one the synchronous path
 // computes after applying the proposal.  Returns RC_ERR_CAPACITY (no error text) when there is no free slot: the caller
 // falls back to the synchronous path.
-struct SplitScratch { unsigned short *d_bucket = nullptr; int *d_rows = nullptr; long long *d_out = nullptr, *h_out = nullptr; std::vector<unsigned short> bucket; std::vector<int> rows; };
+struct SplitScratch {
+    unsigned short *d_bucket = nullptr; int *d_rows = nullptr; long long *d_out = nullptr, *h_out = nullptr;
+    int cap = 0;                 // slot capacity d_out / h_out were sized for (the context's capacity can grow)
+    std::vector<unsigned short> bucket; std::vector<int> rows;
+    void release_out() { if (d_out) (void)hipFree(d_out); if (h_out) (void)hipHostFree(h_out); d_out = nullptr; h_out = nullptr; }
+    ~SplitScratch() { if (d_bucket) (void)hipFree(d_bucket); if (d_rows) (void)hipFree(d_rows); release_out(); }   // every early return of the loop frees it
+};
 
 static int32_t spec_eval_split(rc_ctx *c, rc_ctx::LLCache &cache, SplitScratch &X, const SpecSlot &s, ProposalResult &R)
 {
     const int n = c->n, hi = s.hi;
     int f = -1;
-    for (int k = 0; k < c->kcap; ++k)
+    for (int k = 0; k < (int)s.slabel.size(); ++k)     // (the snapshot's own table: the context's capacity may have grown since)
         if (s.slabel[(size_t)k] == 0) { f = k; break; }
     if (f < 0) return RC_ERR_CAPACITY;
     const int h2 = std::max(hi, f + 1);
@@ -378,9 +388,13 @@ static int32_t spec_eval_split(rc_ctx *c, rc_ctx::LLCache &cache, SplitScratch &
     if (!X.d_bucket) {
         HIPCHK(c, hipMalloc((void **)&X.d_bucket, (size_t)c->ld * sizeof(unsigned short)));
         HIPCHK(c, hipMalloc((void **)&X.d_rows, (size_t)n * sizeof(int)));
-        HIPCHK(c, hipMalloc((void **)&X.d_out, (size_t)(c->kcap + 1) * 4 * sizeof(long long)));
-        HIPCHK(c, hipHostMalloc((void **)&X.h_out, (size_t)(c->kcap + 1) * 4 * sizeof(long long), hipHostMallocDefault));
         X.bucket.resize((size_t)c->ld); X.rows.resize((size_t)n);
+    }
+    if (X.cap < c->kcap) {
+        X.release_out();
+        X.cap = c->kcap;
+        HIPCHK(c, hipMalloc((void **)&X.d_out, (size_t)(X.cap + 1) * 4 * sizeof(long long)));
+        HIPCHK(c, hipHostMalloc((void **)&X.h_out, (size_t)(X.cap + 1) * 4 * sizeof(long long), hipHostMallocDefault));
     }
     // buckets in the internal point order: the snapshot's slot, except that the points moved to the new label go to f
     int si = -1, nrows = 0, new_label = 0;
@@ -435,8 +449,13 @@ static int32_t run_chain_speculative(rc_ctx *c, const rc_chain_options *o, rc_ch
     const int n = c->n;
     const rc_params &P = c->P;
     const int Dmax = std::max(1, std::min(64, getenv("RC_CHAIN_DEPTH") ? atoi(getenv("RC_CHAIN_DEPTH")) : 12));
-    int nw = getenv("RC_CHAIN_WORKERS") ? atoi(getenv("RC_CHAIN_WORKERS")) : (int)std::min<unsigned>(12u, std::max(2u, std::thread::hardware_concurrency()) - 1u);
+    // worker threads: the host's cores shared by the chains this process runs at once (rc_run_chains: one per GPU — eight
+    // chains must not start 96 threads), one core left to each chain's main thread; at most 12
+    const int chains_here = std::max(1, g_chains_running.load());
+    const int cores = (int)std::max(2u, std::thread::hardware_concurrency());
+    int nw = getenv("RC_CHAIN_WORKERS") ? atoi(getenv("RC_CHAIN_WORKERS")) : std::min(12, std::max(1, cores / chains_here - 1));
     nw = std::max(1, std::min(nw, Dmax));
+    const long long grows0 = c->n_grows;
     const int Rn = Dmax + 2;
     SpecPool pool(c, o, Rn);
     pool.start(nw);
@@ -448,6 +467,12 @@ static int32_t run_chain_speculative(rc_ctx *c, const rc_chain_options *o, rc_ch
     int64_t j = 0, conf = 1, i = 1, prev_it = -1;   // prev_it: iteration of the last snapshot taken with the device untouched since
     int D = Dmax, clean_run = 0;
     SplitScratch scratch;
+    // A device error (slot capacity beyond the library's maximum, barrier time-out) of a sweep that was launched on speculation
+    // belongs to an iteration that may yet be voided by an accepted proposal before it: it is kept here, no further iteration
+    // is started, and it is reported only once every iteration before the failed sweep has been confirmed clean — what the
+    // synchronous loop would have reported too.  A rollback before that point discards it with the void sweeps.
+    int32_t spec_err = RC_OK;
+    std::string spec_msg;
     long long n_rollbacks = 0, n_split_evals = 0; double t_rollback = 0, t_sync = 0, t_snap = 0, t_evwait = 0, t_build = 0, t_confirm = 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
@@ -456,10 +481,14 @@ static int32_t run_chain_speculative(rc_ctx *c, const rc_chain_options *o, rc_ch
     auto recording = [&](int64_t it) { return it > o->burnin && (it - o->burnin) % o->thin == 0; };
     while (conf <= N) {
         // 1. start iteration i (i == N + 1: only the closing snapshot, the state the last iteration ended in)
-        if (i <= N + 1 && i - conf <= D) {
+        if (i <= N + 1 && i - conf <= D && spec_err == RC_OK) {
             const auto ta = now();
             rc = sync_and_check(c);                        // the state iteration i starts from is complete; K and sizes visible
-            if (rc != RC_OK) return rc;
+            if (rc != RC_OK) {
+                if (i == conf) return rc;                  // every iteration before i is confirmed: the sweep that failed is real
+                spec_err = rc; spec_msg = c->err;
+                continue;
+            }
             const auto tb = now(); t_sync += secs(ta, tb);
             SpecSlot &s = pool.slots[(size_t)slot_of_it(i)];
             s.it = i;
@@ -497,7 +526,7 @@ static int32_t run_chain_speculative(rc_ctx *c, const rc_chain_options *o, rc_ch
             if (i <= N) {
                 s.labels.resize((size_t)n); s.sizes.assign((size_t)n, 0);
                 for (int q = 0; q < n; ++q) s.labels[(size_t)q] = s.slabel[(size_t)s.pin_lab[q]];
-                for (int k = 0; k < c->kcap; ++k)
+                for (int k = 0; k < (int)s.slabel.size(); ++k)
                     if (s.slabel[(size_t)k] > 0) s.sizes[(size_t)s.slabel[(size_t)k] - 1] = s.ssize[(size_t)k];
                 s.acc.assign((size_t)o->numMH, 0); s.spl.assign((size_t)o->numMH, 0);
                 s.clean = false; s.err = RC_OK; s.split_pending = false;
@@ -510,13 +539,15 @@ static int32_t run_chain_speculative(rc_ctx *c, const rc_chain_options *o, rc_ch
         while (conf <= N && conf < i) {
             const int si = slot_of_it(conf);
             SpecSlot &s = pool.slots[(size_t)si];
-            const bool can_start_more = (i <= N + 1 && i - conf <= D);
+            const bool can_start_more = (spec_err == RC_OK && i <= N + 1 && i - conf <= D);
             if (!pool.done(si)) {
                 if (can_start_more) break;
                 pool.wait(si);
             }
             if (s.err != RC_OK) return fail(c, s.err, "%s", s.errmsg ? s.errmsg : "split-merge proposal failed");
             if (s.clean) {
+                // iteration conf is confirmed, so its sweep was real; if that is the sweep whose failure is on hold, report it now
+                if (spec_err != RC_OK && conf + 1 >= i) return fail(c, spec_err, "%s", spec_msg.c_str());
                 if (recording(conf) && conf + 1 >= i) break;                  // the snapshot this sample is read from comes next
                 for (int64_t mh = 0; mh < o->numMH; ++mh) {
                     if (out->splitmerge_acceptances) out->splitmerge_acceptances[(conf - 1) * o->numMH + mh] = 0;
@@ -562,11 +593,24 @@ static int32_t run_chain_speculative(rc_ctx *c, const rc_chain_options *o, rc_ch
             // rollback: a proposal of iteration `conf` is accepted (or could not be evaluated off-line).  Everything started after it is void.
             const auto tr0 = now(); ++n_rollbacks;
             pool.drain();
-            rc = sync_and_check(c, true);
-            if (rc != RC_OK) return rc;
             c->checkpoint = s.labels;                                          // the state iteration conf started from
-            rc = rc_state_restore(c);
-            if (rc != RC_OK) return rc;
+            if (spec_err != RC_OK) {
+                // the failed sweep came after this iteration and is void with it: rc_set_state installs the snapshot's labels
+                // afresh (the device error word and the half-swept state go with it)
+                spec_err = RC_OK; spec_msg.clear();
+                rc = rc_set_state(c, s.labels.data());
+                if (rc != RC_OK) return rc;
+            } else {
+                rc = sync_and_check(c, true);
+                if (rc != RC_OK) {
+                    // a speculative sweep behind this iteration failed after the last check: void as well
+                    rc = rc_set_state(c, s.labels.data());
+                    if (rc != RC_OK) return rc;
+                } else {
+                    rc = rc_state_restore(c);
+                    if (rc != RC_OK) return rc;
+                }
+            }
             const uint64_t it = o->first_iter + (uint64_t)(conf - 1);
             bool accepted_any = false;
             for (int64_t mh = 0; mh < o->numMH; ++mh) {                        // the synchronous path, mcmc.jl:372-474
@@ -612,9 +656,9 @@ static int32_t run_chain_speculative(rc_ctx *c, const rc_chain_options *o, rc_ch
         fprintf(stderr, "[rc_run_chain speculative] %lld iterations %.3f s: %lld rollbacks %.3f s, %lld splits evaluated off-line; wait for sweep %.3f s, snapshot + launch %.3f s, wait for snapshot %.3f s, job build %.3f s; %d workers depth %d\n",
                 (long long)N, out->runtime_s, n_rollbacks, t_rollback, n_split_evals, t_sync, t_snap, t_evwait, t_build, nw, Dmax);
     (void)t_confirm;
+    c->chain_rollbacks = n_rollbacks; c->chain_split_evals = n_split_evals; c->chain_workers = nw; c->chain_grows = c->n_grows - grows0;
     out->r_final = r_prev;
     out->p_final = p_prev;
-    if (scratch.d_bucket) { (void)hipFree(scratch.d_bucket); (void)hipFree(scratch.d_rows); (void)hipFree(scratch.d_out); (void)hipHostFree(scratch.h_out); }
     return RC_OK;
 }
 
@@ -634,6 +678,16 @@ extern "C" int32_t rc_scalar_updates(uint64_t seed, uint64_t iter, double r, dou
     return RC_OK;
 }
 
+extern "C" int32_t rc_chain_stats(rc_ctx *c, int64_t *rollbacks, int64_t *split_evals, int64_t *workers, int64_t *grows)
+{
+    if (!c) return fail(c, RC_ERR_ARG, "rc_chain_stats: NULL ctx");
+    if (rollbacks) *rollbacks = c->chain_rollbacks;
+    if (split_evals) *split_evals = c->chain_split_evals;
+    if (workers) *workers = c->chain_workers;
+    if (grows) *grows = c->chain_grows;
+    return RC_OK;
+}
+
 extern "C" int32_t rc_run_chain(rc_ctx *c, const rc_chain_options *o, rc_chain_outputs *out)
 {
     if (!c || !o || !out) return fail(c, RC_ERR_ARG, "rc_run_chain: NULL argument");
@@ -645,8 +699,16 @@ extern "C" int32_t rc_run_chain(rc_ctx *c, const rc_chain_options *o, rc_chain_o
     if (o->numMH > 0 && (!c->hostD || !c->hostL)) return fail(c, RC_ERR_STATE, "rc_run_chain: numMH > 0 needs rc_attach_host_matrices");
     if ((o->r_trace == nullptr) != (o->p_trace == nullptr)) return fail(c, RC_ERR_ARG, "rc_run_chain: give both r_trace and p_trace or neither");
     HIPCHK(c, hipSetDevice(c->dev));
+    c->chain_rollbacks = c->chain_split_evals = c->chain_workers = c->chain_grows = 0;
+    struct Running {   // counted while the loop runs (unless rc_run_chains has counted all of its chains already)
+        bool counted;
+        Running() : counted(!t_counted_by_driver) { if (counted) ++g_chains_running; }
+        ~Running() { if (counted) --g_chains_running; }
+    } running;
     if (o->numMH > 0 && o->numiters > 0 && !(getenv("RC_CHAIN_PIPELINE") && atoi(getenv("RC_CHAIN_PIPELINE")) == 0))
         return chain::run_chain_speculative(c, o, out);
+    const long long grows0 = c->n_grows;
+    struct GrowNote { rc_ctx *c; long long g0; ~GrowNote() { c->chain_grows = c->n_grows - g0; } } grow_note{c, grows0};
     const int n = c->n;
     const rc_params &P = c->P;
     int32_t rc = sync_and_check(c, true);

@@ -188,12 +188,21 @@ extern "C" int32_t rc_comm_allreduce_counts(rc_comm *cm, rc_ctx *const *ctxs, co
     }
     const auto t0 = std::chrono::steady_clock::now();
     NCCLCHK(A.GroupStart());
-    for (int i = 0; i < cm->n_local; ++i) {
-        HIPCHK0(hipSetDevice(cm->devs[(size_t)i]));
-        NCCLCHK(A.AllReduce(bufs[(size_t)i], bufs[(size_t)i], count, ncclUint32, ncclSum, cm->comms[(size_t)i], cm->streams[(size_t)i]));
-        NCCLCHK(A.AllReduce(cm->ns[(size_t)i], cm->ns[(size_t)i], 1, ncclInt64, ncclSum, cm->comms[(size_t)i], cm->streams[(size_t)i]));
+    // inside the group nothing returns early: the first error is kept, the group is always closed (an open group would make
+    // every later RCCL call of this thread — rc_comm_destroy included — misbehave or hang), and only then reported
+    ncclResult_t first_nccl = ncclSuccess;
+    hipError_t first_hip = hipSuccess;
+    for (int i = 0; i < cm->n_local && first_nccl == ncclSuccess && first_hip == hipSuccess; ++i) {
+        first_hip = hipSetDevice(cm->devs[(size_t)i]);
+        if (first_hip != hipSuccess) break;
+        first_nccl = A.AllReduce(bufs[(size_t)i], bufs[(size_t)i], count, ncclUint32, ncclSum, cm->comms[(size_t)i], cm->streams[(size_t)i]);
+        if (first_nccl != ncclSuccess) break;
+        first_nccl = A.AllReduce(cm->ns[(size_t)i], cm->ns[(size_t)i], 1, ncclInt64, ncclSum, cm->comms[(size_t)i], cm->streams[(size_t)i]);
     }
-    NCCLCHK(A.GroupEnd());
+    const ncclResult_t end_nccl = A.GroupEnd();
+    if (first_hip != hipSuccess) return fail(nullptr, RC_ERR_HIP, "rc_comm_allreduce_counts: hipSetDevice: %s", hipGetErrorString(first_hip));
+    if (first_nccl != ncclSuccess) return fail(nullptr, RC_ERR_HIP, "rc_comm_allreduce_counts: ncclAllReduce: RCCL error: %s", A.GetErrorString(first_nccl));
+    if (end_nccl != ncclSuccess) return fail(nullptr, RC_ERR_HIP, "rc_comm_allreduce_counts: ncclGroupEnd: RCCL error: %s", A.GetErrorString(end_nccl));
     for (int i = 0; i < cm->n_local; ++i) {
         HIPCHK0(hipSetDevice(cm->devs[(size_t)i]));
         HIPCHK0(hipStreamSynchronize(cm->streams[(size_t)i]));
@@ -206,8 +215,25 @@ extern "C" int32_t rc_comm_allreduce_counts(rc_comm *cm, rc_ctx *const *ctxs, co
     return RC_OK;
 }
 
+static int32_t run_chains_impl(int32_t n_chains, const int32_t *device_ids, const rc_chains_input *in, const rc_chain_options *opt,
+                               rc_chain_outputs *outs, double *posterior_coclustering, int64_t *total_samples, double *allreduce_ms);
+
+// Nothing may be thrown across the C boundary (a std::bad_alloc for the n² host logD at config 5, a std::system_error from
+// std::thread): it would terminate the Julia / Python host.
 extern "C" int32_t rc_run_chains(int32_t n_chains, const int32_t *device_ids, const rc_chains_input *in, const rc_chain_options *opt,
                                  rc_chain_outputs *outs, double *posterior_coclustering, int64_t *total_samples, double *allreduce_ms)
+{
+    try {
+        return run_chains_impl(n_chains, device_ids, in, opt, outs, posterior_coclustering, total_samples, allreduce_ms);
+    } catch (const std::bad_alloc &) {
+        return fail(nullptr, RC_ERR_OOM, "rc_run_chains: out of host memory");
+    } catch (const std::exception &e) {
+        return fail(nullptr, RC_ERR_HIP, "rc_run_chains: %s", e.what());
+    }
+}
+
+static int32_t run_chains_impl(int32_t n_chains, const int32_t *device_ids, const rc_chains_input *in, const rc_chain_options *opt,
+                               rc_chain_outputs *outs, double *posterior_coclustering, int64_t *total_samples, double *allreduce_ms)
 {
     if (n_chains < 1 || !device_ids || !in || !opt || !outs) return fail(nullptr, RC_ERR_ARG, "rc_run_chains: need n_chains >= 1, device_ids, input, options and outputs");
     if (!in->params || !in->init_clusts || (!in->D && !in->points)) return fail(nullptr, RC_ERR_ARG, "rc_run_chains: input needs params, init_clusts and D or points");
@@ -222,12 +248,16 @@ extern "C" int32_t rc_run_chains(int32_t n_chains, const int32_t *device_ids, co
     std::vector<double> hostL;   // log.(D - Diagonal(D) + I) for the split-merge scans when the caller gave none (types.jl:155)
     const double *Lhost = in->logD_or_null;
     if (opt->numMH > 0 && !Lhost) {
-        hostL.resize((size_t)in->n * (size_t)in->n);
+        try { hostL.resize((size_t)in->n * (size_t)in->n); }
+        catch (const std::bad_alloc &) { rc_comm_destroy(cm); return fail(nullptr, RC_ERR_OOM, "rc_run_chains: no host memory for the %lld x %lld logD of the split-merge scans (pass logD, or numMH = 0)", (long long)in->n, (long long)in->n); }
         for (int64_t i = 0; i < in->n; ++i)
             for (int64_t j = 0; j < in->n; ++j) hostL[(size_t)(i * in->n + j)] = (i == j) ? 0.0 : std::log(in->D[(size_t)(i * in->n + j)]);
         Lhost = hostL.data();
     }
+    g_chains_running += n_chains;     // all chains of this call, before any starts: each sizes its worker pool by the share of the host's cores
+    struct Announce { int n; ~Announce() { g_chains_running -= n; } } announce{n_chains};
     auto worker = [&](int ci) {
+        t_counted_by_driver = true;
         rc_ctx *c = nullptr;
         int32_t r = in->D ? rc_create(in->n, in->D, in->logD_or_null, in->storage_bits, device_ids[ci], in->kcap, &c)
                           : rc_create_from_points(in->n, in->dim, in->points, in->storage_bits, device_ids[ci], in->kcap, &c);
@@ -244,7 +274,11 @@ extern "C" int32_t rc_run_chains(int32_t n_chains, const int32_t *device_ids, co
     };
     {
         std::vector<std::thread> th;
-        for (int ci = 0; ci < n_chains; ++ci) th.emplace_back(worker, ci);
+        th.reserve((size_t)n_chains);
+        for (int ci = 0; ci < n_chains; ++ci) {
+            try { th.emplace_back(worker, ci); }
+            catch (const std::system_error &e) { rcs[(size_t)ci] = RC_ERR_HIP; errs[(size_t)ci] = std::string("could not start the chain's host thread: ") + e.what(); break; }
+        }
         for (auto &t : th) t.join();
     }
     auto cleanup = [&]() {

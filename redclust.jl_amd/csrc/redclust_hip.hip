@@ -51,6 +51,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -116,6 +117,11 @@ struct DevScalars {
     int slot_hi;            // 1 + highest slot index used since rc_set_state (rows >= slot_hi of every S buffer are zero)
     int last_change_sweep;  // internal index of the last sweep that changed a label (-1: none)
     int runs;               // number of label runs in natural point order (#{i : slot[i] != slot[i-1]} + 1)
+    // written by the sweep that ran out of slots (RC_DERR_CAPACITY): the host grows the tables and resumes it (recover_capacity)
+    int fail_t;             // internal index of that sweep
+    int resume_after;       // every point <= resume_after (caller's order) is final; the next one needs a new slot
+    int fail_changes;       // label changes it had committed
+    int fail_rounds;        // rounds it had run
 };
 
 // Per-sweep summary written by block 0 of k_resolve straight into host-mapped pinned memory: the host needs K and
@@ -124,7 +130,8 @@ struct DevScalars {
 constexpr int RC_REC_SLOTS = 2;  // sample slots of the asynchronous recorder (rc_run_chain)
 
 struct HostSummary {
-    int K, n_changes, n_rounds, err, slot_hi, seq, runs, pad1;
+    int K, n_changes, n_rounds, err, slot_hi, seq, runs, fail_t;
+    int resume_after, fail_changes, fail_rounds, pad1;   // (see DevScalars)
     int size_label[2 * RC_MAX_KCAP];  // [2k] = size of slot k, [2k+1] = its 1-based label (0 = free)
 };
 
@@ -174,6 +181,9 @@ struct SweepArgs {
     int own_gen, next_gen;  // S generation read (and corrected in place); generation being filled for the next sweep (-1: none)
     int zero_gen;           // S generation this launch clears for the row reduction two sweeps ahead (-1: none)
     int dbg;  // timing ablations only (RC_DEBUG_FLAGS): 1 = skip candidate loop, 2 = skip grid barrier, 4 = skip gumbel
+    // a sweep resumed after the slot tables were grown (recover_capacity): the points <= after0 are final already, changes0 /
+    // rounds0 are what the first part of the sweep had committed / run.  A fresh sweep: -1, 0, 0.
+    int after0, changes0, rounds0;
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -2543,6 +2553,10 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
 #else
 #define RC_PHASE(k) RC_PF({ const long long now_ = __builtin_amdgcn_s_memrealtime(); ps[k] += now_ - pt_; pt_ = now_; })
 #endif
+    // A sweep that ran out of slots (or whose barrier timed out) left the error bit set: the sweeps enqueued behind it must not
+    // touch the state — the host grows the tables, resumes that sweep and replays these (recover_capacity).  The bit was set by a
+    // previous launch (resolvers are chained), so every block of this launch reads the same value.
+    if (__hip_atomic_load(&V.sc->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     Tab T = tab_carve(smem, V.kcap, V.n, blockDim.x >> 6, V.maxb);
     if (V.n > RC_USED_LDS_MAX_N) T.used = V.used_scratch + (size_t)blockIdx.x * (size_t)((V.n + 31) / 32);
     const int t = sa.t, own_gen = sa.own_gen, next_gen = sa.next_gen, kg = t & 1;
@@ -2560,7 +2574,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
     const int last = V.sc->last_change_sweep;   // (read before the first barrier as well: the epilogue rewrites it)
     RC_PF(ps[1] = __builtin_amdgcn_s_memrealtime();)
     const int nchunks = (V.n + RC_PTS - 1) / RC_PTS;
-    int after = -1, round = 0, changes = 0, nbar = 0;
+    int after = sa.after0, round = 0, changes = sa.changes0, nbar = 0;
     int cap = V.maxb;    // changers taken into the next batch (adaptive, identical in every block)
     bool ok = true;
     for (;;) {
@@ -2737,7 +2751,13 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         }
 #endif
         if (T.misc[5]) {   // the first changer needs a slot and every slot is taken
-            if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(&V.sc->err, RC_DERR_CAPACITY);
+            // Everything before it is final (the points between `after` and it drew their own labels under the committed state)
+            // and the state is consistent: the host grows the slot tables and resumes this sweep at that point.
+            if (threadIdx.x == 0 && blockIdx.x == 0) {
+                V.sc->fail_t = t; V.sc->resume_after = T.bx[0] - 1; V.sc->fail_changes = changes; V.sc->fail_rounds = sa.rounds0 + round + 1;
+                V.hsum->fail_t = t; V.hsum->resume_after = T.bx[0] - 1; V.hsum->fail_changes = changes; V.hsum->fail_rounds = sa.rounds0 + round + 1;
+                atomicOr(&V.sc->err, RC_DERR_CAPACITY);
+            }
             ok = false;
             break;
         }
@@ -2825,7 +2845,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         if (changes || t < 2) tab_store(V, T);   // (nothing committed: the tables in global memory are the ones that were loaded)
         if (threadIdx.x == 0) {
             V.sc->n_changes = changes;
-            V.sc->n_rounds = round + 1;
+            V.sc->n_rounds = sa.rounds0 + round + 1;
             if (changes) V.sc->last_change_sweep = t;
         }
         __syncthreads();
@@ -2835,7 +2855,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         snapshot_copy_grid(V, kg, G);
         if ((int)blockIdx.x == b_snap) snapshot_runs(V, &T.misc[2]);
     }
-    if (blockIdx.x == 0) write_summary(V, changes, round + 1, changes != 0 || t < 2);
+    if (blockIdx.x == 0) write_summary(V, changes, sa.rounds0 + round + 1, changes != 0 || t < 2);
     // perm generation t%2 must describe the labels after this sweep (k_bulk of sweep t+2 reads it): all blocks
     if (changes && ok) {
         __syncthreads();
@@ -3061,6 +3081,17 @@ struct rc_ctx {
     double ev_overhead_ms = 0.0;  // subtracted from every timed launch: 0 since the events ride in the dispatch (rc_event_overhead reports it)
     DevScalars last{};
     int dbg = 0;
+    long long chain_rollbacks = 0, chain_split_evals = 0, chain_workers = 0, chain_grows = 0;   // rc_chain_stats: the last rc_run_chain
+    // slot capacity (number of clusters the tables hold).  It grows on demand — rc_set_state with more clusters, a sweep or a
+    // split–merge proposal that needs one more slot — up to kcap_max = min(n, RC_MAX_KCAP); the reference's clustsizes has
+    // length n (types.jl:131-137, mcmc.jl:198-199).  kcap = 0 at rc_create: sized from the first state (kcap_auto).
+    bool kcap_auto = false;
+    bool kcap_fixed = false;      // RC_KCAP_FIXED=1: never grow (the old behaviour: RC_ERR_CAPACITY), for tests of the error path
+    int kcap_max = 0;
+    int n_grows = 0;              // capacity growths so far (rc_capacity_info)
+    struct SweepRec { double r, p; uint64_t seed, sweep_index; long long t; };
+    std::deque<SweepRec> inflight;   // sweeps enqueued since the last successful synchronisation: replayed after a capacity growth
+    bool recovering = false;
     // split–merge support (host-side proposal logic on borrowed host matrices)
     const double *hostD = nullptr, *hostL = nullptr;
     std::vector<double> ownL;            // host logD computed by the library when the caller passes none
@@ -3203,28 +3234,35 @@ static void smprof_report() { g_smprof.report(); }
 
 // Resolver launches of different contexts on one device must not overlap (launch_resolve).  A device that only ever holds
 // one context at a time — the normal case — skips the chain and its two barrier packets per sweep; the first time a second
-// context appears the device is drained once and the chain is used from then on.
-static std::mutex g_res_mutex;
-static hipEvent_t g_res_event[64] = {};
-static int g_res_contexts[64] = {};   // live contexts per device
-static bool g_res_multi[64] = {};
+// context appears the device is drained once and the chain is used until the device is back to one context.  All of this is
+// PER DEVICE (rc_run_chains drives eight devices from eight host threads of one process: their launches share nothing).
+struct ResDevice {
+    std::mutex m;             // held across the resolver launch + event records of this device only
+    hipEvent_t ev = nullptr;  // completion of the last chained resolver on this device
+    int contexts = 0;         // live contexts
+    bool multi = false;       // more than one context has been live at a time: resolvers are chained through `ev`
+};
+static ResDevice g_res[64];
 
 static void res_register(rc_ctx *c)
 {
     bool drain = false;
     {
-        std::lock_guard<std::mutex> lock(g_res_mutex);
-        const int d = c->dev & 63;
-        if (++g_res_contexts[d] > 1 && !g_res_multi[d]) { g_res_multi[d] = true; drain = true; }
+        ResDevice &rd = g_res[c->dev & 63];
+        std::lock_guard<std::mutex> lock(rd.m);
+        if (++rd.contexts > 1 && !rd.multi) { rd.multi = true; drain = true; }
     }
     if (drain) (void)hipDeviceSynchronize();   // launches made without the chain are complete before the newcomer's first one
 }
 
+// called by rc_destroy AFTER the context's streams have been drained: once a single context is left on the device nothing of
+// the leaving one is in flight, so the survivor's resolvers (ordered among themselves by ev_res) need no chain any more
 static void res_unregister(rc_ctx *c)
 {
-    std::lock_guard<std::mutex> lock(g_res_mutex);
-    const int d = c->dev & 63;
-    if (g_res_contexts[d] > 0) --g_res_contexts[d];
+    ResDevice &rd = g_res[c->dev & 63];
+    std::lock_guard<std::mutex> lock(rd.m);
+    if (rd.contexts > 0) --rd.contexts;
+    if (rd.contexts <= 1) rd.multi = false;
 }
 
 extern "C" int32_t rc_destroy(rc_ctx *ctx)
@@ -3232,11 +3270,38 @@ extern "C" int32_t rc_destroy(rc_ctx *ctx)
     smprof_report();
     if (!ctx) return RC_OK;
     (void)hipSetDevice(ctx->dev);
-    if (ctx->registered) { res_unregister(ctx); ctx->registered = false; }
     if (ctx->sA) (void)hipStreamSynchronize(ctx->sA);
     if (ctx->sB) (void)hipStreamSynchronize(ctx->sB);
     if (ctx->sB2) (void)hipStreamSynchronize(ctx->sB2);
+    if (ctx->registered) { res_unregister(ctx); ctx->registered = false; }
     free_all(ctx);
+    return RC_OK;
+}
+
+// The buffers sized by the slot capacity c->kcap: the three generations of the row-sum table, the slot tables, the score
+// cache, the block sums of loglik.  Frees what is there first (capacity growth).  Contents: zeroed where an invariant needs it
+// (rows of free slots are zero; free slots have size 0 / label 0) — rc_set_state fills the rest.
+static int32_t alloc_slot_buffers(rc_ctx *c)
+{
+    void **ptrs[] = {(void **)&c->SD[0], (void **)&c->SD[1], (void **)&c->SD[2], (void **)&c->SL[0], (void **)&c->SL[1], (void **)&c->SL[2],
+                     (void **)&c->slot_size, (void **)&c->slot_label, (void **)&c->slot_pos, (void **)&c->slot_act, (void **)&c->wc, (void **)&c->blocks};
+    for (void **pp : ptrs)
+        if (*pp) { (void)hipFree(*pp); *pp = nullptr; }
+    const size_t ld = (size_t)c->ld, k = (size_t)c->kcap;
+    for (int g = 0; g < 3; ++g) {
+        HIPCHK(c, hipMalloc(&c->SD[g], k * ld * sizeof(long long)));
+        HIPCHK(c, hipMalloc(&c->SL[g], k * ld * sizeof(long long)));
+    }
+    HIPCHK(c, hipMalloc(&c->slot_size, k * sizeof(int)));
+    HIPCHK(c, hipMalloc(&c->slot_label, k * sizeof(int)));
+    HIPCHK(c, hipMalloc(&c->slot_pos, k * sizeof(short)));
+    HIPCHK(c, hipMalloc(&c->slot_act, k * sizeof(short)));
+    if (!getenv("RC_SCORE_CACHE") || atoi(getenv("RC_SCORE_CACHE")) != 0)
+        HIPCHK(c, hipMalloc((void **)&c->wc, k * (size_t)((c->n + RC_PTS - 1) / RC_PTS * RC_PTS) * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->blocks, k * k * 4 * sizeof(long long)));
+    HIPCHK(c, hipMemsetAsync(c->slot_size, 0, k * sizeof(int), c->sA));
+    HIPCHK(c, hipMemsetAsync(c->slot_label, 0, k * sizeof(int), c->sA));
+    HIPCHK(c, hipStreamSynchronize(c->sA));
     return RC_OK;
 }
 
@@ -3308,10 +3373,6 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
         }
         HIPCHK2(hipMemcpy(c->ltab, tab, sizeof(tab), hipMemcpyHostToDevice));
     }
-    for (int g = 0; g < 3; ++g) {
-        HIPCHK2(hipMalloc(&c->SD[g], (size_t)c->kcap * ld * sizeof(long long)));
-        HIPCHK2(hipMalloc(&c->SL[g], (size_t)c->kcap * ld * sizeof(long long)));
-    }
     for (int g = 0; g < 2; ++g) {
         HIPCHK2(hipMalloc(&c->perm[g], (size_t)n * sizeof(int)));
         HIPCHK2(hipMalloc(&c->pslot[g], (size_t)n * sizeof(int)));
@@ -3326,23 +3387,19 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     HIPCHK2(hipMalloc(&c->slot_of, (size_t)n * sizeof(int)));
     HIPCHK2(hipMalloc(&c->rec, 2 * (size_t)n * sizeof(unsigned)));
     HIPCHK2(hipMalloc(&c->tent, (size_t)n * sizeof(int)));
-    HIPCHK2(hipMalloc(&c->slot_size, (size_t)c->kcap * sizeof(int)));
-    HIPCHK2(hipMalloc(&c->slot_label, (size_t)c->kcap * sizeof(int)));
-    HIPCHK2(hipMalloc(&c->slot_pos, (size_t)c->kcap * sizeof(short)));
-    HIPCHK2(hipMalloc(&c->slot_act, (size_t)c->kcap * sizeof(short)));
     c->wc_always = getenv("RC_SCORE_CACHE") && atoi(getenv("RC_SCORE_CACHE")) == 1;
-    if (!getenv("RC_SCORE_CACHE") || atoi(getenv("RC_SCORE_CACHE")) != 0) HIPCHK2(hipMalloc((void **)&c->wc, (size_t)c->kcap * (size_t)((c->n + RC_PTS - 1) / RC_PTS * RC_PTS) * sizeof(double)));
+    {
+        const int32_t rcs = alloc_slot_buffers(c);   // everything sized by the slot capacity (re-allocated when it grows)
+        if (rcs != RC_OK) { cleanup(); return rcs; }
+    }
     if (c->n > RC_USED_LDS_MAX_N) HIPCHK2(hipMalloc((void **)&c->used_scratch, (size_t)std::max(c->num_cus, 256) * (size_t)((c->n + 31) / 32) * sizeof(unsigned)));
     HIPCHK2(hipMalloc(&c->A, (size_t)(n + 1) * sizeof(double)));
     HIPCHK2(hipMalloc(&c->sc, sizeof(DevScalars)));
     HIPCHK2(hipHostMalloc((void **)&c->hsum, sizeof(HostSummary), hipHostMallocMapped));
     std::memset(c->hsum, 0, sizeof(HostSummary));
     HIPCHK2(hipHostGetDevicePointer((void **)&c->hsum_dev, c->hsum, 0));
-    HIPCHK2(hipMalloc(&c->blocks, (size_t)c->kcap * c->kcap * 4 * sizeof(long long)));
     HIPCHK2(hipMemsetAsync(c->Dq, 0, (size_t)n * ld * esz, s));
     HIPCHK2(hipMemsetAsync(c->Dq_src, 0, (size_t)n * ld * esz, s));
-    HIPCHK2(hipMemsetAsync(c->slot_size, 0, (size_t)c->kcap * sizeof(int), s));
-    HIPCHK2(hipMemsetAsync(c->slot_label, 0, (size_t)c->kcap * sizeof(int), s));
     HIPCHK2(hipMemsetAsync(c->sc, 0, sizeof(DevScalars), s));
     HIPCHK2(hipMemsetAsync(flags, 0, 2 * sizeof(unsigned), s));
     HIPCHK2(hipMemsetAsync(mx, 0, 2 * sizeof(u64), s));
@@ -3462,8 +3519,12 @@ static int32_t alloc_ctx(int64_t n, int32_t storage_bits, int32_t device_id, int
 {
     if (n < 1 || n > (1 << 20)) return fail(nullptr, RC_ERR_ARG, "rc_create: n must be in 1..2^20 (got %lld)", (long long)n);
     if (storage_bits != 64 && storage_bits != 32) return fail(nullptr, RC_ERR_ARG, "rc_create: storage_bits must be 64 or 32");
-    if (kcap == 0) kcap = std::min<int64_t>(n, 512);   // up to 512 the resolver's tables leave room for it beside the row reduction
-    if (kcap < 1 || kcap > RC_MAX_KCAP) return fail(nullptr, RC_ERR_ARG, "rc_create: kcap must be in 1..%d", RC_MAX_KCAP);
+    // kcap is the INITIAL slot capacity; it grows on demand up to min(n, RC_MAX_KCAP).  0 = automatic: 128 slots to begin with (the
+    // resolver's tables then sit beside four row-reduction blocks per CU at their smallest), re-sized from the first state's cluster
+    // count by rc_set_state (twice its K, at least 128).
+    const bool kcap_auto = (kcap == 0);
+    if (kcap_auto) kcap = std::min<int64_t>(n, 128);
+    if (kcap < 1 || kcap > RC_MAX_KCAP) return fail(nullptr, RC_ERR_ARG, "rc_create: kcap must be in 0..%d (0 = automatic)", RC_MAX_KCAP);
     if (kcap > n) kcap = n;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -3476,6 +3537,9 @@ static int32_t alloc_ctx(int64_t n, int32_t storage_bits, int32_t device_id, int
     c->ld = (int)(((n + 1023) / 1024) * 1024);
     c->bits = storage_bits;
     c->kcap = (int)kcap;
+    c->kcap_auto = kcap_auto;
+    c->kcap_max = (int)std::min<int64_t>(n, RC_MAX_KCAP);
+    c->kcap_fixed = getenv("RC_KCAP_FIXED") && atoi(getenv("RC_KCAP_FIXED"));
     c->dbg = getenv("RC_DEBUG_FLAGS") ? atoi(getenv("RC_DEBUG_FLAGS")) : 0;
     c->prefetch = !(getenv("RC_NO_PREFETCH") && atoi(getenv("RC_NO_PREFETCH")));
     c->relayout = !(getenv("RC_NO_RELAYOUT") && atoi(getenv("RC_NO_RELAYOUT")));
@@ -3708,9 +3772,13 @@ static int32_t drain_events(rc_ctx *c)
     return RC_OK;
 }
 
-// Waits for the resolve/observable stream (and for the k_bulk stream too when `both`), then surfaces device errors.
+static int32_t recover_capacity(rc_ctx *c);
+
+// Waits for the resolve/observable stream (and for the k_bulk stream too when `both`), then surfaces device errors.  A sweep
+// that ran out of slots is not an error: the tables are grown, the sweep resumed and the sweeps behind it replayed here.
 static int32_t sync_and_check(rc_ctx *c, bool both = false)
 {
+  for (;;) {
     if (c->s_res_last && c->s_res_last != c->sA) HIPCHK(c, hipStreamSynchronize(c->s_res_last));   // the last sweep's resolver
     HIPCHK(c, hipStreamSynchronize(c->sA));
     if (both) {
@@ -3729,9 +3797,14 @@ static int32_t sync_and_check(rc_ctx *c, bool both = false)
         return fail(c, RC_ERR_HIP, "grid barrier timed out inside the sweep kernel (is another process using this GPU? one chain per "
                                    "GPU); the label state is void: call rc_set_state before sweeping again");
     }
-    if (c->last.err & RC_DERR_CAPACITY)
-        return fail(c, RC_ERR_CAPACITY, "number of clusters exceeded the slot capacity kcap=%d given to rc_create", c->kcap);
+    if (c->last.err & RC_DERR_CAPACITY) {
+        const int32_t rcr = recover_capacity(c);
+        if (rcr != RC_OK) return rcr;
+        continue;   // the resumed / replayed sweeps are in flight: wait for them (and recover again if they overflow again)
+    }
+    c->inflight.clear();   // every sweep enqueued so far is complete (resolvers are chained)
     return RC_OK;
+  }
 }
 
 extern "C" int32_t rc_synchronize(rc_ctx *c)
@@ -3741,6 +3814,31 @@ extern "C" int32_t rc_synchronize(rc_ctx *c)
     return sync_and_check(c, true);
 }
 
+// Slot capacity for `need` clusters: twice as many (room to move), at least 128, a power of two, at most kcap_max.
+static int capacity_for(const rc_ctx *c, long long need)
+{
+    long long k = 128;
+    while (k < 2 * need) k *= 2;
+    return (int)std::min<long long>(std::max<long long>(k, need), c->kcap_max);
+}
+
+// Re-sizes everything that depends on the slot capacity (device buffers, the resolver's LDS layout and batch capacity).  The
+// streams must be drained; the label state is void afterwards — the caller installs labels with rc_set_state.
+static int32_t resize_capacity(rc_ctx *c, int new_kcap)
+{
+    if (new_kcap == c->kcap) return RC_OK;
+    c->kcap = new_kcap;
+    int32_t rc = alloc_slot_buffers(c);
+    if (rc != RC_OK) return rc;
+    rc = finish_create(c);
+    if (rc != RC_OK) return rc;
+    c->have_state = false;
+    c->n_grows++;
+    c->B_version = -2; c->ll_version = -1;
+    if (getenv("RC_SM_PROFILE")) fprintf(stderr, "[redclust] slot capacity -> %d (batch capacity %d)\n", c->kcap, c->maxb);
+    return RC_OK;
+}
+
 extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
 {
     if (!c || !clusts) return fail(c, RC_ERR_ARG, "rc_set_state: NULL argument");
@@ -3748,7 +3846,23 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
     HIPCHK(c, hipStreamSynchronize(c->sA));
     HIPCHK(c, hipStreamSynchronize(c->sB));
     HIPCHK(c, hipStreamSynchronize(c->sB2));
+    if (!c->recovering) c->inflight.clear();
     const int n = c->n;
+    {
+        // the capacity follows the state: more clusters than slots -> grow; automatic capacity -> sized from the first state
+        std::vector<unsigned char> seen((size_t)n + 1, 0);
+        long long K0 = 0;
+        for (int i = 0; i < n; ++i) {
+            if (clusts[i] < 1 || clusts[i] > n) return fail(c, RC_ERR_ARG, "rc_set_state: label %lld of point %d outside 1..n", (long long)clusts[i], i + 1);
+            if (!seen[(size_t)clusts[i]]) { seen[(size_t)clusts[i]] = 1; ++K0; }
+        }
+        if (K0 > c->kcap_max)
+            return fail(c, RC_ERR_CAPACITY, "rc_set_state: %lld clusters, the library holds at most min(n, %d) = %d (the slot tables of the sweep kernel live in LDS)", K0, RC_MAX_KCAP, c->kcap_max);
+        if (!c->kcap_fixed && (K0 > c->kcap || (c->kcap_auto && !c->have_state && c->n_grows == 0 && capacity_for(c, K0) > c->kcap))) {
+            int32_t rcg = resize_capacity(c, std::max(c->kcap, capacity_for(c, K0)));
+            if (rcg != RC_OK) return rcg;
+        }
+    }
     // clustsizes = counts(clusts, 1:n), K = sum(clustsizes .> 0)  (types.jl:135-136); slots in label order
     std::vector<int> size_by_label((size_t)n + 1, 0);
     for (int i = 0; i < n; ++i) {
@@ -3992,17 +4106,17 @@ static int32_t launch_resolve(rc_ctx *c, const View &V, const SweepArgs &sa, int
     }
     c->sA_dirty = false;
     if (sa.t >= 1 && c->s_res_last && c->s_res_last != sx) HIPCHK(c, hipStreamWaitEvent(sx, c->ev_res[(sa.t - 1) & 3], 0));
-    std::lock_guard<std::mutex> lock(g_res_mutex);
-    const int d = c->dev & 63;
-    const bool chain = g_res_multi[d];   // several contexts on this device: their resolvers must not overlap (see above)
+    ResDevice &rd = g_res[c->dev & 63];
+    std::lock_guard<std::mutex> lock(rd.m);   // per device: contexts on other GPUs (rc_run_chains' threads) never meet here
+    const bool chain = rd.multi;   // several contexts on this device: their resolvers must not overlap (see above)
     if (chain) {
-        if (g_res_event[d]) HIPCHK(c, hipStreamWaitEvent(sx, g_res_event[d], 0));
-        else HIPCHK(c, hipEventCreateWithFlags(&g_res_event[d], hipEventDisableTiming));
+        if (rd.ev) HIPCHK(c, hipStreamWaitEvent(sx, rd.ev, 0));
+        else HIPCHK(c, hipEventCreateWithFlags(&rd.ev, hipEventDisableTiming));
     }
     k_resolve<<<c->G, res_threads, lds, sx>>>(V, sa, c->G);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(c, RC_ERR_HIP, "k_resolve launch failed: %s", hipGetErrorString(e));
-    if (chain) HIPCHK(c, hipEventRecord(g_res_event[d], sx));
+    if (chain) HIPCHK(c, hipEventRecord(rd.ev, sx));
     HIPCHK(c, hipEventRecord(c->ev_res[sa.t & 3], sx));
     c->s_res_last = sx;
     return RC_OK;
@@ -4010,7 +4124,16 @@ static int32_t launch_resolve(rc_ctx *c, const View &V, const SweepArgs &sa, int
 
 static int32_t pull_labels(rc_ctx *c, std::vector<int64_t> &labels, std::vector<int64_t> &sizes, int64_t &K);
 
+static int32_t sweep_enqueue(rc_ctx *c, double r, double p, uint64_t seed, uint64_t sweep_index, int after0, int changes0, int rounds0);
+
 extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t seed, uint64_t sweep_index)
+{
+    return sweep_enqueue(c, r, p, seed, sweep_index, -1, 0, 0);
+}
+
+// after0 / changes0 / rounds0: -1, 0, 0 for a fresh sweep; a sweep resumed after a capacity growth continues behind point
+// after0 (recover_capacity)
+static int32_t sweep_enqueue(rc_ctx *c, double r, double p, uint64_t seed, uint64_t sweep_index, int after0, int changes0, int rounds0)
 {
     if (!c) return fail(c, RC_ERR_ARG, "rc_gibbs_sweep: NULL ctx");
     if (!c->have_params || !c->have_state) return fail(c, RC_ERR_STATE, "rc_gibbs_sweep: rc_set_params and rc_set_state must be called first");
@@ -4021,7 +4144,7 @@ extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t 
     // reduction would be given up for that reason, and a fresh layout would bring it back, re-lay the points out:
     // drain the pipeline and set the same labels again.  Slot numbers change, the partition and its labels do not, and
     // all sums are exact integers, so the chain is bit-identical with or without this step.
-    if (!c->incremental && c->relayout && c->bulk_kernel < 0 && c->t_next >= 32 &&
+    if (!c->recovering && !c->incremental && c->relayout && c->bulk_kernel < 0 && c->t_next >= 32 &&
         (long long)c->hsum->runs * 32 > (long long)c->n && (long long)c->hsum->K * 64 <= (long long)c->n) {
         std::vector<int64_t> labels, sizes;
         int64_t K = 0;
@@ -4041,6 +4164,12 @@ extern "C" int32_t rc_gibbs_sweep_async(rc_ctx *c, double r, double p, uint64_t 
     sa.sw_lo = (unsigned)sweep_index; sa.sw_hi = (unsigned)(sweep_index >> 32);
     sa.t = (int)t;
     sa.dbg = c->dbg;
+    sa.after0 = after0; sa.changes0 = changes0; sa.rounds0 = rounds0;
+    c->inflight.push_back(rc_ctx::SweepRec{r, p, seed, sweep_index, t});
+    if (c->inflight.size() > 65536) {   // (a caller that never synchronises: bound the replay log — every entry before a completed sweep is dead)
+        int32_t rcq = sync_and_check(c);
+        if (rcq != RC_OK) return rcq;
+    }
 #ifdef RC_TRACE_RESOLVE
     const size_t lds = std::max(tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, c->maxb), 2 * sizeof(int) * (size_t)c->kcap) + 4096;
 #else
@@ -4100,6 +4229,66 @@ extern "C" int32_t rc_gibbs_sweep(rc_ctx *c, double r, double p, uint64_t seed, 
     int32_t rc = rc_gibbs_sweep_async(c, r, p, seed, sweep_index);
     if (rc != RC_OK) return rc;
     return sync_and_check(c);
+}
+
+// A sweep stopped at the first point that needed a new cluster when every slot was taken (k_resolve: RC_DERR_CAPACITY).  The
+// device state is consistent — every point up to hsum->resume_after is final, the others still carry their old labels — and the
+// sweeps enqueued behind it returned at once without touching anything.  The reference's state has room for n clusters
+// (clustsizes of length n, types.jl:131-137; a new cluster is offered whenever maxK allows, mcmc.jl:198-199), so the sweep must
+// simply go on: double the slot capacity, install the current labels again (rc_set_state: a fresh layout and a fresh row-sum
+// table), resume the sweep behind that point and replay the later ones.  Every draw is a pure function of (state, sweep index,
+// point, label), so the chain is exactly the one a larger initial capacity would have produced.
+static int32_t recover_capacity(rc_ctx *c)
+{
+    HIPCHK(c, hipStreamSynchronize(c->sA));
+    HIPCHK(c, hipStreamSynchronize(c->sB));
+    HIPCHK(c, hipStreamSynchronize(c->sB2));
+    {
+        int32_t rc = drain_events(c);
+        if (rc != RC_OK) return rc;
+    }
+    const int fail_t = c->hsum->fail_t, resume_after = c->hsum->resume_after, ch0 = c->hsum->fail_changes, rd0 = c->hsum->fail_rounds;
+    std::deque<rc_ctx::SweepRec> log;
+    log.swap(c->inflight);
+    while (!log.empty() && log.front().t < fail_t) log.pop_front();
+    if (c->kcap_fixed || c->kcap >= c->kcap_max || log.empty() || log.front().t != fail_t) {
+        c->have_state = c->have_state && !log.empty();
+        return fail(c, RC_ERR_CAPACITY, c->kcap >= c->kcap_max && !c->kcap_fixed
+                        ? "number of clusters exceeded %d = min(n, %d), the most the library holds (the slot tables of the sweep kernel live in LDS)"
+                        : "number of clusters exceeded the slot capacity kcap=%d (fixed: RC_KCAP_FIXED)", c->kcap, RC_MAX_KCAP);
+    }
+    // the labels as they stand (straight from the device: the summary's tables are those of the failed launch as well, but the
+    // sweep's error bit would turn pull_labels -> sync_and_check back into this function)
+    std::vector<int> so((size_t)c->n), slabel((size_t)c->kcap);
+    HIPCHK(c, hipMemcpy(so.data(), c->slot_of, so.size() * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(slabel.data(), c->slot_label, slabel.size() * sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<int64_t> labels((size_t)c->n);
+    for (int i = 0; i < c->n; ++i) labels[(size_t)i] = slabel[(size_t)so[(size_t)c->h_pi[(size_t)i]]];
+    c->recovering = true;
+    struct Guard { rc_ctx *c; ~Guard() { c->recovering = false; } } guard{c};
+    int32_t rc = resize_capacity(c, (int)std::min<long long>(c->kcap_max, std::max<long long>(2ll * c->kcap, 128)));
+    if (rc != RC_OK) return rc;
+    rc = rc_set_state(c, labels.data());      // clears the device error word (DevScalars is rewritten) and the summary's
+    if (rc != RC_OK) return rc;
+    c->last.err = 0;
+    bool first = true;
+    for (const rc_ctx::SweepRec &q : log) {
+        rc = first ? sweep_enqueue(c, q.r, q.p, q.seed, q.sweep_index, resume_after, ch0, rd0)
+                   : sweep_enqueue(c, q.r, q.p, q.seed, q.sweep_index, -1, 0, 0);
+        if (rc != RC_OK) return rc;
+        first = false;
+    }
+    return RC_OK;
+}
+
+extern "C" int32_t rc_capacity_info(rc_ctx *c, int64_t *kcap, int64_t *kcap_max, int64_t *n_grows, int64_t *batch_capacity)
+{
+    if (!c) return fail(c, RC_ERR_ARG, "rc_capacity_info: NULL ctx");
+    if (kcap) *kcap = c->kcap;
+    if (kcap_max) *kcap_max = c->kcap_max;
+    if (n_grows) *n_grows = c->n_grows;
+    if (batch_capacity) *batch_capacity = c->maxb;
+    return RC_OK;
 }
 
 extern "C" int32_t rc_last_sweep_stats(rc_ctx *c, rc_sweep_stats *out)
@@ -4617,7 +4806,17 @@ static int32_t apply_labels(rc_ctx *c, const std::vector<int64_t> &cur, const st
         const int lab = (int)next[(size_t)i];
         if (slot_of_label[(size_t)lab] < 0) {
             while (free_scan < c->kcap && slabel[(size_t)free_scan] != 0) ++free_scan;
-            if (free_scan >= c->kcap) return fail(c, RC_ERR_CAPACITY, "split-merge: more than kcap=%d clusters", c->kcap);
+            if (free_scan >= c->kcap) {
+                // one more cluster than slots: grow the tables (as a sweep does, recover_capacity), install the labelling the
+                // device holds again and start over
+                if (c->kcap_fixed || c->kcap >= c->kcap_max)
+                    return fail(c, RC_ERR_CAPACITY, "split-merge: more than %d clusters (slot capacity%s)", c->kcap, c->kcap_fixed ? " fixed by RC_KCAP_FIXED" : " at the library's maximum");
+                int32_t rg = resize_capacity(c, (int)std::min<long long>(c->kcap_max, 2ll * c->kcap));
+                if (rg != RC_OK) return rg;
+                rg = rc_set_state(c, cur.data());
+                if (rg != RC_OK) return rg;
+                return apply_labels(c, cur, next);
+            }
             slot_of_label[(size_t)lab] = free_scan;
             slabel[(size_t)free_scan] = lab;
             ssize[(size_t)free_scan] = 0;

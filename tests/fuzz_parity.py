@@ -26,7 +26,7 @@ def run(cases, first, nlo=40, nhi=1500, kmax=25):
         bits = int(g.choice([64, 64, 32])); stored = bool(g.random() < 0.4) or bits == 32
         os.environ["RC_RES_MAXB"] = str(int(g.choice([512, 512, 64, 16])))
         os.environ["RC_RES_ONE_STREAM"] = str(int(g.integers(0, 2)))
-        kcap = int(g.choice([min(n, 4096), min(n, 4 * K + 64)]))
+        kcap = int(g.choice([min(n, 4096), min(n, 4 * K + 64), 0, 8]))   # 0 / 8: the capacity grows on demand, in the middle of sweeps
         orc0 = O.Oracle(D, P)
         ctx = rc.Context(D, logD=orc0.logD if stored else None, kcap=kcap, storage_bits=bits)
         ctx.set_params(**P)

@@ -27,13 +27,23 @@ def headline():
     data = rc.generatemixture(n, K, seed=1)               # bench.py's data set
     D, truth = data["distancematrix"], data["clusts"]
     P = rc.likelihood_hyperparams(D, truth)
-    ctx = rc.Context(D, kcap=max(128, 2 * K))             # as bench.py: D only, automatic kernel
+    ctx = rc.Context(D)                                   # as bench.py: D only, default (automatic) capacity, automatic kernel
     ctx.set_params(**P)
     ctx.set_state(truth)
     L = ctx.get_matrix(1)
     eD, eL = ctx.debug_rowsums(1)[2:4]
+    # The oracle below is handed the DEVICE's logD (the integers every kernel uses).  That is only a parity statement if those
+    # values are log(D): checked here, at this size, against the host's libm — off the diagonal the table log of the fixed-point
+    # entry differs from log(D[i,j]) by the quantum of logD (2^-eL, rounding to the integer) plus the relative rounding of D's
+    # own entry (<= 2^-33 = 1.2e-10: the derived mode requires every entry to be at least 2^32 quanta); the diagonal is 0
+    # (types.jl:155).  The literal log-likelihood is computed from the host's log(D) as well (test_headline_config_against_oracle).
+    hostL = np.log(np.where(np.eye(n, dtype=bool), 1.0, D))
+    err = np.abs(L - hostL)
+    assert np.all(np.diag(L) == 0.0)
+    assert err.max() <= 2.0 ** -eL + 1.2e-10, (err.max(), eL)
+    del err
     orc = O.Oracle(D, P, logD=L, eL=eL, eD=eD)
-    yield dict(n=n, K=K, D=D, truth=truth, P=P, ctx=ctx, orc=orc, L=L)
+    yield dict(n=n, K=K, D=D, truth=truth, P=P, ctx=ctx, orc=orc, L=L, hostL=hostL)
     ctx.close()
 
 
@@ -86,6 +96,9 @@ def test_headline_config_against_oracle(headline, kind):
     assert abs(ll - ref) <= 1e-9 * abs(ref), (ll, ref)               # tolerance: 1e-9 relative (north_star allows 1e-6)
     lit = orc.loglik_literal()
     assert abs(ll - lit) <= 1e-6 * abs(lit), (ll, lit)               # vs the reference's formulas as written
+    # ... and as written on the HOST's log(D) (libm), not the device's: the north_star's 1e-6 against the CPU reference path
+    lit_host = O.lib().orc_loglik_literal(n, h["D"].reshape(-1), h["hostL"].reshape(-1), orc.clusts, orc.sizes, orc.P)
+    assert abs(ll - lit_host) <= 1e-6 * abs(lit_host), (ll, lit_host)
     lp = ctx.logprior(*rp_schedule(nsweeps - 1))
     assert abs(lp - orc.logprior(*rp_schedule(nsweeps - 1))) <= 1e-12 * abs(lp)
     # the same sweeps enqueued without host synchronisation (what bench.py does) end in the same state
@@ -323,3 +336,122 @@ def test_maximum_slot_capacity_at_headline_size(headline):
     big.close()
     (a, ca, la), (b, cb, lb) = out
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] and ca == cb and la == lb
+
+
+def _literal_oracle(D, P):
+    """The reference's arithmetic as written (oracle literal mode) on the host's own log(D): no fixed-point copies."""
+    orc = O.Oracle.__new__(O.Oracle)
+    orc.L = O.lib()
+    orc.n = D.shape[0]
+    orc.D = np.ascontiguousarray(D)
+    orc.logD = np.ascontiguousarray(np.log(np.where(np.eye(orc.n, dtype=bool), 1.0, D)))
+    orc.P = O.params(P)
+    return orc
+
+
+def _report(name, rec):
+    """Divergence reports go to the test output and, when the run's scratch directory exists, to gpurun_out/ (copied to
+    profiles/ by hand)."""
+    import json
+    import os
+    print(name, json.dumps(rec))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, f"parity_{name}.json"), "w") as f:
+            json.dump(rec, f, indent=1)
+
+
+@pytest.mark.parametrize("n,K,nsweeps", [(2000, 20, 12), (8192, 50, 8)])
+def test_hip_sweep_against_the_reference_arithmetic_as_written(n, K, nsweeps, headline):
+    """the HIP sweep (regrouped arithmetic, fixed-point sums, table log) against the reference's formulas AS
+    WRITTEN (lgamma / log of the full sums in double, src/mcmc.jl:221-247) on the host's libm log(D), from the 2 %-perturbed
+    start, at BASELINE configs 2 and 3.  Two comparisons per sweep: free-running (both chains on their own; the first sweep
+    at which the label vectors differ is reported) and teacher-forced (the literal sweep restarted from the HIP chain's state:
+    the number of labels that differ after ONE sweep from identical states).  The literal formulas cancel terms of magnitude
+    1e8-1e10, so a draw whose two best Gumbel-perturbed scores are closer than their rounding noise may
+    legitimately differ; asserted: identical labels in the first two sweeps, at most 2 labels per sweep under teacher forcing."""
+    if n == 8192:
+        D, truth, P = headline["D"], headline["truth"], headline["P"]
+        ctx = headline["ctx"]
+    else:
+        data = rc.generatemixture(n, K, seed=3)
+        D, truth = data["distancematrix"], data["clusts"]
+        P = rc.likelihood_hyperparams(D, truth)
+        ctx = rc.Context(D)
+        ctx.set_params(**P)
+    init = truth.copy()
+    idx = np.random.default_rng(11).choice(n, n // 50, replace=False)
+    init[idx] = np.random.default_rng(12).integers(1, K + 1, size=len(idx))
+    ctx.set_state(init)
+    free = _literal_oracle(D, P); free.set_state(init)
+    forced = _literal_oracle(D, P)
+    first_div, forced_diff, changes = None, [], []
+    for t in range(nsweeps):
+        r, p = rp_schedule(t)
+        before = ctx.get_state()[0]
+        ctx.gibbs_sweep(r, p, 4242, t)
+        lab = ctx.get_state()[0]
+        changes.append(int(ctx.sweep_stats()["n_changes"]))
+        free.sweep_literal(r, p, 4242, t)
+        if first_div is None and not np.array_equal(lab, free.clusts):
+            first_div = t
+        forced.set_state(before)
+        forced.sweep_literal(r, p, 4242, t)
+        forced_diff.append(int(np.sum(forced.clusts != lab)))
+    _report(f"literal_n{n}", dict(n=n, K=K, sweeps=nsweeps, start="2% of the generating labels re-drawn", label_changes_per_sweep=changes,
+                                  first_divergence_sweep_free_running=first_div, labels_differing_teacher_forced=forced_diff))
+    assert changes[0] > n // 100
+    assert first_div is None or first_div >= 2, first_div
+    assert max(forced_diff) <= 2, forced_diff
+    if n != 8192:
+        ctx.close()
+
+
+@pytest.mark.parametrize("numMH", [0, 1])
+def test_chain_at_baseline_config_2(numMH):
+    """BASELINE configs[1] — N = 2000, K = 20, one chain — as a CHAIN: runsampler's loop (src/mcmc.jl:536-556: r, p,
+    split-merge, sweep, record) through rc_run_chain against the oracle's loop, 300 iterations, free-running scalar updates,
+    numMH = 0 and the reference's default numMH = 1.  Labels / K / r / p / acceptances exactly; log-posterior trace to 1e-9
+    against the oracle's regrouped arithmetic and to 1e-6 (the north_star bar) against the reference's formulas as written on
+    libm's log(D).  Clusters overlap (sigma = 0.2) and 5 % of the labels start re-drawn, so labels move throughout."""
+    n, K, iters, burnin, thin = 2000, 20, 300, 50, 5
+    data = rc.generatemixture(n, K, seed=21, sigma=0.2)
+    D, truth = data["distancematrix"], data["clusts"]
+    P = rc.likelihood_hyperparams(D, truth)
+    init = truth.copy()
+    idx = np.random.default_rng(5).choice(n, n // 20, replace=False)
+    init[idx] = np.random.default_rng(6).integers(1, K + 1, size=len(idx))
+    ctx = rc.Context(D)                                   # derived logD, default capacity: what runsampler creates
+    ctx.set_params(**P)
+    ctx.set_state(init)
+    ctx.cocluster_reset()
+    L = ctx.get_matrix(1)
+    eD, eL = ctx.debug_rowsums(int(init[0]))[2:4]
+    hostL = np.log(np.where(np.eye(n, dtype=bool), 1.0, D))
+    assert np.abs(L - hostL).max() <= 2.0 ** -eL + 1.2e-10
+    orc = O.Oracle(D, P, logD=L, eL=eL, eD=eD)
+    if numMH:
+        ctx.attach_host_matrices(D, L)
+    ch = ctx.run_chain(iters, burnin, thin, 5, numMH, 77, 1.0, 0.5, 1.0)
+    ref = O.run_chain(orc, init, 1.0, 0.5, iters, burnin, thin, 5, numMH, 77, stable=True)
+    assert ch["num_samples"] == len(ref["K"]) == (iters - burnin) // thin
+    for k, kr in (("clusts", "clusts"), ("K", "K"), ("r", "r"), ("p", "p"), ("r_all", "r_all"), ("p_all", "p_all"), ("r_acceptances", "r_acc")):
+        assert np.array_equal(ch[k], ref[kr]), (k, numMH)
+    if numMH:
+        assert np.array_equal(ch["splitmerge_acceptances"], ref["sm_acc"]) and np.array_equal(ch["splitmerge_splits"], ref["sm_split"])
+    assert np.allclose(ch["logposterior"], ref["logposterior"], rtol=1e-9, atol=0)
+    moved = int(np.sum(ch["clusts"][0] != ch["clusts"][-1]))
+    lit = _literal_oracle(D, P)
+    worst = 0.0
+    for j in range(ch["num_samples"]):
+        lit.set_state(ch["clusts"][j])
+        lp = lit.loglik_literal() + lit.logprior(ch["r"][j], ch["p"][j])
+        worst = max(worst, abs(ch["logposterior"][j] - lp) / abs(lp))
+    _report(f"chain_config2_numMH{numMH}", dict(n=n, K=K, iterations=iters, samples=int(ch["num_samples"]), numMH=numMH,
+                                               labels_moved_first_to_last_sample=moved,
+                                               splitmerge_acceptances=int(np.sum(ch["splitmerge_acceptances"])) if numMH else 0,
+                                               max_rel_logposterior_error_vs_literal_on_libm_logD=worst))
+    assert worst <= 1e-6, worst
+    lab, sizes, Kc = ctx.get_state()
+    assert np.array_equal(lab, orc.clusts) and Kc == orc.K
+    ctx.close()
