@@ -88,21 +88,117 @@ def stdout_to_stderr():
         os.dup2(saved, 1); os.close(saved)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def launch_plan(args, environ):
+    """How this invocation runs (decided BEFORE torch is imported or any GPU call is made):
+      "ranks"   --gpus N > 1 and no WORLD_SIZE: this process is only a launcher — it starts a FRESH child,
+                `python -m torch.distributed.run --nproc-per-node N bench.py …` (one rank per GPU over RCCL), relays the child's
+                stdout (rank 0's JSON line) and exits with its code.  Never an exec, never after HIP is initialised.
+      "single"  RC_BENCH_SINGLE_PROCESS=1: N contexts on N devices driven by N host threads of this one process — the shape of
+                rc_run_chains (the C-ABI path of the Julia glue).
+      "rank"    one rank of a torch.distributed.run job (WORLD_SIZE set; must equal --gpus), or the plain 1-GPU run.
+    Raises SystemExit(2) when WORLD_SIZE and --gpus disagree: a SCALE run must never silently measure fewer GPUs."""
+    single = bool(environ.get("RC_BENCH_SINGLE_PROCESS")) and environ.get("RC_BENCH_SINGLE_PROCESS") != "0"
+    world_env = environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if single:
+        if world_env not in (None, "1"):
+            raise SystemExit("bench.py: RC_BENCH_SINGLE_PROCESS=1 drives all GPUs from one process; do not launch it under torch.distributed.run")
+        return "single"
+    if world_env is None:
+        return "ranks" if args.gpus > 1 else "rank"
+    if int(world_env) != args.gpus:
+        sys.stderr.write(f"bench.py: WORLD_SIZE={world_env} but --gpus {args.gpus}: refusing to report a figure for the wrong number of GPUs\n")
+        raise SystemExit(2)
+    return "rank"
+
+
+def launch_ranks(args, argv):
+    """--gpus N without a launcher: start N ranks in a fresh child process group and relay rank 0's line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    out = proc.stdout.decode(errors="replace")
+    lines = [ln for ln in out.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if proc.returncode == 0 and len(lines) == 1:
+        print(lines[0])
+        return 0
+    sys.stderr.write(out)
+    sys.stderr.write(f"bench.py: the {args.gpus}-rank child exited with code {proc.returncode} and printed {len(lines)} result line(s)\n")
+    return proc.returncode or 1
+
+
+def timed_windows(ctx, seed, r, p, steps, warmup, windows, sync_all, sweep0=0):
+    """W warm-up sweeps, then `windows` windows of EXACTLY `steps` sweeps each, every window bracketed by sync_all() (barrier over
+    all chains + device synchronise) on both sides.  Returns (per-window seconds, next sweep index)."""
+    sweep = sweep0
+    for _ in range(warmup):
+        ctx.gibbs_sweep(r, p, seed, sweep, blocking=False); sweep += 1
+    ctx.synchronize()
+    times = []
+    for _ in range(windows):
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.gibbs_sweep(r, p, seed, sweep, blocking=False); sweep += 1
+        ctx.synchronize()
+        sync_all()
+        times.append(time.perf_counter() - t0)
+    return times, sweep
+
+
+def settle(ctx, seed, r, p, ms, sweep):
+    t_s = time.perf_counter()
+    while (time.perf_counter() - t_s) * 1e3 < ms:
+        for _ in range(256):
+            ctx.gibbs_sweep(r, p, seed, sweep, blocking=False); sweep += 1
+        ctx.synchronize()
+    return sweep
+
+
+def median(xs):
+    xs = sorted(xs)
+    m = len(xs) // 2
+    return xs[m] if len(xs) % 2 else 0.5 * (xs[m - 1] + xs[m])
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    plan = launch_plan(args, os.environ)
+    if plan == "ranks":
+        sys.exit(launch_ranks(args, argv))
+
+    import threading
     import torch
+    single = plan == "single"
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    distributed = world > 1 or bool(os.environ.get("RC_BENCH_FORCE_DIST"))  # force: exercise the RCCL path on one GPU
+    world = args.gpus                                                   # == WORLD_SIZE (launch_plan), or the threads of the single-process mode
+    distributed = (not single) and (world > 1 or bool(os.environ.get("RC_BENCH_FORCE_DIST")))  # force: exercise the RCCL path on one GPU
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    need = world if single else local_rank + 1
+    if ndev < need or (not single and world > ndev):
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) are visible here: refusing to report a figure for fewer GPUs than asked for\n")
+        raise SystemExit(3)
     torch.cuda.set_device(local_rank)
     if distributed:
         import torch.distributed as dist
@@ -110,6 +206,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             dist.barrier()
             torch.cuda.synchronize()
+        assert dist.get_world_size() == args.gpus
 
     import redclust_amd as rc
     n, K = N_POINTS, N_CLUST
@@ -117,124 +214,133 @@ def main():
     D, truth = data["distancematrix"], data["clusts"]
     P = rc.likelihood_hyperparams(D, truth)
     r, p = 1.0, 0.5
-    chain_seed = 1 + rank                             # chain seeds 1..N
+    kcap = int(os.environ.get("RC_BENCH_KCAP", 0))    # 0 = the library's default (automatic capacity): what runsampler and the Julia glue use
+    windows = max(1, int(os.environ.get("RC_BENCH_WINDOWS", 5)))
+    settle_ms = float(os.environ.get("RC_BENCH_SETTLE_MS", 400))
+    time_every = int(os.environ.get('RC_BENCH_TIME_EVERY', 1 if args.steps < 64 else 4))
 
-    ctx = rc.Context(D, device=local_rank, kcap=max(128, 2 * K), storage_bits=BITS)
-    ctx.set_params(**P)
-    ctx.set_state(truth)                              # stationary regime: generating labels
-    ctx.cocluster_reset()
+    # the chains of this process: one (its rank's) under torch.distributed.run, `world` of them in the single-process mode
+    devices = list(range(world)) if single else [local_rank]
+    seeds = [1 + d for d in devices] if single else [1 + rank]          # chain seeds 1..N
 
-    def barrier():
+    def make_ctx(dev):
+        c = rc.Context(D, device=dev, kcap=kcap, storage_bits=BITS)
+        c.set_params(**P)
+        c.set_state(truth)                            # stationary regime: generating labels
+        c.cocluster_reset()
+        return c
+    ctxs = [make_ctx(d) for d in devices]
+    ctx = ctxs[0]
+
+    tbar = threading.Barrier(len(ctxs)) if single and len(ctxs) > 1 else None
+
+    def sync_all():
+        if tbar is not None:
+            tbar.wait()
         if distributed:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
-    sweep = 0
-    # Device settle (untimed, before the W warm-up steps): a short window right after the idle set-up phase does not see the clocks
-    # of a running chain — 20 timed sweeps measured 13.2 k sweeps/s after a host-side pause, 12.1 k over the following 200 sweeps and
-    # 14.3 k once a second of sweeps had run (tools/ramp_probe.py) — so the same workload runs for RC_BENCH_SETTLE_MS (default 400,
-    # 0 = off; reported as config.settle_ms) before the warm-up and the timed steps.
-    settle_ms = float(os.environ.get("RC_BENCH_SETTLE_MS", 400))
-    unsettled = None
-    if settle_ms > 0:
-        # the same W + K steps once BEFORE the settle phase (no event timing), reported beside the headline as
-        # config.sweeps_per_s_before_settle: what the window measures straight after the idle set-up phase
+    # Per chain: the W + K steps once BEFORE the settle phase (reported as config.sweeps_per_s_before_settle), a settle phase
+    # (untimed: a short window right after the idle set-up does not see the clocks of a running chain — tools/ramp_probe.py;
+    # RC_BENCH_SETTLE_MS=0 turns both off), then W warm-up steps and RC_BENCH_WINDOWS (5) timed windows of exactly K steps.
+    # HIP events ride in the dispatch of the row-reduction launches of the timed windows (every launch for --steps < 64).
+    results = [None] * len(ctxs)
+
+    def chain_job(ci):
+        c, sd = ctxs[ci], seeds[ci]
+        sweep, unsettled = 0, None
+        if settle_ms > 0:
+            tu, sweep = timed_windows(c, sd, r, p, args.steps, args.warmup, 1, sync_all, sweep)
+            unsettled = tu[0]
+            sweep = settle(c, sd, r, p, settle_ms, sweep)
         for _ in range(args.warmup):
-            ctx.gibbs_sweep(r, p, chain_seed, sweep, blocking=False); sweep += 1
-        ctx.synchronize()
-        t_u = time.perf_counter()
-        for _ in range(args.steps):
-            ctx.gibbs_sweep(r, p, chain_seed, sweep, blocking=False); sweep += 1
-        ctx.synchronize()
-        unsettled = args.steps / (time.perf_counter() - t_u)
-        t_s = time.perf_counter()
-        while (time.perf_counter() - t_s) * 1e3 < settle_ms:
-            for _ in range(256):
-                ctx.gibbs_sweep(r, p, chain_seed, sweep, blocking=False)
-                sweep += 1
-            ctx.synchronize()
-    for _ in range(args.warmup):
-        ctx.gibbs_sweep(r, p, chain_seed, sweep, blocking=False)
-        sweep += 1
-    ctx.synchronize()
-    # HIP events around the row-reduction kernel, on the stream it is launched on: every launch for short runs (the driver's
-    # --steps 20), every 4th otherwise (an event pair costs the stream a few microseconds)
-    time_every = int(os.environ.get('RC_BENCH_TIME_EVERY', 1 if args.steps < 64 else 4))
-    ctx.kernel_timing(enable=0 if os.environ.get('RC_BENCH_NO_TIMING') else time_every)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ctx.gibbs_sweep(r, p, chain_seed, sweep, blocking=False)
-        sweep += 1
-    ctx.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    bulk_ms, bulk_launches = ctx.kernel_timing(enable=0)
-    stats = ctx.sweep_stats()
+            c.gibbs_sweep(r, p, sd, sweep, blocking=False); sweep += 1
+        c.synchronize()
+        c.kernel_timing(enable=0 if os.environ.get('RC_BENCH_NO_TIMING') else time_every)
+        tw, sweep = timed_windows(c, sd, r, p, args.steps, 0, windows, sync_all, sweep)
+        bulk_ms, bulk_launches = c.kernel_timing(enable=0)
+        results[ci] = dict(times=tw, unsettled=unsettled, bulk_ms=bulk_ms, bulk_launches=bulk_launches, sweep=sweep, stats=c.sweep_stats())
+
+    if len(ctxs) == 1:
+        chain_job(0)
+    else:
+        th = [threading.Thread(target=chain_job, args=(ci,)) for ci in range(len(ctxs))]
+        for t in th: t.start()
+        for t in th: t.join()
+        if any(x is None for x in results):
+            raise SystemExit("bench.py: a chain thread failed")
+    # a window's time is the MAX over the chains (threads here, ranks below)
+    win = [max(res["times"][w] for res in results) for w in range(windows)]
+    unsettled_t = max(res["unsettled"] for res in results) if settle_ms > 0 else None
+    if distributed:
+        tmax = torch.tensor(win + [unsettled_t or 0.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        vals = [float(x) for x in tmax.tolist()]
+        win, unsettled_t = vals[:windows], (vals[windows] if settle_ms > 0 else None)
+    dt = median(win)
+    bulk_ms, bulk_launches = results[0]["bulk_ms"], results[0]["bulk_launches"]
+    stats, sweep = results[0]["stats"], results[0]["sweep"]
+    chain_seed = seeds[0]
 
     # same workload in the exact incremental mode (no row reduction while labels are stable) — reported as an extra
     inc_sweeps_per_s = None
     if not os.environ.get("RC_BENCH_NO_INCREMENTAL"):
         ctx.set_mode("incremental")
-        for _ in range(args.warmup):
-            ctx.gibbs_sweep(r, p, chain_seed, sweep, blocking=False); sweep += 1
-        ctx.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            ctx.gibbs_sweep(r, p, chain_seed, sweep, blocking=False); sweep += 1
-        ctx.synchronize()
-        inc_sweeps_per_s = args.steps / (time.perf_counter() - t1)
+        ti, sweep = timed_windows(ctx, chain_seed, r, p, args.steps, args.warmup, 1, lambda: None, sweep)
+        inc_sweeps_per_s = args.steps / ti[0]
         ctx.set_mode("full")
 
     # recorded sample + the one collective of the path: sum all-reduce of the integer co-clustering counts, through the
     # LIBRARY's communicator (rc_comm_create / rc_comm_allreduce_counts: RCCL inside libredclust_hip.so; torch.distributed
-    # only carries the 128-byte unique id).  Also at N = 1: a real communicator of size 1.  If the library path cannot be
-    # set up on every rank the counts are merged with torch.distributed instead and the line says so.
-    ctx.record_sample(False)
-    allreduce_ms, merge_path = None, None
-    lib_ok = 1
-    try:
-        rc.Comm.unique_id()                                  # opens librccl: every rank checks before anyone commits
-    except Exception as e:                                   # noqa: BLE001
-        lib_ok, merge_path = 0, f"torch.distributed all_reduce (library RCCL unavailable: {e})"
-    if distributed:
-        flag = torch.tensor([lib_ok], dtype=torch.int32, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        lib_ok = int(flag.item())
-    total_samples = None
-    if lib_ok:
-        # RCCL prints a version banner on the C stdout when its first communicator comes up: keep this process's stdout
-        # for the one JSON line (fd 1 points at stderr while the communicator is built)
-        with stdout_to_stderr():
-            total_samples, allreduce_ms = rc.library_merge(ctx, local_rank, 1)
-        merge_path = "libredclust_hip.so rc_comm_allreduce_counts (RCCL ncclAllReduce sum uint32, in place)"
-    elif distributed:
-        counts = rc.device_counts_tensor(ctx, local_rank)   # zero-copy view of the library's device buffer
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-        torch.cuda.synchronize()
-        allreduce_ms = (time.perf_counter() - t1) * 1e3
-        total_samples = world
-        merge_path = merge_path or "torch.distributed all_reduce (library RCCL unavailable on some rank)"
-    if distributed:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    # only carries the 128-byte unique id; all ranks agree on the path first — chains.agreed_merge).  Also at N = 1: a real
+    # communicator of size 1.  Single-process mode: one communicator over all devices (ncclCommInitAll), as rc_run_chains.
+    for c in ctxs:
+        c.record_sample(False)
+    with stdout_to_stderr():   # RCCL prints a version banner on the C stdout when its first communicator comes up
+        if single:
+            comm = rc.Comm(devices)
+            try:
+                total_samples, allreduce_ms = comm.allreduce_counts(ctxs, [1] * len(ctxs))
+            finally:
+                comm.close()
+            merge_path = "libredclust_hip.so rc_comm_allreduce_counts over ncclCommInitAll (one process, one context per device)"
+            nranks = len(devices)
+        else:
+            total_samples, allreduce_ms, merge_path = rc.agreed_merge(ctx, local_rank, 1)
+            nranks = dist.get_world_size() if distributed else 1
     # every chain recorded one sample: each point co-clusters with itself once per chain, and the matrix is symmetric
-    counts = rc.device_counts_tensor(ctx, local_rank)
+    counts = rc.device_counts_tensor(ctx, devices[0])
     diag_ok = (bool((counts.diagonal() == world).all().item()) and bool((counts[:, :n] == counts[:, :n].T).all().item())
-               and (total_samples in (None, world)))
+               and total_samples == world)
+
+    # ---- the other figures: rank 0 / chain 0 only, on its own device ---------------------------------------------------
+    extras = rank == 0
+    dev0 = devices[0]
+    for c in ctxs[1:]:
+        c.close()
+
+    # The capacity the library's default gives vs. an explicit one: the context above IS the default (kcap = 0) unless
+    # RC_BENCH_KCAP says otherwise; one window with 512 slots (round 2's default) beside it
+    kcap_info = ctx.capacity_info()
+    kcap512 = None
+    if extras and not os.environ.get("RC_BENCH_NO_KCAP512"):
+        c5 = rc.Context(D, device=dev0, kcap=512, storage_bits=BITS)
+        c5.set_params(**P); c5.set_state(truth)
+        t5, _ = timed_windows(c5, 1, r, p, args.steps, args.warmup + 200, 3, lambda: None)
+        kcap512 = args.steps / median(t5)
+        c5.close()
 
     # Second figure ("exercises movement"): the same N, K with overlapping clusters (sigma = 0.2 instead of 0.1:
     # about 0.5 % of the labels move per sweep and clusters are born and die), burn-in from the generating labels excluded from the timing.
     moving = None
-    if rank == 0 and not os.environ.get("RC_BENCH_NO_MOVING"):
+    Dm = tm = Pm = None
+    if extras and not os.environ.get("RC_BENCH_NO_MOVING"):
         sig = float(os.environ.get("RC_BENCH_MOVING_SIGMA", 0.2))
         dm = rc.generatemixture(n, K, seed=2, sigma=sig)
         Dm, tm = dm["distancematrix"], dm["clusts"]
         Pm = rc.likelihood_hyperparams(Dm, tm)
-        cm = rc.Context(Dm, device=local_rank, kcap=max(512, 8 * K), storage_bits=BITS)
+        cm = rc.Context(Dm, device=dev0, kcap=kcap, storage_bits=BITS)    # default capacity: grows with the chain
         cm.set_params(**Pm)
         cm.set_state(tm)
         sw = 0
@@ -248,46 +354,56 @@ def main():
             cm.gibbs_sweep(r, p, 7, sw, blocking=True); sw += 1   # blocking: the change count of every sweep is read
             st = cm.sweep_stats(); ch += st["n_changes"]; rounds += st["n_rounds"]
         t_block = time.perf_counter() - t1
-        t1 = time.perf_counter()
-        for _ in range(msteps):
-            cm.gibbs_sweep(r, p, 7, sw, blocking=False); sw += 1
-        cm.synchronize()
-        t_async = time.perf_counter() - t1
+        tms, sw = timed_windows(cm, 7, r, p, msteps, 0, 3, lambda: None, sw)
+        t_async = median(tms)
         # SURVEY.md §8(d)'s other movement workload: labels uniform on 1..K from a fixed seed on the headline data — the first sweeps
         # relabel nearly every point (a one-off transient: thousands of changes resolved in batches)
         uni = np.random.default_rng(13).integers(1, K + 1, size=n).astype(np.int64)
-        cu = rc.Context(D, device=local_rank, kcap=max(256, 4 * K), storage_bits=BITS)
+        cu = rc.Context(D, device=dev0, kcap=kcap, storage_bits=BITS)
         cu.set_params(**P); cu.set_state(uni); cu.synchronize()
         uniform_init = []
         for q in range(3):
             t1 = time.perf_counter(); cu.gibbs_sweep(r, p, 7, q, blocking=True); t_q = time.perf_counter() - t1
             st = cu.sweep_stats()
             uniform_init.append({"sweep": q, "ms": t_q * 1e3, "label_changes": st["n_changes"], "resolve_rounds": st["n_rounds"], "K": st["K"]})
+        uni_cap = cu.capacity_info()
         cu.close()
-        moving = {"sigma": sig, "uniform_init_first_sweeps": uniform_init, "sweeps_per_s": msteps / t_async, "ms_per_sweep": t_async / msteps * 1e3,
+        moving = {"sigma": sig, "uniform_init_first_sweeps": uniform_init, "uniform_init_capacity": uni_cap,
+                  "sweeps_per_s": msteps / t_async, "ms_per_sweep": t_async / msteps * 1e3,
+                  "sweeps_per_s_windows": [msteps / x for x in tms],
                   "sweeps_per_s_blocking": msteps / t_block, "label_changes_per_sweep": ch / msteps,
-                  "resolve_rounds_per_sweep": rounds / msteps, "K": cm.sweep_stats()["K"], "steps": msteps,
-                  "note": "overlapping clusters, equilibrium after 60 burn-in sweeps from the generating labels"}
+                  "resolve_rounds_per_sweep": rounds / msteps, "K": cm.sweep_stats()["K"], "steps": msteps, "capacity": cm.capacity_info(),
+                  "note": "overlapping clusters, equilibrium after 60 burn-in sweeps from the generating labels; library-default capacity"}
         cm.close()
-        del Dm
 
     # Third figure: the whole iteration of the reference with its DEFAULT options (MCMCOptionsList(): numMH = 1, numGibbs = 5,
-    # src/types.jl:3-43) — sample_r, sample_p, one split-merge proposal, the Gibbs sweep — through rc_run_chain
+    # src/types.jl:3-43) — sample_r, sample_p, one split-merge proposal, the Gibbs sweep — through rc_run_chain: on the headline
+    # data (separated clusters: proposals are rejected) and on the moving data (proposals get accepted: the speculative pipeline
+    # rolls back), with the pipeline's rollbacks and worker threads
     defaults = None
-    if rank == 0 and not os.environ.get("RC_BENCH_NO_DEFAULTS"):
-        cd = rc.Context(D, device=local_rank, kcap=max(128, 2 * K), storage_bits=BITS)
-        cd.set_params(**P); cd.set_state(truth); cd.cocluster_reset()
-        cd.attach_host_matrices(D)                        # the proposals' restricted scans read the host matrix (logD derived by the library)
-        cd.run_chain(100, 0, 10, 5, 1, 1, r, p, 1.0)               # warm-up (worker threads, pinned buffers, caches)
-        its = 1000
-        t1 = time.perf_counter()
-        chd = cd.run_chain(its, 0, 10, 5, 1, 1, r, p, 1.0, first_iter=100)
-        t_def = time.perf_counter() - t1
-        defaults = {"numMH": 1, "numGibbs": 5, "iterations": its, "iterations_per_s": its / t_def, "ms_per_iteration": t_def / its * 1e3,
-                    "splitmerge_acceptances": int(chd["splitmerge_acceptances"].sum()), "splitmerge_splits": int(chd["splitmerge_splits"].sum()),
-                    "note": "rc_run_chain, speculative split-merge pipeline (proposals of several iterations decided concurrently on host "
-                            "threads; bit-identical to the sequential loop)"}
-        cd.close()
+    if extras and not os.environ.get("RC_BENCH_NO_DEFAULTS"):
+        def default_options_leg(Dx, Px, labels, burn):
+            cd = rc.Context(Dx, device=dev0, kcap=kcap, storage_bits=BITS)
+            cd.set_params(**Px); cd.set_state(labels); cd.cocluster_reset()
+            cd.attach_host_matrices(Dx)                   # the proposals' restricted scans read the host matrix (logD derived by the library)
+            cd.run_chain(burn, 0, 10, 5, 1, 1, r, p, 1.0)             # warm-up (worker threads, pinned buffers, caches; burn-in on the moving data)
+            its = 1000
+            t1 = time.perf_counter()
+            chd = cd.run_chain(its, 0, 10, 5, 1, 1, r, p, 1.0, first_iter=burn)
+            t_def = time.perf_counter() - t1
+            cs = cd.chain_stats()
+            out = {"numMH": 1, "numGibbs": 5, "iterations": its, "iterations_per_s": its / t_def, "ms_per_iteration": t_def / its * 1e3,
+                   "splitmerge_acceptances": int(chd["splitmerge_acceptances"].sum()), "splitmerge_splits": int(chd["splitmerge_splits"].sum()),
+                   "rollbacks": cs["rollbacks"], "splits_evaluated_offline": cs["split_evals"], "workers": cs["workers"],
+                   "K_final": int(chd["K"][-1]) if len(chd["K"]) else None}
+            cd.close()
+            return out
+        defaults = default_options_leg(D, P, truth, 100)
+        defaults["note"] = ("rc_run_chain, speculative split-merge pipeline (proposals of several iterations decided concurrently; "
+                            "bit-identical to the sequential loop); headline data, stationary")
+        if Dm is not None:
+            defaults["moving_data"] = default_options_leg(Dm, Pm, tm, 200)
+    del Dm
 
     if rank == 0:
         # bytes of matrix data the selected row-reduction kernel has to read per sweep: k_bulk reads every entry of D
@@ -306,11 +422,11 @@ def main():
         achieved = survey_bytes / (bulk_avg_ms * 1e-3) / 1e9 if bulk_launches else None       # §8(d) bytes ÷ kernel time
         achieved_read = alg_bytes / (bulk_avg_ms * 1e-3) / 1e9 if bulk_launches else None     # bytes actually read ÷ kernel time
         # HBM bytes per launch of that kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 FETCH_SIZE
-        # correction applied): collected OFFLINE with this same command (tools/prof_r02.sh) and committed — not measured in
+        # correction applied): collected OFFLINE with this same command (tools/prof_r03.sh) and committed — not measured in
         # this run; `traffic_source` names the file
         traffic = traffic_source = None
         tag = kernel_name.replace("<", "_").replace(">", "").replace(", ", "_").replace(" ", "")
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             for name in (f"pmc_traffic_n{n}_{tag}.json", f"pmc_traffic_n{n}_{kernel_family}.json"):
                 f = os.path.join(ROOT, "profiles", rnd, name)
                 if traffic is None and os.path.exists(f) and BITS == 64 and (name.endswith(f"{tag}.json") or not derived):
@@ -318,9 +434,10 @@ def main():
                     traffic_source = f"profiles/{rnd}/{name} (rocprofv3 --pmc, collected offline with the same command)"
         ceiling = None
         try:   # the fraction is also reported against a streaming-read ceiling measured on this box, now
-            ceiling = rc.measure_read_ceiling(local_rank, 2048, 5)
+            ceiling = rc.measure_read_ceiling(dev0, 2048, 5)
         except Exception:   # noqa: BLE001
             pass
+        period_s = dt / args.steps
         out = {
             "metric": "Gibbs sweeps/sec (n×n distM)", "value": value, "unit": "sweeps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -329,34 +446,46 @@ def main():
             "config": {"workload": f"generatemixture N={n} K={K} dim={K} sigma=0.1 dense Float64 distM ({BITS}-bit fixed-point storage), 1 chain per GPU, "
                                    "numMH=0 Gibbs sweep, init = generating labels (stationary), r=1 p=0.5",
                        "chains": world, "n": n, "K": K, "parallelism": f"chains x{world}",
-                       "settle_ms": settle_ms, "sweeps_per_s_before_settle": unsettled, "settle_note": "untimed sweeps of the same workload before the warm-up steps (device clocks of a running chain; RC_BENCH_SETTLE_MS=0 disables)"},
+                       "launch": {"rank": "one process per GPU (torch.distributed.run)", "single": "one process, one host thread + context per GPU (RC_BENCH_SINGLE_PROCESS=1)"}["single" if single else "rank"] if world > 1 else "one process, one GPU",
+                       "rccl_ranks": nranks,
+                       "slot_capacity": kcap_info, "slot_capacity_note": "kcap = 0 at rc_create (the library default, what runsampler and the Julia glue pass): sized from the first state, grows on demand" if kcap == 0 else f"RC_BENCH_KCAP={kcap}",
+                       "value_is": f"median of {windows} windows of exactly {args.steps} steps (each bracketed by barrier + device synchronize)",
+                       "windows_sweeps_per_s": [world * args.steps / x for x in win],
+                       "windows_min_max_sweeps_per_s": [world * args.steps / max(win), world * args.steps / min(win)],
+                       "settle_ms": settle_ms, "sweeps_per_s_before_settle": (world * args.steps / unsettled_t) if unsettled_t else None,
+                       "settle_note": "untimed sweeps of the same workload before the warm-up steps (device clocks of a running chain; RC_BENCH_SETTLE_MS=0 disables)"},
             "logD": "derived on the fly (table log of the fixed-point D)" if derived else "stored",
+            "kcap512_sweeps_per_s": kcap512,
             "sweep_GBps_algorithmic": value / world * survey_bytes / 1e9,          # whole sweep (not just the kernel) at §8(d) bytes
             "sweep_frac_of_hbm_peak": value / world * survey_bytes / 1e9 / HBM_PEAK_GBPS,
             "sweep_GBps_on_bytes_read": value / world * alg_bytes / 1e9,
+            "sweep_frac_of_hbm_peak_on_bytes_read": value / world * alg_bytes / 1e9 / HBM_PEAK_GBPS,   # physical: bytes the kernel reads per sweep PERIOD
             "sweep_GBps_vs_reference_dataflow": value / world * full_bytes / 1e9,  # 2·n²·sizeof per sweep, what the reference reads
             "label_changes_last_sweep": stats["n_changes"], "K_final": stats["K"],
             "moving_regime": moving,
             "reference_default_options": defaults,
             "incremental_mode_sweeps_per_s_rank0": inc_sweeps_per_s,
             "coclustering_allreduce_ms": allreduce_ms, "coclustering_merge_path": merge_path, "coclustering_diag_ok": diag_ok,
-            # roofline of the dominant kernel.  `achieved` / `frac` use the algorithmic bytes SURVEY.md §8(d) prescribes
-            # (see survey_bytes above).  The kernel itself reads less than that — only the upper triangle of the
-            # symmetric matrix — so the physical figures (bytes it must read ÷ time) are given beside them, and
-            # `traffic` is the HBM bytes per launch measured with the PMC counters.
+            # roofline of the dominant kernel.  `frac_on_bytes_read` is the PHYSICAL figure (bytes the kernel has to read — the upper
+            # triangle of D — ÷ its mean launch duration ÷ peak); `achieved` / `frac` use the algorithmic bytes SURVEY.md §8(d)
+            # prescribes (see survey_bytes above), which this design undercuts by symmetry; `traffic` is the HBM bytes per launch
+            # measured with the PMC counters.
             "roofline": {"kernel": kernel_name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "measured_streaming_read_GBps": ceiling, "frac_of_measured_streaming_read": (achieved / ceiling) if achieved and ceiling else None,
                          "frac_on_bytes_read_of_measured_streaming_read": (achieved_read / ceiling) if achieved_read and ceiling else None,
                          "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic, "traffic_source": traffic_source,
-                         "pricing": "achieved / frac: SURVEY.md §8(d) algorithmic bytes per sweep (n²·sizeof when logD is derived on the fly, "
-                                    "2·n²·sizeof when stored) ÷ mean launch duration; *_on_bytes_read: the bytes this kernel has to read "
-                                    "(the upper triangle only) ÷ the same duration",
+                         "pricing": "frac_on_bytes_read (physical): the bytes this kernel has to read (the upper triangle only) ÷ mean launch duration; "
+                                    "achieved / frac: SURVEY.md §8(d) algorithmic bytes per sweep (n²·sizeof when logD is derived on the fly, "
+                                    "2·n²·sizeof when stored) ÷ the same duration; *_per_sweep_period: the same bytes ÷ the sweep period "
+                                    "(launches of consecutive sweeps overlap on two streams, so a launch lasts longer than a period)",
                          "timed_every_nth_launch": time_every,
                          "avg_launch_ms": bulk_avg_ms, "launches": bulk_launches,
                          "algorithmic_bytes_per_launch": survey_bytes,
                          "bytes_read_by_kernel_per_launch": alg_bytes,
                          "achieved_on_bytes_read": achieved_read,
                          "frac_on_bytes_read": (achieved_read / HBM_PEAK_GBPS) if achieved_read else None,
+                         "frac_on_bytes_read_per_sweep_period": alg_bytes / period_s / 1e9 / HBM_PEAK_GBPS,
+                         "frac_per_sweep_period": survey_bytes / period_s / 1e9 / HBM_PEAK_GBPS,
                          "event_pair_overhead_ms_subtracted": ctx.event_overhead_ms()},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -5,6 +5,7 @@ import os
 import tempfile
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -70,3 +71,42 @@ def test_single_process_merge_is_identity():
     out, total, chains = rc.merge_chains(t, 7, dict(rank=0))
     assert out is t and total == 7 and chains == [dict(rank=0)]
     assert rc.chain_seed(1, 3) == 4
+
+
+def _agree_worker(rank, world, initfile, outdir, failing_rank):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import redclust_amd as rc
+    dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
+    counts = torch.full((4, 4), rank + 1, dtype=torch.int32)
+
+    def probe():
+        if rank == failing_rank:
+            raise RuntimeError("librccl could not be opened (injected)")
+
+    def lib_merge(ctx, dev, ns, group):            # stands in for rc_comm_allreduce_counts: must be entered by ALL ranks or none
+        t = ctx.clone(); dist.all_reduce(t); ctx.copy_(t)
+        return world * ns, 0.0
+
+    def fallback(ctx, dev, ns, group):
+        _c, total, _tr = rc.merge_chains(ctx, ns, {}, group)
+        return total
+
+    total, _ms, path = rc.agreed_merge(counts, 0, 3, probe=probe, lib_merge=lib_merge, fallback=fallback)
+    np.save(os.path.join(outdir, f"agree_{rank}.npy"), np.array([total, int(path.startswith("libredclust")), int(counts[0, 0])]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("failing_rank", [-1, 1])
+def test_all_ranks_agree_on_the_merge_path(failing_rank):
+    """chains.agreed_merge: if ONE rank cannot open the library's RCCL, EVERY rank takes the torch.distributed fallback (a rank
+    raising alone would leave the others blocked in the unique-id broadcast or in ncclCommInitRank); if none fails, all use
+    the library path.  Either way the counts are the sum over the chains."""
+    world = 2
+    with tempfile.TemporaryDirectory() as td:
+        mp.spawn(_agree_worker, args=(world, os.path.join(td, "init"), td, failing_rank), nprocs=world, join=True)
+        for rank in range(world):
+            total, lib_path, c00 = np.load(os.path.join(td, f"agree_{rank}.npy"))
+            assert total == 6 and c00 == 3
+            assert lib_path == (1 if failing_rank < 0 else 0)

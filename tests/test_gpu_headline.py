@@ -361,20 +361,23 @@ def _report(name, rec):
             json.dump(rec, f, indent=1)
 
 
-@pytest.mark.parametrize("n,K,nsweeps", [(2000, 20, 12), (8192, 50, 8)])
-def test_hip_sweep_against_the_reference_arithmetic_as_written(n, K, nsweeps, headline):
+@pytest.mark.parametrize("n,K,sigma,nsweeps", [(2000, 20, 0.1, 12), (2000, 20, 0.25, 12), (8192, 50, 0.1, 8), (8192, 50, 0.2, 6)])
+def test_hip_sweep_against_the_reference_arithmetic_as_written(n, K, sigma, nsweeps, headline):
     """the HIP sweep (regrouped arithmetic, fixed-point sums, table log) against the reference's formulas AS
     WRITTEN (lgamma / log of the full sums in double, src/mcmc.jl:221-247) on the host's libm log(D), from the 2 %-perturbed
-    start, at BASELINE configs 2 and 3.  Two comparisons per sweep: free-running (both chains on their own; the first sweep
-    at which the label vectors differ is reported) and teacher-forced (the literal sweep restarted from the HIP chain's state:
-    the number of labels that differ after ONE sweep from identical states).  The literal formulas cancel terms of magnitude
-    1e8-1e10, so a draw whose two best Gumbel-perturbed scores are closer than their rounding noise may
-    legitimately differ; asserted: identical labels in the first two sweeps, at most 2 labels per sweep under teacher forcing."""
-    if n == 8192:
+    start, at BASELINE configs 2 and 3 — on the separated clusters of the benchmark (sigma = 0.1: the chain is back at the
+    generating labels after one sweep) and on overlapping ones (sigma = 0.25 / 0.2: tens of label changes, births and deaths
+    in every sweep; the 8192 case is bench.py's moving_regime data).  Two comparisons per sweep: free-running (both chains on
+    their own; the first sweep at which the label vectors differ is reported) and teacher-forced (the literal sweep restarted
+    from the HIP chain's state: the number of labels that differ after ONE sweep from identical states).  The literal formulas
+    cancel terms of magnitude 1e8-1e10, so a draw whose two best Gumbel-perturbed scores are closer than
+    their rounding noise may legitimately differ; asserted: at most 2 labels per sweep under teacher forcing, and identical
+    free-running labels in the first two sweeps."""
+    if n == 8192 and sigma == 0.1:
         D, truth, P = headline["D"], headline["truth"], headline["P"]
         ctx = headline["ctx"]
     else:
-        data = rc.generatemixture(n, K, seed=3)
+        data = rc.generatemixture(n, K, seed=3 if n == 2000 else 2, sigma=sigma)
         D, truth = data["distancematrix"], data["clusts"]
         P = rc.likelihood_hyperparams(D, truth)
         ctx = rc.Context(D)
@@ -385,25 +388,29 @@ def test_hip_sweep_against_the_reference_arithmetic_as_written(n, K, nsweeps, he
     ctx.set_state(init)
     free = _literal_oracle(D, P); free.set_state(init)
     forced = _literal_oracle(D, P)
-    first_div, forced_diff, changes = None, [], []
+    first_div, forced_diff, changes, Ks = None, [], [], []
     for t in range(nsweeps):
         r, p = rp_schedule(t)
         before = ctx.get_state()[0]
         ctx.gibbs_sweep(r, p, 4242, t)
         lab = ctx.get_state()[0]
-        changes.append(int(ctx.sweep_stats()["n_changes"]))
+        st = ctx.sweep_stats()
+        changes.append(int(st["n_changes"])); Ks.append(int(st["K"]))
         free.sweep_literal(r, p, 4242, t)
         if first_div is None and not np.array_equal(lab, free.clusts):
             first_div = t
         forced.set_state(before)
         forced.sweep_literal(r, p, 4242, t)
         forced_diff.append(int(np.sum(forced.clusts != lab)))
-    _report(f"literal_n{n}", dict(n=n, K=K, sweeps=nsweeps, start="2% of the generating labels re-drawn", label_changes_per_sweep=changes,
-                                  first_divergence_sweep_free_running=first_div, labels_differing_teacher_forced=forced_diff))
+    _report(f"literal_n{n}_sigma{sigma}", dict(n=n, K=K, sigma=sigma, sweeps=nsweeps, start="2% of the generating labels re-drawn",
+                                               label_changes_per_sweep=changes, K_per_sweep=Ks, first_divergence_sweep_free_running=first_div,
+                                               labels_differing_teacher_forced=forced_diff))
     assert changes[0] > n // 100
+    if sigma > 0.1:
+        assert min(changes) > 5, changes                 # labels keep moving
     assert first_div is None or first_div >= 2, first_div
     assert max(forced_diff) <= 2, forced_diff
-    if n != 8192:
+    if not (n == 8192 and sigma == 0.1):
         ctx.close()
 
 
@@ -413,9 +420,10 @@ def test_chain_at_baseline_config_2(numMH):
     split-merge, sweep, record) through rc_run_chain against the oracle's loop, 300 iterations, free-running scalar updates,
     numMH = 0 and the reference's default numMH = 1.  Labels / K / r / p / acceptances exactly; log-posterior trace to 1e-9
     against the oracle's regrouped arithmetic and to 1e-6 (the north_star bar) against the reference's formulas as written on
-    libm's log(D).  Clusters overlap (sigma = 0.2) and 5 % of the labels start re-drawn, so labels move throughout."""
+    libm's log(D).  Clusters overlap (sigma = 0.25: ~25 label changes per sweep, K around 80 with births and deaths) and 5 %
+    of the labels start re-drawn, so labels move throughout."""
     n, K, iters, burnin, thin = 2000, 20, 300, 50, 5
-    data = rc.generatemixture(n, K, seed=21, sigma=0.2)
+    data = rc.generatemixture(n, K, seed=21, sigma=0.25)
     D, truth = data["distancematrix"], data["clusts"]
     P = rc.likelihood_hyperparams(D, truth)
     init = truth.copy()
@@ -452,6 +460,7 @@ def test_chain_at_baseline_config_2(numMH):
                                                splitmerge_acceptances=int(np.sum(ch["splitmerge_acceptances"])) if numMH else 0,
                                                max_rel_logposterior_error_vs_literal_on_libm_logD=worst))
     assert worst <= 1e-6, worst
+    assert moved > 20, moved
     lab, sizes, Kc = ctx.get_state()
     assert np.array_equal(lab, orc.clusts) and Kc == orc.K
     ctx.close()
