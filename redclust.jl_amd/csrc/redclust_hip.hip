@@ -143,6 +143,7 @@ struct View {
     int ldw;                   // n rounded up to whole chunks
     int wc_always;             // 1: fill the cache in every sweep; 0: only when the previous sweep changed labels
     int maxb;                  // batch capacity of the resolver (<= RC_MAXB; smaller when that makes its LDS fit beside the row reduction)
+    const void *Dq48;          // [n][ld] D again, packed to 48 bits per entry (internal order): what k_bulk_syml2's fast path streams; null = none
     const void *Dq, *Lq;       // [n][ld] fixed point: int64 (bits = 64) or int32 (bits = 32); rows/columns in INTERNAL order
     int bits;
     const long long *diagq;    // [n] Dq[i][i]
@@ -166,6 +167,9 @@ struct View {
     unsigned *rec;             // [2][n] per round parity: (own slot << 16) | (target slot + 1) of a tentative changer (0 target = new cluster)
     int *tent;                 // [n] tentative target of every point (owner-private)
     unsigned *arrive[2];       // grid-barrier arrival counters (two generations)
+    const int4 *ufast, *uslow; // unit lists of k_bulk_syml2 (c0, first row, end row, 0), grouped by wave: the units its fast path takes / the rest
+    const int *wfast, *wslow;  // [nwaves + 1] offsets of each wave's units in the two lists (build_syml2_lists: balanced by cost)
+    int nfast, nslow;
     DevScalars *sc;
     HostSummary *hsum;         // device address of the host-mapped summary
     double scD, scL;           // 2^-eD, 2^-eL
@@ -304,46 +308,47 @@ __global__ __launch_bounds__(256) void k_pairwise(const double *__restrict__ pts
         }
 }
 
-// Internal layout: out[w][x] = src[ipi[w]][ipi[x]] (points of a cluster contiguous).  One block row per internal row w.
 // ---------------------------------------------------------------------------------------------------
 // Derived logD.  When the caller gives only D (MCMCData computes logD = log.(D − Diagonal(D) + I) itself,
-// types.jl:155), the fixed-point logD need not be stored at all: Lq(i,j) = rint(log(Dq(i,j)·2^-eD)·2^eL) is a pure
-// function of Dq(i,j), evaluated by every consumer with this one routine, so the row reduction reads HALF the bytes.
-// log(x), x = dq·2^-eD = 2^k·m, m ∈ [1,2): j = top 7 fraction bits of m, c_j = 1 + (j+½)/128, r = m/c_j − 1 ∈ [−1/257, 1/257],
-// log x = k·ln2 + log c_j + log1p(r) with the degree-6 Taylor polynomial of log1p (|error| < 3·10^-18) — ≈25 VALU
-// instructions and one 16-byte table read, against ≈100 for the libm log (tools/log_tune.hip: 268 MB of D streamed
-// with two of these per 16 B in 44.6 µs; with the libm log 119 µs; sum only 40.4 µs).  |result − libm log| ≤ 5·10^-16,
-// far below the quantum 2^-eL; what matters for exactness is only that every consumer uses this same function.
-// ltab[j] = (1/c_j, log c_j).
+// types.jl:155), the fixed-point logD need not be stored at all: Lq(i,j) = rc_qlog(Dq(i,j)) ≈ rint(log(Dq(i,j)·2^-eD)·2^eL) is a
+// pure function of Dq(i,j), evaluated by every consumer with this one routine, so the row reduction reads HALF the bytes.
+// What matters for exactness is only that every consumer uses this same function (all sums are sums of these integers); what
+// matters for parity is that it is log to well below the 1.2e-10 the derived mode allows itself (tests/test_gpu_headline.py
+// checks it against libm at N = 8192).
+//   x = dq·2^-eD = 2^k·m, m ∈ [1,2);  j = top 7 fraction bits of m;  c_j = 1 + (j+½)/128;  r = m/c_j − 1 ∈ [−1/257, 1/257]
+//   log x = k·ln2 + log c_j + log1p(r),   log1p(r) = r + r²(−1/2 + r(1/3 − r/4))   (next term r⁵/5 < 1.8e-13)
+//   Lq = k·LN2S + T_j + 2^eL·log1p(r), rounded to the integer by accumulating on the "magic" 1.5·2^52:
+//        v = fma((double)k, LN2S, T_j), T_j = rint(log c_j·2^eL) + 1.5·2^52 (integer-valued, per context);  w = fma(log1p(r), 2^eL, v);
+//        Lq = bits(w) − bits(1.5·2^52)         (|Lq| < 2^51 by the choice of eL, so v and w stay in [2^52, 2^53): unit spacing)
+// 16 VALU instructions per entry — six of them double-precision FMAs / multiplies — and one 16-byte table read (round 2's form of
+// the same idea took 23: a degree-6 polynomial, the scaling and the rounding as separate steps); the libm log is ~100.
+// ltab[j] = (1/c_j, T_j): 128 entries, rebuilt per context once eL is known (create_impl).
 // ---------------------------------------------------------------------------------------------------
 // Front end: the fixed-point entry is an integer below 2^52 (create_impl caps eD accordingly in the derived mode), so
 // OR-ing it into the mantissa of 2^52 and subtracting 2^52 converts it to a double exactly in two instructions; exponent,
 // table index and mantissa then come from the HIGH dword of that double with 32-bit operations (no count-leading-zeros,
 // no 64-bit shifts).  dq = 0 (padding, masked entries) gives a finite value the callers discard.
-struct QlogPrep { int k, j; double m; };
+struct QlogPrep { int j; double kd, m; };
 __device__ __forceinline__ QlogPrep rc_qlog_prep(long long dq, int eD)
 {
     const double x = __longlong_as_double(dq | 0x4330000000000000ll) - 0x1p52;
     const unsigned hi = (unsigned)__double2hiint(x);
     QlogPrep P;
-    P.k = (int)(hi >> 20) - (1023 + eD);                                    // x·2^-eD = m·2^k, m in [1,2)
+    P.kd = (double)((int)(hi >> 20) - (1023 + eD));                         // x·2^-eD = m·2^k, m in [1,2)
     P.j = (int)((hi >> 13) & 127u);                                         // top 7 fraction bits
     P.m = __hiloint2double((int)((hi & 0x000fffffu) | 0x3ff00000u), __double2loint(x));
     return P;
 }
-// the value rint(log(dq·2^-eD)·2^eL) for dq > 0 — no select on dq: callers that may hold dq <= 0 mask the result
+// the value for dq > 0 — no select on dq: callers that may hold dq <= 0 mask the result
 __device__ __forceinline__ long long rc_qlog_raw(const QlogPrep &P, double2 t, double sL)
 {
     const double r = fma(P.m, t.x, -1.0);
-    double p = fma(r, -1.0 / 6, 1.0 / 5);
-    p = fma(r, p, -1.0 / 4);
-    p = fma(r, p, 1.0 / 3);
+    double p = fma(r, -1.0 / 4, 1.0 / 3);
     p = fma(r, p, -1.0 / 2);
-    p = fma(r * r, p, r);
-    const double L = fma((double)P.k, 0.69314718055994530942, t.y + p);
-    // rint(L·2^eL) as an integer by the magic-number trick (|L·2^eL| < 2^51 by the choice of eL)
-    const double v = fma(L, sL, 0x1.8p52);
-    return __double_as_longlong(v) - __double_as_longlong(0x1.8p52);
+    const double q = fma(r * r, p, r);                                      // log1p(r)
+    const double v = fma(P.kd, 0.69314718055994530942 * sL, t.y);           // (sL is a power of two: the product is ln2 scaled exactly)
+    const double w = fma(q, sL, v);
+    return __double_as_longlong(w) - __double_as_longlong(0x1.8p52);
 }
 __device__ __forceinline__ long long rc_qlog_finish(long long dq, const QlogPrep &P, double2 t, double sL)
 {
@@ -364,8 +369,7 @@ __device__ __forceinline__ long long rc_load_L(const View &V, int row, int col, 
 }
 
 // one-off scan for the derived mode: smallest off-diagonal Dq (must be > 0) and largest |log| (fixes eL)
-__global__ void k_derived_scan(const long long *__restrict__ Dq, int n, int ld, int eD, const double2 *__restrict__ tab,
-                               long long *min_dq, u64 *maxabs_bits)
+__global__ void k_derived_scan(const long long *__restrict__ Dq, int n, int ld, int eD, long long *min_dq, u64 *maxabs_bits)
 {
     long long mn = 0x7fffffffffffffffll;
     double mx = 0.0;
@@ -375,7 +379,7 @@ __global__ void k_derived_scan(const long long *__restrict__ Dq, int n, int ld, 
         if (i == j) continue;
         const long long dq = Dq[i * ld + j];
         mn = min(mn, dq);
-        if (dq > 0) mx = fmax(mx, fabs((double)rc_qlog(dq, eD, 0x1p40, tab) * 0x1p-40));
+        if (dq > 0) mx = fmax(mx, fabs(log(ldexp((double)dq, -eD))));   // (one-off; the table of rc_qlog needs eL, which this fixes)
     }
     atomicMin((long long *)min_dq, mn);
     atomicMax((unsigned long long *)maxabs_bits, (unsigned long long)__double_as_longlong(mx));
@@ -429,6 +433,19 @@ __global__ void k_gather_ll(const long long *__restrict__ src, const int *__rest
 {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w < n) out[w] = src[ipi[w]];
+}
+
+// D once more, 48 bits per entry (two entries in three dwords), for the streaming row reduction: 6 instead of 8 bytes per entry.
+// The derived mode caps eD so that every entry is below 2^47 (create_impl); row pitch ld entries, as Dq.
+__global__ __launch_bounds__(256) void k_pack48(const long long *__restrict__ Dq, size_t pairs, unsigned *__restrict__ out)
+{
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < pairs; t += (size_t)gridDim.x * blockDim.x) {
+        const ll2 v = *(const ll2 *)(Dq + 2 * t);
+        const u64 a = (u64)v.x, b = (u64)v.y;
+        out[3 * t] = (unsigned)a;
+        out[3 * t + 1] = (unsigned)(a >> 32) | ((unsigned)b << 16);
+        out[3 * t + 2] = (unsigned)(b >> 16);
+    }
 }
 
 // fixed-point matrix back to doubles (value = q·2^-e), for checks
@@ -1094,7 +1111,8 @@ template <> struct SymlRaw<long long> { typedef ll2 vec; };
 template <> struct SymlRaw<int> { typedef int vec __attribute__((ext_vector_type(2))); };
 template <bool DERIVED, typename T = long long>
 __device__ __forceinline__ void syml_units(const View &V, long long (*tt)[RC_SL_R][RC_SL_P], int wgen, int sgen, int nitems,
-                                           int jsplit, int gfine, int gcoarse, int first_unit, int nwaves, long long *pf_out)
+                                           int jsplit, int gfine, int gcoarse, int first_unit, int nwaves, long long *pf_out,
+                                           const int4 *__restrict__ ulist = nullptr)
 {
     typedef typename SymlRaw<T>::vec rawvec;
     const int lane = threadIdx.x & 63;
@@ -1119,6 +1137,11 @@ __device__ __forceinline__ void syml_units(const View &V, long long (*tt)[RC_SL_
     // unit index -> (column block, first row, end row)
     int c0 = 0, a0 = 0, a1 = 0, item = 0;
     auto decode = [&](int u, int &oc0, int &oa0, int &oa1, int &oitem) {
+        if (ulist) {                                                     // host-built list (k_bulk_syml2's slow units)
+            const int4 e = ulist[u];
+            oc0 = e.x; oa0 = e.y; oa1 = e.z; oitem = e.y == 0 ? 0 : 1;   // (item 0 = the column block's first unit: adds the diagonal)
+            return;
+        }
         int it = u, J = ncb - 1, g = gcoarse;
         for (;; --J) {
             g = (J >= jsplit) ? gcoarse : gfine;
@@ -1373,11 +1396,15 @@ __device__ __forceinline__ void syml_kernel_body(const View &V, int wgen, int zg
     if (DERIVED) syml_load_table(V, tl);
     (void)zgen;  // generations are cleared and work counters re-armed by k_resolve (SweepArgs.zero_gen)
     __syncthreads();  // the table is visible; from here on the waves are on their own
-    const int w = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    // the wave's number as a SCALAR (readfirstlane: threadIdx.x >> 6 is wave-uniform, but only the programmer knows): unit numbers,
+    // row ranges, tile loops and the row part of every address then live in SGPRs — scalar branches instead of exec-mask
+    // save / restore pairs around every uniform `if`, s_mul / s_add instead of v_mad_i64_i32 per loaded row
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int w = (int)blockIdx.x * 4 + wv;
     long long *pf = nullptr;
     RC_PF(if (w < 8192) pf = (long long *)((char *)V.work[cgen] + 64) + (size_t)w * 16;)
     (void)cgen;
-    syml_units<DERIVED, T>(V, tl[threadIdx.x >> 6], wgen, sgen, nitems, jsplit, gfine, gcoarse, w, (int)gridDim.x * 4, pf);
+    syml_units<DERIVED, T>(V, tl[wv], wgen, sgen, nitems, jsplit, gfine, gcoarse, w, (int)gridDim.x * 4, pf);
 }
 template <bool DERIVED>
 __global__ __launch_bounds__(256, RC_SYML_MINWAVES) void k_bulk_syml(View V, int wgen, int zgen, int sgen, int cgen, int nitems, int jsplit, int gfine, int gcoarse)
@@ -1390,6 +1417,439 @@ __global__ __launch_bounds__(256, RC_SYML_MINWAVES) void k_bulk_syml32(View V, i
     syml_kernel_body<false, int>(V, wgen, zgen, sgen, cgen, nitems, jsplit, gfine, gcoarse);
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// k_bulk_syml2 — the wave-autonomous symmetric reduction again, its common case rewritten around the instruction count (round 3).
+// k_bulk_syml measured: 25.5 M VALU wave-instructions per launch at n = 8192 (48 per matrix entry), 43 % of a wave's cycles issuing,
+// 25 % stalled behind the other waves of its SIMD, 33 % parked on LDS round trips (profiles/r02/sq_counters_n8192.txt; per phase
+// of a 4-row tile: the logs 26 %, direction 2 29 %, direction 1 11 %; the tile's loads are waited for 1 % of the time): bound by
+// its own instruction stream, not by HBM.  What changed, same contract (upper triangle only, exact for any labelling):
+//  * the unit list is built by the host (View.ufast / .uslow): no per-unit decode loop; the wave number is a scalar
+//    (readfirstlane), so unit bounds, row loops and row addresses live in SGPRs;
+//  * FAST units (97 % at n = 8192) lie entirely above the diagonal blocks, hold 128 real columns and a multiple of 8 rows:
+//    no triangle masks at all;
+//  * the log is 16 instructions instead of 23 (rc_qlog);
+//  * direction 2 (S[slot_col][row]) sends ONE pre-added value per lane and row through LDS — x[col 2l] + x[col 2l+1], both
+//    columns of a lane belong to one cluster except in the lane a cluster boundary splits — 8 rows at a time: the wave writes
+//    8 × 64 values per matrix (ds_write_b64) and reads them back as (row = lane >> 3, lane octet = lane & 7), 8 values per lane:
+//    7 adds and a 3-step DPP reduction over 8 lanes per 8 rows, where k_bulk_syml did 7 adds and 4 steps per 4 rows on
+//    twice the LDS traffic; the B accumulators exist only in units whose columns span two clusters;
+//    lanes that a boundary splits, or whose columns belong to a third cluster, add their elements with atomics (exact);
+//  * the log table is shared by the block (2 KiB) and the tile buffers shrink to 8.25 KiB per wave: 35 KiB per block.
+// The remaining units (diagonal blocks, the ragged last column block) go through the round-2 unit code (syml_units with a
+// list), in the same launch, after the fast ones.
+// ---------------------------------------------------------------------------------------------------
+#define RC_S2_PITCH 66   // long longs per p-buffer row: 64 lanes + 2 (528 B: the transposed b128 reads of a lane group fall on 16 different bank quads)
+
+// sums of two / four 64-bit values over each group of 8 consecutive lanes (all lanes of the group receive the totals)
+__device__ __forceinline__ void row8_sum2_dpp(long long &a, long long &b)
+{
+    unsigned r0 = (unsigned)(u64)a, r1 = (unsigned)((u64)a >> 32), r2 = (unsigned)(u64)b, r3 = (unsigned)((u64)b >> 32);
+#define RC_DPP_STEP2(ctrl)                                           \
+    "v_add_co_u32_dpp %0, vcc, %0, %0 " ctrl "\n\t"                  \
+    "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc " ctrl "\n\t"            \
+    "v_add_co_u32_dpp %2, vcc, %2, %2 " ctrl "\n\t"                  \
+    "v_addc_co_u32_dpp %3, vcc, %3, %3, vcc " ctrl "\n\t"
+    asm volatile("s_nop 1\n\t"
+                 RC_DPP_STEP2("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 RC_DPP_STEP2("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 RC_DPP_STEP2("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 "s_nop 0"
+                 : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3)
+                 :
+                 : "vcc");
+#undef RC_DPP_STEP2
+    a = (long long)(((u64)r1 << 32) | r0); b = (long long)(((u64)r3 << 32) | r2);
+}
+
+// storage of D as the fast path streams it: int64 entries (16 B per lane and row), or — PACK — the 48-bit packed copy (12 B per
+// lane and row: two entries in three dwords; View.Dq48), unpacked with three 32-bit operations
+typedef unsigned rc_u3 __attribute__((ext_vector_type(3)));
+typedef rc_u3 rc_u3a4 __attribute__((aligned(4)));
+template <bool PACK> struct S2Raw;
+template <> struct S2Raw<false> {
+    typedef ll2 T;
+    static __device__ __forceinline__ ll2 unpack(const ll2 &r) { return r; }
+};
+template <> struct S2Raw<true> {
+    typedef rc_u3 T;
+    static __device__ __forceinline__ ll2 unpack(const rc_u3 &r)
+    {
+        ll2 x;
+        x.x = (long long)((u64)r.x | ((u64)(r.y & 0xffffu) << 32));
+        x.y = (long long)((u64)((r.y >> 16) | (r.z << 16)) | ((u64)(r.z >> 16) << 32));
+        return x;
+    }
+};
+
+// a uniform pointer, opaque to the optimiser (it would otherwise fold the lane offset into the base and carry one 64-bit address
+// per loaded row in vector registers): address = scalar pair + 32-bit lane offset, the scalar-base form of the global instructions
+#define RC_GLOBAL_AS __attribute__((address_space(1)))
+#define RC_CONST_AS __attribute__((address_space(4)))
+template <typename T>
+__device__ __forceinline__ RC_GLOBAL_AS T *rc_uniform_ptr(T *p)
+{
+    const u64 v = (u64)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (RC_GLOBAL_AS T *)(((u64)hi << 32) | lo);   // (global address space kept: a generic pointer would make these flat loads)
+}
+
+// lane i receives lane i + 1's / lane i - 1's value (0 beyond the wave): wave-wide DPP shifts (gfx9: wave_shl / wave_shr)
+__device__ __forceinline__ int wave_from_next(int v)
+{
+    int r = 0;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1" : "+v"(r) : "v"(v));
+    return r;
+}
+__device__ __forceinline__ long long wave_from_prev64(long long v)
+{
+    unsigned lo = 0, hi = 0;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "v_mov_b32_dpp %1, %3 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1"
+                 : "+v"(lo), "+v"(hi) : "v"((unsigned)(u64)v), "v"((unsigned)((u64)v >> 32)));
+    return (long long)(((u64)hi << 32) | lo);
+}
+
+template <bool DERIVED, bool PACK>
+__device__ __forceinline__ void syml2_fast(const View &V, long long *pb /* [2][8][RC_S2_PITCH], wave-private */, long long *bounce /* [128], wave-private */,
+                                           const double2 *tab /* [128], block-shared */,
+                                           int wgen, int sgen, int first_unit, int end_unit /* this wave's units: [first_unit, end_unit) of V.ufast */,
+                                           long long *pf_out = nullptr)
+{
+    typedef typename S2Raw<PACK>::T raw_t;
+    RC_PF(long long pf_wait = 0; long long pf_tiles = 0; long long pf_setup = 0; long long pf_log = 0; long long pf_d2 = 0; long long pf_issue = 0; long long pf_ldsw = 0; long long pf_d1 = 0;)
+    RC_PF(const long long pf_t0 = __builtin_amdgcn_s_memtime(); const long long pf_r0 = __builtin_amdgcn_s_memrealtime();)
+    (void)pf_out;
+    const int lane = threadIdx.x & 63;
+    const int tr = lane >> 3, tq = lane & 7;                            // transposed role: row of the 8-row group, lane octet
+    const size_t ld = (size_t)V.ld;
+    // every address is (uniform pointer) + (32-bit unsigned lane offset): the loads then take the scalar-base form and no per-row
+    // 64-bit address lives in vector registers
+    const long long *__restrict__ Dq = (const long long *)V.Dq;
+    const unsigned *__restrict__ D48 = (const unsigned *)V.Dq48;              // PACK: 6 bytes per entry, rows of ld entries
+    const long long *__restrict__ Lq = (const long long *)V.Lq;
+    const unsigned lane2 = 2u * (unsigned)lane, lane3 = 3u * (unsigned)lane;
+    const int *__restrict__ slot = V.snap[sgen];
+    long long *SD = V.SD[wgen], *SL = V.SL[wgen];
+    const int qeD = V.qeD;
+    const double qsL = V.qsL;
+#ifndef RC_S2_EXP
+#define RC_S2_EXP 0      // timing experiments only (tools/syml_variants.py): 1 no atomics, 2 no logs, 4 no direction 2, 8 no direction 1
+#endif
+    auto add64 = [](long long *p, long long v) {
+#ifdef RC_S2_WG_ATOMICS   // timing experiment only (NOT coherent across XCDs): do atomics that stay in the issuing XCD's L2 run faster?
+        if (!(RC_S2_EXP & 1) || v == 0x7fffffffffffffffll) __hip_atomic_fetch_add((u64 *)p, (u64)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+        if (!(RC_S2_EXP & 1) || v == 0x7fffffffffffffffll) __hip_atomic_fetch_add((u64 *)p, (u64)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    };
+    long long *const pD = pb, *const pL = pb + 8 * RC_S2_PITCH;
+    // TWO tiles (8 rows) in flight per wave: with the instruction count of a tile cut to a third, a tile is consumed faster than HBM
+    // answers under load (measured with everything but the loads removed).  The rows are taken in pairs; the pair two tiles ahead is
+    // requested the moment a pair is taken, so the registers holding loaded rows never exceed two tiles plus a pair.
+#ifndef RC_S2_NP
+#define RC_S2_NP 2       // row pairs in flight per wave: 4 = two tiles ahead, 2 = one (4 spills inside the loop at 128 registers: fatal, see k_bulk_syml2)
+#endif
+#ifndef RC_S2_LOGS
+#define RC_S2_LOGS 2     // logs evaluated together (table reads first, then the arithmetic): 4 or 2 (4 spills, as above)
+#endif
+    constexpr int NP = RC_S2_NP;
+    raw_t d[NP][2];
+    ll2 l[NP][2];
+    auto issue_pair = [&](int sl, int row, int cb0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const size_t e = (size_t)(row + u) * ld + (size_t)cb0;        // uniform: first entry of the wave's row segment
+            if (PACK) d[sl][u] = __builtin_nontemporal_load((RC_GLOBAL_AS const typename std::conditional<PACK, rc_u3a4, ll2>::type *)(rc_uniform_ptr(D48 + e / 2 * 3) + lane3));
+            else d[sl][u] = __builtin_nontemporal_load((RC_GLOBAL_AS const typename std::conditional<PACK, rc_u3a4, ll2>::type *)(rc_uniform_ptr(Dq + e) + lane2));
+            if (!DERIVED) l[sl][u] = __builtin_nontemporal_load((RC_GLOBAL_AS const ll2 *)(rc_uniform_ptr(Lq + e) + lane2));
+        }
+    };
+    // (uniform by construction — the wave number is a scalar — but say so: unit bounds, row loops and row addresses stay in SGPRs)
+    RC_CONST_AS const int *const ufast_w = (RC_CONST_AS const int *)(u64)V.ufast;   // scalar loads (a vector load here would make the wave wait for all its prefetched rows: one counter)
+    auto load_unit = [&](int u_) {
+        return make_int4(__builtin_amdgcn_readfirstlane(ufast_w[4 * u_]), __builtin_amdgcn_readfirstlane(ufast_w[4 * u_ + 1]), __builtin_amdgcn_readfirstlane(ufast_w[4 * u_ + 2]), 0);
+    };
+    int unit = __builtin_amdgcn_readfirstlane(first_unit);
+    end_unit = __builtin_amdgcn_readfirstlane(end_unit);
+    int4 U = make_int4(0, 0, 0, 0), Un = make_int4(0, 0, 0, 0);
+    int cs0 = -1, cs1 = -1;
+    if (unit < end_unit) {
+        U = load_unit(unit);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) issue_pair(q, U.y + 2 * q, U.x);
+        cs0 = slot[U.x + 2 * lane]; cs1 = slot[U.x + 2 * lane + 1];     // (fast units hold 128 real columns)
+    }
+    while (unit < end_unit) {
+        RC_PF(long long pf_u0 = __builtin_amdgcn_s_memtime();)
+        const int c0 = U.x, a0 = U.y, a1 = U.z;
+        const int nunit = unit + 1;
+        const bool have_next = nunit < end_unit;
+        if (have_next) Un = load_unit(nunit);
+        int ncs0 = -1, ncs1 = -1;
+        // the two clusters that own most of the 128 columns (as k_bulk_syml: majority among four probes)
+        int dsA, dsB = -1;
+        {
+            const int k0 = __builtin_amdgcn_readfirstlane(cs0);
+            const u64 not0 = __ballot(cs0 != k0), not1 = __ballot(cs1 != k0);
+            if (not0 | not1) {
+                const int l0 = not0 ? __ffsll((long long)not0) - 1 : 64, l1 = not1 ? __ffsll((long long)not1) - 1 : 64;
+                const int k1 = (l0 <= l1) ? __builtin_amdgcn_readlane(cs0, l0 & 63) : __builtin_amdgcn_readlane(cs1, l1 & 63);
+                const int k2 = __builtin_amdgcn_readlane(cs0, 32), k3 = __builtin_amdgcn_readlane(cs1, 63);
+                auto count = [&](int k) { return __popcll(__ballot(cs0 == k)) + __popcll(__ballot(cs1 == k)); };
+                const int n0 = count(k0), n1 = count(k1), n2 = (k2 == k0 || k2 == k1) ? 0 : count(k2),
+                          n3 = (k3 == k0 || k3 == k1 || k3 == k2) ? 0 : count(k3);
+                int ka = k0, na = n0, kb = k1, nbb = n1;
+                if (nbb > na) { int t_ = ka; ka = kb; kb = t_; t_ = na; na = nbb; nbb = t_; }
+                if (n2 > na) { kb = ka; nbb = na; ka = k2; na = n2; } else if (n2 > nbb) { kb = k2; nbb = n2; }
+                if (n3 > na) { kb = ka; nbb = na; ka = k3; na = n3; } else if (n3 > nbb) { kb = k3; nbb = n3; }
+                dsA = ka; dsB = kb;
+            } else {
+                dsA = k0;
+            }
+            dsA = __builtin_amdgcn_readfirstlane(dsA); dsB = __builtin_amdgcn_readfirstlane(dsB);
+        }
+        // A lane is "whole" when its two columns belong to one of the two clusters together: its pre-added value goes through LDS.
+        // A lane that the boundary between the two clusters splits (column 2 l in one, 2 l + 1 in the other — every other boundary)
+        // is a DONOR: it keeps its first column as its value and hands the second to the lane on its right, whose columns are the
+        // second cluster's (one wave-wide DPP shift per row and matrix, only in units that have such a lane).  Every other lane
+        // (a third cluster, a stray point) adds its elements with atomics, row by row.
+        const bool diag = a1 > c0;                                        // uniform: the unit reaches into the diagonal block — triangle mask
+        const int colx = c0 + (int)lane2, coly = colx + 1;
+        const bool hasB = dsB >= 0;                                       // uniform
+        const bool in0 = cs0 == dsA || (hasB && cs0 == dsB), in1 = cs1 == dsA || (hasB && cs1 == dsB);
+        const bool whole0 = (cs0 == cs1) && in0;
+        const int r_cs0 = wave_from_next(cs0), r_whole = wave_from_next(whole0 ? 1 : 0);
+        const bool donor = !whole0 && in0 && in1 && lane < 63 && r_whole != 0 && r_cs0 == cs1;
+        const bool whole = whole0 || donor;                               // contributes a value of class(cs0) through LDS
+        const bool any_odd = __ballot(!whole) != 0;                       // uniform
+        const bool any_donor = __ballot(donor) != 0;                      // uniform
+        // class of the source lanes: bit l set = lane l's pre-added value belongs to cluster B.  Kept as the (scalar) ballot and cut
+        // to the eight source lanes 8 tq .. 8 tq + 7 of a transposed value where it is used: a per-lane copy is one more long-lived
+        // vector register, and a spilled register in this loop is fatal — its reload waits on the counter the prefetched rows use
+        const u64 bB = __ballot(whole && cs0 == dsB);
+        long long aD0 = 0, aD1 = 0, aL0 = 0, aL1 = 0;                   // direction 1, slot `cur`
+        long long rDA = 0, rLA = 0, rDB = 0, rLB = 0;                   // direction 2: row h0 + 8 (lane & 7) + (lane >> 3)
+        int cur = -1;
+        // The 64-bit atomics execute at the memory side, 64-byte request by 64-byte request, at about a fifth of the read rate
+        // — so every atomic instruction should fill its requests.  A lane's direction-1 sums are two adjacent columns (16 contiguous
+        // bytes, but one instruction adds only one of them: 16 half-used requests each), its direction-2 totals the rows
+        // 8 (l & 7) + (l >> 3) (64 different requests per instruction): both go through a 1 KiB bounce in the wave's LDS first,
+        // after which lane l holds column c0 + l and c0 + 64 + l, or row h0 + l — 8 full requests per instruction.
+        auto flush1 = [&]() {
+            if (cur >= 0) {
+                long long *const rowD = SD + (size_t)cur * ld + c0, *const rowL = SL + (size_t)cur * ld + c0;
+                __builtin_amdgcn_wave_barrier();
+                *(ll2 *)&bounce[2 * lane] = ll2{aD0, aD1};
+                __builtin_amdgcn_wave_barrier();
+                const long long d0 = bounce[lane], d1 = bounce[64 + lane];
+                __builtin_amdgcn_wave_barrier();
+                *(ll2 *)&bounce[2 * lane] = ll2{aL0, aL1};
+                __builtin_amdgcn_wave_barrier();
+                const long long l0 = bounce[lane], l1 = bounce[64 + lane];
+                __builtin_amdgcn_wave_barrier();
+                if (d0) add64(rowD + lane, d0);
+                if (d1) add64(rowD + 64 + lane, d1);
+                if (l0) add64(rowL + lane, l0);
+                if (l1) add64(rowL + 64 + lane, l1);
+            }
+            aD0 = aD1 = aL0 = aL1 = 0;
+        };
+        for (int h0 = a0; h0 < a1; h0 += 64) {                            // 64-row halves (direction-2 totals live one row per lane)
+            const int h1 = min(h0 + 64, a1);
+            const int rowslots = (h0 + lane < h1) ? slot[h0 + lane] : -1; // slot of row h0 + lane (read back with readlane)
+            RC_PF(pf_setup += __builtin_amdgcn_s_memtime() - pf_u0;)
+            for (int a = h0; a < h1; a += 8) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {                             // the group's four row pairs
+                    const int sl = q % NP, ar = a + 2 * q;
+                    RC_PF({ const long long w0 = __builtin_amdgcn_s_memtime(); if (NP == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); pf_wait += __builtin_amdgcn_s_memtime() - w0; pf_tiles += 1; })
+                    ll2 x[2], y[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) { x[u] = S2Raw<PACK>::unpack(d[sl][u]); if (!DERIVED) y[u] = l[sl][u]; }
+                    // the pair NP pairs ahead goes into the registers this one leaves: of this unit, or of the wave's next unit
+                    if (ar + 2 * NP < a1) issue_pair(sl, ar + 2 * NP, c0);
+                    else if (have_next) {
+                        issue_pair(sl, Un.y + (ar + 2 * NP - a1), Un.x);
+                        if (q == 3) { ncs0 = slot[Un.x + 2 * lane]; ncs1 = slot[Un.x + 2 * lane + 1]; }
+                    }
+                    RC_PF(const long long pl0 = __builtin_amdgcn_s_memtime();)
+                    if (RC_S2_EXP & 2) {
+                        y[0] = x[0]; y[1] = x[1];
+                    } else if (DERIVED) {                                 // RC_S2_LOGS logs together: table reads first, then the arithmetic
+#pragma unroll
+                        for (int g_ = 0; g_ < 4; g_ += RC_S2_LOGS) {
+                            QlogPrep pp[RC_S2_LOGS];
+                            double2 tv[RC_S2_LOGS];
+#pragma unroll
+                            for (int u = 0; u < RC_S2_LOGS; ++u) pp[u] = rc_qlog_prep(((g_ + u) & 1) ? x[(g_ + u) >> 1].y : x[(g_ + u) >> 1].x, qeD);
+#pragma unroll
+                            for (int u = 0; u < RC_S2_LOGS; ++u) tv[u] = tab[pp[u].j];
+#pragma unroll
+                            for (int u = 0; u < RC_S2_LOGS; ++u) {
+                                const long long v = rc_qlog_raw(pp[u], tv[u], qsL);
+                                if ((g_ + u) & 1) y[(g_ + u) >> 1].y = v; else y[(g_ + u) >> 1].x = v;
+                            }
+                        }
+                    }
+                    if (diag) {   // strictly upper triangle: element (row, col) lives iff col > row (the logs of dead entries are garbage: masked too)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            if (!(colx > ar + u)) { x[u].x = 0; y[u].x = 0; }
+                            if (!(coly > ar + u)) { x[u].y = 0; y[u].y = 0; }
+                        }
+                    }
+                    RC_PF(asm volatile("" ::: "memory"); const long long pw0 = __builtin_amdgcn_s_memtime(); pf_log += pw0 - pl0;)
+                    // direction 2: one pre-added value per lane, row and matrix into the wave's buffer
+                    if (!(RC_S2_EXP & 4)) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            long long vd = x[u].x + x[u].y, vl = y[u].x + y[u].y;
+                            if (any_donor) {
+                                const long long gd = wave_from_prev64(donor ? x[u].y : 0), gl = wave_from_prev64(donor ? y[u].y : 0);
+                                vd = (donor ? x[u].x : vd) + gd; vl = (donor ? y[u].x : vl) + gl;
+                            }
+                            if (any_odd && !whole) { vd = 0; vl = 0; }
+                            pD[(2 * q + u) * RC_S2_PITCH + lane] = vd;
+                            pL[(2 * q + u) * RC_S2_PITCH + lane] = vl;
+                        }
+                    }
+                    if (any_odd) {   // uniform, rare: the elements of the lanes that are not whole
+                        if (!whole) {
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                const int row = ar + u;
+                                add64(SD + (size_t)cs0 * ld + row, x[u].x); add64(SL + (size_t)cs0 * ld + row, y[u].x);
+                                add64(SD + (size_t)cs1 * ld + row, x[u].y); add64(SL + (size_t)cs1 * ld + row, y[u].y);
+                            }
+                        }
+                    }
+                    RC_PF(const long long pd0 = __builtin_amdgcn_s_memtime(); pf_ldsw += pd0 - pw0;)
+                    // direction 1
+                    if (RC_S2_EXP & 8) { aD0 += x[0].x ^ x[1].y; aL0 += y[0].x ^ y[1].y; } else {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int sr = __builtin_amdgcn_readlane(rowslots, ar + u - h0);
+                            if (sr != cur) { flush1(); cur = sr; }
+                            aD0 += x[u].x; aD1 += x[u].y; aL0 += y[u].x; aL1 += y[u].y;
+                        }
+                    }
+                    RC_PF(asm volatile("" ::: "memory"); pf_d1 += __builtin_amdgcn_s_memtime() - pd0;)
+                }
+                // direction 2: transposed read of the 8-row group (same-wave LDS operations execute in order)
+                if (RC_S2_EXP & 4) continue;
+                RC_PF(const long long pr0 = __builtin_amdgcn_s_memtime();)
+                __builtin_amdgcn_wave_barrier();
+                long long vD[8], vL[8];
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    const ll2 qd = *(const ll2 *)&pD[tr * RC_S2_PITCH + 8 * tq + j], ql = *(const ll2 *)&pL[tr * RC_S2_PITCH + 8 * tq + j];
+                    vD[j] = qd.x; vD[j + 1] = qd.y; vL[j] = ql.x; vL[j + 1] = ql.y;
+                }
+                __builtin_amdgcn_wave_barrier();
+                const bool mine = tq == ((a - h0) >> 3);
+                if (!hasB) {
+                    long long sD = ((vD[0] + vD[1]) + (vD[2] + vD[3])) + ((vD[4] + vD[5]) + (vD[6] + vD[7]));
+                    long long sL = ((vL[0] + vL[1]) + (vL[2] + vL[3])) + ((vL[4] + vL[5]) + (vL[6] + vL[7]));
+                    row8_sum2_dpp(sD, sL);
+                    if (mine) { rDA += sD; rLA += sL; }
+                } else {
+                    const unsigned mB = (unsigned)(bB >> (8 * tq)) & 0xFFu;
+                    long long sDA = 0, sLA = 0, sDB = 0, sLB = 0;
+                    if (mB == 0) {
+                        sDA = ((vD[0] + vD[1]) + (vD[2] + vD[3])) + ((vD[4] + vD[5]) + (vD[6] + vD[7]));
+                        sLA = ((vL[0] + vL[1]) + (vL[2] + vL[3])) + ((vL[4] + vL[5]) + (vL[6] + vL[7]));
+                    } else if (mB == 0xffu) {
+                        sDB = ((vD[0] + vD[1]) + (vD[2] + vD[3])) + ((vD[4] + vD[5]) + (vD[6] + vD[7]));
+                        sLB = ((vL[0] + vL[1]) + (vL[2] + vL[3])) + ((vL[4] + vL[5]) + (vL[6] + vL[7]));
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            if ((mB >> j) & 1) { sDB += vD[j]; sLB += vL[j]; } else { sDA += vD[j]; sLA += vL[j]; }
+                        }
+                    }
+                    row8_sum2_dpp(sDA, sLA);
+                    row8_sum2_dpp(sDB, sLB);
+                    if (mine) { rDA += sDA; rLA += sLA; rDB += sDB; rLB += sLB; }
+                }
+                RC_PF(asm volatile("" ::: "memory"); pf_d2 += __builtin_amdgcn_s_memtime() - pr0;)
+            }
+            RC_PF(pf_u0 = __builtin_amdgcn_s_memtime();)
+            // direction 2 write-out: lane l holds the totals of row h0 + 8 (l & 7) + (l >> 3); through the bounce lane l gets row h0 + l
+            {
+                const int mine_ = 8 * tq + tr, row = h0 + lane;
+                __builtin_amdgcn_wave_barrier();
+                bounce[mine_] = rDA; bounce[64 + mine_] = rLA;
+                __builtin_amdgcn_wave_barrier();
+                const long long tD = bounce[lane], tL = bounce[64 + lane];
+                __builtin_amdgcn_wave_barrier();
+                if (row < h1) {
+                    if (tD) add64(SD + (size_t)dsA * ld + row, tD);
+                    if (tL) add64(SL + (size_t)dsA * ld + row, tL);
+                }
+                if (hasB) {
+                    bounce[mine_] = rDB; bounce[64 + mine_] = rLB;
+                    __builtin_amdgcn_wave_barrier();
+                    const long long uD = bounce[lane], uL = bounce[64 + lane];
+                    __builtin_amdgcn_wave_barrier();
+                    if (row < h1) {
+                        if (uD) add64(SD + (size_t)dsB * ld + row, uD);
+                        if (uL) add64(SL + (size_t)dsB * ld + row, uL);
+                    }
+                }
+            }
+            rDA = rLA = rDB = rLB = 0;
+        }
+        flush1();
+        // diagonal (S includes j = i): D[a][a] -> S[slot_a][a], added by the column block's first unit; logD's diagonal is 0
+        if (a0 == 0) {
+            const int col0 = c0 + 2 * lane;
+            const long long x0 = V.diagq[col0], x1 = V.diagq[col0 + 1];
+            if (x0) add64(SD + (size_t)cs0 * ld + col0, x0);
+            if (x1) add64(SD + (size_t)cs1 * ld + col0 + 1, x1);
+        }
+        unit = nunit; U = Un; cs0 = ncs0; cs1 = ncs1;
+        RC_PF(pf_setup += __builtin_amdgcn_s_memtime() - pf_u0;)
+    }
+    RC_PF(if (lane == 0 && pf_out) { pf_out[0] = __builtin_amdgcn_s_memtime() - pf_t0; pf_out[1] = pf_wait; pf_out[2] = pf_tiles; pf_out[3] = pf_setup;
+                                     pf_out[4] = __builtin_amdgcn_s_memrealtime() - pf_r0; pf_out[5] = pf_log; pf_out[6] = pf_d2;
+                                     pf_out[7] = (pf_r0 << 20) | (long long)((__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF) << 16) |
+                                                 (long long)(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (15 << 11)) & 0xFFFF);
+                                     pf_out[8] = pf_issue; pf_out[9] = pf_ldsw; pf_out[10] = pf_d1; })
+}
+
+// 36.8 KiB of LDS per block: [log table 2 KiB][4 waves x 8.25 KiB of p-buffers][4 x 1 KiB bounces].  Four blocks per CU stay
+// possible, which is what makes the compiler hold the kernel to 128 registers (three of these waves and one resolver wave per SIMD
+// fill its 512).  Nothing in this kernel may spill: a scratch reload waits on vmcnt, the counter the prefetched rows use, i.e. for
+// every row in flight (one spilled class mask made each 8-row group of a two-cluster unit wait for all its loads: 5,400 cycles
+// instead of 730) — which is why the ragged units have their own launch (k_bulk_syml_list) instead of sharing this kernel's
+// register allocation.
+template <bool DERIVED, bool PACK>
+__global__ __launch_bounds__(256, RC_SYML_MINWAVES) void k_bulk_syml2(View V, int wgen, int sgen, int cgen)
+{
+    __shared__ __attribute__((aligned(16))) long long lds[256 + 4 * (2 * 8 * RC_S2_PITCH + 128)];
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int w = (int)blockIdx.x * 4 + wv;
+    double2 *tab = (double2 *)lds;
+    if (DERIVED && threadIdx.x < 128) tab[threadIdx.x] = V.ltab[threadIdx.x];
+    __syncthreads();
+    long long *pf = nullptr;
+    RC_PF(if (w < 8192 - 256) pf = (long long *)((char *)V.work[cgen] + 64) + (size_t)w * 16;)
+    syml2_fast<DERIVED, PACK>(V, lds + 256 + (size_t)wv * (2 * 8 * RC_S2_PITCH), lds + 256 + 4 * (2 * 8 * RC_S2_PITCH) + (size_t)wv * 128, tab, wgen, sgen, V.wfast[w], V.wfast[w + 1], pf);
+    (void)cgen;
+}
+
+// the units k_bulk_syml2's fast path does not take (a ragged last column block: n not a multiple of 128), by the round-2 unit code,
+// dealt round-robin; launched behind it on the same stream when there are any (both add into S with exact integer atomics)
+template <bool DERIVED>
+__global__ __launch_bounds__(256, RC_SYML_MINWAVES) void k_bulk_syml_list(View V, int wgen, int sgen)
+{
+    __shared__ __attribute__((aligned(16))) long long tl[4][2][RC_SL_R][RC_SL_P];
+    if (DERIVED) syml_load_table(V, tl);
+    __syncthreads();
+    const int wv = (int)(threadIdx.x >> 6);
+    syml_units<DERIVED, long long>(V, tl[wv], wgen, sgen, V.nslow, 0, 8, 8, (int)blockIdx.x * 4 + wv, (int)gridDim.x * 4, nullptr, V.uslow);
+}
 
 // k_bulk_sym32 — the same symmetric reduction for 32-bit storage: 32-row × 256-column int32 tiles (1 KiB row
 // segments), all 256 threads take a column in direction 1 and then a (row, matrix, 64-column quarter) in direction 2.
@@ -3011,6 +3471,7 @@ struct rc_ctx {
                                // reduction fills is cleared by k_resolve two sweeps earlier), so they may overlap and no launch gap
                                // separates them
     void *Dq = nullptr, *Lq = nullptr;  // int64 or int32 fixed point, INTERNAL point order (what the kernels read)
+    void *Dq48 = nullptr;               // derived mode: Dq packed to 48 bits per entry (k_pack48), what k_bulk_syml2's fast path streams
     void *Dq_src = nullptr, *Lq_src = nullptr;  // the same matrices in the caller's point order (source of every re-layout)
     long long *diagq = nullptr, *diag_src = nullptr;
     int *pi = nullptr, *ipi = nullptr;  // device: original -> internal, internal -> original
@@ -3021,6 +3482,9 @@ struct rc_ctx {
     int sw_coarse = 0;                   // RC_SW_COARSE: rows per unit of k_bulk_syml (8..128, multiple of 4); 0 = chosen by syml_geometry
     size_t syml_pad = 0;                // RC_SYML_PAD: unused dynamic LDS per k_bulk_syml block (bytes), caps the blocks per CU
     int symw_per_cu = 3;                // RC_SYMW_PER_CU: blocks of k_bulk_syml / k_bulk_symw per CU (LDS: 40 KiB per block; the fourth slot is the resolver's)
+    int4 *ufast = nullptr, *uslow = nullptr;   // unit lists of k_bulk_syml2 (build_syml2_lists)
+    int *wfast = nullptr, *wslow = nullptr;
+    int nfast = 0, nslow = 0, syml2_blocks = 0, syml2_g = 0;
     bool derived = false;               // logD derived from Dq on the fly (rc_qlog), not stored
     double2 *ltab = nullptr;            // device table of rc_qlog
     int n_relayouts = 0;                // re-layouts done so far (rc_set_state + automatic ones)
@@ -3148,7 +3612,7 @@ static View make_view(const rc_ctx *c)
     View V{};
     V.n = c->n; V.ld = c->ld; V.kcap = c->kcap; V.maxb = c->maxb; V.used_scratch = c->used_scratch;
     V.wc = c->wc; V.wc_always = c->wc_always; V.ldw = (c->n + RC_PTS - 1) / RC_PTS * RC_PTS;
-    V.Dq = c->Dq; V.Lq = c->Lq; V.bits = c->bits; V.diagq = c->diagq; V.pi = c->pi;
+    V.Dq = c->Dq; V.Lq = c->Lq; V.Dq48 = c->Dq48; V.bits = c->bits; V.diagq = c->diagq; V.pi = c->pi;
     V.derived = c->derived ? 1 : 0; V.qsD = std::ldexp(1.0, -c->eD); V.qsL = std::ldexp(1.0, c->eL); V.ltab = c->ltab; V.qeD = c->eD;
     for (int g = 0; g < 3; ++g) { V.SD[g] = c->SD[g]; V.SL[g] = c->SL[g]; }
     for (int g = 0; g < 2; ++g) { V.perm[g] = c->perm[g]; V.pslot[g] = c->pslot[g]; V.keys[g] = c->keys[g]; V.arrive[g] = c->arrive[g]; V.snap[g] = c->lsnap[g]; V.work[g] = c->work[g]; V.cword[g] = c->cword[g]; }
@@ -3156,6 +3620,7 @@ static View make_view(const rc_ctx *c)
     V.slot_of = c->slot_of; V.slot_size = c->slot_size; V.slot_label = c->slot_label;
     V.slot_pos = c->slot_pos; V.slot_act = c->slot_act;
     V.A = c->A; V.sc = c->sc; V.hsum = c->hsum_dev;
+    V.ufast = c->ufast; V.uslow = c->uslow; V.nfast = c->nfast; V.nslow = c->nslow; V.wfast = c->wfast; V.wslow = c->wslow;
     V.scD = std::ldexp(1.0, -c->eD); V.scL = std::ldexp(1.0, -c->eL);
     V.alpha = c->P.alpha; V.beta = c->P.beta; V.zeta = c->P.zeta; V.gamma = c->P.gamma;
     V.delta1 = c->P.delta1; V.delta2 = c->P.delta2;
@@ -3187,10 +3652,10 @@ static void free_all(rc_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->dev);
-    void *ptrs[] = {c->ltab, c->Dq, c->Lq, c->Dq_src, c->Lq_src, c->diag_src, c->pi, c->ipi, c->diagq, c->SD[0], c->SD[1], c->SD[2], c->SL[0], c->SL[1], c->SL[2], c->slot_of,
+    void *ptrs[] = {c->Dq48, c->ltab, c->Dq, c->Lq, c->Dq_src, c->Lq_src, c->diag_src, c->pi, c->ipi, c->diagq, c->SD[0], c->SD[1], c->SD[2], c->SL[0], c->SL[1], c->SL[2], c->slot_of,
                     c->slot_size, c->slot_label, c->slot_pos, c->slot_act, c->perm[0], c->perm[1], c->pslot[0],
                     c->pslot[1], c->lsnap[0], c->lsnap[1], c->work[0], c->work[1], c->cword[0], c->cword[1], c->rec, c->tent, c->A, c->keys[0], c->keys[1], c->arrive[0], c->arrive[1], c->sc, c->blocks,
-                    c->counts, c->cc_out, c->snap, c->d_moves, c->used_scratch, c->wc};
+                    c->counts, c->cc_out, c->snap, c->d_moves, c->used_scratch, c->wc, c->ufast, c->uslow, c->wfast, c->wslow};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->hsum) (void)hipHostFree(c->hsum);
@@ -3364,15 +3829,6 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     HIPCHK2(hipMalloc(&c->pi, (size_t)n * sizeof(int)));
     HIPCHK2(hipMalloc(&c->ipi, (size_t)n * sizeof(int)));
     HIPCHK2(hipMalloc(&c->ltab, 128 * sizeof(double2)));
-    {
-        double tab[256];
-        for (int j = 0; j < 128; ++j) {
-            const double cj = 1.0 + ((double)j + 0.5) * (1.0 / 128);
-            tab[2 * j] = 1.0 / cj;
-            tab[2 * j + 1] = std::log(cj);
-        }
-        HIPCHK2(hipMemcpy(c->ltab, tab, sizeof(tab), hipMemcpyHostToDevice));
-    }
     for (int g = 0; g < 2; ++g) {
         HIPCHK2(hipMalloc(&c->perm[g], (size_t)n * sizeof(int)));
         HIPCHK2(hipMalloc(&c->pslot[g], (size_t)n * sizeof(int)));
@@ -3440,10 +3896,13 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     double maxD, maxL = 0;
     std::memcpy(&maxD, &hmx[0], 8);
     c->eD = quant_exponent(n, maxD, c->bits);
-    if (derived && maxD > 0.0) {   // rc_qlog converts the entries to double through the mantissa of 2^52: every Dq < 2^51 (binding for n < 2048)
+    if (derived && maxD > 0.0) {
+        // every Dq < 2^47: the streaming row reduction reads a 48-bit packed copy of D (k_pack48: 6 instead of 8 bytes per entry;
+        // quantum 2^-47 of the largest entry — binding for n < 32768), and rc_qlog converts the entries to double through the
+        // mantissa of 2^52
         int ex;
         std::frexp(maxD, &ex);
-        c->eD = std::min(c->eD, 51 - ex);
+        c->eD = std::min(c->eD, (getenv("RC_NO_PACK48") && atoi(getenv("RC_NO_PACK48"))) ? 51 - ex : 47 - ex);
     }
     if (c->bits == 64) k_quantize<long long><<<gb, 256, 0, s>>>(tmpD, (int)n, c->ld, c->eD, (long long *)c->Dq_src, c->diag_src);
     else k_quantize<int><<<gb, 256, 0, s>>>(tmpD, (int)n, c->ld, c->eD, (int *)c->Dq_src, c->diag_src);
@@ -3452,7 +3911,7 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
         HIPCHK2(hipMalloc(&mn, sizeof(long long)));
         const long long big = 0x7fffffffffffffffll;
         HIPCHK2(hipMemcpyAsync(mn, &big, sizeof(big), hipMemcpyHostToDevice, s));
-        k_derived_scan<<<gb, 256, 0, s>>>((const long long *)c->Dq_src, (int)n, c->ld, c->eD, c->ltab, mn, mx + 1);
+        k_derived_scan<<<gb, 256, 0, s>>>((const long long *)c->Dq_src, (int)n, c->ld, c->eD, mn, mx + 1);
         long long hmn = 0;
         hipError_t e1 = hipMemcpyAsync(&hmn, mn, sizeof(hmn), hipMemcpyDeviceToHost, s);
         hipError_t e2 = hipMemcpyAsync(&hmx[1], mx + 1, sizeof(u64), hipMemcpyDeviceToHost, s);
@@ -3485,6 +3944,16 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
         c->eL = std::min(c->eL, 50 - ex);
     }
     c->derived = derived;
+    {
+        // table of rc_qlog: (1/c_j, rint(log c_j · 2^eL) + 1.5·2^52), c_j = 1 + (j+½)/128 — in long double, once eL is known
+        double tab[256];
+        for (int j = 0; j < 128; ++j) {
+            const long double cj = 1.0L + ((long double)j + 0.5L) / 128.0L;
+            tab[2 * j] = (double)(1.0L / cj);
+            tab[2 * j + 1] = (double)(rintl(logl(cj) * ldexpl(1.0L, c->eL)) + 0x1.8p52L);
+        }
+        HIPCHK2(hipMemcpy(c->ltab, tab, sizeof(tab), hipMemcpyHostToDevice));
+    }
     if (derived && !(getenv("RC_NO_LQ_COPY") && atoi(getenv("RC_NO_LQ_COPY")))) {
         // random-access copy of the derived values for the resolver (see k_derived_fill); the row reduction ignores it
         HIPCHK2(hipMalloc(&c->Lq, (size_t)n * ld * esz));
@@ -3508,6 +3977,10 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     HIPCHK2(hipMemcpyAsync(c->Dq, c->Dq_src, (size_t)n * ld * esz, hipMemcpyDeviceToDevice, s));
     if (c->Lq) HIPCHK2(hipMemcpyAsync(c->Lq, c->Lq_src, (size_t)n * ld * esz, hipMemcpyDeviceToDevice, s));
     HIPCHK2(hipMemcpyAsync(c->diagq, c->diag_src, (size_t)n * sizeof(long long), hipMemcpyDeviceToDevice, s));
+    if (c->derived && c->bits == 64 && !(getenv("RC_NO_PACK48") && atoi(getenv("RC_NO_PACK48")))) {
+        HIPCHK2(hipMalloc(&c->Dq48, (size_t)n * ld * 6));
+        k_pack48<<<4096, 256, 0, s>>>((const long long *)c->Dq, (size_t)n * ld / 2, (unsigned *)c->Dq48);
+    }
     HIPCHK2(hipStreamSynchronize(s));
     HIPCHK2(hipGetLastError());
     cleanup();
@@ -3557,13 +4030,134 @@ static int32_t alloc_ctx(int64_t n, int32_t storage_bits, int32_t device_id, int
 
 // Symmetric-kernel variant of a context: RC_SYM_VARIANT, else the wave-autonomous kernel when logD is derived and the block-tiled
 // ones when it is stored.
-static int sym_variant_of(const rc_ctx *c) { return c->sym_variant >= 0 ? c->sym_variant : (c->derived ? 2 : 0); }
-// the wave-autonomous kernel (three 40 KiB blocks per CU) is the symmetric kernel of this context
-static bool uses_syml(const rc_ctx *c) { return sym_variant_of(c) == 2; }
+static int sym_variant_of(const rc_ctx *c) { return c->sym_variant >= 0 ? c->sym_variant : (c->derived ? 3 : 0); }
+// the wave-autonomous kernels (three 40-42 KiB blocks per CU) are the symmetric kernel of this context: 3 = k_bulk_syml2 (round 3),
+// 2 = k_bulk_syml (round 2)
+static bool uses_syml(const rc_ctx *c) { return sym_variant_of(c) >= 2; }
+
+// Unit lists of k_bulk_syml2 for `cap_blocks` resident 4-wave blocks.  Column block J (128 columns) holds the rows 0 .. 128 J + 127
+// of the upper triangle.  Rows [0, 128 J) lie entirely above the diagonal block: FAST units of g rows (a multiple of 8; the rest of a
+// block is a shorter unit) — no mask of any kind in their tiles.  The diagonal block itself (and every unit of a ragged last column
+// block) is SLOW: the round-2 unit code with its triangle masks, ~3x the cost per 4-row tile, so it is cut fine (RC_S2_SLOW_ROWS
+// rows per unit).  The launch lasts as long as its slowest wave, so the units are dealt to the waves by cost — longest first, each
+// to the least loaded wave — and a wave reads its share as a contiguous range of each list.  g is chosen for the shortest makespan.
+#ifndef RC_S2_SLOW_ROWS
+#define RC_S2_SLOW_ROWS 16
+#endif
+static int32_t build_syml2_lists(rc_ctx *c)
+{
+    const int n = c->n, ncb = (n + RC_SW_COLS - 1) / RC_SW_COLS, cap_blocks = c->symw_per_cu * c->num_cus, nwaves = 4 * cap_blocks;
+    struct Unit { int4 u; int cost; bool fast; };
+    const int slow_factor = getenv("RC_S2_SLOW_COST") ? std::max(1, atoi(getenv("RC_S2_SLOW_COST"))) : 3;
+    auto make_units = [&](int g, std::vector<Unit> &out) {
+        out.clear();
+        for (int J = ncb - 1; J >= 0; --J) {
+            const int c0 = J * RC_SW_COLS, rows = std::min(c0 + RC_SW_COLS, n);
+            const bool whole = c0 + RC_SW_COLS <= n;                      // 128 real columns
+            const int fast_rows = whole ? (rows & ~7) : 0;               // (the diagonal block included: the fast path masks its triangle)
+            for (int a0 = 0; a0 < fast_rows; a0 += g) {
+                const int a1 = std::min(a0 + g, fast_rows);
+                out.push_back({make_int4(c0, a0, a1, 0), (a1 - a0) / 4 + 2, true});
+            }
+            for (int a0 = fast_rows; a0 < rows; a0 += RC_S2_SLOW_ROWS) {
+                const int a1 = std::min(a0 + RC_S2_SLOW_ROWS, rows);
+                out.push_back({make_int4(c0, a0, a1, 0), slow_factor * ((a1 - a0 + 3) / 4) + 3, false});
+            }
+        }
+    };
+    auto schedule = [&](std::vector<Unit> &units, std::vector<int> &owner) -> long long {   // longest first, to the least loaded wave
+        std::vector<int> order(units.size());
+        for (size_t q = 0; q < order.size(); ++q) order[q] = (int)q;
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return units[(size_t)x].cost > units[(size_t)y].cost; });
+        std::vector<std::pair<long long, int>> heap;                   // (load, wave), min-heap
+        heap.reserve((size_t)nwaves);
+        for (int w = 0; w < nwaves; ++w) heap.push_back({0, w});
+        auto cmp = [](const std::pair<long long, int> &x, const std::pair<long long, int> &y) { return x > y; };
+        std::make_heap(heap.begin(), heap.end(), cmp);
+        owner.assign(units.size(), 0);
+        long long makespan = 0;
+        for (int q : order) {
+            std::pop_heap(heap.begin(), heap.end(), cmp);
+            auto &top = heap.back();
+            owner[(size_t)q] = top.second;
+            top.first += units[(size_t)q].cost;
+            makespan = std::max(makespan, top.first);
+            std::push_heap(heap.begin(), heap.end(), cmp);
+        }
+        return makespan;
+    };
+    std::vector<Unit> units, best_units;
+    std::vector<int> owner, best_owner;
+    long long best = -1;
+    int best_g = 64;
+    const int g_lo = c->sw_coarse > 0 ? (c->sw_coarse + 7) / 8 * 8 : 16, g_hi = c->sw_coarse > 0 ? g_lo : 256;
+    for (int g = g_lo; g <= g_hi; g += 8) {
+        make_units(g, units);
+        const long long mk = schedule(units, owner);
+        if (best < 0 || mk < best || (mk == best && g > best_g)) { best = mk; best_g = g; best_units = units; best_owner = owner; }
+    }
+    // group by wave (stable: heavy column blocks first inside a wave), fast and slow lists apart
+    std::vector<int4> fast, slow;
+    std::vector<int> wfast((size_t)nwaves + 1, 0), wslow((size_t)nwaves + 1, 0);
+    for (size_t q = 0; q < best_units.size(); ++q) (best_units[q].fast ? wfast : wslow)[(size_t)best_owner[q] + 1]++;
+    for (int w = 0; w < nwaves; ++w) { wfast[(size_t)w + 1] += wfast[(size_t)w]; wslow[(size_t)w + 1] += wslow[(size_t)w]; }
+    fast.resize((size_t)wfast[(size_t)nwaves]); slow.resize((size_t)wslow[(size_t)nwaves]);
+    {
+        std::vector<int> pf(wfast.begin(), wfast.end() - 1), ps(wslow.begin(), wslow.end() - 1);
+        for (size_t q = 0; q < best_units.size(); ++q) {
+            const int w = best_owner[q];
+            if (best_units[q].fast) fast[(size_t)pf[(size_t)w]++] = best_units[q].u; else slow[(size_t)ps[(size_t)w]++] = best_units[q].u;
+        }
+    }
+    // RC_S2_STAGGER=1 (experiment, off): each fast unit cut at a row that differs from wave to wave and taken lower part last, so that
+    // the flushes of a launch spread over its duration instead of coming at the same moments in every wave.  Measured: no gain
+    // (74.9 against 73.5 us) — the ~18 us the atomics cost a launch (55 us without them) are not a drain at its end: 18 MB of 64-bit
+    // atomics at the ~1 TB/s the memory side executes them is a per-CU occupancy of the vector memory path, spread or not.
+    if (getenv("RC_S2_STAGGER") && atoi(getenv("RC_S2_STAGGER"))) {
+        std::vector<int4> fast2;
+        std::vector<int> wfast2((size_t)nwaves + 1, 0);
+        fast2.reserve(2 * fast.size());
+        for (int w = 0; w < nwaves; ++w) {
+            wfast2[(size_t)w] = (int)fast2.size();
+            for (int q = wfast[(size_t)w]; q < wfast[(size_t)w + 1]; ++q) {
+                const int4 u = fast[(size_t)q];
+                const int groups = (u.z - u.y) / 8;
+                if (groups < 4) { fast2.push_back(u); continue; }
+                const unsigned h = (unsigned)w * 2654435761u + (unsigned)q * 40503u;
+                const int cut = u.y + 8 * (1 + (int)((h >> 8) % (unsigned)(groups - 1)));
+                fast2.push_back(make_int4(u.x, cut, u.z, 0));
+                fast2.push_back(make_int4(u.x, u.y, cut, 0));
+            }
+        }
+        wfast2[(size_t)nwaves] = (int)fast2.size();
+        fast.swap(fast2); wfast.swap(wfast2);
+    }
+    for (void *pfree : {(void *)c->ufast, (void *)c->uslow, (void *)c->wfast, (void *)c->wslow})
+        if (pfree) (void)hipFree(pfree);
+    c->ufast = c->uslow = nullptr; c->wfast = c->wslow = nullptr;
+    HIPCHK(c, hipMalloc(&c->ufast, std::max<size_t>(1, fast.size()) * sizeof(int4)));
+    HIPCHK(c, hipMalloc(&c->uslow, std::max<size_t>(1, slow.size()) * sizeof(int4)));
+    HIPCHK(c, hipMalloc(&c->wfast, wfast.size() * sizeof(int)));
+    HIPCHK(c, hipMalloc(&c->wslow, wslow.size() * sizeof(int)));
+    if (!fast.empty()) HIPCHK(c, hipMemcpy(c->ufast, fast.data(), fast.size() * sizeof(int4), hipMemcpyHostToDevice));
+    if (!slow.empty()) HIPCHK(c, hipMemcpy(c->uslow, slow.data(), slow.size() * sizeof(int4), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->wfast, wfast.data(), wfast.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->wslow, wslow.data(), wslow.size() * sizeof(int), hipMemcpyHostToDevice));
+    c->nfast = (int)fast.size(); c->nslow = (int)slow.size(); c->syml2_g = best_g;
+    c->syml2_blocks = cap_blocks;      // every resident wave has its (possibly empty) share
+    if (getenv("RC_SM_PROFILE"))
+        fprintf(stderr, "[rc_create] k_bulk_syml2: %d fast units of %d rows, %d slow units of %d rows over %d waves, makespan %lld tile costs\n",
+                c->nfast, best_g, c->nslow, RC_S2_SLOW_ROWS, nwaves, best);
+    return RC_OK;
+}
 
 // launch geometry and LDS attributes that depend on (n, kcap, bits)
 static int32_t finish_create(rc_ctx *c)
 {
+    if (c->bits == 64 && !c->ufast) {
+        int32_t rcl = build_syml2_lists(c);
+        if (rcl != RC_OK) return rcl;
+    }
     if (!c->registered) { res_register(c); c->registered = true; }
     {
         // Resolver batch capacity.  The resolver of sweep t has to be resident beside the row-reduction blocks of sweep t+1
@@ -3884,8 +4478,31 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
     // caller's order (k_resolve maps i -> pi[i]).
     std::vector<int> ipi((size_t)n), pi((size_t)n);
     for (int i = 0; i < n; ++i) ipi[(size_t)i] = i;
-    if (c->relayout)
+    if (c->relayout) {
         std::stable_sort(ipi.begin(), ipi.end(), [&](int a, int b) { return clusts[a] < clusts[b]; });
+        // Every cluster's run gets an EVEN length and hence an even start: the last point of each odd-sized cluster goes to the
+        // tail of the order.  The row reduction gives a lane two adjacent columns (2 l, 2 l + 1); a cluster boundary at an odd
+        // position splits a lane between two clusters, and such a lane's elements cannot go through the pre-added direction-2
+        // path (k_bulk_syml2: element-wise atomics for every row of every unit of that column block — a third of all units with
+        // boundaries at arbitrary positions).  The tail — one point per odd-sized cluster, every singleton — is ragged, but it is
+        // a column block or two.  Exactness does not depend on any of this.
+        // (Kept as an experiment, RC_EVEN_RUNS=1: the ragged tail it creates costs more than it saves once the boundary lanes are
+        // handled inside the kernel — k_bulk_syml2's donor lanes.)
+        if (uses_syml(c) && getenv("RC_EVEN_RUNS") && atoi(getenv("RC_EVEN_RUNS"))) {
+            std::vector<int> body, tail;
+            body.reserve((size_t)n);
+            for (int w = 0; w < n;) {
+                int e = w;
+                while (e < n && clusts[ipi[(size_t)e]] == clusts[ipi[(size_t)w]]) ++e;
+                const int keep = (e - w) & ~1;
+                for (int q = w; q < w + keep; ++q) body.push_back(ipi[(size_t)q]);
+                if (keep < e - w) tail.push_back(ipi[(size_t)e - 1]);
+                w = e;
+            }
+            body.insert(body.end(), tail.begin(), tail.end());
+            ipi.swap(body);
+        }
+    }
     for (int w = 0; w < n; ++w) pi[(size_t)ipi[(size_t)w]] = w;
     if (pi != c->h_pi) {
         c->h_pi = pi; c->h_ipi = ipi;
@@ -3901,6 +4518,7 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
             k_relayout<int><<<g, 256, 0, c->sA>>>((const int *)c->Lq_src, c->ipi, n, c->ld, (int *)c->Lq);
         }
         k_gather_ll<<<(n + 255) / 256, 256, 0, c->sA>>>(c->diag_src, c->ipi, n, c->diagq);
+        if (c->Dq48) k_pack48<<<4096, 256, 0, c->sA>>>((const long long *)c->Dq, (size_t)n * c->ld / 2, (unsigned *)c->Dq48);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->sA));
     }
@@ -4009,7 +4627,16 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
         const int ncb = (c->n + RC_SW_COLS - 1) / RC_SW_COLS;
         const int cap_blocks = c->symw_per_cu * c->num_cus;          // resident 4-wave blocks
         auto rows_of = [&](int J) { return std::min(RC_SW_COLS * J + RC_SW_COLS, c->n); };
-        if (sym_variant == 2) {
+        if (sym_variant == 3) {
+            if (c->derived && c->Dq48) { auto kf_ = k_bulk_syml2<true, true>; RC_BULK_LAUNCH(kf_, c->syml2_blocks, 256, c->syml_pad, V, (int)(t % 3), (int)(t & 1), (int)(t & 1)); }
+            else if (c->derived) { auto kf_ = k_bulk_syml2<true, false>; RC_BULK_LAUNCH(kf_, c->syml2_blocks, 256, c->syml_pad, V, (int)(t % 3), (int)(t & 1), (int)(t & 1)); }
+            else { auto kf_ = k_bulk_syml2<false, false>; RC_BULK_LAUNCH(kf_, c->syml2_blocks, 256, c->syml_pad, V, (int)(t % 3), (int)(t & 1), (int)(t & 1)); }
+            if (c->nslow > 0) {   // ragged last column block: its units by the round-2 code, behind the main launch
+                const int nb = std::min((c->nslow + 3) / 4, cap_blocks);
+                if (c->derived) k_bulk_syml_list<true><<<nb, 256, 0, sb>>>(V, (int)(t % 3), (int)(t & 1));
+                else k_bulk_syml_list<false><<<nb, 256, 0, sb>>>(V, (int)(t % 3), (int)(t & 1));
+            }
+        } else if (sym_variant == 2) {
             int gc = 0, nitems = 0;
             const int jsplit = 0, gfine = 8;   // (every column block in gc-row units)
             syml_geometry(c, cap_blocks, &gc, &nitems);
@@ -5308,7 +5935,8 @@ extern "C" int32_t rc_bulk_kernel_info(rc_ctx *c, int32_t *which, double *algori
     if (which) *which = c->last_bulk_kernel;
     // matrices the kernel reads: D and logD, or D alone when logD is derived on the fly
     const double nmat = c->derived ? 1.0 : 2.0;
-    if (algorithmic_bytes) *algorithmic_bytes = c->last_bulk_kernel ? nmat * (n * (n + 1) / 2) * esz : nmat * n * n * esz;
+    const double esz_read = (c->last_bulk_kernel && sym_variant_of(c) == 3 && c->Dq48) ? 6.0 : esz;   // k_bulk_syml2 streams the 48-bit packed copy
+    if (algorithmic_bytes) *algorithmic_bytes = c->last_bulk_kernel ? nmat * (n * (n + 1) / 2) * esz_read : nmat * n * n * esz;
     return RC_OK;
 }
 
@@ -5319,7 +5947,8 @@ extern "C" const char *rc_bulk_kernel_name(rc_ctx *c)
     if (!c) return "";
     if (!c->last_bulk_kernel) return c->derived ? "k_bulk<long long, true>" : (c->bits == 64 ? "k_bulk<long long, false>" : "k_bulk<int, false>");
     if (c->bits != 64) return sym_variant_of(c) == 2 ? "k_bulk_syml32" : "k_bulk_sym32";
-    const int v = c->sym_variant >= 0 ? c->sym_variant : (c->derived ? 2 : 0);
+    const int v = sym_variant_of(c);
+    if (v == 3) return c->derived ? (c->Dq48 ? "k_bulk_syml2<true, true>" : "k_bulk_syml2<true, false>") : "k_bulk_syml2<false, false>";
     if (v == 2) return c->derived ? "k_bulk_syml<true>" : "k_bulk_syml<false>";
     if (v == 1) return c->derived ? "k_bulk_symw<true>" : "k_bulk_symw<false>";
     return c->derived ? "k_bulk_sym<true>" : "k_bulk_sym<false>";

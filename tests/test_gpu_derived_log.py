@@ -30,7 +30,7 @@ def is_derived(ctx):
     ctx.gibbs_sweep(1.0, 0.5, 0, 10 ** 9)            # any sweep, so that the kernel info is populated
     name, nbytes = ctx.bulk_kernel_info()
     n = ctx.n
-    return nbytes in (n * (n + 1) / 2 * 8, n * n * 8.0)
+    return nbytes in (n * (n + 1) / 2 * 8, n * (n + 1) / 2 * 6, n * n * 8.0)   # (6: the 48-bit packed copy k_bulk_syml2 streams)
 
 
 def test_derived_log_values_and_rowsums():
@@ -42,7 +42,12 @@ def test_derived_log_values_and_rowsums():
     ref = np.log(np.where(np.eye(100, dtype=bool), 1.0, D))
     quantum = np.ldexp(1.0, -orc.eL)
     assert np.all(np.diag(L) == 0) and np.array_equal(L, L.T)
-    assert np.max(np.abs(L - ref)) <= quantum + 1e-15          # table log vs libm: 4.5e-16, plus the rounding to the quantum
+    # rc_qlog vs libm's log of the host's D: the degree-4 polynomial of log1p (next term r^5/5 < 1.8e-13 for |r| < 1/257), the
+    # rounding of the fixed-point entry itself (D is stored to 2^-eD, 47 significant bits of the largest entry: relative 2^-(eD+1)/D)
+    # and the rounding to the quantum of logD
+    bound = quantum + 2e-13 + np.ldexp(1.0, -orc.eD - 1) / np.where(np.eye(100, dtype=bool), 1.0, D)
+    assert np.all(np.abs(L - ref) <= bound), float(np.max(np.abs(L - ref)))
+    assert np.max(np.abs(L - ref)) <= 1e-12
     onehot = (init[:, None] == np.arange(1, 101)[None, :]).astype(np.int64)
     for lab in np.unique(init):
         sd, sl, eD, eL = ctx.debug_rowsums(int(lab))

@@ -1,7 +1,7 @@
 """Oracle parity AT THE BENCHMARKED SIZES, on the code path bench.py times (-m gpu).
 
 * BASELINE config 3 (N=8192, K=50, the roofline configuration): the context is created exactly as bench.py creates it —
-  D only (logD derived on the fly), no forced kernel, so the automatic choice k_bulk_syml<true> + k_resolve runs — and is
+  D only (logD derived on the fly), no forced kernel, so the automatic choice k_bulk_syml2<true, true> + k_resolve runs — and is
   compared with the CPU oracle sweep by sweep: labels / sizes / K / change counts exactly, fixed-point row sums of both
   matrices bit for bit, loglik within 1e-9 (stable restatement) and 1e-6 (literal restatement) relative.
 * a size between the kernel-choice threshold (4096) and the headline size, on the automatic path across a re-layout.
@@ -80,9 +80,9 @@ def test_headline_config_against_oracle(headline, kind):
         assert st["n_changes"] == orc.last_changes and st["K"] == orc.K, (kind, t, st, orc.last_changes)
         moved += st["n_changes"]
     # the sweep right after rc_set_state sees a cluster-contiguous layout: this is the kernel bench.py times
-    assert names[0] == "k_bulk_syml<true>", names
+    assert names[0] == "k_bulk_syml2<true, true>", names
     if kind == "stationary":
-        assert all(x == "k_bulk_syml<true>" for x in names), names
+        assert all(x == "k_bulk_syml2<true, true>" for x in names), names
     else:
         assert moved > (50 if kind == "perturbed" else n // 2)
     # the row-sum table after the corrections of four sweeps, both matrices, bit for bit
@@ -123,7 +123,7 @@ def test_headline_rowsum_checksums(headline):
         sd, sl, eD, eL = ctx.debug_rowsums(int(lab))
         tot_d += sd; tot_l += sl
     assert np.array_equal(tot_d, orc.Dq.sum(axis=1)) and np.array_equal(tot_l, orc.Lq.sum(axis=1))
-    assert ctx.bulk_kernel_name() == "k_bulk_syml<true>"
+    assert ctx.bulk_kernel_name() == "k_bulk_syml2<true, true>"
     ctx.cocluster_reset()
     ctx.record_sample(False)
     ctx.gibbs_sweep(1.0, 0.5, 5, 0)
@@ -139,7 +139,7 @@ def test_headline_rowsum_checksums(headline):
 
 
 def test_auto_path_between_threshold_and_headline_size_crosses_relayout():
-    """n = 5000 (4096 < n < 8192), shuffled points, overlapping clusters: the automatic path starts on k_bulk_syml<true>,
+    """n = 5000 (4096 < n < 8192), shuffled points, overlapping clusters: the automatic path starts on k_bulk_syml2<true, true>,
     label movement fragments the layout (the full-read kernel takes over), the library re-lays the points out after 32
     sweeps and returns to the symmetric kernel — every sweep compared with the oracle."""
     n, K = 5000, 5
@@ -163,8 +163,8 @@ def test_auto_path_between_threshold_and_headline_size_crosses_relayout():
         assert np.array_equal(lab, orc.clusts) and np.array_equal(sizes, orc.sizes) and Kc == orc.K, t
         if relaid_at is None and ctx.layout_info()[0] > l0:
             relaid_at = t
-    assert names[0] == "k_bulk_syml<true>" and "k_bulk<long long, true>" in names, names
-    assert relaid_at is not None and names[relaid_at] == "k_bulk_syml<true>", (relaid_at, names)
+    assert names[0] == "k_bulk_syml2<true, true>" and "k_bulk<long long, true>" in names, names
+    assert relaid_at is not None and names[relaid_at] == "k_bulk_syml2<true, true>", (relaid_at, names)
     for k in np.unique(orc.clusts)[:3]:
         sd, sl = ctx.debug_rowsums(int(k))[:2]
         m = orc.clusts == k

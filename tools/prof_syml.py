@@ -1,4 +1,4 @@
-"""Per-wave cycle stamps of k_bulk_syml from a profiling build (-DRC_PROF_SYML, RC_LIB_PATH=build_exp/lib_prof.so):
+"""Per-wave cycle stamps of k_bulk_syml from a profiling build (-DRC_PROF_SYML, RC_LIB_PATH=build_r3/lib_prof.so):
 total cycles per wave, cycles parked on the tile's loads (s_waitcnt vmcnt(0) at the top of each tile), tiles, set-up."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,7 +7,7 @@ import redclust_amd as rc
 n, K = 8192, 50
 d = rc.generatemixture(n, K, seed=1); D, truth = d["distancematrix"], d["clusts"]
 P = rc.likelihood_hyperparams(D, truth)
-ctx = rc.Context(D, kcap=128); ctx.set_params(**P); ctx.set_state(truth)
+ctx = rc.Context(D); ctx.set_params(**P); ctx.set_state(truth)
 blocking = bool(int(os.environ.get("BLOCKING", "0")))
 for t in range(40): ctx.gibbs_sweep(1.0, 0.5, 1, t, blocking=blocking)
 ctx.synchronize()
@@ -16,8 +16,9 @@ out = np.zeros((8192, 16), np.int64)
 L.rc_debug_prof.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
 for gen in (0, 1):
     L.rc_debug_prof(ctx.h, gen, out.ctypes.data_as(C.c_void_p))
-    m = out[:, 0] > 0
+    m = (out[:, 0] > 0) & (out[:, 0] < 10_000_000) & (out[:, 2] > 0) & (out[:, 2] < 1000)   # (the resolver's own stamps share the tail of the buffer)
     o = out[m]
+    np.save(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', f'prof_syml_gen{gen}.npy'), out)
     tot, wait, tiles, setup, real, lg, d2, r0 = (o[:, k] for k in range(8))
     iss, ldsw, d1 = o[:, 8], o[:, 9], o[:, 10]
     hw = r0 & 0xFFFFF; r0 = r0 >> 20
