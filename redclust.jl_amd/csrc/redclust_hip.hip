@@ -91,7 +91,15 @@ typedef unsigned long long u64;
 
 #define RC_KEY_NONE 0xFFFFFFFFFFFFFFFFull
 #define RC_RES_THREADS 512  // k_resolve block: 32 points x 16 candidate streams; 2 waves/SIMD so it co-resides with k_bulk
-#define RC_PTS 32           // points per chunk (lanes of a half wave)
+#ifndef RC_PTS
+#define RC_PTS 32           // points per chunk of the resolver (a power of two <= 32): a block's threads are RC_PTS points x (threads / RC_PTS)
+                            // candidate streams; chunks are dealt to the blocks cyclically.  Finer chunks would spread the points still
+                            // open in a later round of a sweep — a suffix of the point order — over more blocks (at n = 8192 a 32-point
+                            // chunk is all a block has), but every chunk pays the pass's fixed costs (block barriers, the reduction
+                            // over the streams): measured in the moving regime 2,520 sweeps/s with 32, 2,490 with 16, 2,020 with 8
+#endif
+#define RC_PTS_LOG2 (RC_PTS == 32 ? 5 : RC_PTS == 16 ? 4 : RC_PTS == 8 ? 3 : RC_PTS == 4 ? 2 : -1)
+static_assert(RC_PTS_LOG2 > 0, "RC_PTS must be 4, 8, 16 or 32");
 #define RC_MAX_KCAP 4096
 #define RC_RES_ONE_STREAM_MAX_N 1024   // up to this size the in-order resolver chain wins (n = 1000: 26 k -> 32 k sweeps/s; n >= 2000: even or worse)
 #define RC_USED_LDS_MAX_N 16384   // up to this n the label-occupancy bitset of the resolver lives in LDS (n/8 bytes)
@@ -2438,7 +2446,7 @@ __device__ __forceinline__ void hot_accumulate(const View &V, const Tab &T, int 
 __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long long *SD, const long long *SL,
                            int chunk, int lo, int hi, int mode, int nb, u64 *cword, unsigned *rec, unsigned stamp, int cmode)
 {
-    const int pt = threadIdx.x & (RC_PTS - 1), st = threadIdx.x >> 5, NS = blockDim.x >> 5;
+    const int pt = threadIdx.x & (RC_PTS - 1), st = threadIdx.x >> RC_PTS_LOG2, NS = blockDim.x >> RC_PTS_LOG2;
     const int wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
     const int i = chunk * RC_PTS + pt;
     const bool valid = (i < V.n) && (i > lo) && (i <= hi);
@@ -2562,10 +2570,11 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
         }
     }
     if (hot >= 0) __syncthreads();   // (the records of the hot slot alias the reduction scratch)
-    // reduce over the candidate streams: the two halves of each wave by shuffle, then the waves through LDS
-    {
-        const double ov = __shfl_xor(bestv, 32);
-        const int op = __shfl_xor(bestpos, 32), os = __shfl_xor(bestslot, 32);
+    // reduce over the candidate streams: the 64 / RC_PTS streams of each wave by shuffles, then the waves through LDS
+#pragma unroll
+    for (int off = RC_PTS; off < 64; off <<= 1) {
+        const double ov = __shfl_xor(bestv, off);
+        const int op = __shfl_xor(bestpos, off), os = __shfl_xor(bestslot, off);
         best_merge(bestv, bestpos, bestslot, ov, op, os);
     }
     if ((threadIdx.x & 63) < RC_PTS) {
@@ -2575,14 +2584,17 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
     }
     __syncthreads();
     if (wave == 0) {
-        const int half = (threadIdx.x >> 5) & 1;  // lanes 0-31: waves [0, NW/2), lanes 32-63: the rest
-        const int w0 = half ? (NW + 1) / 2 : 0, w1 = half ? NW : (NW + 1) / 2;
+        // lane l: point l % RC_PTS, wave group l / RC_PTS (waves g, g + 64 / RC_PTS, ...); then the groups by shuffles
+        const int grp = (int)(threadIdx.x & 63) >> RC_PTS_LOG2, half = grp;   // (half == 0: the lanes that end up holding a point's result)
         double bv = -INFINITY;
         int bp = 0x7fffffff, bs = -2;
-        for (int w = w0; w < w1; ++w) best_merge(bv, bp, bs, T.red_v[w * RC_PTS + pt], T.red_pos[w * RC_PTS + pt], T.red_slot[w * RC_PTS + pt]);
-        const double ov = __shfl_xor(bv, 32);
-        const int op = __shfl_xor(bp, 32), os = __shfl_xor(bs, 32);
-        best_merge(bv, bp, bs, ov, op, os);
+        for (int w = grp; w < NW; w += 64 / RC_PTS) best_merge(bv, bp, bs, T.red_v[w * RC_PTS + pt], T.red_pos[w * RC_PTS + pt], T.red_slot[w * RC_PTS + pt]);
+#pragma unroll
+        for (int off = RC_PTS; off < 64; off <<= 1) {
+            const double ov = __shfl_xor(bv, off);
+            const int op = __shfl_xor(bp, off), os = __shfl_xor(bs, off);
+            best_merge(bv, bp, bs, ov, op, os);
+        }
         bool changed = false;
         int target = own;
         if (half == 0 && valid) {
@@ -2598,7 +2610,7 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
                 V.tent[i] = target;
                 if (changed) __hip_atomic_store(rec + i, ((unsigned)own << 16) | (unsigned)(target + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            const u64 m = __ballot(changed) & 0xFFFFFFFFull;
+            const u64 m = __ballot(changed) & ((1ull << RC_PTS) - 1ull);
             if (m) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the records are out before the mask that announces them
                 if (threadIdx.x == 0) __hip_atomic_store(cword + chunk, ((u64)stamp << 32) | m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2926,7 +2938,7 @@ __device__ int commit_batch(const View &V, const SweepArgs &sa, Tab &T, int nc, 
     if (threadIdx.x == 0) T.misc[13] = (int)(__builtin_amdgcn_s_memrealtime() - pc0_);
 #endif
     const int nchunks = (V.n + RC_PTS - 1) / RC_PTS;
-    const int pt = threadIdx.x & (RC_PTS - 1), st = threadIdx.x >> 5, NS = blockDim.x >> 5;
+    const int pt = threadIdx.x & (RC_PTS - 1), st = threadIdx.x >> RC_PTS_LOG2, NS = blockDim.x >> RC_PTS_LOG2;
     long long *SDo = V.SD[own_gen], *SLo = V.SL[own_gen];
     long long *SDn = next_gen >= 0 ? V.SD[next_gen] : nullptr, *SLn = next_gen >= 0 ? V.SL[next_gen] : nullptr;
     const int hi_slots = T.misc[7];   // slots in use, births of this batch included
@@ -4598,7 +4610,12 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
     // parity streams it ran on this very stream: in order already, and every event wait is a barrier packet the command
     // processor works through on the critical path (12-19 µs between two kernels of one stream with five of them, ~4 without)
     if (t >= 2 && (c->res_one_stream || c->incremental)) HIPCHK(c, hipStreamWaitEvent(sb, c->ev_res[(t - 2) & 3], 0));
-    const int splits = (c->n + c->rows_per_split - 1) / c->rows_per_split;
+    // While labels move, the resolver of the previous sweep — several rounds, the critical path — runs beside this reduction and the
+    // two compete for the CUs: the full-read kernel then takes half as many, longer splits (one block per CU at n = 8192 instead of
+    // two), which leaves the resolver the issue slots it needs and still finishes inside its run (moving regime of bench.py:
+    // 2,530 -> 3,230 sweeps/s; 1,024-row splits 2,890, 2,048-row splits 2,100: then the reduction is the longer of the two)
+    const int rows_split = (c->hsum->n_changes > 32 && !getenv("RC_BULK_ROWS")) ? std::max(c->rows_per_split, std::min(512, 2 * c->rows_per_split)) : c->rows_per_split;
+    const int splits = (c->n + rows_split - 1) / rows_split;
     dim3 gb((unsigned)(c->ld / (c->bits == 64 ? 512 : 1024)), (unsigned)splits);
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     const bool timed = c->timing && (c->timing_every <= 1 || (t % c->timing_every) == 0);
@@ -4669,11 +4686,11 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
         // bulk_lds: unused dynamic LDS that caps k_bulk at bulk_blocks_per_cu workgroups per CU, which (i) spreads the
         // grid evenly over the CUs and (ii) leaves registers/wave slots on every CU for the concurrent k_resolve
         if (c->bits == 64 && c->derived)
-            { auto kf_ = k_bulk<long long, true>; RC_BULK_LAUNCH(kf_, gb, 256, c->bulk_lds, V, c->rows_per_split, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1)); }
+            { auto kf_ = k_bulk<long long, true>; RC_BULK_LAUNCH(kf_, gb, 256, c->bulk_lds, V, rows_split, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1)); }
         else if (c->bits == 64)
-            { auto kf_ = k_bulk<long long>; RC_BULK_LAUNCH(kf_, gb, 256, c->bulk_lds, V, c->rows_per_split, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1)); }
+            { auto kf_ = k_bulk<long long>; RC_BULK_LAUNCH(kf_, gb, 256, c->bulk_lds, V, rows_split, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1)); }
         else
-            { auto kf_ = k_bulk<int>; RC_BULK_LAUNCH(kf_, gb, 256, c->bulk_lds, V, c->rows_per_split, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1)); }
+            { auto kf_ = k_bulk<int>; RC_BULK_LAUNCH(kf_, gb, 256, c->bulk_lds, V, rows_split, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1)); }
     }
 #undef RC_BULK_LAUNCH
     if (timed) c->ev_pending.push_back(ev);

@@ -6,7 +6,7 @@ import numpy as np
 import redclust_amd as rc
 n, K = 8192, 50
 sig = float(sys.argv[1]) if len(sys.argv) > 1 else 0.2
-kcap = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+kcap = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 inc = len(sys.argv) > 3 and sys.argv[3] == "incremental"
 d = rc.generatemixture(n, K, seed=2, sigma=sig); D, truth = d["distancematrix"], d["clusts"]
 P = rc.likelihood_hyperparams(D, truth)

@@ -6,7 +6,7 @@ import numpy as np
 import redclust_amd as rc
 n, K = 8192, 50
 sig = float(sys.argv[1]) if len(sys.argv) > 1 else 0.2
-kcap = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+kcap = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 d = rc.generatemixture(n, K, seed=2, sigma=sig); D, truth = d["distancematrix"], d["clusts"]
 P = rc.likelihood_hyperparams(D, truth)
 ctx = rc.Context(D, kcap=kcap); ctx.set_params(**P); ctx.set_state(truth); ctx.set_mode("incremental")
@@ -15,7 +15,7 @@ ctx.synchronize()
 L = rc.lib()
 out = np.zeros((8192, 16), np.int64)
 L.rc_debug_prof.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
-for t in range(60, 64):
+for t in range(60, 68):
     ctx.gibbs_sweep(1.0, 0.5, 7, t, blocking=True)
     st = ctx.sweep_stats()
     L.rc_debug_prof(ctx.h, t & 1, out.ctypes.data_as(C.c_void_p))
