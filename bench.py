@@ -403,6 +403,22 @@ def main():
                             "bit-identical to the sequential loop); headline data, stationary")
         if Dm is not None:
             defaults["moving_data"] = default_options_leg(Dm, Pm, tm, 200)
+        # ... and where proposals ARE accepted, so that the pipeline rolls back (an accepted proposal voids the iterations launched
+        # behind it): the headline data with every second cluster merged into its neighbour (25 clusters of two), accepted proposals
+        # kept (splitmerge = "intended"; as written, mcmc.jl:470 drops them, quirk Q1): the splits come back one by one
+        merged = truth.copy(); merged[merged % 2 == 0] -= 1
+        cr = rc.Context(D, device=dev0, kcap=kcap, storage_bits=BITS)
+        cr.set_params(**P); cr.set_state(merged); cr.cocluster_reset(); cr.attach_host_matrices(D)
+        its = 400
+        t1 = time.perf_counter()
+        chr_ = cr.run_chain(its, 0, 10, 5, 1, 3, r, p, 1.0, splitmerge="intended")
+        t_rb = time.perf_counter() - t1
+        cs = cr.chain_stats()
+        defaults["with_accepted_proposals"] = {"iterations": its, "iterations_per_s": its / t_rb, "splitmerge_acceptances": int(chr_["splitmerge_acceptances"].sum()),
+                                               "splitmerge_splits": int(chr_["splitmerge_splits"].sum()), "rollbacks": cs["rollbacks"], "workers": cs["workers"],
+                                               "K_start": int(len(np.unique(merged))), "K_final": int(chr_["K"][-1]),
+                                               "note": "init = generating labels with cluster pairs merged, splitmerge='intended': accepted splits roll the speculative pipeline back"}
+        cr.close()
     del Dm
 
     if rank == 0:

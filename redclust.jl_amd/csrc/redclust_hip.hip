@@ -1586,7 +1586,7 @@ __device__ __forceinline__ void syml2_fast(const View &V, long long *pb /* [2][8
         U = load_unit(unit);
 #pragma unroll
         for (int q = 0; q < NP; ++q) issue_pair(q, U.y + 2 * q, U.x);
-        cs0 = slot[U.x + 2 * lane]; cs1 = slot[U.x + 2 * lane + 1];     // (fast units hold 128 real columns)
+        cs0 = slot[min(U.x + 2 * lane, V.n - 1)]; cs1 = slot[min(U.x + 2 * lane + 1, V.n - 1)];   // (a ragged last block: padding columns take the last point's slot and carry zeros)
     }
     while (unit < end_unit) {
         RC_PF(long long pf_u0 = __builtin_amdgcn_s_memtime();)
@@ -1622,7 +1622,7 @@ __device__ __forceinline__ void syml2_fast(const View &V, long long *pb /* [2][8
         // is a DONOR: it keeps its first column as its value and hands the second to the lane on its right, whose columns are the
         // second cluster's (one wave-wide DPP shift per row and matrix, only in units that have such a lane).  Every other lane
         // (a third cluster, a stray point) adds its elements with atomics, row by row.
-        const bool diag = a1 > c0;                                        // uniform: the unit reaches into the diagonal block — triangle mask
+        const bool diag = a1 > c0 || c0 + RC_SW_COLS > V.n;               // uniform: the unit reaches into the diagonal block (triangle mask) or holds padding columns
         const int colx = c0 + (int)lane2, coly = colx + 1;
         const bool hasB = dsB >= 0;                                       // uniform
         const bool in0 = cs0 == dsA || (hasB && cs0 == dsB), in1 = cs1 == dsA || (hasB && cs1 == dsB);
@@ -1679,7 +1679,7 @@ __device__ __forceinline__ void syml2_fast(const View &V, long long *pb /* [2][8
                     if (ar + 2 * NP < a1) issue_pair(sl, ar + 2 * NP, c0);
                     else if (have_next) {
                         issue_pair(sl, Un.y + (ar + 2 * NP - a1), Un.x);
-                        if (q == 3) { ncs0 = slot[Un.x + 2 * lane]; ncs1 = slot[Un.x + 2 * lane + 1]; }
+                        if (q == 3) { ncs0 = slot[min(Un.x + 2 * lane, V.n - 1)]; ncs1 = slot[min(Un.x + 2 * lane + 1, V.n - 1)]; }
                     }
                     RC_PF(const long long pl0 = __builtin_amdgcn_s_memtime();)
                     if (RC_S2_EXP & 2) {
@@ -1703,8 +1703,8 @@ __device__ __forceinline__ void syml2_fast(const View &V, long long *pb /* [2][8
                     if (diag) {   // strictly upper triangle: element (row, col) lives iff col > row (the logs of dead entries are garbage: masked too)
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
-                            if (!(colx > ar + u)) { x[u].x = 0; y[u].x = 0; }
-                            if (!(coly > ar + u)) { x[u].y = 0; y[u].y = 0; }
+                            if (!(colx > ar + u && colx < V.n)) { x[u].x = 0; y[u].x = 0; }
+                            if (!(coly > ar + u && coly < V.n)) { x[u].y = 0; y[u].y = 0; }
                         }
                     }
                     RC_PF(asm volatile("" ::: "memory"); const long long pw0 = __builtin_amdgcn_s_memtime(); pf_log += pw0 - pl0;)
@@ -1812,7 +1812,7 @@ __device__ __forceinline__ void syml2_fast(const View &V, long long *pb /* [2][8
         // diagonal (S includes j = i): D[a][a] -> S[slot_a][a], added by the column block's first unit; logD's diagonal is 0
         if (a0 == 0) {
             const int col0 = c0 + 2 * lane;
-            const long long x0 = V.diagq[col0], x1 = V.diagq[col0 + 1];
+            const long long x0 = col0 < V.n ? V.diagq[col0] : 0, x1 = col0 + 1 < V.n ? V.diagq[col0 + 1] : 0;
             if (x0) add64(SD + (size_t)cs0 * ld + col0, x0);
             if (x1) add64(SD + (size_t)cs1 * ld + col0 + 1, x1);
         }
@@ -4065,8 +4065,7 @@ static int32_t build_syml2_lists(rc_ctx *c)
         out.clear();
         for (int J = ncb - 1; J >= 0; --J) {
             const int c0 = J * RC_SW_COLS, rows = std::min(c0 + RC_SW_COLS, n);
-            const bool whole = c0 + RC_SW_COLS <= n;                      // 128 real columns
-            const int fast_rows = whole ? (rows & ~7) : 0;               // (the diagonal block included: the fast path masks its triangle)
+            const int fast_rows = rows & ~7;                             // (diagonal block and padding columns included: the fast path masks them)
             for (int a0 = 0; a0 < fast_rows; a0 += g) {
                 const int a1 = std::min(a0 + g, fast_rows);
                 out.push_back({make_int4(c0, a0, a1, 0), (a1 - a0) / 4 + 2, true});
@@ -4577,7 +4576,7 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
 static bool choose_sym(const rc_ctx *c)
 {
     return c->bulk_kernel == 1 || (c->bulk_kernel < 0 && (long long)c->hsum->runs * 32 <= (long long)c->n &&
-                                   !(c->derived && c->n <= 4096));
+                                   !(c->derived && c->n <= (sym_variant_of(c) == 3 ? 2560 : 4096)));
 }
 
 // Static unit list of the wave-autonomous symmetric reduction for `cap_blocks` resident 4-wave blocks.  Every column block

@@ -11,7 +11,7 @@ if os.environ.get("SHUFFLE"):
     sh = np.random.default_rng(3).permutation(n)
     D = np.ascontiguousarray(D[np.ix_(sh, sh)]); truth = truth[sh]
 P = rc.likelihood_hyperparams(D, truth) if n <= 16384 else dict(delta1=20.0, delta2=30.0, alpha=1e6, beta=1e5, zeta=1e9, gamma=1e9, eta=1.0, sigma=1.0, u=1.0, v=1.0, repulsion=True, maxK=0)
-ctx = rc.Context(D, kcap=max(128, 2 * K), storage_bits=bits); ctx.set_params(**P); ctx.set_state(truth)
+ctx = rc.Context(D, storage_bits=bits); ctx.set_params(**P); ctx.set_state(truth)
 for t in range(10): ctx.gibbs_sweep(1.0, 0.5, 1, t, blocking=False)
 ctx.synchronize()
 t0 = time.perf_counter()
@@ -19,4 +19,4 @@ for t in range(10, 10 + steps): ctx.gibbs_sweep(1.0, 0.5, 1, t, blocking=False)
 t_enq = time.perf_counter() - t0
 ctx.synchronize()
 dt = time.perf_counter() - t0
-print(f"n={n} K={K} bits={bits}: {steps / dt:.1f} sweeps/s ({dt / steps * 1e3:.3f} ms/sweep; host enqueue {t_enq / steps * 1e6:.1f} us/sweep) changes {ctx.sweep_stats()}")
+print(f"n={n} K={K} bits={bits} {ctx.bulk_kernel_name()}: {steps / dt:.1f} sweeps/s ({dt / steps * 1e3:.3f} ms/sweep; host enqueue {t_enq / steps * 1e6:.1f} us/sweep) changes {ctx.sweep_stats()}")
