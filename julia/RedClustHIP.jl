@@ -249,6 +249,27 @@ function runsampler_hip_chains(data::MCMCData,
 end
 
 """
+    HIPBackend(device = 0)
+
+The reference's own name for the sampler: `RedClust.runsampler` gets one more method, selected by a backend in front of its usual
+arguments — `runsampler(HIPBackend(), data, options, params, init)` is `runsampler_hip(data, options, params, init; device = 0)`.
+The one line of a user's script that changes (INTEGRATION.md §1): `result = runsampler(data, options, params)` becomes
+`result = runsampler(HIPBackend(), data, options, params)`; everything before it (`MCMCData`, `fitprior`, `MCMCOptionsList`) and
+after it (`getpointestimate`, `summarise`, the plots) works on the same structs as before.
+"""
+struct HIPBackend
+    device::Int
+end
+HIPBackend() = HIPBackend(0)
+
+RedClust.runsampler(b::HIPBackend, data::MCMCData,
+    options::MCMCOptionsList=MCMCOptionsList(),
+    params::Union{PriorHyperparamsList,Nothing}=nothing,
+    init::Union{MCMCState,Nothing}=nothing; kwargs...) = runsampler_hip(data, options, params, init; device=b.device, kwargs...)
+
+export runsampler_hip, runsampler_hip_chains, getpointestimate_hip, HIPBackend
+
+"""
     getpointestimate_hip(result; loss = "VI", device = 0) -> (clust, i)
 
 `getpointestimate(result; method = "MPEL", loss)` (src/pointestimate.jl:49-58) with the numsamples² loss matrix computed

@@ -151,8 +151,8 @@ if __name__ == "__main__":
         bad = run_chains(cases, first)
     elif len(sys.argv) > 3 and sys.argv[3] == "oracle_chains":
         bad = run_chains_oracle(cases, first)
-    elif len(sys.argv) > 3 and sys.argv[3] == "large":     # beyond the kernel-choice threshold: symmetric kernels, re-layouts
-        bad = run(cases, first, 4100, 7000, 60)
+    elif len(sys.argv) > 3 and sys.argv[3] == "large":     # beyond the kernel-choice threshold (n > 2560): symmetric kernels, ragged column blocks, re-layouts
+        bad = run(cases, first, 2600, 7000, 60)
     else:
         bad = run(cases, first)
     print(f"fuzz: {cases} cases from seed {first}, {bad} bad")

@@ -320,6 +320,9 @@ def test_julia_glue_ccalls_match_the_header():
     sig = re.search(r"function runsampler_hip\(data::MCMCData,\s*options::MCMCOptionsList=MCMCOptionsList\(\),\s*"
                     r"params::Union\{PriorHyperparamsList,Nothing\}=nothing,\s*init::Union\{MCMCState,Nothing\}=nothing;", jl)
     assert sig, "runsampler_hip does not have runsampler's signature and defaults"
+    # ... and the reference's own name: one more method of RedClust.runsampler, selected by a backend argument in front
+    assert re.search(r"RedClust\.runsampler\(b::HIPBackend, data::MCMCData,\s*options::MCMCOptionsList=MCMCOptionsList\(\),", jl)
+    assert "export runsampler_hip, runsampler_hip_chains, getpointestimate_hip, HIPBackend" in jl
     assert 'fitprior(data.D, "k-medoids", true; verbose=verbose)' in jl and "kmedoids(data.D," in jl
     assert "seed % UInt64" in jl and "UInt64(seed)" not in jl
     assert "numMH == 0 ||" not in jl and "not offloaded" not in jl
