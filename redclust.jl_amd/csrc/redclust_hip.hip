@@ -1509,6 +1509,12 @@ __device__ __forceinline__ int wave_from_next(int v)
     asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1" : "+v"(r) : "v"(v));
     return r;
 }
+__device__ __forceinline__ int wave_from_prev(int v)
+{
+    int r = 0;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1" : "+v"(r) : "v"(v));
+    return r;
+}
 __device__ __forceinline__ long long wave_from_prev64(long long v)
 {
     unsigned lo = 0, hi = 0;
@@ -1564,13 +1570,22 @@ __device__ __forceinline__ void syml2_fast(const View &V, long long *pb /* [2][8
     constexpr int NP = RC_S2_NP;
     raw_t d[NP][2];
     ll2 l[NP][2];
-    auto issue_pair = [&](int sl, int row, int cb0) {
+    // the rows are requested strictly in order — down a unit, then on into the wave's next unit — so the (uniform) address of the
+    // next row to request is carried along and advanced by the row pitch: two scalar adds per row instead of a 64-bit multiply
+    const size_t pitchD = PACK ? ld / 2 * 3 : ld;                          // row pitch in elements of the streamed type's base pointer
+    RC_GLOBAL_AS const unsigned *np48 = nullptr;
+    RC_GLOBAL_AS const long long *npD = nullptr, *npL = nullptr;
+    auto set_next = [&](int row, int cb0) {
+        const size_t e = (size_t)row * ld + (size_t)cb0;
+        if (PACK) np48 = rc_uniform_ptr(D48 + e / 2 * 3); else npD = rc_uniform_ptr(Dq + e);
+        if (!DERIVED) npL = rc_uniform_ptr(Lq + e);
+    };
+    auto issue_pair = [&](int sl) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const size_t e = (size_t)(row + u) * ld + (size_t)cb0;        // uniform: first entry of the wave's row segment
-            if (PACK) d[sl][u] = __builtin_nontemporal_load((RC_GLOBAL_AS const typename std::conditional<PACK, rc_u3a4, ll2>::type *)(rc_uniform_ptr(D48 + e / 2 * 3) + lane3));
-            else d[sl][u] = __builtin_nontemporal_load((RC_GLOBAL_AS const typename std::conditional<PACK, rc_u3a4, ll2>::type *)(rc_uniform_ptr(Dq + e) + lane2));
-            if (!DERIVED) l[sl][u] = __builtin_nontemporal_load((RC_GLOBAL_AS const ll2 *)(rc_uniform_ptr(Lq + e) + lane2));
+            if (PACK) { d[sl][u] = __builtin_nontemporal_load((RC_GLOBAL_AS const typename std::conditional<PACK, rc_u3a4, ll2>::type *)(np48 + lane3)); np48 += pitchD; }
+            else { d[sl][u] = __builtin_nontemporal_load((RC_GLOBAL_AS const typename std::conditional<PACK, rc_u3a4, ll2>::type *)(npD + lane2)); npD += pitchD; }
+            if (!DERIVED) { l[sl][u] = __builtin_nontemporal_load((RC_GLOBAL_AS const ll2 *)(npL + lane2)); npL += ld; }
         }
     };
     // (uniform by construction — the wave number is a scalar — but say so: unit bounds, row loops and row addresses stay in SGPRs)
@@ -1584,8 +1599,9 @@ __device__ __forceinline__ void syml2_fast(const View &V, long long *pb /* [2][8
     int cs0 = -1, cs1 = -1;
     if (unit < end_unit) {
         U = load_unit(unit);
+        set_next(U.y, U.x);
 #pragma unroll
-        for (int q = 0; q < NP; ++q) issue_pair(q, U.y + 2 * q, U.x);
+        for (int q = 0; q < NP; ++q) issue_pair(q);
         cs0 = slot[min(U.x + 2 * lane, V.n - 1)]; cs1 = slot[min(U.x + 2 * lane + 1, V.n - 1)];   // (a ragged last block: padding columns take the last point's slot and carry zeros)
     }
     while (unit < end_unit) {
@@ -1666,6 +1682,10 @@ __device__ __forceinline__ void syml2_fast(const View &V, long long *pb /* [2][8
         for (int h0 = a0; h0 < a1; h0 += 64) {                            // 64-row halves (direction-2 totals live one row per lane)
             const int h1 = min(h0 + 64, a1);
             const int rowslots = (h0 + lane < h1) ? slot[h0 + lane] : -1; // slot of row h0 + lane (read back with readlane)
+            // rows whose slot differs from the row before (bit l: row h0 + l; row h0 itself is compared with the slot being summed):
+            // a pair of rows without such a bit — nearly all — adds into the running sums without looking at slots
+            u64 chg = __ballot(rowslots != wave_from_prev(rowslots) && lane > 0 && h0 + lane < h1);
+            if (__builtin_amdgcn_readfirstlane(rowslots) != cur) chg |= 1ull;
             RC_PF(pf_setup += __builtin_amdgcn_s_memtime() - pf_u0;)
             for (int a = h0; a < h1; a += 8) {
 #pragma unroll
@@ -1676,9 +1696,10 @@ __device__ __forceinline__ void syml2_fast(const View &V, long long *pb /* [2][8
 #pragma unroll
                     for (int u = 0; u < 2; ++u) { x[u] = S2Raw<PACK>::unpack(d[sl][u]); if (!DERIVED) y[u] = l[sl][u]; }
                     // the pair NP pairs ahead goes into the registers this one leaves: of this unit, or of the wave's next unit
-                    if (ar + 2 * NP < a1) issue_pair(sl, ar + 2 * NP, c0);
+                    if (ar + 2 * NP < a1) issue_pair(sl);
                     else if (have_next) {
-                        issue_pair(sl, Un.y + (ar + 2 * NP - a1), Un.x);
+                        if (ar + 2 * NP == a1) set_next(Un.y, Un.x);     // the first rows of the wave's next unit
+                        issue_pair(sl);
                         if (q == 3) { ncs0 = slot[min(Un.x + 2 * lane, V.n - 1)]; ncs1 = slot[min(Un.x + 2 * lane + 1, V.n - 1)]; }
                     }
                     RC_PF(const long long pl0 = __builtin_amdgcn_s_memtime();)
@@ -1734,7 +1755,9 @@ __device__ __forceinline__ void syml2_fast(const View &V, long long *pb /* [2][8
                     }
                     RC_PF(const long long pd0 = __builtin_amdgcn_s_memtime(); pf_ldsw += pd0 - pw0;)
                     // direction 1
-                    if (RC_S2_EXP & 8) { aD0 += x[0].x ^ x[1].y; aL0 += y[0].x ^ y[1].y; } else {
+                    if (RC_S2_EXP & 8) { aD0 += x[0].x ^ x[1].y; aL0 += y[0].x ^ y[1].y; } else if (((chg >> (ar - h0)) & 3ull) == 0) {
+                        aD0 += x[0].x + x[1].x; aD1 += x[0].y + x[1].y; aL0 += y[0].x + y[1].x; aL1 += y[0].y + y[1].y;
+                    } else {
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
                             const int sr = __builtin_amdgcn_readlane(rowslots, ar + u - h0);
