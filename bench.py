@@ -404,21 +404,35 @@ def main():
         if Dm is not None:
             defaults["moving_data"] = default_options_leg(Dm, Pm, tm, 200)
         # ... and where proposals ARE accepted, so that the pipeline rolls back (an accepted proposal voids the iterations launched
-        # behind it): the headline data with every second cluster merged into its neighbour (25 clusters of two), accepted proposals
-        # kept (splitmerge = "intended"; as written, mcmc.jl:470 drops them, quirk Q1): the splits come back one by one
-        merged = truth.copy(); merged[merged % 2 == 0] -= 1
-        cr = rc.Context(D, device=dev0, kcap=kcap, storage_bits=BITS)
-        cr.set_params(**P); cr.set_state(merged); cr.cocluster_reset(); cr.attach_host_matrices(D)
-        its = 400
-        t1 = time.perf_counter()
-        chr_ = cr.run_chain(its, 0, 10, 5, 1, 3, r, p, 1.0, splitmerge="intended")
-        t_rb = time.perf_counter() - t1
-        cs = cr.chain_stats()
-        defaults["with_accepted_proposals"] = {"iterations": its, "iterations_per_s": its / t_rb, "splitmerge_acceptances": int(chr_["splitmerge_acceptances"].sum()),
-                                               "splitmerge_splits": int(chr_["splitmerge_splits"].sum()), "rollbacks": cs["rollbacks"], "workers": cs["workers"],
-                                               "K_start": int(len(np.unique(merged))), "K_final": int(chr_["K"][-1]),
-                                               "note": "init = generating labels with cluster pairs merged, splitmerge='intended': accepted splits roll the speculative pipeline back"}
-        cr.close()
+        # behind it).  On the synthetic sets the Gibbs sweep repairs any labelling by itself and no proposal is ever accepted
+        # (tried: clusters merged in pairs, cut in halves, sigma up to 0.5: tools/acc_probe.py), so this leg runs the reference's own
+        # example data — paper dataset 1 (n = 100, tests/golden/paper_datasets.npz, extracted from data/example_datasets.h5) from
+        # random labels, accepted proposals kept (splitmerge = "intended") — speculative against synchronous loop, same chain.
+        try:
+            z = np.load(os.path.join(ROOT, "tests", "golden", "paper_datasets.npz"))
+            D1, lab1 = np.ascontiguousarray(z["D1"]), z["labels1"]
+            P1 = rc.likelihood_hyperparams(D1, lab1)
+            init1 = np.random.default_rng(1).integers(1, 11, size=100).astype(np.int64)
+            legs = {}
+            for name, env in (("speculative", None), ("synchronous", "0")):
+                if env is None: os.environ.pop("RC_CHAIN_PIPELINE", None)
+                else: os.environ["RC_CHAIN_PIPELINE"] = env
+                cr = rc.Context(D1, device=dev0)
+                cr.set_params(**P1); cr.set_state(init1); cr.cocluster_reset(); cr.attach_host_matrices(D1)
+                its = 3000
+                t1 = time.perf_counter()
+                chr_ = cr.run_chain(its, 0, 10, 5, 1, 3, r, p, 1.0, splitmerge="intended")
+                t_rb = time.perf_counter() - t1
+                cs = cr.chain_stats()
+                legs[name] = {"iterations_per_s": its / t_rb, "splitmerge_acceptances": int(chr_["splitmerge_acceptances"].sum()),
+                              "splitmerge_splits": int(chr_["splitmerge_splits"].sum()), "rollbacks": cs["rollbacks"], "workers": cs["workers"], "K_final": int(chr_["K"][-1])}
+                cr.close()
+            os.environ.pop("RC_CHAIN_PIPELINE", None)
+            defaults["with_accepted_proposals"] = dict(legs, iterations=3000, data="paper dataset 1 (n = 100), random initial labels, splitmerge='intended'",
+                                                       same_chain=legs["speculative"]["splitmerge_acceptances"] == legs["synchronous"]["splitmerge_acceptances"]
+                                                       and legs["speculative"]["K_final"] == legs["synchronous"]["K_final"])
+        except Exception as e:   # noqa: BLE001
+            defaults["with_accepted_proposals"] = {"error": str(e)}
     del Dm
 
     if rank == 0:
