@@ -9,6 +9,7 @@ sig = float(sys.argv[1]) if len(sys.argv) > 1 else 0.2
 d = rc.generatemixture(n, K, seed=2, sigma=sig); D, truth = d["distancematrix"], d["clusts"]
 P = rc.likelihood_hyperparams(D, truth)
 ctx = rc.Context(D); ctx.set_params(**P); ctx.set_state(truth)
+if os.environ.get("MODE"): ctx.set_mode(os.environ["MODE"])        # MODE=incremental: what runsampler uses
 sw = 0
 for _ in range(60):
     ctx.gibbs_sweep(1.0, 0.5, 7, sw, blocking=False); sw += 1
@@ -27,6 +28,6 @@ for rep in range(3):
     ctx.synchronize()
     rates.append(200 / (time.perf_counter() - t0))
 lab = ctx.get_state()[0]
-print(json.dumps(dict(lib=os.environ.get("RC_LIB_PATH", "in-tree"), sigma=sig, sweeps_per_s=sorted(rates)[1], rates=rates, blocking_sweeps_per_s=100 / t_block,
+print(json.dumps(dict(mode=os.environ.get("MODE", "full"), lib=os.environ.get("RC_LIB_PATH", "in-tree"), sigma=sig, sweeps_per_s=sorted(rates)[1], rates=rates, blocking_sweeps_per_s=100 / t_block,
                       changes_per_sweep=ch / 100, rounds_per_sweep=rounds / 100, K=ctx.sweep_stats()["K"], kernel=ctx.bulk_kernel_name(),
                       checksum=hashlib.sha256(lab.tobytes()).hexdigest()[:16], capacity=ctx.capacity_info())))
