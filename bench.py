@@ -356,6 +356,10 @@ def main():
         t_block = time.perf_counter() - t1
         tms, sw = timed_windows(cm, 7, r, p, msteps, 0, 3, lambda: None, sw)
         t_async = median(tms)
+        # the same chain in the exact incremental mode (what runsampler and the Julia glue use: no row reduction beside the resolver)
+        cm.set_mode("incremental")
+        tmi, sw = timed_windows(cm, 7, r, p, msteps, 10, 3, lambda: None, sw)
+        cm.set_mode("full")
         # SURVEY.md §8(d)'s other movement workload: labels uniform on 1..K from a fixed seed on the headline data — the first sweeps
         # relabel nearly every point (a one-off transient: thousands of changes resolved in batches)
         uni = np.random.default_rng(13).integers(1, K + 1, size=n).astype(np.int64)
@@ -371,6 +375,7 @@ def main():
         moving = {"sigma": sig, "uniform_init_first_sweeps": uniform_init, "uniform_init_capacity": uni_cap,
                   "sweeps_per_s": msteps / t_async, "ms_per_sweep": t_async / msteps * 1e3,
                   "sweeps_per_s_windows": [msteps / x for x in tms],
+                  "sweeps_per_s_incremental_mode": msteps / median(tmi),
                   "sweeps_per_s_blocking": msteps / t_block, "label_changes_per_sweep": ch / msteps,
                   "resolve_rounds_per_sweep": rounds / msteps, "K": cm.sweep_stats()["K"], "steps": msteps, "capacity": cm.capacity_info(),
                   "note": "overlapping clusters, equilibrium after 60 burn-in sweeps from the generating labels; library-default capacity"}
