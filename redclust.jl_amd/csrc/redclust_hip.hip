@@ -170,7 +170,7 @@ struct View {
     int *snap[2];              // [n] slot of every point as it was when the generation was written (k_bulk_sym reads these)
     int *work[2];              // work-item counters of k_bulk_sym (two generations)
     const double *A;           // [n+1] size table
-    u64 *keys[2];              // [n+2] one word per resolve round: first violation (batch rounds) (two generations)
+    u64 *keys[2];              // [2n+8] one word per resolve round: first violation (batch rounds) (two generations)
     u64 *cword[2];             // [2][nchunks + 1] per round parity and 32-point chunk: (round stamp << 32) | mask of tentative changers (two generations)
     unsigned *rec;             // [2][n] per round parity: (own slot << 16) | (target slot + 1) of a tentative changer (0 target = new cluster)
     int *tent;                 // [n] tentative target of every point (owner-private)
@@ -2082,6 +2082,7 @@ struct Tab {
 #define RC_BF_BIRTH 2   // the target is a new cluster (slot bb, label blab)
 #define RC_BF_RENAME 4  // a singleton that takes a fresh, smaller label (slot unchanged, label blab)
 #define RC_BF_NOOP 8    // a singleton that draws "new cluster" and keeps its label: nothing changes
+#define RC_BF_STAY 16   // (with NOOP) a carried-over guess whose target cluster no longer exists: the entry is a placeholder, the guess is "stays"
 
 #define RC_A16(x) (((x) + 15) & ~(size_t)15)
 #define RC_TAB_NOFF 30
@@ -2467,7 +2468,8 @@ __device__ __forceinline__ void hot_accumulate(const View &V, const Tab &T, int 
 // new-cluster candidate.  The cached value is the very double the computation would produce again, so decisions are
 // unchanged; a computed candidate costs ~330 VALU instructions, a cached one a load (moving regime, K = 206: eight passes per sweep).
 __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long long *SD, const long long *SL,
-                           int chunk, int lo, int hi, int mode, int nb, u64 *cword, unsigned *rec, unsigned stamp, int cmode)
+                           int chunk, int lo, int hi, int mode, int nb, u64 *cword, unsigned *rec, unsigned stamp, int cmode,
+                           u64 *cword_next = nullptr, unsigned *rec_next = nullptr, unsigned stamp_next = 0u)
 {
     const int pt = threadIdx.x & (RC_PTS - 1), st = threadIdx.x >> RC_PTS_LOG2, NS = blockDim.x >> RC_PTS_LOG2;
     const int wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
@@ -2629,17 +2631,37 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
             changed = (target != own);
         }
         if (mode == 0) {
-            if (half == 0 && valid) {
-                V.tent[i] = target;
-                if (changed) __hip_atomic_store(rec + i, ((unsigned)own << 16) | (unsigned)(target + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (half == 0 && valid && changed)
+                __hip_atomic_store(rec + i, ((unsigned)own << 16) | (unsigned)(target + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const u64 m = __ballot(changed) & ((1ull << RC_PTS) - 1ull);
             if (m) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the records are out before the mask that announces them
                 if (threadIdx.x == 0) __hip_atomic_store(cword + chunk, ((u64)stamp << 32) | m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-        } else if (half == 0 && valid && target != V.tent[i]) {
-            atomicMin(T.blk_key, (u64)(unsigned)i);
+        } else {
+            // The guess this draw is checked against is what the batch says the point does: its entry (the slot it joins; "new
+            // cluster" for a birth, a rename or a singleton that keeps its label; "stays" for a placeholder), or no entry = stays.
+            if (half == 0 && valid) {
+                int guess = own;
+                if (j < nb && T.bx[j] == i) {
+                    const int fl = T.bflag[j];
+                    guess = (fl & RC_BF_STAY) ? own : (fl & (RC_BF_BIRTH | RC_BF_RENAME | RC_BF_NOOP)) ? -1 : (int)T.bb[j];
+                }
+                if (target != guess) atomicMin(T.blk_key, (u64)(unsigned)i);
+                // ... and the draw itself is the point's guess in the next round (announced in the other parity's buffers): it
+                // already accounts for the changers before the point, which a fresh draw under the committed state would not
+                if (changed) __hip_atomic_store(rec_next + i, ((unsigned)own << 16) | (unsigned)(target + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // the points of this chunk beyond the batch's range keep the guess they had
+            bool carried = false;
+            if (half == 0 && i < V.n && i > hi) {
+                const u64 w = __hip_atomic_load(cword + chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                carried = ((unsigned)(w >> 32) == stamp) && (((unsigned)w >> pt) & 1u);
+                if (carried) __hip_atomic_store(rec_next + i, __hip_atomic_load(rec + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const u64 m = __ballot(changed || carried) & ((1ull << RC_PTS) - 1ull);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (threadIdx.x == 0) __hip_atomic_store(cword_next + chunk, ((u64)stamp_next << 32) | m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     __syncthreads();
@@ -2768,23 +2790,25 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
         const long long pc0_ = __builtin_amdgcn_s_memrealtime(); ++pf_ch_;
 #endif
         int va = 0, vt = -1, vla = 0, vcda = 0, vcdt = 0;
-        bool vfast = false, vsafe = false;
+        bool vfast = false, vsafe = false, vstay = false;
         if (q0 + lane < nb0) {
             va = T.ba[q0 + lane]; vt = T.bb[q0 + lane]; vla = T.label[va];
+            // target == source: the placeholder of a carried-over guess whose target cluster is gone (the assembly wrote it so)
+            vstay = (vt == va);
             vcda = T.candie[va]; vcdt = vt >= 0 ? (int)T.candie[vt] : 0;
             // a singleton nobody in the batch joins, drawing "new cluster": alone at its turn whatever happened before
             vfast = vt < 0 && T.size[va] == 1 && !T.joined[va];
             // a move between two clusters neither of which can become empty inside the batch: a plain move whatever the
             // order, nothing to simulate (the sizes of such clusters are not tracked here at all)
-            vsafe = vt >= 0 && !vcda && !vcdt;
+            vsafe = vt >= 0 && !vstay && !vcda && !vcdt;
         }
-        const u64 safemask = __ballot(vsafe);
+        const u64 safemask = __ballot(vsafe), staymask = __ballot(vstay), fastmask = __ballot(vfast);
         // results of entry q0 + lane (stored after the chunk).  The plain moves are not visited at all: their target is the
         // tentative one, and cluster count / smallest empty label are those left by the last visited entry before them
-        int ob = vt, olab = 0, oflag = 0, oK = K;
+        int ob = vt, olab = 0, oflag = vstay ? (RC_BF_NOOP | RC_BF_STAY) : 0, oK = K;
         const int cnt = min(64, nb0 - q0);
         int done = cnt;
-        u64 todo = ~safemask & (cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull));
+        u64 todo = ~safemask & ~staymask & (cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull));
 #ifdef RC_PROF_SIM
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const long long psim0_ = __builtin_amdgcn_s_memrealtime(); pf_pro_ += psim0_ - pc0_;
@@ -2806,6 +2830,36 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
             todo &= ~(1ull << e);
             ++nvisited;
             const int q = q0 + e;
+            if (regs && ((fastmask >> e) & 1ull)) {
+                // A lone singleton that draws "new cluster" and is still here: the smallest empty label is smaller than its own
+                // (the others were settled above), so it takes that label and frees its own — slot, sizes and cluster count stay.
+                // These renames are most of the serial entries of the moving regime (twenty per batch); on this short path an
+                // entry is ~45 instructions of one wave instead of ~200 through the general case below.
+                se = __builtin_amdgcn_readfirstlane(se); neff = __builtin_amdgcn_readfirstlane(neff); first_eff = __builtin_amdgcn_readfirstlane(first_eff);
+                const int la_ = __builtin_amdgcn_readlane(vla, e), lab_ = se;
+                if (lane == ((lab_ - 1) >> 5)) U |= 1u << ((lab_ - 1) & 31);
+                if (lane == ((la_ - 1) >> 5)) U &= ~(1u << ((la_ - 1) & 31));   // (a label beyond 2048 has no lane: never the smallest empty one)
+                {   // smallest empty label above lab_: its bit index is >= lab_ (the freed label la_ > lab_ is among the candidates)
+                    const int w0 = lab_ >> 5;
+                    unsigned inv = (lane >= w0) ? ~U : 0u;
+                    if (lane == w0) inv &= ~((1u << (lab_ & 31)) - 1u);
+                    const u64 anyw = __ballot(inv != 0u);
+                    se = V.n + 1;
+                    if (anyw) {
+                        const int fl = __ffsll((long long)anyw) - 1;
+                        const int r = fl * 32 + __ffs(__builtin_amdgcn_readlane((int)inv, fl));   // 1-based label
+                        if (r <= V.n) se = r;
+                    }
+                    if (la_ < se) se = la_;   // (labels beyond the bitset's 64 words are not seen by the scan)
+                }
+                if (lane == e) { ob = va; olab = lab_; oflag = RC_BF_RENAME; }
+                if (first_eff < 0) first_eff = q;
+                ++neff;
+#ifdef RC_PROF_SIM
+                ++pf_ser_;
+#endif
+                continue;
+            }
             const int a = __builtin_amdgcn_readlane(va, e), la = __builtin_amdgcn_readlane(vla, e);
             // the running state is the same in every lane: keep it in scalar registers (one wave applies these entries one after
             // the other, ~10 cycles per dependent instruction; with the state in vector registers every decision below was a
@@ -2820,14 +2874,27 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
                 // The could-die flags come from the chunk's prefetch; the running sizes — kept only for slots that could die — are
                 // the one LDS round trip of an entry, and only if one of its two slots is such a slot.
                 const bool cda = __builtin_amdgcn_readlane(vcda, e) != 0, cdt = __builtin_amdgcn_readlane(vcdt, e) != 0;
+                // a lone singleton that draws "new cluster" (nobody in the batch joins it): alone at its turn, no size to look up —
+                // it takes the smallest empty label if that is smaller than its own.  These are most of the serial entries of the
+                // moving regime (twenty renames per batch); without the LDS round trip for the sizes an entry is ~40 instructions.
+                const bool lone = ((fastmask >> e) & 1ull) != 0ull;
                 int sza = 0, szt = 0;
-                if (cda || cdt) {
+                if (!lone && (cda || cdt)) {
                     const int x_ = T.size[a], y_ = T.size[tgt >= 0 ? tgt : a];   // (both issued before either is waited for)
                     sza = __builtin_amdgcn_readfirstlane(x_); szt = __builtin_amdgcn_readfirstlane(y_);
                 }
                 b = tgt;
-                if (tgt >= 0) {
-                    if (cdt && szt == 0) { nb = q; hi = T.bx[q] - 1; stop = true; done = e; break; }
+                if (lone) {
+                    b = a;
+                    if (se < la) { flag = RC_BF_RENAME; lab = se; old = la; }
+                    else flag = RC_BF_NOOP;
+                } else if (tgt >= 0 && cdt && szt == 0) {
+                    // the target cluster was emptied by an earlier entry: the guess is void.  The entry stays as a placeholder that
+                    // does nothing ("stays" is the new guess; the validation draws the point under the state as it is at its turn
+                    // and, if it does move, the round ends there with that draw as the next guess — cutting the batch here instead
+                    // ended the round for certain and left every point behind it with a guess nobody had checked)
+                    b = a; flag = RC_BF_NOOP | RC_BF_STAY;
+                } else if (tgt >= 0) {
                     if (cda && sza == 1) { flag = RC_BF_DEATH; old = la; K -= 1; }
                 } else if (cda && sza == 1) {
                     b = a;
@@ -3067,44 +3134,55 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
     // grid barrier; block 0 rewrites the count in its epilogue).  Same results either way.
     const bool use_wc = V.wc != nullptr && sa.dbg == 0 && (V.wc_always || V.sc->n_changes > 0);
     const int last = V.sc->last_change_sweep;   // (read before the first barrier as well: the epilogue rewrites it)
+    const int prev_rounds = V.sc->n_rounds;     // rounds of the previous sweep = the key words it used (its generation is re-armed in the epilogue)
     RC_PF(ps[1] = __builtin_amdgcn_s_memrealtime();)
     const int nchunks = (V.n + RC_PTS - 1) / RC_PTS;
     int after = sa.after0, round = 0, changes = sa.changes0, nbar = 0;
     int cap = V.maxb;    // changers taken into the next batch (adaptive, identical in every block)
     bool ok = true;
-    for (;;) {
-        const unsigned stamp = (unsigned)round + 1u;
-        // The announcements of a round (chunk words, changer records) live in the buffers of the round's PARITY: after a
-        // structural commit the blocks go on to the next round without a second barrier, and a block that is ahead must
-        // not overwrite what a block that is behind is still reading (it cannot get two rounds ahead: the next round's
-        // first barrier holds it).
-        u64 *const cword = cword_gen + (size_t)(round & 1) * (size_t)(nchunks + 1);
-        unsigned *const rec = V.rec + (size_t)(round & 1) * (size_t)V.n;
+    // Guesses.  A round validates GUESSES of what every open point does — any guess will do for correctness: a point is final
+    // only once its draw under the exact sequential state (committed state + the batch entries before it, all of them validated)
+    // equals its guess.  Round 0 guesses by drawing every point under the committed state (the tentative pass).  A later round
+    // takes the draws of the previous round's VALIDATION as guesses: they already account for the changers before each point
+    // (all but the one that was violated), so they are better guesses than a fresh tentative pass — fewer rounds — and they
+    // cost nothing: no tentative pass and no barrier before the batch is assembled, one grid barrier per round instead of two.
+    // The announcements (chunk words, changer records) are double-buffered: a round reads buffer `cur` (words stamped `gstamp`)
+    // and its validation writes the other one, so a block that is ahead never overwrites what a block behind still reads.
+    // `exact`: every guess after `after` was drawn under the committed state as it is now (true after the tentative pass and
+    // after a validation under a batch without effective entries): then the points up to the first effective changer are
+    // final as they are, and a batch without effective entries ends the sweep.
+    int cur = 0;
+    unsigned gstamp = 1u;
+    bool exact = true;
+    {
         RC_CHAOS_AT(0);
         RC_PF(pt_ = __builtin_amdgcn_s_memrealtime(); ps[13] += 1;)
-        // 1. tentative decisions of the points after `after`
-        if (use_wc && round > 0) tab_partition(V, T, false);
         for (int c = blockIdx.x; c < nchunks; c += G)
-            if (c * RC_PTS + RC_PTS - 1 > after) eval_chunk(V, sa, T, SD, SL, c, after, V.n, 0, 0, cword, rec, stamp, use_wc ? (round > 0 ? 2 : 1) : 0);
-        // the pass has stored the new scores of the slots the last commit touched, for every point that is still open: clean again
-        if (use_wc && round > 0) { for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) T.dirty[k] = 0; }
-        if (sa.dbg & 2) break;
+            if (c * RC_PTS + RC_PTS - 1 > after) eval_chunk(V, sa, T, SD, SL, c, after, V.n, 0, 0, cword_gen, V.rec, gstamp, use_wc ? 1 : 0);
         RC_PHASE(6)
 #ifndef RC_PROF_COMMIT
-        RC_PF(if (round == 0) ps[2] = __builtin_amdgcn_s_memrealtime();)
+        RC_PF(ps[2] = __builtin_amdgcn_s_memrealtime();)
 #endif
-        ok = grid_barrier(V, T, arrive, G, (unsigned)(++nbar), RC_KEY_NONE, keys + round);
-        RC_PF(if (round == 0) ps[3] = __builtin_amdgcn_s_memrealtime();)
+        if (!(sa.dbg & 2)) ok = grid_barrier(V, T, arrive, G, (unsigned)(++nbar), RC_KEY_NONE, keys);
+        RC_PF(ps[3] = __builtin_amdgcn_s_memrealtime();)
         RC_PHASE(7)
-        if (!ok) break;
+    }
+    while (ok && !(sa.dbg & 2)) {
+        u64 *const cword = cword_gen + (size_t)cur * (size_t)(nchunks + 1), *const cword_next = cword_gen + (size_t)(cur ^ 1) * (size_t)(nchunks + 1);
+        unsigned *const rec = V.rec + (size_t)cur * (size_t)V.n, *const rec_next = V.rec + (size_t)(cur ^ 1) * (size_t)V.n;
         RC_CHAOS_AT(1);
-        // 2. the ordered batch of tentative changers
+        RC_PF(pt_ = __builtin_amdgcn_s_memrealtime();)
+        // 1. the ordered batch of guessed changers after `after` (the bits of the points up to `after` in its chunk are history)
         int any = 0;
         for (int c = threadIdx.x; c <= nchunks; c += blockDim.x) {
             int cnt = 0;
             if (c < nchunks && c * RC_PTS + RC_PTS - 1 > after) {
                 const u64 w = __hip_atomic_load(cword + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((unsigned)(w >> 32) == stamp) cnt = __popc((unsigned)w);
+                if ((unsigned)(w >> 32) == gstamp) {
+                    unsigned m = (unsigned)w;
+                    if (c * RC_PTS <= after) m &= ~0u << (after - c * RC_PTS + 1);
+                    cnt = __popc(m);
+                }
             }
             T.ccnt[c] = (unsigned short)cnt;
             any |= cnt;
@@ -3116,7 +3194,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         __syncthreads();
         const int any_all = T.misc[2];
         __syncthreads();
-        if (!any_all) break;  // no point wants to move: the sweep is complete (the stationary fast path)
+        if (!any_all && exact) break;  // no point wants to move, and every one of them drew under the state as it is: the sweep is complete (the stationary fast path)
         // exclusive offsets by wave 0: every lane scans its run of chunks, the lanes' totals by shuffles (a scan by one
         // thread costs two LDS round trips per chunk: 14 µs at n = 8192, half of a stationary resolver pass)
         if (threadIdx.x < 64) {
@@ -3143,13 +3221,22 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
             while (hi_ - lo_ > 1) { const int mid = (lo_ + hi_) >> 1; if ((int)T.ccnt[mid] <= o) lo_ = mid; else hi_ = mid; }
             const int c = lo_;
             unsigned m = (unsigned)__hip_atomic_load(cword + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c * RC_PTS <= after) m &= ~0u << (after - c * RC_PTS + 1);
             for (int r_ = o - (int)T.ccnt[c]; r_ > 0; --r_) m &= m - 1;
             const int x = c * RC_PTS + __ffs((int)m) - 1;
             if (o < cap) {
                 const unsigned rc = __hip_atomic_load(rec + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                T.bx[o] = x; T.bu[o] = V.pi[x]; T.ba[o] = (short)(rc >> 16); T.bb[o] = (short)((int)(rc & 0xFFFFu) - 1);
-                if (rc & 0xFFFFu) T.joined[(rc & 0xFFFFu) - 1] = 1;
-                atomicAdd(&T.seg[rc >> 16], 1);   // leaves its cluster
+                const int own_ = (int)(rc >> 16), tgt_ = (int)(rc & 0xFFFFu) - 1;
+                T.bx[o] = x; T.bu[o] = V.pi[x]; T.ba[o] = (short)own_;
+                if (tgt_ >= 0 && T.size[tgt_] == 0) {
+                    // a carried-over guess whose target is not a cluster of the committed state (born by an entry that was not
+                    // committed, or emptied since): the entry stays as a placeholder that does nothing, the guess becomes "stays"
+                    T.bb[o] = (short)own_;
+                } else {
+                    T.bb[o] = (short)tgt_;
+                    if (tgt_ >= 0) T.joined[tgt_] = 1;
+                    atomicAdd(&T.seg[own_], 1);   // leaves its cluster
+                }
             } else {
                 T.misc[2] = x;  // first changer that does not fit into the batch
             }
@@ -3157,7 +3244,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         __syncthreads();
         // what every changer does when the batch is applied in order.  The label bitset (for the labels of births) is
         // scratch of batch_sim: rebuilt from the committed labels every time
-        {
+        if (total > 0) {
             const int nw_ = (V.n + 31) / 32;
             for (int w = threadIdx.x; w < nw_; w += blockDim.x) T.used[w] = 0u;
             __syncthreads();
@@ -3236,39 +3323,54 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
             }
         }
         __syncthreads();
-        const int nb = T.misc[3], hi = T.misc[4];
+        const int nb = T.misc[3], hi = T.misc[4], neff = T.misc[9];
         RC_PHASE(9)
         RC_CHAOS_AT(2);
 #ifdef RC_TRACE_RESOLVE   // diagnostic builds: per-round record of block RC_TRACE_BLOCK (default 0) behind the work counter
         if ((int)blockIdx.x == (sa.dbg >> 8) && threadIdx.x == 0 && round < 120) {   // kept in LDS until the sweep is over
             int *tr = (int *)(smem + tab_bytes_dev(V.kcap, V.n, blockDim.x >> 6, V.maxb)) + (size_t)round * 8;
-            tr[0] = round; tr[1] = total; tr[2] = nb; tr[3] = hi; tr[4] = T.bx[0]; tr[5] = after; tr[6] = T.misc[9]; tr[7] = T.misc[8];
+            tr[0] = round; tr[1] = total; tr[2] = nb; tr[3] = hi; tr[4] = nb ? T.bx[0] : -1; tr[5] = after; tr[6] = neff; tr[7] = T.misc[8] | (exact ? 0x10000 : 0);
         }
 #endif
         if (T.misc[5]) {   // the first changer needs a slot and every slot is taken
-            // Everything before it is final (the points between `after` and it drew their own labels under the committed state)
-            // and the state is consistent: the host grows the slot tables and resumes this sweep at that point.
+            // Everything up to `after` is final — with exact guesses also the points between it and this changer (they drew their
+            // own labels under the committed state) — and the state is consistent: the host grows the slot tables and resumes
+            // this sweep behind that point (with a tentative pass).
             if (threadIdx.x == 0 && blockIdx.x == 0) {
-                V.sc->fail_t = t; V.sc->resume_after = T.bx[0] - 1; V.sc->fail_changes = changes; V.sc->fail_rounds = sa.rounds0 + round + 1;
-                V.hsum->fail_t = t; V.hsum->resume_after = T.bx[0] - 1; V.hsum->fail_changes = changes; V.hsum->fail_rounds = sa.rounds0 + round + 1;
+                const int ra = exact ? T.bx[0] - 1 : after;
+                V.sc->fail_t = t; V.sc->resume_after = ra; V.sc->fail_changes = changes; V.sc->fail_rounds = sa.rounds0 + round + 1;
+                V.hsum->fail_t = t; V.hsum->resume_after = ra; V.hsum->fail_changes = changes; V.hsum->fail_rounds = sa.rounds0 + round + 1;
                 atomicOr(&V.sc->err, RC_DERR_CAPACITY);
             }
             ok = false;
             break;
         }
-        if (T.misc[9] == 0) {
-            // only singletons that drew "new cluster" and keep their labels: nothing to validate or commit
+        if (neff == 0 && exact) {
+            // only singletons that drew "new cluster" and keep their labels: nothing to validate or commit, and the guesses
+            // behind the batch are still exact (nothing changed)
             if (hi == V.n - 1) break;
             after = hi;
             ++round;
-            if (round > V.n) break;
             continue;
         }
-        // 3. validation of the points after the first changer, each under the changers that precede it
-        const int first = T.bx[T.misc[10]];   // the points up to the first effective changer saw no change at all
+        // 2. validation of the open points of the batch's range, each under the changers that precede it.  With exact guesses the
+        // points up to the first effective changer saw no change at all and are final as they are.
+        const int vlo = (exact && neff > 0) ? T.bx[T.misc[10]] : after;
         if (use_wc) tab_partition(V, T, true);
-        for (int c = blockIdx.x; c < nchunks; c += G)
-            if (c * RC_PTS + RC_PTS - 1 > first && c * RC_PTS <= hi) eval_chunk(V, sa, T, SD, SL, c, first, hi, 1, nb, cword, rec, stamp, use_wc ? 2 : 0);
+        for (int c = blockIdx.x; c < nchunks; c += G) {
+            if (c * RC_PTS + RC_PTS - 1 > vlo && c * RC_PTS <= hi)
+                eval_chunk(V, sa, T, SD, SL, c, vlo, hi, 1, nb, cword, rec, gstamp, use_wc ? 2 : 0, cword_next, rec_next, gstamp + 1u);
+            else if (c * RC_PTS > hi && threadIdx.x < 64) {
+                // a chunk behind the batch's range: its guesses are carried over as they are
+                const u64 w = __hip_atomic_load(cword + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned m = ((unsigned)(w >> 32) == gstamp) ? (unsigned)w : 0u;
+                const int i_ = c * RC_PTS + (int)threadIdx.x;
+                if (threadIdx.x < RC_PTS && ((m >> threadIdx.x) & 1u))
+                    __hip_atomic_store(rec_next + i_, __hip_atomic_load(rec + i_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (threadIdx.x == 0) __hip_atomic_store(cword_next + c, ((u64)(gstamp + 1u) << 32) | m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         __syncthreads();
         RC_PHASE(10)
         const u64 mine = *T.blk_key;
@@ -3276,7 +3378,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         RC_PHASE(11)
         if (!ok) break;
         RC_CHAOS_AT(3);
-        // 4. commit the changers before the first violation
+        // 3. commit the changers before the first violation
         const u64 vk = __hip_atomic_load(keys + round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int limit = (vk == RC_KEY_NONE) ? hi + 1 : (int)vk;   // points < limit are final
         int nc = 0;
@@ -3298,8 +3400,13 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
 #endif
         cap = (nc < nb) ? min(V.maxb, max(RC_CAP_FLOOR, nc + nc / 2)) : min(V.maxb, 2 * cap);
         after = limit - 1;
+        cur ^= 1;
+        gstamp += 1u;
+        // the new guesses were drawn under the committed state plus the batch: exact if the batch changed nothing and covered every point
+        exact = (neff == 0 && hi == V.n - 1);
         ++round;
-        if (round > V.n) break;  // cannot happen: every round finalises at least the first changer
+        if (limit >= V.n) break;          // every point validated: the sweep is complete
+        if (round > 2 * V.n + 4) break;   // cannot happen: the first open point's guess is exact at the latest in the round after it was violated
     }
 #ifdef RC_TRACE_RESOLVE
     __syncthreads();
@@ -3332,7 +3439,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         // the row reduction of this sweep is complete (stream order): re-arm its work counter for sweep t+2
         if (threadIdx.x == 0) *V.work[kg] = 0;
         // re-arm the other key / chunk-word / barrier generation for the next sweep (its last user, sweep t-1, is done)
-        for (int q = threadIdx.x; q < V.n + 2; q += blockDim.x) V.keys[kg ^ 1][q] = RC_KEY_NONE;
+        for (int q = threadIdx.x; q < min(prev_rounds + 2, 2 * V.n + 8); q += blockDim.x) V.keys[kg ^ 1][q] = RC_KEY_NONE;   // (the words sweep t-1 used)
         for (int q = threadIdx.x; q < 2 * (nchunks + 1); q += blockDim.x) V.cword[kg ^ 1][q] = 0;
         for (int q = threadIdx.x; q < RC_BAR_WORDS; q += blockDim.x) V.arrive[kg ^ 1][q] = 0u;
     }
@@ -3520,6 +3627,8 @@ struct rc_ctx {
     int4 *ufast = nullptr, *uslow = nullptr;   // unit lists of k_bulk_syml2 (build_syml2_lists)
     int *wfast = nullptr, *wslow = nullptr;
     int nfast = 0, nslow = 0, syml2_blocks = 0, syml2_g = 0;
+    // the same lists for two blocks per CU: used while labels move (the 512-thread resolver of the previous sweep then fits beside the reduction)
+    struct S2Alt { int4 *ufast = nullptr, *uslow = nullptr; int *wfast = nullptr, *wslow = nullptr; int nfast = 0, nslow = 0, blocks = 0; } s2alt;
     bool derived = false;               // logD derived from Dq on the fly (rc_qlog), not stored
     double2 *ltab = nullptr;            // device table of rc_qlog
     int n_relayouts = 0;                // re-layouts done so far (rc_set_state + automatic ones)
@@ -3690,7 +3799,7 @@ static void free_all(rc_ctx *c)
     void *ptrs[] = {c->Dq48, c->ltab, c->Dq, c->Lq, c->Dq_src, c->Lq_src, c->diag_src, c->pi, c->ipi, c->diagq, c->SD[0], c->SD[1], c->SD[2], c->SL[0], c->SL[1], c->SL[2], c->slot_of,
                     c->slot_size, c->slot_label, c->slot_pos, c->slot_act, c->perm[0], c->perm[1], c->pslot[0],
                     c->pslot[1], c->lsnap[0], c->lsnap[1], c->work[0], c->work[1], c->cword[0], c->cword[1], c->rec, c->tent, c->A, c->keys[0], c->keys[1], c->arrive[0], c->arrive[1], c->sc, c->blocks,
-                    c->counts, c->cc_out, c->snap, c->d_moves, c->used_scratch, c->wc, c->ufast, c->uslow, c->wfast, c->wslow};
+                    c->counts, c->cc_out, c->snap, c->d_moves, c->used_scratch, c->wc, c->ufast, c->uslow, c->wfast, c->wslow, c->s2alt.ufast, c->s2alt.uslow, c->s2alt.wfast, c->s2alt.wslow};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->hsum) (void)hipHostFree(c->hsum);
@@ -3872,7 +3981,7 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
         HIPCHK2(hipMemsetAsync(c->work[g], 0, RC_WORK_BYTES, s));
         HIPCHK2(hipMalloc(&c->cword[g], 2 * ((size_t)(n + RC_PTS - 1) / RC_PTS + 1) * sizeof(u64)));
         HIPCHK2(hipMemsetAsync(c->cword[g], 0, 2 * ((size_t)(n + RC_PTS - 1) / RC_PTS + 1) * sizeof(u64), s));
-        HIPCHK2(hipMalloc(&c->keys[g], (size_t)(n + 2) * sizeof(u64)));
+        HIPCHK2(hipMalloc(&c->keys[g], (size_t)(2 * n + 8) * sizeof(u64)));
         HIPCHK2(hipMalloc(&c->arrive[g], RC_BAR_WORDS * sizeof(unsigned)));
     }
     HIPCHK2(hipMalloc(&c->slot_of, (size_t)n * sizeof(int)));
@@ -4079,9 +4188,9 @@ static bool uses_syml(const rc_ctx *c) { return sym_variant_of(c) >= 2; }
 #ifndef RC_S2_SLOW_ROWS
 #define RC_S2_SLOW_ROWS 16
 #endif
-static int32_t build_syml2_lists(rc_ctx *c)
+static int32_t build_syml2_lists(rc_ctx *c, int per_cu = 0)
 {
-    const int n = c->n, ncb = (n + RC_SW_COLS - 1) / RC_SW_COLS, cap_blocks = c->symw_per_cu * c->num_cus, nwaves = 4 * cap_blocks;
+    const int n = c->n, ncb = (n + RC_SW_COLS - 1) / RC_SW_COLS, cap_blocks = (per_cu > 0 ? per_cu : c->symw_per_cu) * c->num_cus, nwaves = 4 * cap_blocks;
     struct Unit { int4 u; int cost; bool fast; };
     const int slow_factor = getenv("RC_S2_SLOW_COST") ? std::max(1, atoi(getenv("RC_S2_SLOW_COST"))) : 3;
     auto make_units = [&](int g, std::vector<Unit> &out) {
@@ -4185,11 +4294,28 @@ static int32_t build_syml2_lists(rc_ctx *c)
     return RC_OK;
 }
 
+// The lists for two blocks per CU (moving regime, enqueue_bulk): built by the same routine into the context's primary fields,
+// which are put back afterwards.
+static int32_t build_syml2_alt(rc_ctx *c)
+{
+    if (c->symw_per_cu <= 2 || (getenv("RC_S2_NO_ALT") && atoi(getenv("RC_S2_NO_ALT")))) return RC_OK;
+    int4 *uf = c->ufast, *us = c->uslow;
+    int *wf = c->wfast, *ws = c->wslow;
+    const int nf = c->nfast, ns = c->nslow, nb = c->syml2_blocks, g = c->syml2_g;
+    c->ufast = c->uslow = nullptr; c->wfast = c->wslow = nullptr;
+    const int32_t rc = build_syml2_lists(c, 2);
+    c->s2alt.ufast = c->ufast; c->s2alt.uslow = c->uslow; c->s2alt.wfast = c->wfast; c->s2alt.wslow = c->wslow;
+    c->s2alt.nfast = c->nfast; c->s2alt.nslow = c->nslow; c->s2alt.blocks = c->syml2_blocks;
+    c->ufast = uf; c->uslow = us; c->wfast = wf; c->wslow = ws; c->nfast = nf; c->nslow = ns; c->syml2_blocks = nb; c->syml2_g = g;
+    return rc;
+}
+
 // launch geometry and LDS attributes that depend on (n, kcap, bits)
 static int32_t finish_create(rc_ctx *c)
 {
     if (c->bits == 64 && !c->ufast) {
         int32_t rcl = build_syml2_lists(c);
+        if (rcl == RC_OK) rcl = build_syml2_alt(c);
         if (rcl != RC_OK) return rcl;
     }
     if (!c->registered) { res_register(c); c->registered = true; }
@@ -4513,7 +4639,19 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
     std::vector<int> ipi((size_t)n), pi((size_t)n);
     for (int i = 0; i < n; ++i) ipi[(size_t)i] = i;
     if (c->relayout) {
-        std::stable_sort(ipi.begin(), ipi.end(), [&](int a, int b) { return clusts[a] < clusts[b]; });
+        // Small clusters FIRST (then by label).  A moving chain holds dozens to hundreds of singletons.  As COLUMNS of the upper
+        // triangle every one of them is a cluster of its own — no pre-added direction-2 path, one atomic per element and row — so
+        // they belong where the columns are shortest: the first column block or two (128 / 256 rows above the diagonal), not
+        // wherever their labels fall (sorted by label the 154 singletons of the sigma = 0.2 chain sit at the END: two column
+        // blocks of 8000 rows each, 2.4 M element-wise atomics per launch, 260-340 us for k_bulk_syml2 instead of 70).  As ROWS they
+        // cost a coalesced flush of direction 1 per row, in the first unit of every column block.  RC_LAYOUT_SMALL=0: by label only.
+        {
+            static const int small_max = getenv("RC_LAYOUT_SMALL") ? atoi(getenv("RC_LAYOUT_SMALL")) : 7;
+            std::stable_sort(ipi.begin(), ipi.end(), [&](int a, int b) {
+                const bool la = size_by_label[(size_t)clusts[a]] > small_max, lb = size_by_label[(size_t)clusts[b]] > small_max;
+                return la != lb ? lb : clusts[a] < clusts[b];
+            });
+        }
         // Every cluster's run gets an EVEN length and hence an even start: the last point of each odd-sized cluster goes to the
         // tail of the order.  The row reduction gives a lane two adjacent columns (2 l, 2 l + 1); a cluster boundary at an odd
         // position splits a lane between two clusters, and such a lane's elements cannot go through the pre-added direction-2
@@ -4572,7 +4710,7 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
         HIPCHK(c, hipMemsetAsync(c->SL[g], 0, (size_t)c->kcap * c->ld * sizeof(long long), c->sA));
     }
     for (int g = 0; g < 2; ++g) {
-        HIPCHK(c, hipMemsetAsync(c->keys[g], 0xFF, (size_t)(n + 2) * sizeof(u64), c->sA));
+        HIPCHK(c, hipMemsetAsync(c->keys[g], 0xFF, (size_t)(2 * n + 8) * sizeof(u64), c->sA));
         HIPCHK(c, hipMemsetAsync(c->cword[g], 0, 2 * ((size_t)(n + RC_PTS - 1) / RC_PTS + 1) * sizeof(u64), c->sA));
         HIPCHK(c, hipMemsetAsync(c->arrive[g], 0, RC_BAR_WORDS * sizeof(unsigned), c->sA));
         HIPCHK(c, hipMemsetAsync(c->work[g], 0, 64, c->sA));
@@ -4667,13 +4805,24 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
         const int cap_blocks = c->symw_per_cu * c->num_cus;          // resident 4-wave blocks
         auto rows_of = [&](int J) { return std::min(RC_SW_COLS * J + RC_SW_COLS, c->n); };
         if (sym_variant == 3) {
-            if (c->derived && c->Dq48) { auto kf_ = k_bulk_syml2<true, true>; RC_BULK_LAUNCH(kf_, c->syml2_blocks, 256, c->syml_pad, V, (int)(t % 3), (int)(t & 1), (int)(t & 1)); }
-            else if (c->derived) { auto kf_ = k_bulk_syml2<true, false>; RC_BULK_LAUNCH(kf_, c->syml2_blocks, 256, c->syml_pad, V, (int)(t % 3), (int)(t & 1), (int)(t & 1)); }
-            else { auto kf_ = k_bulk_syml2<false, false>; RC_BULK_LAUNCH(kf_, c->syml2_blocks, 256, c->syml_pad, V, (int)(t % 3), (int)(t & 1), (int)(t & 1)); }
-            if (c->nslow > 0) {   // ragged last column block: its units by the round-2 code, behind the main launch
-                const int nb = std::min((c->nslow + 3) / 4, cap_blocks);
-                if (c->derived) k_bulk_syml_list<true><<<nb, 256, 0, sb>>>(V, (int)(t % 3), (int)(t & 1));
-                else k_bulk_syml_list<false><<<nb, 256, 0, sb>>>(V, (int)(t % 3), (int)(t & 1));
+            // While labels move the resolver of the previous sweep runs its rounds with 512-thread blocks (two waves per SIMD at 128
+            // registers), which do not fit on a CU beside three of this kernel's blocks: they would wait for the reduction to retire
+            // and the two launches run one after the other.  Two blocks per CU (their own unit lists) leave the room: N = 8192, 40
+            // label changes per sweep: 3.2 k -> 3.9 k sweeps/s.
+            View V2 = V;
+            int s2_blocks = c->syml2_blocks, s2_nslow = c->nslow;
+            if (c->hsum->n_changes > 32 && c->s2alt.ufast) {
+                V2.ufast = c->s2alt.ufast; V2.uslow = c->s2alt.uslow; V2.wfast = c->s2alt.wfast; V2.wslow = c->s2alt.wslow;
+                V2.nfast = c->s2alt.nfast; V2.nslow = c->s2alt.nslow;
+                s2_blocks = c->s2alt.blocks; s2_nslow = c->s2alt.nslow;
+            }
+            if (c->derived && c->Dq48) { auto kf_ = k_bulk_syml2<true, true>; RC_BULK_LAUNCH(kf_, s2_blocks, 256, c->syml_pad, V2, (int)(t % 3), (int)(t & 1), (int)(t & 1)); }
+            else if (c->derived) { auto kf_ = k_bulk_syml2<true, false>; RC_BULK_LAUNCH(kf_, s2_blocks, 256, c->syml_pad, V2, (int)(t % 3), (int)(t & 1), (int)(t & 1)); }
+            else { auto kf_ = k_bulk_syml2<false, false>; RC_BULK_LAUNCH(kf_, s2_blocks, 256, c->syml_pad, V2, (int)(t % 3), (int)(t & 1), (int)(t & 1)); }
+            if (s2_nslow > 0) {   // ragged last column block: its units by the round-2 code, behind the main launch
+                const int nb = std::min((s2_nslow + 3) / 4, cap_blocks);
+                if (c->derived) k_bulk_syml_list<true><<<nb, 256, 0, sb>>>(V2, (int)(t % 3), (int)(t & 1));
+                else k_bulk_syml_list<false><<<nb, 256, 0, sb>>>(V2, (int)(t % 3), (int)(t & 1));
             }
         } else if (sym_variant == 2) {
             int gc = 0, nitems = 0;
@@ -5945,7 +6094,7 @@ extern "C" int32_t rc_set_mode(rc_ctx *c, int32_t mode)
             HIPCHK(c, hipMemsetAsync(c->SL[g], 0, (size_t)c->kcap * c->ld * sizeof(long long), c->sA));
         }
         for (int g = 0; g < 2; ++g) {
-            HIPCHK(c, hipMemsetAsync(c->keys[g], 0xFF, (size_t)(c->n + 2) * sizeof(u64), c->sA));
+            HIPCHK(c, hipMemsetAsync(c->keys[g], 0xFF, (size_t)(2 * c->n + 8) * sizeof(u64), c->sA));
             HIPCHK(c, hipMemsetAsync(c->cword[g], 0, 2 * ((size_t)(c->n + RC_PTS - 1) / RC_PTS + 1) * sizeof(u64), c->sA));
             HIPCHK(c, hipMemsetAsync(c->arrive[g], 0, RC_BAR_WORDS * sizeof(unsigned), c->sA));
             HIPCHK(c, hipMemsetAsync(c->work[g], 0, 64, c->sA));
