@@ -2544,12 +2544,22 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
             for (int pos = st; pos < ((a.dbg & 1) ? 0 : K); pos += NS) consider(T.act[pos]);
         } else {
             const int Kc = T.misc[14];
-            for (int pos = st; pos < Kc; pos += NS) {          // clean slots: the stored score
-                const int k = T.act2[pos];
-                if (k == own) continue;
-                const double v = wrow[(size_t)k * V.ldw];
-                const int lab = T.label[k];
-                if (bestslot == -2 || v > bestv || (v == bestv && lab < bestpos)) { bestv = v; bestpos = lab; bestslot = k; }
+            for (int pos = st; pos < Kc; pos += 4 * NS) {      // clean slots: the stored score — four loads in flight (one per turn was a memory round trip per candidate)
+                int kk[4];
+                double vv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int p_ = pos + q * NS;
+                    kk[q] = (p_ < Kc) ? (int)T.act2[p_] : own;
+                    vv[q] = (kk[q] != own) ? wrow[(size_t)kk[q] * V.ldw] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (kk[q] == own) continue;
+                    const double v = vv[q];
+                    const int lab = T.label[kk[q]];
+                    if (bestslot == -2 || v > bestv || (v == bestv && lab < bestpos)) { bestv = v; bestpos = lab; bestslot = kk[q]; }
+                }
             }
             for (int pos = Kc + st; pos < K; pos += NS) {      // slots a change touched
                 const int k = T.act2[pos];
@@ -3153,7 +3163,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
     // final as they are, and a batch without effective entries ends the sweep.
     int cur = 0;
     unsigned gstamp = 1u;
-    bool exact = true;
+    bool exact = true, used_current = false;
     {
         RC_CHAOS_AT(0);
         RC_PF(pt_ = __builtin_amdgcn_s_memrealtime(); ps[13] += 1;)
@@ -3244,7 +3254,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         __syncthreads();
         // what every changer does when the batch is applied in order.  The label bitset (for the labels of births) is
         // scratch of batch_sim: rebuilt from the committed labels every time
-        if (total > 0) {
+        if (total > 0 && !used_current) {
             const int nw_ = (V.n + 31) / 32;
             for (int w = threadIdx.x; w < nw_; w += blockDim.x) T.used[w] = 0u;
             __syncthreads();
@@ -3254,6 +3264,9 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
             }
             __syncthreads();
         }
+        // (with the simulation's state in registers — kcap < 2048 — the bitset is only read there, and a commit that changes a
+        // label rebuilds it from the committed labels, tab_structural: it stays current for the rest of the sweep)
+        if (total > 0) used_current = V.kcap < 2048;
         RC_PHASE(8)
         // clusters that could become empty inside the batch (more leavers than would leave one member): only their sizes matter
         for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) T.candie[k] = (T.size[k] - T.seg[k] < 1);
