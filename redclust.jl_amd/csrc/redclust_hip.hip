@@ -2662,14 +2662,9 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
                 // already accounts for the changers before the point, which a fresh draw under the committed state would not
                 if (changed) __hip_atomic_store(rec_next + i, ((unsigned)own << 16) | (unsigned)(target + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            // the points of this chunk beyond the batch's range keep the guess they had
-            bool carried = false;
-            if (half == 0 && i < V.n && i > hi) {
-                const u64 w = __hip_atomic_load(cword + chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                carried = ((unsigned)(w >> 32) == stamp) && (((unsigned)w >> pt) & 1u);
-                if (carried) __hip_atomic_store(rec_next + i, __hip_atomic_load(rec + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            const u64 m = __ballot(changed || carried) & ((1ull << RC_PTS) - 1ull);
+            // (points of this chunk beyond the batch's range: a batch that does not reach the end of the sweep is followed by a fresh
+            // tentative pass, see resolve_body)
+            const u64 m = __ballot(changed) & ((1ull << RC_PTS) - 1ull);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (threadIdx.x == 0) __hip_atomic_store(cword_next + chunk, ((u64)stamp_next << 32) | m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -3153,33 +3148,47 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
     // Guesses.  A round validates GUESSES of what every open point does — any guess will do for correctness: a point is final
     // only once its draw under the exact sequential state (committed state + the batch entries before it, all of them validated)
     // equals its guess.  Round 0 guesses by drawing every point under the committed state (the tentative pass).  A later round
-    // takes the draws of the previous round's VALIDATION as guesses: they already account for the changers before each point
-    // (all but the one that was violated), so they are better guesses than a fresh tentative pass — fewer rounds — and they
-    // cost nothing: no tentative pass and no barrier before the batch is assembled, one grid barrier per round instead of two.
+    // takes the draws of the previous round's VALIDATION as guesses, provided that batch reached the end of the sweep: they
+    // already account for the changers before each point (all but the one that was violated), so they are better guesses than
+    // a fresh tentative pass — the round after a violation usually goes through whole — and they cost nothing: no tentative
+    // pass and no barrier before the batch is assembled, one grid barrier per round instead of two.
     // The announcements (chunk words, changer records) are double-buffered: a round reads buffer `cur` (words stamped `gstamp`)
     // and its validation writes the other one, so a block that is ahead never overwrites what a block behind still reads.
     // `exact`: every guess after `after` was drawn under the committed state as it is now (true after the tentative pass and
     // after a validation under a batch without effective entries): then the points up to the first effective changer are
     // final as they are, and a batch without effective entries ends the sweep.
     int cur = 0;
-    unsigned gstamp = 1u;
+    unsigned gstamp = 0u;
     bool exact = true, used_current = false;
-    {
-        RC_CHAOS_AT(0);
-        RC_PF(pt_ = __builtin_amdgcn_s_memrealtime(); ps[13] += 1;)
-        for (int c = blockIdx.x; c < nchunks; c += G)
-            if (c * RC_PTS + RC_PTS - 1 > after) eval_chunk(V, sa, T, SD, SL, c, after, V.n, 0, 0, cword_gen, V.rec, gstamp, use_wc ? 1 : 0);
-        RC_PHASE(6)
-#ifndef RC_PROF_COMMIT
-        RC_PF(ps[2] = __builtin_amdgcn_s_memrealtime();)
-#endif
-        if (!(sa.dbg & 2)) ok = grid_barrier(V, T, arrive, G, (unsigned)(++nbar), RC_KEY_NONE, keys);
-        RC_PF(ps[3] = __builtin_amdgcn_s_memrealtime();)
-        RC_PHASE(7)
-    }
-    while (ok && !(sa.dbg & 2)) {
+    // `redraw`: the guesses of this round are drawn afresh under the committed state (round 0; and after a batch that did not reach
+    // the end of the sweep — more changers than a batch takes, or a cut: the points behind it carry guesses nobody has validated
+    // since the state they were drawn under, and in the sweeps where this happens round after round — the first ones from a poor
+    // labelling, thousands of changers — such guesses are nearly always wrong: 203 rounds instead of 102 for the first sweep from
+    // random labels when they were kept).
+    bool redraw = true, first_pass = true;
+    while (ok) {
         u64 *const cword = cword_gen + (size_t)cur * (size_t)(nchunks + 1), *const cword_next = cword_gen + (size_t)(cur ^ 1) * (size_t)(nchunks + 1);
         unsigned *const rec = V.rec + (size_t)cur * (size_t)V.n, *const rec_next = V.rec + (size_t)(cur ^ 1) * (size_t)V.n;
+        if (redraw) {
+            RC_CHAOS_AT(0);
+            RC_PF(pt_ = __builtin_amdgcn_s_memrealtime(); ps[13] += 1;)
+            gstamp += 1u;   // (words carried into this buffer are void: a chunk without changers writes none)
+            // with the score cache a later pass computes only the slots a commit touched, and the cache is current again after it
+            if (use_wc && !first_pass) tab_partition(V, T, false);
+            for (int c = blockIdx.x; c < nchunks; c += G)
+                if (c * RC_PTS + RC_PTS - 1 > after) eval_chunk(V, sa, T, SD, SL, c, after, V.n, 0, 0, cword, rec, gstamp, use_wc ? (first_pass ? 1 : 2) : 0);
+            if (use_wc && !first_pass) { for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) T.dirty[k] = 0; }
+            if (sa.dbg & 2) break;
+            RC_PHASE(6)
+#ifndef RC_PROF_COMMIT
+            RC_PF(if (first_pass) ps[2] = __builtin_amdgcn_s_memrealtime();)
+#endif
+            ok = grid_barrier(V, T, arrive, G, (unsigned)(++nbar), RC_KEY_NONE, keys + round);
+            RC_PF(if (first_pass) ps[3] = __builtin_amdgcn_s_memrealtime();)
+            RC_PHASE(7)
+            if (!ok) break;
+            exact = true; redraw = false; first_pass = false;
+        }
         RC_CHAOS_AT(1);
         RC_PF(pt_ = __builtin_amdgcn_s_memrealtime();)
         // 1. the ordered batch of guessed changers after `after` (the bits of the points up to `after` in its chunk are history)
@@ -3373,16 +3382,6 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         for (int c = blockIdx.x; c < nchunks; c += G) {
             if (c * RC_PTS + RC_PTS - 1 > vlo && c * RC_PTS <= hi)
                 eval_chunk(V, sa, T, SD, SL, c, vlo, hi, 1, nb, cword, rec, gstamp, use_wc ? 2 : 0, cword_next, rec_next, gstamp + 1u);
-            else if (c * RC_PTS > hi && threadIdx.x < 64) {
-                // a chunk behind the batch's range: its guesses are carried over as they are
-                const u64 w = __hip_atomic_load(cword + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned m = ((unsigned)(w >> 32) == gstamp) ? (unsigned)w : 0u;
-                const int i_ = c * RC_PTS + (int)threadIdx.x;
-                if (threadIdx.x < RC_PTS && ((m >> threadIdx.x) & 1u))
-                    __hip_atomic_store(rec_next + i_, __hip_atomic_load(rec + i_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (threadIdx.x == 0) __hip_atomic_store(cword_next + c, ((u64)(gstamp + 1u) << 32) | m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
         }
         __syncthreads();
         RC_PHASE(10)
@@ -3405,11 +3404,13 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
 #ifdef RC_PROF_COMMIT
         RC_PF(ps[2] += T.misc[13];)
 #endif
-        // Validation costs (points covered) x (changers before them); everything behind the first violation is wasted.
-        // When less than a third of a batch could be committed the next one is cut to three times what was (at least 64),
-        // otherwise it doubles.
+        // Validation costs (points covered) x (changers before them); behind the first violation it only yields the next round's
+        // guesses.  After a round that hit a violation the next batch takes one and a half times what was committed, at least
+        // RC_CAP_FLOOR entries; after a round without one it doubles.  The floor is above the ~170 changers a sweep of the moving
+        // regime of bench.py announces, so that its batches reach the end of the sweep and the guesses carry over (floor 128 / 256 /
+        // 512: 4.73 / 4.84 / 4.86 k sweeps/s there, and 15.4 / 15.3 / 17.0 ms for the first sweep from random labels).
 #ifndef RC_CAP_FLOOR
-#define RC_CAP_FLOOR 128
+#define RC_CAP_FLOOR 256
 #endif
         cap = (nc < nb) ? min(V.maxb, max(RC_CAP_FLOOR, nc + nc / 2)) : min(V.maxb, 2 * cap);
         after = limit - 1;
@@ -3419,6 +3420,7 @@ __device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *sm
         exact = (neff == 0 && hi == V.n - 1);
         ++round;
         if (limit >= V.n) break;          // every point validated: the sweep is complete
+        redraw = (hi < V.n - 1);          // the batch did not cover the rest of the sweep
         if (round > 2 * V.n + 4) break;   // cannot happen: the first open point's guess is exact at the latest in the round after it was violated
     }
 #ifdef RC_TRACE_RESOLVE
