@@ -6179,8 +6179,9 @@ extern "C" int32_t rc_set_bulk_kernel(rc_ctx *c, int32_t which)
 }
 
 
-// Milliseconds a HIP event pair reports around an empty kernel on the row-reduction stream (calibrated when timing is
-// enabled); rc_kernel_timing's totals are net of it.
+// What is subtracted from every timed launch: 0 — the two events of a timed launch ride in its dispatch (enqueue_bulk) and report the
+// kernel's own start and stop; nothing is calibrated any more (round 1 recorded marker pairs and subtracted what a pair reports around
+// an empty kernel).  Kept so that the bench line can state it.
 extern "C" int32_t rc_event_overhead_ms(rc_ctx *c, double *out)
 {
     if (!c || !out) return fail(c, RC_ERR_ARG, "rc_event_overhead_ms: NULL argument");

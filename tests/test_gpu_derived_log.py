@@ -112,9 +112,10 @@ def test_derived_equals_stored_given_the_same_logD_and_modes_agree():
                 assert np.array_equal(x.get_state()[0], orc.clusts), (name, "after the proposal of iteration", t)
         sa, sb = a.get_state(), b.get_state()
         assert np.array_equal(sa[0], sb[0]) and sa[2] == sb[2]
-    # same partition, block sums exact in each context — but the derived-mode context stores D with one bit less
-    # (create_impl caps eD so that the table log sees 52 significant bits), and the slot order of the long-double sum
-    # differs after c.set_state: equal to the last bits, not bit for bit
+    # same partition, block sums exact in each context — but the derived-mode context stores D with fewer fraction bits
+    # (create_impl caps eD at 47 - ex for the 48-bit packed copy; the stored-logD context keeps 62 - ex - ceil(log2 n)), so
+    # the integer block sums differ in their last quanta: equal to the last bits, not bit for bit.  (The order of the
+    # long-double sum is the same in all three: loglik_host sums in ascending label order.)
     la, lb, lc = a.loglik(), b.loglik(), c.loglik()
     assert abs(la - lb) <= 1e-12 * abs(la) and abs(la - lc) <= 1e-12 * abs(la), (la, lb, lc)
     for x in (a, b, c):
