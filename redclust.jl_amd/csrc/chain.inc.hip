@@ -207,7 +207,32 @@ struct SpecSlot {
     int32_t err = RC_OK;
     const char *errmsg = nullptr;
     int state = 0;                           // 0 idle, 1 queued / running, 2 done   (guarded by SpecPool::m)
+    int rec_busy = 0;                        // record jobs queued or running that read this snapshot (guarded by SpecPool::m)
 };
+
+// host part of a recorded sample (mcmc.jl:546-553), from the snapshot of the state the iteration ended in: pure function of the
+// snapshot — run by a worker (the log-likelihood's K² scalar terms are 1-2 ms of long-double arithmetic when the chain moves)
+static void spec_record_host(const rc_ctx *c, rc_ctx::LLCache &cache, const SpecSlot &after, int64_t j, double r, double p, rc_chain_outputs *out)
+{
+    const int nslots = (int)after.ssize.size();
+    if (out->clusts) {   // sortlabels (utils.jl:69-74): relabel by order of first appearance
+        int64_t *dst = out->clusts + (size_t)j * c->n;
+        std::vector<int> map((size_t)nslots, 0);
+        int next = 0;
+        for (int i = 0; i < c->n; ++i) {
+            int &m = map[(size_t)after.pin_lab[i]];
+            if (m == 0) m = ++next;
+            dst[i] = m;
+        }
+    }
+    const double ll = loglik_host_c(c, cache, after.hi, after.ssize.data(), after.pin_B, after.slabel.data());         // mcmc.jl:551
+    const double lp = logprior_host(c, after.ssize.data(), after.slabel.data(), r, p, nslots);
+    if (out->K) out->K[j] = after.K;
+    if (out->r) out->r[j] = r;
+    if (out->p) out->p[j] = p;
+    if (out->loglik) out->loglik[j] = ll;
+    if (out->logposterior) out->logposterior[j] = ll + lp;                                       // mcmc.jl:552
+}
 
 struct SpecPool {
     rc_ctx *c;
@@ -217,6 +242,10 @@ struct SpecPool {
     std::mutex m;
     std::condition_variable cv_work, cv_done;
     std::deque<int> queue;
+    struct RecJob { int si; int64_t j; double r, p; };
+    std::deque<RecJob> rec_queue;            // recorded samples whose host part is still to be computed (confirmed iterations: never cancelled)
+    int rec_open = 0;                        // record jobs queued or running
+    rc_chain_outputs *out = nullptr;
     bool stop = false;
 
     SpecPool(rc_ctx *c_, const rc_chain_options *o_, int nslots) : c(c_), o(o_), slots((size_t)nslots) {}
@@ -227,15 +256,30 @@ struct SpecPool {
     void run()
     {
         rc_ctx::LLCache cache;
+        (void)hipSetDevice(c->dev);          // (the worker waits for snapshot events)
         for (;;) {
-            int si;
+            int si = -1;
+            RecJob rj{-1, 0, 0, 0};
             {
                 std::unique_lock<std::mutex> lk(m);
-                cv_work.wait(lk, [&] { return stop || !queue.empty(); });
+                cv_work.wait(lk, [&] { return stop || !queue.empty() || !rec_queue.empty(); });
                 if (stop) return;
-                si = queue.front(); queue.pop_front();
+                if (!rec_queue.empty()) { rj = rec_queue.front(); rec_queue.pop_front(); }
+                else { si = queue.front(); queue.pop_front(); }
+            }
+            if (rj.si >= 0) {
+                SpecSlot &a = slots[(size_t)rj.si];
+                if (a.ev) (void)hipEventSynchronize(a.ev);     // the snapshot's copies have arrived
+                spec_record_host(c, cache, a, rj.j, rj.r, rj.p, out);
+                {
+                    std::lock_guard<std::mutex> lk(m);
+                    --a.rec_busy; --rec_open;
+                }
+                cv_done.notify_all();
+                continue;
             }
             SpecSlot &s = slots[(size_t)si];
+            if (s.ev) (void)hipEventSynchronize(s.ev);         // the snapshot's copies have arrived (the main thread did not wait for them)
             // the proposal's view of the snapshot — labels by point, sizes by label — is built here, not by the chain's main thread
             // (15 µs per iteration at n = 8192 on the path between two sweeps)
             {
@@ -273,6 +317,17 @@ struct SpecPool {
         }
         cv_work.notify_one();
     }
+    void submit_record(int si, int64_t j, double r, double p)
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            ++slots[(size_t)si].rec_busy; ++rec_open;
+            rec_queue.push_back(RecJob{si, j, r, p});
+        }
+        cv_work.notify_one();
+    }
+    void wait_records(int si) { std::unique_lock<std::mutex> lk(m); cv_done.wait(lk, [&] { return slots[(size_t)si].rec_busy == 0; }); }   // before the slot's snapshot is overwritten
+    void wait_all_records() { std::unique_lock<std::mutex> lk(m); cv_done.wait(lk, [&] { return rec_open == 0; }); }
     bool done(int si) { std::lock_guard<std::mutex> lk(m); return slots[(size_t)si].state == 2; }
     void wait(int si) { std::unique_lock<std::mutex> lk(m); cv_done.wait(lk, [&] { return slots[(size_t)si].state == 2; }); }
     void drain()   // nothing queued or running afterwards; every slot idle
@@ -291,6 +346,8 @@ struct SpecPool {
         }
         cv_work.notify_all();
         for (auto &t : threads) t.join();
+        if (c->sC) (void)hipStreamSynchronize(c->sC);   // the slots' events and pinned buffers go: no copy may be in flight,
+        c->ev_blocks_busy = nullptr;                    // and nobody may wait on an event of theirs afterwards
         for (auto &s : slots) {
             if (s.dev_row) (void)hipFree(s.dev_row);
             if (s.pin_lab) (void)hipHostFree(s.pin_lab);
@@ -307,6 +364,7 @@ static int32_t spec_snapshot(rc_ctx *c, SpecSlot &s, const SpecSlot *prev, bool 
 {
     *need_wait = true;
     if (prev && prev->pin_B && prev->dev_row && s.dev_row && s.capB >= prev->hi) {
+        if (prev->ev) HIPCHK(c, hipEventSynchronize(prev->ev));   // prev's host copies are complete (nobody else has waited for them)
         s.hi = prev->hi; s.K = prev->K; s.ssize = prev->ssize; s.slabel = prev->slabel;
         std::memcpy(s.pin_lab, prev->pin_lab, (size_t)c->n * sizeof(unsigned short));
         std::memcpy(s.pin_B, prev->pin_B, (size_t)prev->hi * prev->hi * 4 * sizeof(long long));
@@ -331,18 +389,24 @@ static int32_t spec_snapshot(rc_ctx *c, SpecSlot &s, const SpecSlot *prev, bool 
     }
     int32_t rc = order_A_after_sweeps(c);
     if (rc != RC_OK) return rc;
+    // Stream A — where the sweeps of the incremental mode run, and what the next resolver waits for in full mode — carries only
+    // the two kernels that read the live state; the copies to the host (16 KB of labels, hi² x 32 B of block sums: 2 MB at 256
+    // slots, 60-80 µs over PCIe) follow on the copy stream, beside the next sweep instead of in front of it.
     k_snapshot<<<(c->ldc + 255) / 256, 256, 0, c->sA>>>(c->slot_of, c->pi, c->n, c->ldc, s.dev_row);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(s.pin_lab, s.dev_row, (size_t)c->n * sizeof(unsigned short), hipMemcpyDeviceToHost, c->sA));
-    rc = loglik_enqueue(c, s.hi, s.pin_B);
+    rc = loglik_enqueue(c, s.hi, s.pin_B, c->sC);      // (records ev_k behind k_blocksums on stream A and makes stream C wait for it)
     if (rc != RC_OK) return rc;
-    HIPCHK(c, hipEventRecord(s.ev, c->sA));
+    HIPCHK(c, hipMemcpyAsync(s.pin_lab, s.dev_row, (size_t)c->n * sizeof(unsigned short), hipMemcpyDeviceToHost, c->sC));
+    HIPCHK(c, hipEventRecord(s.ev, c->sC));
+    c->ev_blocks_busy = s.ev;
     return RC_OK;
 }
 
-// the recorded sample of an iteration (mcmc.jl:546-553) from the snapshot of the state it ended in
-static int32_t spec_record(rc_ctx *c, SpecSlot &after, int64_t j, double r, double p, rc_chain_outputs *out)
+// the recorded sample of an iteration (mcmc.jl:546-553) from the snapshot of the state it ended in: the device part here (the label
+// row into the co-clustering queue), the host part as a job of the pool (spec_record_host)
+static int32_t spec_record(rc_ctx *c, SpecPool &pool, int after_si, int64_t j, double r, double p)
 {
+    SpecSlot &after = pool.slots[(size_t)after_si];
     int32_t rc = ensure_counts(c);
     if (rc != RC_OK) return rc;
     HIPCHK(c, hipMemcpyAsync(c->snap + (size_t)c->snap_cnt * c->ldc, after.dev_row, (size_t)c->ldc * sizeof(unsigned short),
@@ -351,23 +415,7 @@ static int32_t spec_record(rc_ctx *c, SpecSlot &after, int64_t j, double r, doub
         rc = flush_counts(c);
         if (rc != RC_OK) return rc;
     }
-    if (out->clusts) {   // sortlabels (utils.jl:69-74): relabel by order of first appearance
-        int64_t *dst = out->clusts + (size_t)j * c->n;
-        std::vector<int> map((size_t)c->kcap, 0);
-        int next = 0;
-        for (int i = 0; i < c->n; ++i) {
-            int &m = map[(size_t)after.pin_lab[i]];
-            if (m == 0) m = ++next;
-            dst[i] = m;
-        }
-    }
-    const double ll = loglik_host(c, after.hi, after.ssize.data(), after.pin_B, after.slabel.data());                 // mcmc.jl:551
-    const double lp = logprior_host(c, after.ssize.data(), after.slabel.data(), r, p);
-    if (out->K) out->K[j] = after.K;
-    if (out->r) out->r[j] = r;
-    if (out->p) out->p[j] = p;
-    if (out->loglik) out->loglik[j] = ll;
-    if (out->logposterior) out->logposterior[j] = ll + lp;                                       // mcmc.jl:552
+    pool.submit_record(after_si, j, r, p);
     return RC_OK;
 }
 
@@ -470,6 +518,7 @@ static int32_t run_chain_speculative(rc_ctx *c, const rc_chain_options *o, rc_ch
     const long long grows0 = c->n_grows;
     const int Rn = Dmax + 2;
     SpecPool pool(c, o, Rn);
+    pool.out = out;
     pool.start(nw);
     auto slot_of_it = [&](int64_t it) -> int { return (int)(it % Rn); };
     int32_t rc = sync_and_check(c, true);
@@ -503,6 +552,7 @@ static int32_t run_chain_speculative(rc_ctx *c, const rc_chain_options *o, rc_ch
             }
             const auto tb = now(); t_sync += secs(ta, tb);
             SpecSlot &s = pool.slots[(size_t)slot_of_it(i)];
+            pool.wait_records(slot_of_it(i));              // (a recorded sample may still be read from the snapshot this slot held)
             s.it = i;
             if (i <= N) {
                 const uint64_t it = o->first_iter + (uint64_t)(i - 1);
@@ -539,7 +589,7 @@ static int32_t run_chain_speculative(rc_ctx *c, const rc_chain_options *o, rc_ch
                 if (rc != RC_OK) return rc;
             }
             const auto tc = now(); t_snap += secs(tb, tc);
-            if (need_wait) HIPCHK(c, hipEventSynchronize(s.ev));
+            (void)need_wait;                               // (the worker that takes the job waits for the snapshot's copies)
             const auto td = now(); t_evwait += secs(tc, td);
             if (i <= N) {
                 s.clean = false; s.err = RC_OK; s.split_pending = false;
@@ -568,7 +618,7 @@ static int32_t run_chain_speculative(rc_ctx *c, const rc_chain_options *o, rc_ch
                 }
                 if (recording(conf)) {
                     if (j >= o->max_samples) return fail(c, RC_ERR_ARG, "rc_run_chain: more samples than max_samples=%lld", (long long)o->max_samples);
-                    rc = spec_record(c, pool.slots[(size_t)slot_of_it(conf + 1)], j++, s.r, s.p, out);
+                    rc = spec_record(c, pool, slot_of_it(conf + 1), j++, s.r, s.p);
                     if (rc != RC_OK) return rc;
                 }
                 { std::lock_guard<std::mutex> lk(pool.m); s.state = 0; }
@@ -661,6 +711,7 @@ static int32_t run_chain_speculative(rc_ctx *c, const rc_chain_options *o, rc_ch
         }
     }
     pool.drain();
+    pool.wait_all_records();
     rc = sync_and_check(c, true);
     if (rc != RC_OK) return rc;
     out->num_samples = j;

@@ -3686,6 +3686,9 @@ struct rc_ctx {
     bool res_one_stream = false;      // small problems: every resolver on stream B (in order, no event between consecutive resolvers), every row reduction on B2
     hipStream_t s_res_last = nullptr; // stream of the last resolver launch (sB / sB2 by sweep parity, sA in incremental mode)
     hipEvent_t ev_a = nullptr;        // marker on stream A: work that reads the state and must precede the next resolver
+    hipStream_t sC = nullptr;         // copy stream of the speculative loop's snapshots (device -> pinned host), off the sweeps' critical path
+    hipEvent_t ev_k = nullptr;        // the snapshot's kernels are done (stream A) — what stream C waits for
+    hipEvent_t ev_blocks_busy = nullptr;   // the last asynchronous copy out of c->blocks on stream C (nullptr: none): the next k_blocksums waits for it
     bool sA_dirty = false;
     long long t_next = 0;     // internal index of the next sweep (0 after rc_set_state)
     long long bulk_enq = -1;  // highest sweep index whose k_bulk has been enqueued
@@ -3826,6 +3829,8 @@ static void free_all(rc_ctx *c)
     for (auto &e : c->ev_pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &e : c->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+    if (c->ev_k) (void)hipEventDestroy(c->ev_k);
+    if (c->sC) (void)hipStreamDestroy(c->sC);
     for (int q = 0; q < 4; ++q) {
         if (c->ev_bulk[q]) (void)hipEventDestroy(c->ev_bulk[q]);
         if (c->ev_res[q]) (void)hipEventDestroy(c->ev_res[q]);
@@ -3909,6 +3914,7 @@ static int32_t alloc_slot_buffers(rc_ctx *c)
 {
     void **ptrs[] = {(void **)&c->SD[0], (void **)&c->SD[1], (void **)&c->SD[2], (void **)&c->SL[0], (void **)&c->SL[1], (void **)&c->SL[2],
                      (void **)&c->slot_size, (void **)&c->slot_label, (void **)&c->slot_pos, (void **)&c->slot_act, (void **)&c->wc, (void **)&c->blocks};
+    if (c->sC) { HIPCHK(c, hipStreamSynchronize(c->sC)); c->ev_blocks_busy = nullptr; }   // (a snapshot copy out of c->blocks may be in flight)
     for (void **pp : ptrs)
         if (*pp) { (void)hipFree(*pp); *pp = nullptr; }
     const size_t ld = (size_t)c->ld, k = (size_t)c->kcap;
@@ -3949,6 +3955,8 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
         else HIPCHK(c, hipStreamCreateWithPriority(&c->sB2, hipStreamNonBlocking, pr_least));
     }
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_k, hipEventDisableTiming));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->sC, hipStreamNonBlocking));
     for (int q = 0; q < 4; ++q) {
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_bulk[q], hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_res[q], hipEventDisableTiming));
@@ -4615,6 +4623,7 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
     HIPCHK(c, hipStreamSynchronize(c->sA));
     HIPCHK(c, hipStreamSynchronize(c->sB));
     HIPCHK(c, hipStreamSynchronize(c->sB2));
+    if (c->sC) HIPCHK(c, hipStreamSynchronize(c->sC));
     if (!c->recovering) c->inflight.clear();
     const int n = c->n;
     {
@@ -5243,15 +5252,22 @@ static double loglik_host(rc_ctx *c, int hi, const int *ssize, const long long *
 
 // enqueues the block sums of the current state on stream A and their copy into the pinned buffer `dst`
 // (hi·hi·4 int64); the caller synchronises (stream or event) before reading
-static int32_t loglik_enqueue(rc_ctx *c, int hi, long long *dst)
+// copy_stream != nullptr: the copy to the host goes to that stream behind the kernel (the caller records its own completion event
+// there and sets c->ev_blocks_busy to it); stream A — the sweeps' stream in incremental mode — carries only the kernel.
+static int32_t loglik_enqueue(rc_ctx *c, int hi, long long *dst, hipStream_t copy_stream = nullptr)
 {
     int gen = 0;
     int32_t rc = ensure_S(c, &gen);
     if (rc != RC_OK) return rc;
     View V = make_view(c);
+    if (c->ev_blocks_busy) { HIPCHK(c, hipStreamWaitEvent(c->sA, c->ev_blocks_busy, 0)); c->ev_blocks_busy = nullptr; }   // (c->blocks is one buffer)
     k_blocksums<<<hi, 256, (size_t)hi * 4 * sizeof(u64), c->sA>>>(V, gen, hi, c->blocks);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(dst, c->blocks, (size_t)hi * hi * 4 * sizeof(long long), hipMemcpyDeviceToHost, c->sA));
+    if (copy_stream) {
+        HIPCHK(c, hipEventRecord(c->ev_k, c->sA));
+        HIPCHK(c, hipStreamWaitEvent(copy_stream, c->ev_k, 0));
+    }
+    HIPCHK(c, hipMemcpyAsync(dst, c->blocks, (size_t)hi * hi * 4 * sizeof(long long), hipMemcpyDeviceToHost, copy_stream ? copy_stream : c->sA));
     return RC_OK;
 }
 
@@ -5349,19 +5365,21 @@ extern "C" int32_t rc_within_between(rc_ctx *c, rc_wb_stats *out)
 }
 
 // logprior (mcmc.jl:58-78) from slot sizes / labels
-static double logprior_host(rc_ctx *c, const int *ssize, const int *slabel, double r, double p)
+// (nslots: length of ssize / slabel — the capacity at the time the tables were taken, which the context's may have outgrown since)
+static double logprior_host(const rc_ctx *c, const int *ssize, const int *slabel, double r, double p, int nslots = -1)
 {
     const rc_params &P = c->P;
     const double n = c->n;
+    if (nslots < 0) nslots = c->kcap;
     double K = 0;
-    for (int k = 0; k < c->kcap; ++k) K += ssize[k] > 0;
+    for (int k = 0; k < nslots; ++k) K += ssize[k] > 0;
     // logpdf(Gamma(η, 1/σ), r) + logpdf(Beta(u, v), p)   (mcmc.jl:73)
     const double lgam = P.eta * std::log(P.sigma) - std::lgamma(P.eta) + (P.eta - 1) * std::log(r) - P.sigma * r;
     const double lbet = std::lgamma(P.u + P.v) - std::lgamma(P.u) - std::lgamma(P.v) + (P.u - 1) * std::log(p) + (P.v - 1) * std::log(1 - p);
     double L = std::lgamma(K + 1) + (n - K) * std::log(p) + (r * K) * std::log(1 - p) - K * std::lgamma(r) + lgam + lbet;
     // Σ_j log n_j + lgΓ(n_j + r − 1) over non-empty clusters in ascending label order (mcmc.jl:74-76)
     std::vector<std::pair<int, int>> bylabel;
-    for (int k = 0; k < c->kcap; ++k)
+    for (int k = 0; k < nslots; ++k)
         if (ssize[k] > 0) bylabel.push_back({slabel[k], ssize[k]});
     std::sort(bylabel.begin(), bylabel.end());
     for (auto &e : bylabel) L += std::log((double)e.second) + std::lgamma((double)e.second + r - 1);
