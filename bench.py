@@ -387,9 +387,10 @@ def main():
     # rolls back), with the pipeline's rollbacks and worker threads
     defaults = None
     if extras and not os.environ.get("RC_BENCH_NO_DEFAULTS"):
-        def default_options_leg(Dx, Px, labels, burn):
+        def default_options_leg(Dx, Px, labels, burn, mode="full"):
             cd = rc.Context(Dx, device=dev0, kcap=kcap, storage_bits=BITS)
             cd.set_params(**Px); cd.set_state(labels); cd.cocluster_reset()
+            cd.set_mode(mode)                             # "full": the library default (as `value`); "incremental": what runsampler and the Julia glue set
             cd.attach_host_matrices(Dx)                   # the proposals' restricted scans read the host matrix (logD derived by the library)
             cd.run_chain(burn, 0, 10, 5, 1, 1, r, p, 1.0)             # warm-up (worker threads, pinned buffers, caches; burn-in on the moving data)
             its = 1000
@@ -397,7 +398,7 @@ def main():
             chd = cd.run_chain(its, 0, 10, 5, 1, 1, r, p, 1.0, first_iter=burn)
             t_def = time.perf_counter() - t1
             cs = cd.chain_stats()
-            out = {"numMH": 1, "numGibbs": 5, "iterations": its, "iterations_per_s": its / t_def, "ms_per_iteration": t_def / its * 1e3,
+            out = {"numMH": 1, "numGibbs": 5, "mode": mode, "iterations": its, "iterations_per_s": its / t_def, "ms_per_iteration": t_def / its * 1e3,
                    "splitmerge_acceptances": int(chd["splitmerge_acceptances"].sum()), "splitmerge_splits": int(chd["splitmerge_splits"].sum()),
                    "rollbacks": cs["rollbacks"], "splits_evaluated_offline": cs["split_evals"], "workers": cs["workers"],
                    "K_final": int(chd["K"][-1]) if len(chd["K"]) else None}
@@ -408,6 +409,7 @@ def main():
                             "bit-identical to the sequential loop); headline data, stationary")
         if Dm is not None:
             defaults["moving_data"] = default_options_leg(Dm, Pm, tm, 200)
+            defaults["moving_data_incremental_mode"] = default_options_leg(Dm, Pm, tm, 200, "incremental")
         # ... and where proposals ARE accepted, so that the pipeline rolls back (an accepted proposal voids the iterations launched
         # behind it).  On the synthetic sets the Gibbs sweep repairs any labelling by itself and no proposal is ever accepted
         # (tried: clusters merged in pairs, cut in halves, sigma up to 0.5: tools/acc_probe.py), so this leg runs the reference's own

@@ -83,6 +83,7 @@ def run_chains(cases, first):
         iters, burn, thin = int(g.integers(5, 60)), int(g.integers(0, 5)), int(g.integers(1, 4))
         numGibbs, numMH = int(g.integers(0, 6)), int(g.integers(1, 4))
         mode = str(g.choice(["as_written", "intended"])); stored = bool(g.random() < 0.5)
+        if np.random.default_rng(seed + 4242).random() < 0.2: numMH = 0      # the pipelined loop without proposals (a separate generator keeps the other cases of a seed what they were)
         outs = []
         for env in ({"RC_CHAIN_PIPELINE": "0"}, {"RC_CHAIN_DEPTH": str(int(g.integers(1, 30))), "RC_CHAIN_WORKERS": str(int(g.integers(1, 9)))}):
             for k in keys: os.environ.pop(k, None)

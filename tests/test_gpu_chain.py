@@ -202,6 +202,33 @@ def test_speculative_loop_equals_the_synchronous_loop(mode):
             assert np.array_equal(runs[tag][f], ref[f]), (tag, f)
 
 
+@pytest.mark.parametrize("thin", [1, 3])
+def test_pipelined_loop_without_proposals_equals_the_synchronous_loop(thin):
+    """numMH = 0 runs through the pipelined loop as well (snapshots only for the iterations that are recorded, the host part of a
+    recorded sample — sortlabels, log-likelihood terms, log-prior — computed by the worker pool): every output equals the
+    synchronous loop's (RC_CHAIN_PIPELINE=0), on a chain that moves."""
+    D, truth = paper(2)
+    P = dict(T.likelihood_hyperparams(D, truth), repulsion=False)
+    init = np.random.default_rng(3).integers(1, 9, 100).astype(np.int64)
+    runs = {}
+    for tag, env in (("sync", {"RC_CHAIN_PIPELINE": "0"}), ("pipe", {}), ("pipe_shallow", {"RC_CHAIN_DEPTH": "1", "RC_CHAIN_WORKERS": "1"})):
+        for k in ("RC_CHAIN_PIPELINE", "RC_CHAIN_DEPTH", "RC_CHAIN_WORKERS"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        ctx = rc.Context(D, kcap=8); ctx.set_params(**P); ctx.set_state(init); ctx.cocluster_reset()      # (the capacity grows on the way)
+        ch = ctx.run_chain(90, 7, thin, 5, 0, 5, 1.0, 0.5, 0.7)
+        ch["cocluster"] = ctx.cocluster(max(ch["num_samples"], 1)); ch["final"] = ctx.get_state()[0]
+        runs[tag] = ch
+        ctx.close()
+    for k in ("RC_CHAIN_PIPELINE", "RC_CHAIN_DEPTH", "RC_CHAIN_WORKERS"):
+        os.environ.pop(k, None)
+    ref = runs["sync"]
+    assert ref["num_samples"] == (90 - 7) // thin and len(np.unique(ref["K"])) > 1
+    for tag in ("pipe", "pipe_shallow"):
+        for f in ("clusts", "K", "r", "p", "loglik", "logposterior", "r_acceptances", "r_all", "p_all", "cocluster", "final", "r_final", "p_final", "num_samples"):
+            assert np.array_equal(runs[tag][f], ref[f]), (tag, f)
+
+
 def test_parameters_changed_between_proposals_invalidate_the_cached_likelihood():
     """rc_set_params between two rc_splitmerge calls with unchanged labels (allowed by the C ABI): the second proposal must
     use block sums / log-likelihood terms of the NEW parameters — it equals the proposal of a fresh context that only ever
