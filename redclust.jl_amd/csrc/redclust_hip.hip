@@ -5260,7 +5260,12 @@ static int32_t loglik_enqueue(rc_ctx *c, int hi, long long *dst, hipStream_t cop
     int32_t rc = ensure_S(c, &gen);
     if (rc != RC_OK) return rc;
     View V = make_view(c);
-    if (c->ev_blocks_busy) { HIPCHK(c, hipStreamWaitEvent(c->sA, c->ev_blocks_busy, 0)); c->ev_blocks_busy = nullptr; }   // (c->blocks is one buffer)
+    if (c->ev_blocks_busy) {   // c->blocks is one buffer: the last copy out of it must be complete — it nearly always is by now, and a
+        // wait packet on stream A is a cross-stream hop on the path between two sweeps (10-20 µs) even when the event has fired
+        if (hipEventQuery(c->ev_blocks_busy) != hipSuccess) HIPCHK(c, hipStreamWaitEvent(c->sA, c->ev_blocks_busy, 0));
+        (void)hipGetLastError();   // (hipErrorNotReady is not an error)
+        c->ev_blocks_busy = nullptr;
+    }
     k_blocksums<<<hi, 256, (size_t)hi * 4 * sizeof(u64), c->sA>>>(V, gen, hi, c->blocks);
     HIPCHK(c, hipGetLastError());
     if (copy_stream) {
