@@ -173,7 +173,6 @@ struct View {
     u64 *keys[2];              // [2n+8] one word per resolve round: first violation (batch rounds) (two generations)
     u64 *cword[2];             // [2][nchunks + 1] per round parity and 32-point chunk: (round stamp << 32) | mask of tentative changers (two generations)
     unsigned *rec;             // [2][n] per round parity: (own slot << 16) | (target slot + 1) of a tentative changer (0 target = new cluster)
-    int *tent;                 // [n] tentative target of every point (owner-private)
     unsigned *arrive[2];       // grid-barrier arrival counters (two generations)
     const int4 *ufast, *uslow; // unit lists of k_bulk_syml2 (c0, first row, end row, 0), grouped by wave: the units its fast path takes / the rest
     const int *wfast, *wslow;  // [nwaves + 1] offsets of each wave's units in the two lists (build_syml2_lists: balanced by cost)
@@ -3074,15 +3073,16 @@ __device__ int commit_batch(const View &V, const SweepArgs &sa, Tab &T, int nc, 
 
 // ---------------------------------------------------------------------------------------------------
 // k_resolve — one persistent launch per sweep.  Each round:
-//   1. every remaining point is scored and drawn in parallel under the committed state (tentative decisions);
-//   2. barrier; every block assembles the same ordered batch of tentative changers (up to RC_MAXB, cut before the
-//      first one that would create, empty or rename a cluster);
-//   3. every point after the first changer is re-drawn under the committed state plus the batch changers that
-//      precede it; the smallest point whose decision differs from its tentative one is the first violation;
-//   4. barrier; the batch changers before the violation are committed at once.
+//   1. (round 0, and after a batch that did not reach the end of the sweep) every open point is scored and drawn in parallel
+//      under the committed state: the guesses; barrier.  Otherwise the guesses are the draws of the previous round's step 3;
+//   2. every block assembles the same ordered batch of guessed changers (up to the batch capacity) and simulates it in order
+//      (batch_sim: moves, births, deaths, renames — label-keyed noise makes structural changes batchable);
+//   3. every open point of the batch's range is drawn again under the committed state plus the batch entries that precede it;
+//      the smallest point whose draw differs from what the batch says it does is the first violation; every draw is announced
+//      as the point's guess for the next round;
+//   4. barrier; the batch entries before the violation are committed at once.
 // By induction over the point order this is exactly the sequential sweep: a point before the first violation saw
-// precisely the changes of its predecessors.  Independent changes therefore cost two barriers per round instead of
-// one barrier each; a structural change (birth / death / rename) is committed alone as before.
+// precisely the changes of its predecessors.  (resolve_body says more about the guesses.)
 // G blocks (G <= #CUs; they need not start together: the spin is bounded only by a generous timeout, and k_bulk
 // never waits on this kernel).  Sweep t reads S generation own_gen, corrects own_gen and next_gen, uses key /
 // chunk-word / barrier generation t%2 (and re-arms generation (t+1)%2), and leaves perm / snapshot generation t%2
@@ -3655,7 +3655,6 @@ struct rc_ctx {
     int *lsnap[2] = {nullptr, nullptr}, *work[2] = {nullptr, nullptr};  // label snapshots / work counters of k_bulk_sym
     u64 *cword[2] = {nullptr, nullptr};
     unsigned *rec = nullptr;
-    int *tent = nullptr;
     int bulk_kernel = -1;      // RC_BULK_KERNEL: -1 auto, 0 k_bulk (full read, any layout), 1 k_bulk_sym (upper triangle)
     int last_bulk_kernel = 0;  // what the last enqueue chose
     int sym_item_tiles = 8;
@@ -3778,7 +3777,7 @@ static View make_view(const rc_ctx *c)
     V.derived = c->derived ? 1 : 0; V.qsD = std::ldexp(1.0, -c->eD); V.qsL = std::ldexp(1.0, c->eL); V.ltab = c->ltab; V.qeD = c->eD;
     for (int g = 0; g < 3; ++g) { V.SD[g] = c->SD[g]; V.SL[g] = c->SL[g]; }
     for (int g = 0; g < 2; ++g) { V.perm[g] = c->perm[g]; V.pslot[g] = c->pslot[g]; V.keys[g] = c->keys[g]; V.arrive[g] = c->arrive[g]; V.snap[g] = c->lsnap[g]; V.work[g] = c->work[g]; V.cword[g] = c->cword[g]; }
-    V.rec = c->rec; V.tent = c->tent;
+    V.rec = c->rec;
     V.slot_of = c->slot_of; V.slot_size = c->slot_size; V.slot_label = c->slot_label;
     V.slot_pos = c->slot_pos; V.slot_act = c->slot_act;
     V.A = c->A; V.sc = c->sc; V.hsum = c->hsum_dev;
@@ -3816,7 +3815,7 @@ static void free_all(rc_ctx *c)
     (void)hipSetDevice(c->dev);
     void *ptrs[] = {c->Dq48, c->ltab, c->Dq, c->Lq, c->Dq_src, c->Lq_src, c->diag_src, c->pi, c->ipi, c->diagq, c->SD[0], c->SD[1], c->SD[2], c->SL[0], c->SL[1], c->SL[2], c->slot_of,
                     c->slot_size, c->slot_label, c->slot_pos, c->slot_act, c->perm[0], c->perm[1], c->pslot[0],
-                    c->pslot[1], c->lsnap[0], c->lsnap[1], c->work[0], c->work[1], c->cword[0], c->cword[1], c->rec, c->tent, c->A, c->keys[0], c->keys[1], c->arrive[0], c->arrive[1], c->sc, c->blocks,
+                    c->pslot[1], c->lsnap[0], c->lsnap[1], c->work[0], c->work[1], c->cword[0], c->cword[1], c->rec, c->A, c->keys[0], c->keys[1], c->arrive[0], c->arrive[1], c->sc, c->blocks,
                     c->counts, c->cc_out, c->snap, c->d_moves, c->used_scratch, c->wc, c->ufast, c->uslow, c->wfast, c->wslow, c->s2alt.ufast, c->s2alt.uslow, c->s2alt.wfast, c->s2alt.wslow};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -4009,7 +4008,6 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     }
     HIPCHK2(hipMalloc(&c->slot_of, (size_t)n * sizeof(int)));
     HIPCHK2(hipMalloc(&c->rec, 2 * (size_t)n * sizeof(unsigned)));
-    HIPCHK2(hipMalloc(&c->tent, (size_t)n * sizeof(int)));
     c->wc_always = getenv("RC_SCORE_CACHE") && atoi(getenv("RC_SCORE_CACHE")) == 1;
     {
         const int32_t rcs = alloc_slot_buffers(c);   // everything sized by the slot capacity (re-allocated when it grows)
