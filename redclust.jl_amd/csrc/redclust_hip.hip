@@ -195,6 +195,7 @@ struct SweepArgs {
     // a sweep resumed after the slot tables were grown (recover_capacity): the points <= after0 are final already, changes0 /
     // rounds0 are what the first part of the sweep had committed / run.  A fresh sweep: -1, 0, 0.
     int after0, changes0, rounds0;
+    int prune;   // candidates that cannot win skip their noise ("Pruned candidates", eval_chunk): exact either way; the host turns it on while few labels move
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -483,7 +484,7 @@ __global__ void k_quantize(const double *__restrict__ X, int n, int ld, int e, T
 // perm / pslot: rows grouped by slot (order inside a group is irrelevant — sums are exact integers).
 // One block.  LDS: 2*kcap ints.
 // ---------------------------------------------------------------------------------------------------
-__device__ void build_perm_block(const View &V, int gen, int *lds_off /*kcap*/, int *lds_cur /*kcap*/)
+__device__ __forceinline__ void build_perm_block(const View &V, int gen, int *lds_off /*kcap*/, int *lds_cur /*kcap*/)
 {
     int *perm = V.perm[gen], *pslot = V.pslot[gen];
     for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) lds_cur[k] = 0;
@@ -509,7 +510,7 @@ __device__ void build_perm_block(const View &V, int gen, int *lds_off /*kcap*/, 
 // The same order built by all G blocks of the resolver at the end of a sweep: the slot offsets are the running sums of the
 // slot sizes (every block holds them), block b places the points of its share of the slots — one pass over slot_of per block,
 // positions inside a slot from LDS counters (the order inside a cluster is arbitrary here as above).  lds: 2·kcap + 1 ints.
-__device__ void build_perm_grid(const View &V, int gen, const int *size /*LDS, [hi]*/, int hi, int G, int *lds)
+__device__ __forceinline__ void build_perm_grid(const View &V, int gen, const int *size /*LDS, [hi]*/, int hi, int G, int *lds)
 {
     int *off = lds, *cur = lds + V.kcap + 1;
     for (int k = threadIdx.x; k <= V.kcap; k += blockDim.x) { off[k] = (k < hi) ? size[k] : 0; if (k < V.kcap) cur[k] = 0; }
@@ -2121,7 +2122,7 @@ __host__ __device__ inline size_t tab_layout(int kcap, int n, int nw, size_t *of
     return o;
 }
 
-__device__ Tab tab_carve(char *smem, int kcap, int n, int nw, int maxb = RC_MAXB)
+__device__ __forceinline__ Tab tab_carve(char *smem, int kcap, int n, int nw, int maxb = RC_MAXB)
 {
     size_t off[RC_TAB_NOFF];
     tab_layout(kcap, n, nw, off, maxb);
@@ -2140,7 +2141,7 @@ __device__ Tab tab_carve(char *smem, int kcap, int n, int nw, int maxb = RC_MAXB
     return T;
 }
 
-__device__ inline size_t tab_bytes_dev(int kcap, int n, int nw, int maxb = RC_MAXB)
+__device__ __forceinline__ size_t tab_bytes_dev(int kcap, int n, int nw, int maxb = RC_MAXB)
 {
     size_t off[RC_TAB_NOFF];
     return tab_layout(kcap, n, nw, off, maxb);
@@ -2159,7 +2160,7 @@ __device__ __forceinline__ double tab_base(const View &V, const SweepArgs &a, in
 }
 
 // per-slot score constants of the active slots.  All threads; ends synchronised.
-__device__ void tab_bases(const View &V, const SweepArgs &a, Tab &T)
+__device__ __forceinline__ void tab_bases(const View &V, const SweepArgs &a, Tab &T)
 {
     for (int k = threadIdx.x; k < T.misc[7]; k += blockDim.x) {
         const int s = T.size[k];
@@ -2172,7 +2173,7 @@ __device__ void tab_bases(const View &V, const SweepArgs &a, Tab &T)
 }
 
 // After a birth / death / rename: label bitset, smallest empty label, candidate ranks.  Ends synchronised.
-__device__ void tab_structural(const View &V, Tab &T)
+__device__ __forceinline__ void tab_structural(const View &V, Tab &T)
 {
     const int nw = (V.n + 31) / 32, hi = T.misc[7];
     for (int w = threadIdx.x; w < nw; w += blockDim.x) T.used[w] = 0u;
@@ -2213,7 +2214,7 @@ __device__ void tab_structural(const View &V, Tab &T)
     __syncthreads();
 }
 
-__device__ void tab_load(const View &V, Tab &T)
+__device__ __forceinline__ void tab_load(const View &V, Tab &T)
 {
     for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) {
         T.size[k] = V.slot_size[k];
@@ -2229,7 +2230,7 @@ __device__ void tab_load(const View &V, Tab &T)
     __syncthreads();
 }
 
-__device__ void tab_store(const View &V, const Tab &T)
+__device__ __forceinline__ void tab_store(const View &V, const Tab &T)
 {
     for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) {
         V.slot_size[k] = T.size[k];
@@ -2245,11 +2246,11 @@ __device__ void tab_store(const View &V, const Tab &T)
 
 // label snapshot of generation g and the run count of the labels in natural point order.  One block.
 // the two halves of snapshot_labels for the resolver's epilogue: the copy by all blocks, the run count by one
-__device__ void snapshot_copy_grid(const View &V, int g, int G)
+__device__ __forceinline__ void snapshot_copy_grid(const View &V, int g, int G)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V.n; i += G * blockDim.x) V.snap[g][i] = V.slot_of[i];
 }
-__device__ void snapshot_runs(const View &V, int *lds_cnt)
+__device__ __forceinline__ void snapshot_runs(const View &V, int *lds_cnt)
 {
     if (threadIdx.x == 0) *lds_cnt = 0;
     __syncthreads();
@@ -2261,7 +2262,7 @@ __device__ void snapshot_runs(const View &V, int *lds_cnt)
     __syncthreads();
 }
 
-__device__ void snapshot_labels(const View &V, int g, int *lds_cnt)
+__device__ __forceinline__ void snapshot_labels(const View &V, int g, int *lds_cnt)
 {
     if (threadIdx.x == 0) *lds_cnt = 0;
     __syncthreads();
@@ -2279,7 +2280,7 @@ __device__ void snapshot_labels(const View &V, int g, int *lds_cnt)
 
 // tables = false: the slot sizes and labels in the record are still right (a sweep that changed nothing) — 2·kcap stores to
 // host memory less in the tail of block 0, which is the end of the launch in the stationary regime
-__device__ void write_summary(const View &V, int n_changes, int n_rounds, bool tables = true)
+__device__ __forceinline__ void write_summary(const View &V, int n_changes, int n_rounds, bool tables = true)
 {
     if (tables)
         for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) {
@@ -2456,6 +2457,20 @@ __device__ __forceinline__ void hot_accumulate(const View &V, const Tab &T, int 
     }
 }
 
+// Pruned candidates.  The Gumbel noise of a candidate is at most RC_GUMBEL_MAX (u <= 1 - 2^-53: -log(-log u) <= 36.7369), so a
+// candidate whose noise-free score v0 satisfies v0 + RC_GUMBEL_MAX < (a score some other candidate of the point has for certain)
+// cannot be the argmax, whatever its uniform is: its counter hash and the two logs of the noise — 180 of a candidate's ~330 VALU
+// instructions — are skipped.  The comparison is strict and the bound exact, so no draw changes.  The certain score is the point's
+// own cluster's (evaluated first, by one stream of every wave, and handed to the wave's other stream by a shuffle) or the
+// stream's best so far.  In the score cache a pruned candidate is a quiet NaN whose low word holds v0 + RC_GUMBEL_MAX as a float
+// rounded up: a later pass skips it again if the bound is still below what it has, and computes it exactly otherwise.
+#define RC_GUMBEL_MAX 36.74
+__device__ __forceinline__ double rc_pruned_tag(double bound)
+{
+    return __hiloint2double(0x7ff80000, (int)__float_as_uint(__double2float_ru(bound)));
+}
+__device__ __forceinline__ double rc_pruned_bound(double tagged) { return (double)__uint_as_float((unsigned)__double2loint(tagged)); }
+
 // Score cache (cmode; V.wc).  The score of (point i, cluster k ≠ i's own) — size term, likelihood, noise of (sweep, i, label) —
 // changes inside a sweep only when a committed change touches slot k (size, row sums or label) or, under validation, when a
 // batch entry before i does.  The first tentative pass of a sweep evaluates every point against every cluster and stores the
@@ -2466,7 +2481,7 @@ __device__ __forceinline__ void hot_accumulate(const View &V, const Tab &T, int 
 // Always computed: the point's own cluster (its score excludes the point itself), the clusters born in the batch, the
 // new-cluster candidate.  The cached value is the very double the computation would produce again, so decisions are
 // unchanged; a computed candidate costs ~330 VALU instructions, a cached one a load (moving regime, K = 206: eight passes per sweep).
-__device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long long *SD, const long long *SL,
+__device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long long *SD, const long long *SL,
                            int chunk, int lo, int hi, int mode, int nb, u64 *cword, unsigned *rec, unsigned stamp, int cmode,
                            u64 *cword_next = nullptr, unsigned *rec_next = nullptr, unsigned stamp_next = 0u)
 {
@@ -2478,6 +2493,7 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
     double bestv = -INFINITY;
     int bestpos = 0x7fffffff, bestslot = -2;
     int own = 0, u = 0, j = 0;
+    const bool prune = a.prune != 0 && !(a.dbg & 5);
     if (valid) {
         u = V.pi[i];  // matrices, S and slot_of are stored in the internal (cluster-contiguous) point order
         own = V.slot_of[u];
@@ -2532,6 +2548,14 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
             double lik = V.cL * SLr - (V.alpha + V.delta1 * (double)s) * log1p(SDr / V.beta);
             if (V.repulsion) lik += (V.zeta + V.delta2 * (double)s) * log1p(SDr / V.gamma);
             double v = base + lik;
+#ifndef RC_NO_PRUNE
+            if (prune && !isown) {
+                if (bestslot != -2 && v + RC_GUMBEL_MAX < bestv) {                    // cannot win: no noise needed
+                    if (cmode != 0 && mode == 0) wrow[(size_t)k * V.ldw] = rc_pruned_tag(v + RC_GUMBEL_MAX);
+                    return;
+                }
+            }
+#endif
             if (!(a.dbg & 4)) {
                 const double un = rc_uniform(a, (unsigned)i, (unsigned)lab);
                 v = v + (-log(-log(un)));
@@ -2539,10 +2563,37 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
             if (cmode != 0 && mode == 0 && !isown) wrow[(size_t)k * V.ldw] = v;   // tentative passes keep the cache current
             if (bestslot == -2 || v > bestv || (v == bestv && lab < bestpos)) { bestv = v; bestpos = lab; bestslot = k; }
         };
+        // With pruning every stream starts with the point's own cluster (itself removed): its score is the bar the stream's other
+        // candidates must be able to reach (see "Pruned candidates"; the same candidate in several streams is harmless: equal score,
+        // equal label).  Without, the own cluster is one candidate of one stream.
         if (cmode != 2) {
-            for (int pos = st; pos < ((a.dbg & 1) ? 0 : K); pos += NS) consider(T.act[pos]);
+            for (int pos = prune ? -1 : st; pos < ((a.dbg & 1) ? 0 : K); pos = (pos < 0) ? st : pos + NS) {
+                const int k = (pos < 0) ? own : (int)T.act[pos];
+                if (prune && pos >= 0 && k == own) continue;
+                consider(k);
+            }
         } else {
             const int Kc = T.misc[14];
+            // own cluster first, then the slots a change touched (computed), then the clean ones (stored scores)
+            for (int pos = (prune || st == ((K + 1) % NS)) ? -1 : Kc + st; pos < K; pos = (pos < 0) ? Kc + st : pos + NS) {
+                const int k = (pos < 0) ? own : (int)T.act2[pos];
+                if (pos >= 0) {
+                    if (k == own) continue;
+                    if (mode == 1 && !T.dirty[k]) {                // a slot of the batch: untouched for this point if no entry of its group precedes it
+                        const int e0 = k ? T.seg[k - 1] : 0;
+                        if (e0 == T.seg[k] || T.pairs[e0] >= j) {
+                            const double v = wrow[(size_t)k * V.ldw];
+                            if (v == v) {
+                                const int lab = T.label[k];
+                                if (bestslot == -2 || v > bestv || (v == bestv && lab < bestpos)) { bestv = v; bestpos = lab; bestslot = k; }
+                                continue;
+                            }
+                            if (bestslot != -2 && rc_pruned_bound(v) < bestv) continue;    // pruned when it was stored, and still out of reach
+                        }
+                    }
+                }
+                consider(k);
+            }
             for (int pos = st; pos < Kc; pos += 4 * NS) {      // clean slots: the stored score — four loads in flight (one per turn was a memory round trip per candidate)
                 int kk[4];
                 double vv[4];
@@ -2552,29 +2603,24 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
                     kk[q] = (p_ < Kc) ? (int)T.act2[p_] : own;
                     vv[q] = (kk[q] != own) ? wrow[(size_t)kk[q] * V.ldw] : 0.0;
                 }
+                unsigned needm = 0u;   // (a bit mask, not an array indexed at run time: that would live in scratch memory)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if (kk[q] == own) continue;
                     const double v = vv[q];
+                    if (v != v) {                                 // pruned when it was stored: still out of reach?
+                        if (!(bestslot != -2 && rc_pruned_bound(v) < bestv)) needm |= 1u << q;
+                        continue;
+                    }
                     const int lab = T.label[kk[q]];
                     if (bestslot == -2 || v > bestv || (v == bestv && lab < bestpos)) { bestv = v; bestpos = lab; bestslot = kk[q]; }
                 }
-            }
-            for (int pos = Kc + st; pos < K; pos += NS) {      // slots a change touched
-                const int k = T.act2[pos];
-                if (k == own) continue;
-                if (mode == 1 && !T.dirty[k]) {                // a slot of the batch: untouched for this point if no entry of its group precedes it
-                    const int e0 = k ? T.seg[k - 1] : 0;
-                    if (e0 == T.seg[k] || T.pairs[e0] >= j) {
-                        const double v = wrow[(size_t)k * V.ldw];
-                        const int lab = T.label[k];
-                        if (bestslot == -2 || v > bestv || (v == bestv && lab < bestpos)) { bestv = v; bestpos = lab; bestslot = k; }
-                        continue;
-                    }
+                while (needm) {                                      // (rare: computed exactly, and stored if this pass keeps the cache)
+                    const int q = __ffs((int)needm) - 1;
+                    needm &= needm - 1u;
+                    consider(q == 0 ? kk[0] : q == 1 ? kk[1] : q == 2 ? kk[2] : kk[3]);
                 }
-                consider(k);
             }
-            if (st == ((K + 1) % NS)) consider(own);            // the point's own cluster, itself removed
         }
         // clusters created by the changers before i: singletons {x_q}, row sums = row x_q of the matrices
         if (mode == 1 && j > 0) {
@@ -2685,7 +2731,7 @@ __device__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long
 #define RC_BAR_GROUPS 8
 #define RC_BAR_STRIDE 32                      // unsigneds per line
 #define RC_BAR_WORDS ((2 * RC_BAR_GROUPS + 1) * RC_BAR_STRIDE)
-__device__ bool grid_barrier(const View &V, Tab &T, unsigned *arrive, int G, unsigned nbar, u64 my_key, u64 *key_word)
+__device__ __forceinline__ bool grid_barrier(const View &V, Tab &T, unsigned *arrive, int G, unsigned nbar, u64 my_key, u64 *key_word)
 {
     int &sh_ok = T.misc[6];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2717,7 +2763,7 @@ __device__ bool grid_barrier(const View &V, Tab &T, unsigned *arrive, int G, uns
 // T.act2 = the active slots with those whose cached scores are still valid first (T.misc[14] of them): not touched by a
 // committed change of this sweep nor — with_batch, for the validation pass — by an entry of the current batch.  The order
 // inside the two parts is arbitrary (ties between candidates are broken by label, not by position).  Ends synchronised.
-__device__ void tab_partition(const View &V, Tab &T, bool with_batch)
+__device__ __forceinline__ void tab_partition(const View &V, Tab &T, bool with_batch)
 {
     if (threadIdx.x == 0) { T.misc[14] = 0; T.misc[15] = 0; }
     __syncthreads();
@@ -2732,7 +2778,7 @@ __device__ void tab_partition(const View &V, Tab &T, bool with_batch)
 }
 
 // smallest label > lab (1-based) whose bit is clear in the occupancy bitset; n + 1 if none
-__device__ int next_empty_label(const Tab &T, int n, int lab)
+__device__ __forceinline__ int next_empty_label(const Tab &T, int n, int lab)
 {
     const int nw = (n + 31) / 32;
     int w = lab >> 5;                              // bit index of label lab+1 is lab
@@ -2758,7 +2804,7 @@ __device__ int next_empty_label(const Tab &T, int n, int lab)
 // T.size is used in place (the caller restores it from the entries), T.used is scratch (the caller builds it).
 // misc: [3] entries kept, [4] last point covered, [5] capacity failure, [8] births, [9] entries that change something,
 // [10] index of the first of them.
-__device__ void batch_sim(const View &V, Tab &T, int total, int cap)
+__device__ __forceinline__ void batch_sim(const View &V, Tab &T, int total, int cap)
 {
     const int lane = threadIdx.x & 63;
     const int nb0 = min(total, cap);
@@ -3007,7 +3053,7 @@ __device__ void batch_sim(const View &V, Tab &T, int total, int cap)
 // with its own, so the sum is exact whatever the interleaving).  A row of a cluster that dies ends as exact zeros, a
 // new cluster's row starts from zeros (invariant: rows of free slots are zero).  mcmc.jl:250-252 plus the bookkeeping.
 // Returns the number of label changes among the nc entries.
-__device__ int commit_batch(const View &V, const SweepArgs &sa, Tab &T, int nc, int G, int own_gen, int next_gen)
+__device__ __forceinline__ int commit_batch(const View &V, const SweepArgs &sa, Tab &T, int nc, int G, int own_gen, int next_gen)
 {
     if (threadIdx.x == 0) { T.misc[11] = 0; T.misc[12] = 0; if (nc) T.misc[0] = T.bK[nc - 1]; }
     __syncthreads();
@@ -3106,7 +3152,7 @@ __device__ __forceinline__ void chaos_delay(int site, int round)
 #define RC_CHAOS_AT(site)
 #endif
 
-__device__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *smem)
+__device__ __forceinline__ void resolve_body(const View &V, const SweepArgs &sa, int G, char *smem)
 {
     // The resolver is the latency-critical part of a sweep and shares its SIMDs with the waves of the other stream's row
     // reduction (three of those and one of these per SIMD): it takes instruction-issue priority over them — without it a
@@ -5002,6 +5048,10 @@ static int32_t sweep_enqueue(rc_ctx *c, double r, double p, uint64_t seed, uint6
     sa.t = (int)t;
     sa.dbg = c->dbg;
     sa.after0 = after0; sa.changes0 = changes0; sa.rounds0 = rounds0;
+    // Pruning pays where most candidates are far from the point's own cluster — the stationary regime (N = 8192, K = 50: 15.7 k -> 16.4 k
+    // sweeps/s) — and costs a few per cent where a chain moves among many small clusters (every stream evaluates the own cluster first)
+    static const bool prune_off = getenv("RC_NO_PRUNE") && atoi(getenv("RC_NO_PRUNE"));
+    sa.prune = (!prune_off && c->hsum->n_changes <= 32) ? 1 : 0;
     c->inflight.push_back(rc_ctx::SweepRec{r, p, seed, sweep_index, t});
     if (c->inflight.size() > 65536) {   // (a caller that never synchronises: bound the replay log — every entry before a completed sweep is dead)
         int32_t rcq = sync_and_check(c);
