@@ -2563,6 +2563,16 @@ __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Ta
             if (cmode != 0 && mode == 0 && !isown) wrow[(size_t)k * V.ldw] = v;   // tentative passes keep the cache current
             if (bestslot == -2 || v > bestv || (v == bestv && lab < bestpos)) { bestv = v; bestpos = lab; bestslot = k; }
         };
+        // A point that is a cluster of its own has no own cluster to set the bar: every stream then starts with the new-cluster
+        // candidate instead (log, hash and noise: cheap, and a singleton's usual draw).  Lanes of a wave run in lock step — one
+        // point without a bar makes its whole wave compute the noise of every candidate.
+        const bool new_ok = (V.maxK == 0 || (long long)Ki < V.maxK) && Ki < V.n;
+        const bool new_first = prune && single && new_ok;
+        if (new_first) {
+            const double un = rc_uniform(a, (unsigned)i, 0u);
+            bestv = (log((double)(Ki + 1)) + a.r * a.log1mp) + (-log(-log(un)));
+            bestpos = RC_NEWKEY; bestslot = -1;
+        }
         // With pruning every stream starts with the point's own cluster (itself removed): its score is the bar the stream's other
         // candidates must be able to reach (see "Pruned candidates"; the same candidate in several streams is harmless: equal score,
         // equal label).  Without, the own cluster is one candidate of one stream.
@@ -2643,7 +2653,7 @@ __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Ta
             }
         }
         // new-cluster candidate, last in the candidate order (mcmc.jl:198-203, 228-230); one stream handles it
-        if (st == (K % NS) && (V.maxK == 0 || (long long)Ki < V.maxK) && Ki < V.n) {
+        if (!new_first && st == (K % NS) && new_ok) {
             const double un = rc_uniform(a, (unsigned)i, 0u);
             const double v = (log((double)(Ki + 1)) + a.r * a.log1mp) + (-log(-log(un)));
             if (v > bestv || bestslot == -2) { bestv = v; bestpos = RC_NEWKEY; bestslot = -1; }
@@ -5051,7 +5061,8 @@ static int32_t sweep_enqueue(rc_ctx *c, double r, double p, uint64_t seed, uint6
     // Pruning pays where most candidates are far from the point's own cluster — the stationary regime (N = 8192, K = 50: 15.7 k -> 16.4 k
     // sweeps/s) — and costs a few per cent where a chain moves among many small clusters (every stream evaluates the own cluster first)
     static const bool prune_off = getenv("RC_NO_PRUNE") && atoi(getenv("RC_NO_PRUNE"));
-    sa.prune = (!prune_off && c->hsum->n_changes <= 32) ? 1 : 0;
+    static const bool prune_always = getenv("RC_PRUNE_ALWAYS") && atoi(getenv("RC_PRUNE_ALWAYS"));
+    sa.prune = (!prune_off && (prune_always || c->hsum->n_changes <= 32)) ? 1 : 0;
     c->inflight.push_back(rc_ctx::SweepRec{r, p, seed, sweep_index, t});
     if (c->inflight.size() > 65536) {   // (a caller that never synchronises: bound the replay log — every entry before a completed sweep is dead)
         int32_t rcq = sync_and_check(c);
