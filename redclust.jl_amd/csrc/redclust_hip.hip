@@ -2527,6 +2527,7 @@ __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Ta
         const int Ki = ((mode == 1 && j > 0) ? (int)T.bK[j - 1] : K) - single;
         const long long dg = V.diagq[u];
         double *const wrow = V.wc + i;   // column i of the score cache (used only when cmode != 0)
+        const double inv_beta = 1.0 / V.beta, inv_gamma = 1.0 / V.gamma;
         auto consider = [&](const int k) {
             const int isown = (k == own);
             int sz = T.size[k], lab = T.label[k];
@@ -2545,6 +2546,23 @@ __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Ta
             sd -= (isown ? dg : 0);                                              // i itself excluded (clusts[i] = -1)
             const double SDr = (double)sd * V.scD, SLr = (double)sl * V.scL;      // logD diagonal is 0 (types.jl:155)
             const double base = touched ? tab_base(V, a, s) : (isown ? T.base_s[k] : T.base_o[k]);
+#ifndef RC_NO_PRUNE
+            if (prune && !isown && bestslot != -2) {
+                // cheap test first: log1p(x) >= x / (1 + x) and log1p(y) <= y bound the noise-free score from above with two
+                // multiplications and a refined reciprocal instead of two divisions and two log1p (~20 against ~150 instructions);
+                // the slack covers every rounding of this estimate (relative 1e-9 of the terms' magnitudes, far above 2^-53)
+                const double A_ = V.alpha + V.delta1 * (double)s, x_ = SDr * inv_beta, d_ = 1.0 + x_;
+                double rc_ = __builtin_amdgcn_rcp(d_);
+                rc_ = rc_ * (2.0 - d_ * rc_);                                         // one Newton step: relative error ~1e-15
+                const double t1 = V.cL * SLr, t2 = A_ * (x_ * rc_);
+                const double zy = V.repulsion ? (V.zeta + V.delta2 * (double)s) * (SDr * inv_gamma) : 0.0;
+                const double ub = (((base + t1) - t2) + zy) + (RC_GUMBEL_MAX + 1e-3) + 1e-9 * (fabs(base) + fabs(t1) + A_ * x_ + zy);
+                if (ub < bestv) {
+                    if (cmode != 0 && mode == 0) wrow[(size_t)k * V.ldw] = rc_pruned_tag(ub);
+                    return;
+                }
+            }
+#endif
             double lik = V.cL * SLr - (V.alpha + V.delta1 * (double)s) * log1p(SDr / V.beta);
             if (V.repulsion) lik += (V.zeta + V.delta2 * (double)s) * log1p(SDr / V.gamma);
             double v = base + lik;
