@@ -5078,8 +5078,8 @@ static int32_t sweep_enqueue(rc_ctx *c, double r, double p, uint64_t seed, uint6
     sa.after0 = after0; sa.changes0 = changes0; sa.rounds0 = rounds0;
     // Pruning pays where most candidates are far from the point's own cluster — the stationary regime (N = 8192, K = 50: 15.7 k -> 16.4 k
     // sweeps/s) — and costs a few per cent where a chain moves among many small clusters (every stream evaluates the own cluster first)
-    static const bool prune_off = getenv("RC_NO_PRUNE") && atoi(getenv("RC_NO_PRUNE"));
-    static const bool prune_always = getenv("RC_PRUNE_ALWAYS") && atoi(getenv("RC_PRUNE_ALWAYS"));
+    const bool prune_off = getenv("RC_NO_PRUNE") && atoi(getenv("RC_NO_PRUNE"));                 // (read per sweep: tests switch them)
+    const bool prune_always = getenv("RC_PRUNE_ALWAYS") && atoi(getenv("RC_PRUNE_ALWAYS"));
     sa.prune = (!prune_off && (prune_always || c->hsum->n_changes <= 32)) ? 1 : 0;
     c->inflight.push_back(rc_ctx::SweepRec{r, p, seed, sweep_index, t});
     if (c->inflight.size() > 65536) {   // (a caller that never synchronises: bound the replay log — every entry before a completed sweep is dead)

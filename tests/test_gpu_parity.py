@@ -625,3 +625,46 @@ def test_within_between_split_from_block_sums():
     for k in ("delta1", "delta2", "alpha", "beta", "zeta", "gamma"):
         assert np.isclose(P_dev[k], P_host[k], rtol=1e-9), k
     ctx.close()
+
+
+@pytest.mark.parametrize("cache", ["0", "1"])
+def test_pruned_candidates_change_no_draw(cache):
+    """The resolver skips the Gumbel noise of candidates that provably cannot win (noise <= 36.74; a cheap upper bound of the
+    noise-free score first, the exact score second; pruned entries NaN-tagged in the score cache).  Forced on in every sweep,
+    forced off, and the oracle: the same moving chain (births, deaths, singletons), with the score cache off and always on."""
+    data = rc.generatemixture(700, 6, seed=5, sigma=0.45)
+    D, truth = data["distancematrix"], data["clusts"]
+    P = rc.likelihood_hyperparams(D, truth)
+    init = np.random.default_rng(2).integers(1, 40, 700).astype(np.int64)
+    keys = ("RC_NO_PRUNE", "RC_PRUNE_ALWAYS", "RC_SCORE_CACHE")
+    saved = {k: os.environ.get(k) for k in keys}
+    try:
+        os.environ["RC_SCORE_CACHE"] = cache
+        ctx = rc.Context(D)
+        ctx.set_params(**P)
+        L = ctx.get_matrix(1)
+        ctx.set_state(init)
+        eD, eL = ctx.debug_rowsums(int(init[0]))[2:4]
+        orc = O.Oracle(ctx.get_matrix(0), P, logD=L, eL=eL, eD=eD)
+        orc.set_state(init)
+        other = rc.Context(D)
+        other.set_params(**P)
+        other.set_state(init)
+        moved = 0
+        for t in range(12):
+            r, p = rp_schedule(t)
+            os.environ.pop("RC_NO_PRUNE", None); os.environ["RC_PRUNE_ALWAYS"] = "1"
+            ctx.gibbs_sweep(r, p, 31, t)
+            os.environ.pop("RC_PRUNE_ALWAYS", None); os.environ["RC_NO_PRUNE"] = "1"
+            other.gibbs_sweep(r, p, 31, t)
+            orc.sweep_stable(r, p, 31, t)
+            a, b = ctx.get_state(), other.get_state()
+            assert np.array_equal(a[0], orc.clusts) and np.array_equal(b[0], orc.clusts), (cache, t)
+            assert a[2] == b[2] == orc.K and ctx.sweep_stats()["n_changes"] == other.sweep_stats()["n_changes"] == orc.last_changes
+            moved += orc.last_changes
+        assert moved > 100
+        ctx.close(); other.close()
+    finally:
+        for k, v in saved.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
