@@ -4261,7 +4261,7 @@ static int32_t alloc_ctx(int64_t n, int32_t storage_bits, int32_t device_id, int
     if (getenv("RC_SYML_PAD")) c->syml_pad = (size_t)std::max(0, atoi(getenv("RC_SYML_PAD")));
     if (getenv("RC_SW_COARSE")) c->sw_coarse = std::min(128, std::max(8, atoi(getenv("RC_SW_COARSE")) & ~3));
     if (getenv("RC_BULK_KERNEL")) c->bulk_kernel = !strcmp(getenv("RC_BULK_KERNEL"), "sym") ? 1 : (!strcmp(getenv("RC_BULK_KERNEL"), "perm") ? 0 : -1);
-    if (getenv("RC_RES_THREADS")) c->res_threads = (atoi(getenv("RC_RES_THREADS")) == 256) ? 256 : 512;
+    if (getenv("RC_RES_THREADS")) { const int rt_ = atoi(getenv("RC_RES_THREADS")); c->res_threads = (rt_ == 64 || rt_ == 128 || rt_ == 256) ? rt_ : 512; }
     if (getenv("RC_SYM_ITEM_TILES")) c->sym_item_tiles = std::max(1, atoi(getenv("RC_SYM_ITEM_TILES")));
     *out = c;
     return RC_OK;
