@@ -508,7 +508,10 @@ static int32_t run_chain_speculative(rc_ctx *c, const rc_chain_options *o, rc_ch
     const rc_params &P = c->P;
     // iterations in flight: a proposal is 0.8 ms of a worker's time, an iteration 70-100 µs of the main thread's — a dozen
     // iterations deep the main thread waited for the oldest job
-    const int Dmax = std::max(1, std::min(64, getenv("RC_CHAIN_DEPTH") ? atoi(getenv("RC_CHAIN_DEPTH")) : 24));
+    int Dmax = std::max(1, std::min(64, getenv("RC_CHAIN_DEPTH") ? atoi(getenv("RC_CHAIN_DEPTH")) : 24));
+    // every iteration in flight holds a snapshot of the K x K block sums in pinned memory (32 B per pair: 2 MB at 256 slots, 134 MB at
+    // 2048): a chain that starts among many hundreds of clusters keeps fewer in flight
+    if (!getenv("RC_CHAIN_DEPTH") && c->hsum->slot_hi > 512) Dmax = std::min(Dmax, c->hsum->slot_hi > 1024 ? 3 : 8);
     // worker threads: the host's cores shared by the chains this process runs at once (rc_run_chains: one per GPU — eight
     // chains must not start 200 threads), one core left to each chain's main thread; at most 24
     const int chains_here = std::max(1, g_chains_running.load());
