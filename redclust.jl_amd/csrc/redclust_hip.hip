@@ -2493,7 +2493,9 @@ __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Ta
     double bestv = -INFINITY;
     int bestpos = 0x7fffffff, bestslot = -2;
     int own = 0, u = 0, j = 0;
-    const bool prune = a.prune != 0 && !(a.dbg & 5);
+    // (tentative passes only: `mode` is a literal at both call sites, so the validation copy of this function carries no pruning code
+    // at all — with it, as dead weight, the moving regime ran 3 % slower; sweeps that prune hardly ever validate)
+    const bool prune = mode == 0 && a.prune != 0 && !(a.dbg & 5);
     if (valid) {
         u = V.pi[i];  // matrices, S and slot_of are stored in the internal (cluster-contiguous) point order
         own = V.slot_of[u];
@@ -2602,26 +2604,7 @@ __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Ta
             }
         } else {
             const int Kc = T.misc[14];
-            // own cluster first, then the slots a change touched (computed), then the clean ones (stored scores)
-            for (int pos = (prune || st == ((K + 1) % NS)) ? -1 : Kc + st; pos < K; pos = (pos < 0) ? Kc + st : pos + NS) {
-                const int k = (pos < 0) ? own : (int)T.act2[pos];
-                if (pos >= 0) {
-                    if (k == own) continue;
-                    if (mode == 1 && !T.dirty[k]) {                // a slot of the batch: untouched for this point if no entry of its group precedes it
-                        const int e0 = k ? T.seg[k - 1] : 0;
-                        if (e0 == T.seg[k] || T.pairs[e0] >= j) {
-                            const double v = wrow[(size_t)k * V.ldw];
-                            if (v == v) {
-                                const int lab = T.label[k];
-                                if (bestslot == -2 || v > bestv || (v == bestv && lab < bestpos)) { bestv = v; bestpos = lab; bestslot = k; }
-                                continue;
-                            }
-                            if (bestslot != -2 && rc_pruned_bound(v) < bestv) continue;    // pruned when it was stored, and still out of reach
-                        }
-                    }
-                }
-                consider(k);
-            }
+            // the clean slots first (stored scores: their loads are in flight while nothing else is), ...
             for (int pos = st; pos < Kc; pos += 4 * NS) {      // clean slots: the stored score — four loads in flight (one per turn was a memory round trip per candidate)
                 int kk[4];
                 double vv[4];
@@ -2648,6 +2631,26 @@ __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Ta
                     needm &= needm - 1u;
                     consider(q == 0 ? kk[0] : q == 1 ? kk[1] : q == 2 ? kk[2] : kk[3]);
                 }
+            }
+            // ... then the point's own cluster and the slots a change touched (computed)
+            for (int pos = (prune || st == ((K + 1) % NS)) ? -1 : Kc + st; pos < K; pos = (pos < 0) ? Kc + st : pos + NS) {
+                const int k = (pos < 0) ? own : (int)T.act2[pos];
+                if (pos >= 0) {
+                    if (k == own) continue;
+                    if (mode == 1 && !T.dirty[k]) {                // a slot of the batch: untouched for this point if no entry of its group precedes it
+                        const int e0 = k ? T.seg[k - 1] : 0;
+                        if (e0 == T.seg[k] || T.pairs[e0] >= j) {
+                            const double v = wrow[(size_t)k * V.ldw];
+                            if (v == v) {
+                                const int lab = T.label[k];
+                                if (bestslot == -2 || v > bestv || (v == bestv && lab < bestpos)) { bestv = v; bestpos = lab; bestslot = k; }
+                                continue;
+                            }
+                            if (bestslot != -2 && rc_pruned_bound(v) < bestv) continue;    // pruned when it was stored, and still out of reach
+                        }
+                    }
+                }
+                consider(k);
             }
         }
         // clusters created by the changers before i: singletons {x_q}, row sums = row x_q of the matrices
