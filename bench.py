@@ -10,9 +10,17 @@ north_star's roofline target is quoted on); D and logD are already resident in H
 starts.  Chains are independent: with N GPUs every rank runs its own chain (weak scaling) and the only
 collective is the final sum all-reduce of the n×n co-clustering counts (outside the timed region, reported).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (k_bulk, HBM-bound, timed
-with HIP events on the library's own stream) and `cpu_baseline` (the C restatement of the reference's loop,
-faithful-cost mode, one host core, bounded sample).
+Prints ONE JSON line on rank 0 (contract in the task statement) with
+  `roofline`      the dominant kernel of the headline workload, k_bulk_syml2 (row reduction over the 48-bit packed upper triangle
+                  of D, logD derived with a table log): PHYSICAL figures only — the bytes the kernel reads ÷ its mean launch duration
+                  (HIP events carried in the dispatch, on the library's own stream) ÷ the 8 TB/s HBM peak; `bound` names what
+                  limits it (VALU issue + memory-side atomics: its 201 MB working set is served from the 256 MiB Infinity Cache,
+                  not from HBM), `compute` prices its VALU instruction stream, `equivalent_dataflow_GBps` keeps SURVEY.md §8(d)'s
+                  algorithmic pricing (never as a fraction: the kernel reads 3/8 of those bytes);
+  `other_configs` the other single-GPU BASELINE configurations, timed in this run: config 5 (N = 32768, K = 200, 32-bit storage, built
+                  from points — HBM-resident: a real HBM roofline for k_bulk_sym32) and config 2 (N = 2000, K = 20: sweeps/s and
+                  rc_run_chain iterations/s for numiters = 10000);
+  `cpu_baseline`  the C restatement of the reference's loop, faithful-cost mode, one host core, bounded sample.
 """
 import argparse
 import json
@@ -178,6 +186,102 @@ def median(xs):
     return xs[m] if len(xs) % 2 else 0.5 * (xs[m - 1] + xs[m])
 
 
+def profile_json(*names):
+    """The newest committed profiles/rNN/<name> among `names` (offline rocprofv3 --pmc results this run cannot collect itself)."""
+    for rnd in ("r04", "r03", "r02", "r01"):
+        for name in names:
+            f = os.path.join(ROOT, "profiles", rnd, name)
+            if os.path.exists(f):
+                try:
+                    return json.load(open(f)), f"profiles/{rnd}/{name}"
+                except Exception:   # noqa: BLE001
+                    pass
+    return None, None
+
+
+def kernel_roofline(ctx, rc, steps, sweep_fn, traffic_names, counters_names, kernel_timing_every=1):
+    """Physical roofline of the row-reduction kernel the context runs: bytes it has to read (rc_bulk_kernel_info) ÷ its mean launch
+    duration (HIP events in the dispatch) ÷ 8 TB/s.  sweep_fn(k) enqueues k sweeps and synchronises."""
+    sweep_fn(max(8, steps // 4))                                   # warm-up
+    ctx.kernel_timing(enable=kernel_timing_every)
+    t0 = time.perf_counter()
+    sweep_fn(steps)
+    dt = time.perf_counter() - t0
+    bulk_ms, launches = ctx.kernel_timing(enable=0)
+    fam, nbytes = ctx.bulk_kernel_info()
+    avg_ms = bulk_ms / max(launches, 1)
+    achieved = nbytes / (avg_ms * 1e-3) / 1e9 if launches else None
+    traffic, src = profile_json(*traffic_names)
+    return {"kernel": ctx.bulk_kernel_name(), "bytes_read_per_launch": nbytes, "avg_launch_ms": avg_ms, "launches": launches,
+            "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
+            "per_sweep_period": {"ms": dt / steps * 1e3, "GBps": nbytes / (dt / steps) / 1e9, "frac": nbytes / (dt / steps) / 1e9 / HBM_PEAK_GBPS},
+            "traffic": traffic["k_bulk_hbm_bytes_per_launch"] if traffic else None, "traffic_source": src}, dt
+
+
+def config5_leg(rc, dev0, kcap, steps):
+    """BASELINE config 5 on one GPU: N = 32768, K = 200, 32-bit fixed-point storage, built from the points on the device (no n x n host
+    matrix).  2 x 2.15 GB (upper triangles of D and logD) are read per sweep: far beyond the 256 MiB Infinity Cache, so this is the
+    workload on which an HBM roofline is meaningful."""
+    n, K = 32768, 200
+    t0 = time.perf_counter()
+    data = rc.generatemixture(n, K, seed=1, points_only=True)
+    pts, truth = data["points"], data["clusts"]
+    ctx = rc.Context.from_points(pts, kcap=kcap, storage_bits=32, device=dev0)
+    P = rc.likelihood_hyperparams_device(ctx, truth)
+    ctx.set_params(**P); ctx.set_state(truth)
+    setup_s = time.perf_counter() - t0
+    sweep = [0]
+
+    def run(k):
+        for _ in range(k):
+            ctx.gibbs_sweep(1.0, 0.5, 1, sweep[0], blocking=False); sweep[0] += 1
+        ctx.synchronize()
+    roof, _ = kernel_roofline(ctx, rc, steps, run, ("pmc_traffic_n32768_k_bulk_sym32.json",), ())
+    tw = []
+    for _ in range(3):
+        t1 = time.perf_counter(); run(steps); tw.append(time.perf_counter() - t1)
+    dt = median(tw)
+    st = ctx.sweep_stats()
+    out = {"workload": f"generatemixture N={n} K={K} dim={K} sigma=0.1 from points (rc_create_from_points), 32-bit fixed-point storage of D and logD, "
+                       "numMH=0 Gibbs sweep, init = generating labels, r=1 p=0.5, library-default capacity",
+           "sweeps_per_s": steps / dt, "ms_per_sweep": dt / steps * 1e3, "steps": steps, "windows_sweeps_per_s": [steps / x for x in tw],
+           "label_changes_last_sweep": st["n_changes"], "K_final": st["K"], "capacity": ctx.capacity_info(), "setup_s": setup_s,
+           "dtype": "i32 fixed-point storage of D and logD (2^-30 of the largest entry), i64 exact sums, f64 scores",
+           "roofline": dict(roof, bound="hbm", note="k_bulk_sym32 reads the upper triangles of D and logD (n(n+1)/2 x 4 B each = 4.29 GB per sweep): HBM-resident")}
+    ctx.close()
+    return out
+
+
+def config2_leg(rc, dev0, kcap, steps):
+    """BASELINE config 2: N = 2000, K = 20 dense Float64 distM, one chain, numiters = 10000 — the sweep alone (as `value`) and the whole
+    iteration of runsampler through rc_run_chain (sample_r, sample_p, [split-merge,] sweep, recording with the reference's default
+    burn-in and thinning), in the library-default full mode and in the incremental mode the hosts use."""
+    n, K, numiters = 2000, 20, 10000
+    data = rc.generatemixture(n, K, seed=1)
+    D, truth = data["distancematrix"], data["clusts"]
+    P = rc.likelihood_hyperparams(D, truth)
+    ctx = rc.Context(D, device=dev0, kcap=kcap)
+    ctx.set_params(**P); ctx.set_state(truth); ctx.cocluster_reset()
+    tw, _ = timed_windows(ctx, 1, 1.0, 0.5, max(steps, 200), 50, 3, lambda: None)
+    out = {"workload": f"generatemixture N={n} K={K} dim={K} sigma=0.1 dense Float64 distM, 1 chain, init = generating labels",
+           "sweeps_per_s": max(steps, 200) / median(tw), "kernel": ctx.bulk_kernel_name(), "numiters": numiters}
+    ctx.attach_host_matrices(D)
+    for name, numMH, mode in (("numMH0", 0, "full"), ("numMH0_incremental_mode", 0, "incremental"), ("reference_defaults_numMH1", 1, "full"),
+                              ("reference_defaults_numMH1_incremental_mode", 1, "incremental")):
+        ctx.set_state(truth); ctx.cocluster_reset(); ctx.set_mode(mode)
+        ctx.run_chain(200, 0, 1, 5, numMH, 1, 1.0, 0.5, 1.0)                      # warm-up (worker threads, pinned buffers)
+        t1 = time.perf_counter()
+        ch = ctx.run_chain(numiters, numiters // 5, 1, 5, numMH, 1, 1.0, 0.5, 1.0, first_iter=200)   # MCMCOptionsList defaults: burnin = numiters / 5, thin = 1
+        dt = time.perf_counter() - t1
+        cs = ctx.chain_stats()
+        out[name] = {"iterations_per_s": numiters / dt, "seconds_for_numiters": dt, "samples": int(ch["num_samples"]), "numMH": numMH, "numGibbs": 5, "mode": mode,
+                     "K_final": int(ch["K"][-1]), "workers": cs["workers"], "rollbacks": cs["rollbacks"],
+                     "splitmerge_acceptances": int(ch["splitmerge_acceptances"].sum()) if numMH else 0}
+    ctx.set_mode("full")
+    ctx.close()
+    return out
+
+
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
@@ -248,6 +352,15 @@ def main():
     results = [None] * len(ctxs)
 
     def chain_job(ci):
+        try:
+            chain_job_body(ci)
+        except BaseException:      # noqa: BLE001 — a failed chain must not leave the others waiting at the window barrier for ever
+            import traceback
+            traceback.print_exc()
+            if tbar is not None:
+                tbar.abort()
+
+    def chain_job_body(ci):
         c, sd = ctxs[ci], seeds[ci]
         sweep, unsettled = 0, None
         if settle_ms > 0:
@@ -387,13 +500,13 @@ def main():
     # rolls back), with the pipeline's rollbacks and worker threads
     defaults = None
     if extras and not os.environ.get("RC_BENCH_NO_DEFAULTS"):
-        def default_options_leg(Dx, Px, labels, burn, mode="full"):
+        def default_options_leg(Dx, Px, labels, burn, mode="full", workers=0, its=1000):
             cd = rc.Context(Dx, device=dev0, kcap=kcap, storage_bits=BITS)
             cd.set_params(**Px); cd.set_state(labels); cd.cocluster_reset()
             cd.set_mode(mode)                             # "full": the library default (as `value`); "incremental": what runsampler and the Julia glue set
+            cd.set_option("chain_workers", workers)       # 0 = automatic: the host's cores (minus one) up to 24
             cd.attach_host_matrices(Dx)                   # the proposals' restricted scans read the host matrix (logD derived by the library)
             cd.run_chain(burn, 0, 10, 5, 1, 1, r, p, 1.0)             # warm-up (worker threads, pinned buffers, caches; burn-in on the moving data)
-            its = 1000
             t1 = time.perf_counter()
             chd = cd.run_chain(its, 0, 10, 5, 1, 1, r, p, 1.0, first_iter=burn)
             t_def = time.perf_counter() - t1
@@ -407,6 +520,13 @@ def main():
         defaults = default_options_leg(D, P, truth, 100)
         defaults["note"] = ("rc_run_chain, speculative split-merge pipeline (proposals of several iterations decided concurrently; "
                             "bit-identical to the sequential loop); headline data, stationary")
+        # the same leg with 2, 4, 8 and 24 worker threads: on an 8-GPU node every chain has cores / 8 of the host
+        if not os.environ.get("RC_BENCH_NO_WORKER_SWEEP"):
+            defaults["by_worker_threads"] = {}
+            for w in (2, 4, 8, 24):
+                leg = default_options_leg(D, P, truth, 100, workers=w, its=600)
+                defaults["by_worker_threads"][str(w)] = {"iterations_per_s": leg["iterations_per_s"], "workers": leg["workers"]}
+            defaults["host_cores"] = os.cpu_count()
         if Dm is not None:
             defaults["moving_data"] = default_options_leg(Dm, Pm, tm, 200)
             defaults["moving_data_incremental_mode"] = default_options_leg(Dm, Pm, tm, 200, "incremental")
@@ -435,50 +555,102 @@ def main():
                               "splitmerge_splits": int(chr_["splitmerge_splits"].sum()), "rollbacks": cs["rollbacks"], "workers": cs["workers"], "K_final": int(chr_["K"][-1])}
                 cr.close()
             os.environ.pop("RC_CHAIN_PIPELINE", None)
+            # ... and where MANY are accepted: the first 500 iterations of the same data from ONE cluster and from random labels with
+            # three proposals per iteration (splitmerge = "intended") — rollbacks, and what a rolled-back iteration costs (it is redone
+            # by the synchronous path and the speculation restarts behind it) against the synchronous loop on the same chain
+            hot = {}
+            for start, init_h in (("one_cluster", np.ones(100, np.int64)), ("random_labels", init1)):
+                legs_h = {}
+                for name, pipe in (("speculative", 1), ("synchronous", 0)):
+                    cr = rc.Context(D1, device=dev0)
+                    cr.set_params(**P1); cr.set_state(init_h); cr.cocluster_reset(); cr.attach_host_matrices(D1)
+                    cr.set_option("chain_pipeline", pipe)
+                    its = 500
+                    t1 = time.perf_counter()
+                    chh = cr.run_chain(its, 0, 10, 5, 3, 5, r, p, 1.0, splitmerge="intended")
+                    t_h = time.perf_counter() - t1
+                    cs = cr.chain_stats()
+                    legs_h[name] = {"iterations_per_s": its / t_h, "seconds": t_h, "proposals": 3 * its, "splitmerge_acceptances": int(chh["splitmerge_acceptances"].sum()),
+                                    "splitmerge_splits": int(chh["splitmerge_splits"].sum()), "rollbacks": cs["rollbacks"], "workers": cs["workers"], "K_final": int(chh["K"][-1])}
+                    cr.close()
+                a_, b_ = legs_h["speculative"], legs_h["synchronous"]
+                rb = max(a_["rollbacks"], 1)
+                hot[start] = dict(legs_h, acceptance_rate=a_["splitmerge_acceptances"] / (3 * 500),
+                                  same_chain=a_["splitmerge_acceptances"] == b_["splitmerge_acceptances"] and a_["K_final"] == b_["K_final"],
+                                  # time the pipelined loop spends beyond what the synchronous loop needs for the SAME iterations, per rollback (negative: still ahead)
+                                  extra_ms_per_rollback_vs_synchronous=(a_["seconds"] - b_["seconds"]) / rb * 1e3)
+            defaults["with_many_accepted_proposals"] = dict(hot, iterations=500, numMH=3, data="paper dataset 1 (n = 100), splitmerge='intended'")
             defaults["with_accepted_proposals"] = dict(legs, iterations=3000, data="paper dataset 1 (n = 100), random initial labels, splitmerge='intended'",
                                                        same_chain=legs["speculative"]["splitmerge_acceptances"] == legs["synchronous"]["splitmerge_acceptances"]
                                                        and legs["speculative"]["K_final"] == legs["synchronous"]["K_final"])
         except Exception as e:   # noqa: BLE001
             defaults["with_accepted_proposals"] = {"error": str(e)}
     del Dm
+    other = None
+    if extras and not os.environ.get("RC_BENCH_NO_OTHER_CONFIGS"):
+        other = {}
+        for name, fn in (("config2_N2000_K20", lambda: config2_leg(rc, dev0, kcap, args.steps)),
+                         ("config5_N32768_K200_32bit", lambda: config5_leg(rc, dev0, kcap, max(10, min(args.steps, 40))))):
+            try:
+                other[name] = fn()
+            except Exception as e:   # noqa: BLE001 — reported in the line, never silently dropped
+                other[name] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
-        # bytes of matrix data the selected row-reduction kernel has to read per sweep: k_bulk reads every entry of D
-        # and logD (2·n²·sizeof); k_bulk_sym exploits symmetry and reads the upper triangle only
-        kernel_family, alg_bytes = ctx.bulk_kernel_info()     # bytes the kernel that ran has to read per launch
+        # bytes of matrix data the selected row-reduction kernel has to read per launch: k_bulk_syml2 streams the 48-bit packed upper
+        # triangle of D (n(n+1)/2 x 6 B) and derives logD on the fly; k_bulk_sym reads the upper triangles of both stored matrices;
+        # k_bulk every entry of the matrices it reads
+        kernel_family, read_bytes = ctx.bulk_kernel_info()
         kernel_name = ctx.bulk_kernel_name()
         esz = BITS / 8.0
-        # logD derived on the fly (no logD given, 64-bit storage): one matrix is read instead of two
-        derived = alg_bytes < 1.5 * (n * (n + 1) / 2 if kernel_family != "k_bulk" else n * n) * esz
-        # a sweep is priced at 2·n²·sizeof (D and logD read once each), or n²·sizeof "if the build
-        # recomputes log on the fly instead of staging logD"
+        derived = read_bytes < 1.5 * (n * (n + 1) / 2 if kernel_family != "k_bulk" else n * n) * esz
+        packed48 = kernel_name.startswith("k_bulk_syml2<true, true")
+        # a sweep is priced at 2·n²·sizeof (D and logD read once each), or n²·sizeof "if the build recomputes log on
+        # the fly instead of staging logD".  This design reads less than either (symmetry, 48-bit packing), so that pricing is an
+        # EQUIVALENT-DATAFLOW rate, reported under that name and never as a fraction of a bandwidth peak.
         survey_bytes = (1.0 if derived else 2.0) * n * n * esz
         full_bytes = 2.0 * n * n * esz
         value = world * args.steps / dt
+        period_s = dt / args.steps
         bulk_avg_ms = bulk_ms / max(bulk_launches, 1)
-        achieved = survey_bytes / (bulk_avg_ms * 1e-3) / 1e9 if bulk_launches else None       # §8(d) bytes ÷ kernel time
-        achieved_read = alg_bytes / (bulk_avg_ms * 1e-3) / 1e9 if bulk_launches else None     # bytes actually read ÷ kernel time
-        # HBM bytes per launch of that kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 FETCH_SIZE
-        # correction applied): collected OFFLINE with this same command (tools/prof_r03.sh) and committed — not measured in
-        # this run; `traffic_source` names the file
-        traffic = traffic_source = None
+        achieved = read_bytes / (bulk_avg_ms * 1e-3) / 1e9 if bulk_launches else None        # bytes the kernel reads ÷ its mean launch duration
         tag = kernel_name.replace("<", "_").replace(">", "").replace(", ", "_").replace(" ", "")
-        for rnd in ("r03", "r02", "r01"):
-            for name in (f"pmc_traffic_n{n}_{tag}.json", f"pmc_traffic_n{n}_{kernel_family}.json"):
-                f = os.path.join(ROOT, "profiles", rnd, name)
-                if traffic is None and os.path.exists(f) and BITS == 64 and (name.endswith(f"{tag}.json") or not derived):
-                    traffic = json.load(open(f))["k_bulk_hbm_bytes_per_launch"]
-                    traffic_source = f"profiles/{rnd}/{name} (rocprofv3 --pmc, collected offline with the same command)"
+        # rocprofv3 --pmc results of this same command, collected OFFLINE (tools/prof_r04.sh) and committed: bytes at the L2's memory
+        # side per launch (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes) and the instruction counters of the kernel
+        traffic_rec, traffic_source = profile_json(f"pmc_traffic_n{n}_{tag}.json", f"pmc_traffic_n{n}_{kernel_family}.json") if BITS == 64 else (None, None)
+        counters, counters_source = profile_json(f"counters_n{n}_{tag}.json") if BITS == 64 else (None, None)
+        working_set_fits_mall = read_bytes <= 256 * 2 ** 20
+        if kernel_name.startswith("k_bulk_syml2") and working_set_fits_mall:
+            bound = "valu_issue+memory_side_atomics"
+            served = ("Infinity Cache: the %.0f MB the kernel reads per launch stay resident in the 256 MiB last-level cache from one sweep to the next "
+                      "(FETCH_SIZE counts those hits at the L2's memory side); HBM itself is close to idle" % (read_bytes / 1e6))
+        else:
+            bound = "hbm"
+            served = "HBM" if not working_set_fits_mall else "Infinity Cache / HBM"
+        compute = None
+        if counters and bulk_launches:
+            # VALU issue time of one launch: wave instructions x measured cycles per instruction and SIMD ÷ (SIMDs x clock)
+            # (tools/valu_rate.hip: 1.9 cycles for 32-bit ALU ops with >= 3 waves per SIMD, 3.0-3.9 for 64-bit integer, FP64, DPP
+            # and conversion instructions; the kernel's mix is priced at the figure the counters file states)
+            simds = 4 * 256
+            issue_s = counters["SQ_INSTS_VALU"] * counters["cycles_per_valu_inst"] / (simds * counters["clock_ghz"] * 1e9)
+            compute = {"valu_wave_insts_per_launch": counters["SQ_INSTS_VALU"], "salu_wave_insts_per_launch": counters.get("SQ_INSTS_SALU"),
+                       "lds_bank_conflict_rate": (counters["SQ_LDS_BANK_CONFLICT"] / counters["SQ_LDS_IDX_ACTIVE"]) if counters.get("SQ_LDS_IDX_ACTIVE") else None,
+                       "atomic_bytes_per_launch": counters.get("WRITE_SIZE_bytes"), "cycles_per_valu_inst": counters["cycles_per_valu_inst"],
+                       "simds": simds, "clock_ghz": counters["clock_ghz"], "valu_issue_us_per_launch": issue_s * 1e6,
+                       "frac_of_launch": issue_s / (bulk_avg_ms * 1e-3), "source": counters_source}
         ceiling = None
-        try:   # the fraction is also reported against a streaming-read ceiling measured on this box, now
+        try:   # also against a streaming-read ceiling measured on this box, now (2 GiB: HBM, not the cache)
             ceiling = rc.measure_read_ceiling(dev0, 2048, 5)
         except Exception:   # noqa: BLE001
             pass
-        period_s = dt / args.steps
+        dtype = (f"u48-packed fixed-point D (quantum 2^-47 of the largest entry; the {BITS}-bit master copy stays in HBM), logD = degree-4 table log of it "
+                 "rounded to fixed point (|error| <= 2^-eL + 2.6e-13 + entry rounding), i64 exact sums, f64 scores") if packed48 else \
+                f"i{BITS} fixed-point storage of D" + (" (logD derived: table log)" if derived else " and logD") + ", i64 exact sums, f64 scores"
         out = {
             "metric": "Gibbs sweeps/sec (n×n distM)", "value": value, "unit": "sweeps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": f"i{BITS} fixed-point storage, i64 exact sums, f64 scores",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic",
             "config": {"workload": f"generatemixture N={n} K={K} dim={K} sigma=0.1 dense Float64 distM ({BITS}-bit fixed-point storage), 1 chain per GPU, "
                                    "numMH=0 Gibbs sweep, init = generating labels (stationary), r=1 p=0.5",
@@ -489,40 +661,35 @@ def main():
                        "value_is": f"median of {windows} windows of exactly {args.steps} steps (each bracketed by barrier + device synchronize)",
                        "windows_sweeps_per_s": [world * args.steps / x for x in win],
                        "windows_min_max_sweeps_per_s": [world * args.steps / max(win), world * args.steps / min(win)],
+                       "timed_region_s": sum(win),
                        "settle_ms": settle_ms, "sweeps_per_s_before_settle": (world * args.steps / unsettled_t) if unsettled_t else None,
                        "settle_note": "untimed sweeps of the same workload before the warm-up steps (device clocks of a running chain; RC_BENCH_SETTLE_MS=0 disables)"},
             "logD": "derived on the fly (table log of the fixed-point D)" if derived else "stored",
             "kcap512_sweeps_per_s": kcap512,
-            "sweep_GBps_algorithmic": value / world * survey_bytes / 1e9,          # whole sweep (not just the kernel) at §8(d) bytes
-            "sweep_frac_of_hbm_peak": value / world * survey_bytes / 1e9 / HBM_PEAK_GBPS,
-            "sweep_GBps_on_bytes_read": value / world * alg_bytes / 1e9,
-            "sweep_frac_of_hbm_peak_on_bytes_read": value / world * alg_bytes / 1e9 / HBM_PEAK_GBPS,   # physical: bytes the kernel reads per sweep PERIOD
-            "sweep_GBps_vs_reference_dataflow": value / world * full_bytes / 1e9,  # 2·n²·sizeof per sweep, what the reference reads
             "label_changes_last_sweep": stats["n_changes"], "K_final": stats["K"],
             "moving_regime": moving,
             "reference_default_options": defaults,
+            "other_configs": other,
             "incremental_mode_sweeps_per_s_rank0": inc_sweeps_per_s,
             "coclustering_allreduce_ms": allreduce_ms, "coclustering_merge_path": merge_path, "coclustering_diag_ok": diag_ok,
-            # roofline of the dominant kernel.  `frac_on_bytes_read` is the PHYSICAL figure (bytes the kernel has to read — the upper
-            # triangle of D — ÷ its mean launch duration ÷ peak); `achieved` / `frac` use the algorithmic bytes SURVEY.md §8(d)
-            # prescribes (see survey_bytes above), which this design undercuts by symmetry; `traffic` is the HBM bytes per launch
-            # measured with the PMC counters.
-            "roofline": {"kernel": kernel_name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            # Roofline of the dominant kernel — physical figures only.  achieved = the bytes this kernel reads per launch ÷ its mean
+            # launch duration; frac = achieved ÷ the 8 TB/s HBM peak (<= 1 by construction, reproducible from the rocprofv3 kernel
+            # stats under profiles/); `bound` names what limits the kernel; `served_from` the memory level its bytes come from.
+            "roofline": {"kernel": kernel_name, "bound": bound, "served_from": served,
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
+                         "bytes_read_per_launch": read_bytes, "avg_launch_ms": bulk_avg_ms, "launches": bulk_launches, "timed_every_nth_launch": time_every,
+                         "per_sweep_period": {"ms": period_s * 1e3, "GBps": read_bytes / period_s / 1e9, "frac": read_bytes / period_s / 1e9 / HBM_PEAK_GBPS,
+                                              "note": "the same bytes ÷ ms_per_step (launches of consecutive sweeps overlap on two streams, so a launch lasts longer than a period)"},
+                         "traffic": traffic_rec["k_bulk_hbm_bytes_per_launch"] if traffic_rec else None, "traffic_source": traffic_source,
+                         "traffic_note": "bytes at the L2's memory side per launch (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes, collected offline with this command); Infinity-Cache hits are counted there",
+                         "compute": compute,
                          "measured_streaming_read_GBps": ceiling, "frac_of_measured_streaming_read": (achieved / ceiling) if achieved and ceiling else None,
-                         "frac_on_bytes_read_of_measured_streaming_read": (achieved_read / ceiling) if achieved_read and ceiling else None,
-                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic, "traffic_source": traffic_source,
-                         "pricing": "frac_on_bytes_read (physical): the bytes this kernel has to read (the upper triangle only) ÷ mean launch duration; "
-                                    "achieved / frac: SURVEY.md §8(d) algorithmic bytes per sweep (n²·sizeof when logD is derived on the fly, "
-                                    "2·n²·sizeof when stored) ÷ the same duration; *_per_sweep_period: the same bytes ÷ the sweep period "
-                                    "(launches of consecutive sweeps overlap on two streams, so a launch lasts longer than a period)",
-                         "timed_every_nth_launch": time_every,
-                         "avg_launch_ms": bulk_avg_ms, "launches": bulk_launches,
-                         "algorithmic_bytes_per_launch": survey_bytes,
-                         "bytes_read_by_kernel_per_launch": alg_bytes,
-                         "achieved_on_bytes_read": achieved_read,
-                         "frac_on_bytes_read": (achieved_read / HBM_PEAK_GBPS) if achieved_read else None,
-                         "frac_on_bytes_read_per_sweep_period": alg_bytes / period_s / 1e9 / HBM_PEAK_GBPS,
-                         "frac_per_sweep_period": survey_bytes / period_s / 1e9 / HBM_PEAK_GBPS,
+                         # SURVEY.md §8(d)'s algorithmic pricing of the same launches (n²·sizeof per sweep with logD derived, 2·n²·sizeof stored):
+                         # what a kernel that read every entry of the matrices would have to stream to keep up — NOT a bandwidth
+                         "equivalent_dataflow_GBps": (survey_bytes / (bulk_avg_ms * 1e-3) / 1e9) if bulk_launches else None,
+                         "equivalent_dataflow_bytes_per_sweep": survey_bytes,
+                         "equivalent_dataflow_GBps_per_sweep_period": survey_bytes / period_s / 1e9,
+                         "reference_dataflow_bytes_per_sweep": full_bytes,
                          "event_pair_overhead_ms_subtracted": ctx.event_overhead_ms()},
         }
         if world == 1 and not args.no_cpu_baseline:

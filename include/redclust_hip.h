@@ -161,6 +161,11 @@ int32_t rc_state_restore(rc_ctx *ctx);
 int32_t rc_debug_rowsums(rc_ctx *ctx, int64_t label, int64_t *sumD_q /* n */, int64_t *sumL_q /* n */,
                          int32_t *eD, int32_t *eL);
 
+/* Fixed-point row totals of the matrices as the caller gave them: totD_q[i] = Σ_j Dq[i,j], totL_q[i] = Σ_j Lq[i,j] (value =
+ * q·2^-e, exponents from rc_debug_rowsums).  Computed by a plain per-row kernel that shares nothing with the row-reduction
+ * kernels: Σ_labels rc_debug_rowsums(label)[i] must equal it (the full matsum(x) of src/utils.jl:18-24 row by row). */
+int32_t rc_debug_rowtotals(rc_ctx *ctx, int64_t *totD_q /* n */, int64_t *totL_q /* n */);
+
 /* Timing of the dominant kernel (row-bucket reduction) measured with HIP events on the stream it is launched
  * on: accumulated milliseconds and number of timed launches since the last reset.  enable: 0 = off, 1 = time
  * every launch, N > 1 = time every N-th launch, negative = just read the counters.  The two events of a timed
@@ -171,16 +176,29 @@ int32_t rc_kernel_timing(rc_ctx *ctx, int32_t enable, double *bulk_ms_total, int
  * what such a pair reports around an empty kernel; kept so that the bench line can say so). */
 int32_t rc_event_overhead_ms(rc_ctx *ctx, double *out);
 
-/* Which row-reduction kernel the last enqueued sweep used — 0: k_bulk (reads every entry of D and logD, any point
- * order), 1: k_bulk_sym (reads only the upper triangle; chosen automatically when the points of a cluster are
- * contiguous in the point order, override with RC_BULK_KERNEL=perm|sym|auto) — and the matrix bytes that kernel
- * has to read per launch. */
+/* Which row-reduction kernel the last enqueued sweep used — *which = 0: k_bulk (reads every entry of D and logD, any point
+ * order), 1: one of the symmetric kernels (upper triangle only; chosen automatically when the points of a cluster are
+ * contiguous in the internal point order, override with rc_set_bulk_kernel or RC_BULK_KERNEL=perm|sym|auto).  Which symmetric
+ * kernel that is depends on the storage: k_bulk_syml2 (64-bit storage, the default: wave-autonomous units; with logD derived
+ * it streams the 48-bit packed copy of D), k_bulk_sym (64-bit, logD stored: block-tiled), k_bulk_sym32 (32-bit storage) —
+ * rc_bulk_kernel_name says which.  *algorithmic_bytes = the matrix bytes that kernel has to read per launch (what bench.py's
+ * roofline prices): every entry of the matrices it reads for k_bulk, the upper triangle incl. diagonal for the symmetric
+ * ones, at 6 bytes per entry for the packed copy. */
 int32_t rc_bulk_kernel_info(rc_ctx *ctx, int32_t *which, double *algorithmic_bytes);
-/* The kernel's name as a profiler shows it (k_bulk<long long, false>, k_bulk_sym<false>, k_bulk_syml<true> ...: the
- * template flag says whether logD is derived on the fly). */
+/* The kernel's name as a profiler shows it (k_bulk_syml2<true, true>: logD derived, packed copy; k_bulk<long long, false>,
+ * k_bulk_sym<false>, k_bulk_sym32 ...). */
 const char *rc_bulk_kernel_name(rc_ctx *ctx);
-/* Force the kernel: -1 automatic, 0 k_bulk, 1 k_bulk_sym (tests / measurements; results are identical). */
+/* Force the kernel family: -1 automatic, 0 k_bulk (full read), 1 the symmetric kernel of this context (tests / measurements;
+ * results are identical bit for bit). */
 int32_t rc_set_bulk_kernel(rc_ctx *ctx, int32_t which);
+/* Run-time options of one context.  Defaults come from the environment once, when the context is created (INTEGRATION.md
+ * "Environment switches"); nothing reads the environment per sweep or per chain.
+ *   "prune"          -1 automatic (default), 0 never, 1 always: candidates that cannot win skip their Gumbel noise (exact either way)
+ *   "chain_workers"  worker threads of rc_run_chain (0 = automatic: the host's cores shared by the chains of this process)
+ *   "chain_depth"    iterations rc_run_chain keeps in flight (0 = automatic: 24)
+ *   "chain_pipeline" 1 (default): the pipelined loop; 0: its synchronous form (the same chain bit for bit)
+ * No reference counterpart (the reference has no tuning knobs on this path). */
+int32_t rc_set_option(rc_ctx *ctx, const char *name, int64_t value);
 /* Internal point layout.  rc_set_state stores D and logD with the points of a cluster contiguous (a stable sort of
  * the caller's points by label), so that k_bulk_sym applies whatever order the caller's points come in; the sweep
  * still visits the points in the caller's order and every output is in the caller's order.  Label movement

@@ -86,6 +86,21 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return SO
 
 
+def build_diag(extra_defines=(), name="libredclust_hip_diag.so", verbose: bool = False) -> str:
+    """The tuning / diagnostic build (-DRC_DIAG: the RC_* environment switches INTEGRATION.md lists as diagnostic exist only
+    here; extra_defines e.g. ("RC_CHAOS=15",), ("RC_POISON",)).  Written to build_exp/ (git- and gpurun-ignored: build it on
+    the box that uses it, select it with RC_LIB_PATH)."""
+    out_dir = os.path.join(ROOT, "build_exp")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, name)
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DRC_DIAG"] + [f"-D{d}" for d in extra_defines] + \
+          ["-o", so, os.path.join(CSRC, "redclust_hip.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return so
+
+
 _dp = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 _ip = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
 _up = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
@@ -119,8 +134,10 @@ SIGNATURES = {
     "rc_state_checkpoint": (C.c_int32, [C.c_void_p]),
     "rc_state_restore": (C.c_int32, [C.c_void_p]),
     "rc_debug_rowsums": (C.c_int32, [C.c_void_p, C.c_int64, _ip, _ip, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "rc_debug_rowtotals": (C.c_int32, [C.c_void_p, _ip, _ip]),
     "rc_bulk_kernel_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "rc_set_bulk_kernel": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "rc_set_option": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64]),
     "rc_bulk_kernel_name": (C.c_char_p, [C.c_void_p]),
     "rc_within_between": (C.c_int32, [C.c_void_p, C.POINTER(RcWbStats)]),
     "rc_run_chain": (C.c_int32, [C.c_void_p, C.POINTER(RcChainOptions), C.POINTER(RcChainOutputs)]),
@@ -332,6 +349,13 @@ class Context:
         self._chk(self.L.rc_debug_rowsums(self.h, int(label), sd, sl, C.byref(eD), C.byref(eL)))
         return sd, sl, eD.value, eL.value
 
+    def debug_rowtotals(self):
+        """rc_debug_rowtotals: (Σ_j Dq[i,j], Σ_j Lq[i,j]) of every row, fixed point, by a kernel independent of the row reductions."""
+        td = np.zeros(self.n, np.int64)
+        tl = np.zeros(self.n, np.int64)
+        self._chk(self.L.rc_debug_rowtotals(self.h, td, tl))
+        return td, tl
+
     def bulk_kernel_info(self):
         w, b = C.c_int32(), C.c_double()
         self._chk(self.L.rc_bulk_kernel_info(self.h, C.byref(w), C.byref(b)))
@@ -342,6 +366,10 @@ class Context:
 
     def set_bulk_kernel(self, which):
         self._chk(self.L.rc_set_bulk_kernel(self.h, {"auto": -1, "perm": 0, "sym": 1}[which]))
+
+    def set_option(self, name, value):
+        """rc_set_option: "prune" (-1 automatic / 0 / 1), "chain_workers", "chain_depth" (0 = automatic), "chain_pipeline" (0 / 1)."""
+        self._chk(self.L.rc_set_option(self.h, name.encode(), int(value)))
 
     def run_chain(self, numiters, burnin, thin, numGibbs, numMH, seed, r0, p0, proposalsd_r, splitmerge="as_written",
                   rp_trace=None, first_iter=0):

@@ -508,15 +508,15 @@ static int32_t run_chain_speculative(rc_ctx *c, const rc_chain_options *o, rc_ch
     const rc_params &P = c->P;
     // iterations in flight: a proposal is 0.8 ms of a worker's time, an iteration 70-100 µs of the main thread's — a dozen
     // iterations deep the main thread waited for the oldest job
-    int Dmax = std::max(1, std::min(64, getenv("RC_CHAIN_DEPTH") ? atoi(getenv("RC_CHAIN_DEPTH")) : 24));
+    int Dmax = std::max(1, std::min(64, c->opt_chain_depth > 0 ? c->opt_chain_depth : 24));
     // every iteration in flight holds a snapshot of the K x K block sums in pinned memory (32 B per pair: 2 MB at 256 slots, 134 MB at
     // 2048): a chain that starts among many hundreds of clusters keeps fewer in flight
-    if (!getenv("RC_CHAIN_DEPTH") && c->hsum->slot_hi > 512) Dmax = std::min(Dmax, c->hsum->slot_hi > 1024 ? 3 : 8);
+    if (c->opt_chain_depth <= 0 && c->hsum->slot_hi > 512) Dmax = std::min(Dmax, c->hsum->slot_hi > 1024 ? 3 : 8);
     // worker threads: the host's cores shared by the chains this process runs at once (rc_run_chains: one per GPU — eight
     // chains must not start 200 threads), one core left to each chain's main thread; at most 24
     const int chains_here = std::max(1, g_chains_running.load());
     const int cores = (int)std::max(2u, std::thread::hardware_concurrency());
-    int nw = getenv("RC_CHAIN_WORKERS") ? atoi(getenv("RC_CHAIN_WORKERS")) : std::min(24, std::max(1, cores / chains_here - 1));
+    int nw = c->opt_chain_workers > 0 ? c->opt_chain_workers : std::min(24, std::max(1, cores / chains_here - 1));
     nw = std::max(1, std::min(nw, Dmax));
     const long long grows0 = c->n_grows;
     const int Rn = Dmax + 2;
@@ -734,7 +734,7 @@ static int32_t run_chain_speculative(rc_ctx *c, const rc_chain_options *o, rc_ch
     if (rc != RC_OK) return rc;
     out->num_samples = j;
     out->runtime_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (getenv("RC_SM_PROFILE"))
+    if (c->sm_profile)
         fprintf(stderr, "[rc_run_chain speculative] %lld iterations %.3f s: %lld rollbacks %.3f s, %lld splits evaluated off-line; wait for sweep %.3f s, snapshot + launch %.3f s, wait for snapshot %.3f s, job build %.3f s; %d workers depth %d\n",
                 (long long)N, out->runtime_s, n_rollbacks, t_rollback, n_split_evals, t_sync, t_snap, t_evwait, t_build, nw, Dmax);
     (void)t_confirm;
@@ -791,7 +791,7 @@ extern "C" int32_t rc_run_chain(rc_ctx *c, const rc_chain_options *o, rc_chain_o
     // are recorded, and the host part of a recorded sample is a job of its worker pool instead of the main thread's (thin = 1, the
     // reference's default, at N = 8192: 8.4 k -> 11 k it/s stationary, 1.4 k -> 3 k while 40 labels move per sweep).  The loop below
     // is the synchronous form (RC_CHAIN_PIPELINE=0): same chain, bit for bit.
-    if (o->numiters > 0 && !(getenv("RC_CHAIN_PIPELINE") && atoi(getenv("RC_CHAIN_PIPELINE")) == 0))
+    if (o->numiters > 0 && c->opt_chain_pipeline)
         return chain::run_chain_speculative(c, o, out);
     const long long grows0 = c->n_grows;
     struct GrowNote { rc_ctx *c; long long g0; ~GrowNote() { c->chain_grows = c->n_grows - g0; } } grow_note{c, grows0};

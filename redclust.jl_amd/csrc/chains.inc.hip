@@ -40,7 +40,7 @@ static Api &api()
     static Api A;
     static std::once_flag once;
     std::call_once(once, [] {
-        const char *names[] = {getenv("RC_RCCL_PATH"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        const char *names[] = {rc_env("RC_RCCL_PATH"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char *nm : names) {
             if (!nm || !*nm) continue;
             A.handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
@@ -250,8 +250,7 @@ static int32_t run_chains_impl(int32_t n_chains, const int32_t *device_ids, cons
     if (opt->numMH > 0 && !Lhost) {
         try { hostL.resize((size_t)in->n * (size_t)in->n); }
         catch (const std::bad_alloc &) { rc_comm_destroy(cm); return fail(nullptr, RC_ERR_OOM, "rc_run_chains: no host memory for the %lld x %lld logD of the split-merge scans (pass logD, or numMH = 0)", (long long)in->n, (long long)in->n); }
-        for (int64_t i = 0; i < in->n; ++i)
-            for (int64_t j = 0; j < in->n; ++j) hostL[(size_t)(i * in->n + j)] = (i == j) ? 0.0 : std::log(in->D[(size_t)(i * in->n + j)]);
+        host_log_matrix(in->D, in->n, hostL.data());   // once for all chains, in parallel over the host's cores
         Lhost = hostL.data();
     }
     g_chains_running += n_chains;     // all chains of this call, before any starts: each sizes its worker pool by the share of the host's cores

@@ -70,6 +70,17 @@
 
 #include "../../include/redclust_hip.h"
 
+// Environment switches (INTEGRATION.md "Environment switches").  The OPERATIONAL ones are read when a context is created (or, for the
+// RC_CHAIN_* ones, copied into the context then) — never per sweep; the few that make sense at run time can be changed afterwards
+// with rc_set_option.  The TUNING / DIAGNOSTIC ones exist only in builds with -DRC_DIAG (tools/, build_exp/): in the product build
+// rc_env_diag is a constant null and the code behind it folds away.
+static inline const char *rc_env(const char *name) { return getenv(name); }
+#ifdef RC_DIAG
+static inline const char *rc_env_diag(const char *name) { return getenv(name); }
+#else
+static inline const char *rc_env_diag(const char *) { return nullptr; }
+#endif
+
 #ifdef RC_POISON   // diagnostic builds: every device allocation starts out filled with 0xAB, so that a read of memory that
                    // was never initialised gives the same wrong answer on every machine instead of depending on what the
                    // allocator recycled
@@ -426,6 +437,32 @@ __global__ __launch_bounds__(256) void k_get_rows(const T *__restrict__ Q, const
     for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
         const long long q = (long long)Q[(size_t)r * ld + j];
         out[(size_t)blockIdx.y * n + j] = derive ? ((j == r) ? 0.0 : (double)rc_qlog(q, eD, sL, tab) * scale) : (double)q * scale;
+    }
+}
+
+// Σ_j X[i][j] of every row of D and of logD in the CALLER's point order (the *_src copies; derived logD through rc_qlog, 0 on the
+// diagonal): a plain one-block-per-row sum that shares nothing with the row-reduction kernels (not their layout, not their packed
+// copy, not their unit lists) — the tests hold Σ_k S[k][i] against it at sizes where the checker cannot hold the matrix (config 5).
+template <typename T>
+__global__ __launch_bounds__(256) void k_rowtotals(const T *__restrict__ Dq, const T *__restrict__ Lq_or_null, int n, int ld, int derive,
+                                                   int eD, double sL, const double2 *__restrict__ tab, long long *__restrict__ outD,
+                                                   long long *__restrict__ outL)
+{
+    __shared__ long long red[2][4];
+    const int i = blockIdx.x;
+    long long sd = 0, sl = 0;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        const long long q = (long long)Dq[(size_t)i * ld + j];
+        sd += q;
+        if (Lq_or_null) sl += (long long)Lq_or_null[(size_t)i * ld + j];
+        else if (derive && j != i) sl += rc_qlog(q, eD, sL, tab);
+    }
+    for (int off = 32; off > 0; off >>= 1) { sd += __shfl_down(sd, off); sl += __shfl_down(sl, off); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sd; red[1][threadIdx.x >> 6] = sl; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        outD[i] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        outL[i] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     }
 }
 
@@ -3789,6 +3826,15 @@ struct rc_ctx {
     // length n (types.jl:131-137, mcmc.jl:198-199).  kcap = 0 at rc_create: sized from the first state (kcap_auto).
     bool kcap_auto = false;
     bool kcap_fixed = false;      // RC_KCAP_FIXED=1: never grow (the old behaviour: RC_ERR_CAPACITY), for tests of the error path
+    // run-time options: defaults from the environment when the context is created, changed afterwards with rc_set_option — nothing
+    // reads the environment per sweep or per chain
+    int opt_prune = -1;           // "prune": -1 automatic (on behind a sweep that changed at most 2 labels), 0 never, 1 always   (RC_NO_PRUNE / RC_PRUNE_ALWAYS)
+    int opt_chain_workers = 0;    // "chain_workers": worker threads of rc_run_chain, 0 = automatic   (RC_CHAIN_WORKERS)
+    int opt_chain_depth = 0;      // "chain_depth": iterations in flight, 0 = automatic   (RC_CHAIN_DEPTH)
+    int opt_chain_pipeline = 1;   // "chain_pipeline": 0 = the synchronous form of the loop   (RC_CHAIN_PIPELINE)
+    bool bulk_rows_forced = false;// (diagnostic builds: RC_BULK_ROWS pins the split length of k_bulk)
+    bool sm_profile = false;      // (diagnostic builds: RC_SM_PROFILE)
+    bool broken = false;          // a capacity growth ran out of device memory half-way: every later call returns RC_ERR_STATE
     int kcap_max = 0;
     int n_grows = 0;              // capacity growths so far (rc_capacity_info)
     struct SweepRec { double r, p; uint64_t seed, sweep_index; long long t; };
@@ -3921,7 +3967,7 @@ static void free_all(rc_ctx *c)
 struct SmProfile {
     double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long calls = 0;
-    bool on = getenv("RC_SM_PROFILE") && atoi(getenv("RC_SM_PROFILE"));
+    bool on = rc_env_diag("RC_SM_PROFILE") && atoi(rc_env_diag("RC_SM_PROFILE"));
     std::chrono::steady_clock::time_point last;
     void start() { if (on) { last = std::chrono::steady_clock::now(); ++calls; } }
     void lap(int k) { if (on) { auto now = std::chrono::steady_clock::now(); t[k] += std::chrono::duration<double>(now - last).count(); last = now; } }
@@ -4002,7 +4048,7 @@ static int32_t alloc_slot_buffers(rc_ctx *c)
     HIPCHK(c, hipMalloc(&c->slot_label, k * sizeof(int)));
     HIPCHK(c, hipMalloc(&c->slot_pos, k * sizeof(short)));
     HIPCHK(c, hipMalloc(&c->slot_act, k * sizeof(short)));
-    if (!getenv("RC_SCORE_CACHE") || atoi(getenv("RC_SCORE_CACHE")) != 0)
+    if (!rc_env("RC_SCORE_CACHE") || atoi(rc_env("RC_SCORE_CACHE")) != 0)
         HIPCHK(c, hipMalloc((void **)&c->wc, k * (size_t)((c->n + RC_PTS - 1) / RC_PTS * RC_PTS) * sizeof(double)));
     HIPCHK(c, hipMalloc(&c->blocks, k * k * 4 * sizeof(long long)));
     HIPCHK(c, hipMemsetAsync(c->slot_size, 0, k * sizeof(int), c->sA));
@@ -4021,13 +4067,13 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     int pr_least = 0, pr_greatest = 0;
     HIPCHK(c, hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
     HIPCHK(c, hipStreamCreateWithPriority(&c->sA, hipStreamNonBlocking, pr_greatest));
-    if (getenv("RC_ONE_STREAM") && atoi(getenv("RC_ONE_STREAM"))) {
+    if (rc_env_diag("RC_ONE_STREAM") && atoi(rc_env_diag("RC_ONE_STREAM"))) {
         c->sB = c->sA;  // experiment: everything in order on one stream, no cross-stream events
         c->sB2 = c->sA;
         c->prefetch = false;
     } else {
         HIPCHK(c, hipStreamCreateWithPriority(&c->sB, hipStreamNonBlocking, pr_least));
-        if (getenv("RC_ONE_BULK_STREAM") && atoi(getenv("RC_ONE_BULK_STREAM"))) c->sB2 = c->sB;
+        if (rc_env_diag("RC_ONE_BULK_STREAM") && atoi(rc_env_diag("RC_ONE_BULK_STREAM"))) c->sB2 = c->sB;
         else HIPCHK(c, hipStreamCreateWithPriority(&c->sB2, hipStreamNonBlocking, pr_least));
     }
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
@@ -4064,7 +4110,7 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     HIPCHK2(hipMalloc(&mx, 2 * sizeof(u64)));
     const size_t esz = (size_t)c->bits / 8;
     // logD not given: derive it from Dq on the fly instead of storing it (rc_qlog; halves the bytes of every sweep)
-    bool derived = !logD && c->bits == 64 && !(getenv("RC_STORED_LOG") && atoi(getenv("RC_STORED_LOG")));
+    bool derived = !logD && c->bits == 64 && !(rc_env("RC_STORED_LOG") && atoi(rc_env("RC_STORED_LOG")));
     HIPCHK2(hipMalloc(&c->Dq, (size_t)n * ld * esz));
     HIPCHK2(hipMalloc(&c->Dq_src, (size_t)n * ld * esz));
     HIPCHK2(hipMalloc(&c->diagq, (size_t)n * sizeof(long long)));
@@ -4085,7 +4131,7 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     }
     HIPCHK2(hipMalloc(&c->slot_of, (size_t)n * sizeof(int)));
     HIPCHK2(hipMalloc(&c->rec, 2 * (size_t)n * sizeof(unsigned)));
-    c->wc_always = getenv("RC_SCORE_CACHE") && atoi(getenv("RC_SCORE_CACHE")) == 1;
+    c->wc_always = rc_env("RC_SCORE_CACHE") && atoi(rc_env("RC_SCORE_CACHE")) == 1;
     {
         const int32_t rcs = alloc_slot_buffers(c);   // everything sized by the slot capacity (re-allocated when it grows)
         if (rcs != RC_OK) { cleanup(); return rcs; }
@@ -4144,7 +4190,7 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
         // mantissa of 2^52
         int ex;
         std::frexp(maxD, &ex);
-        c->eD = std::min(c->eD, (getenv("RC_NO_PACK48") && atoi(getenv("RC_NO_PACK48"))) ? 51 - ex : 47 - ex);
+        c->eD = std::min(c->eD, (rc_env_diag("RC_NO_PACK48") && atoi(rc_env_diag("RC_NO_PACK48"))) ? 51 - ex : 47 - ex);
     }
     if (c->bits == 64) k_quantize<long long><<<gb, 256, 0, s>>>(tmpD, (int)n, c->ld, c->eD, (long long *)c->Dq_src, c->diag_src);
     else k_quantize<int><<<gb, 256, 0, s>>>(tmpD, (int)n, c->ld, c->eD, (int *)c->Dq_src, c->diag_src);
@@ -4163,7 +4209,16 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
         // log(Dq·2^-eD) differs from log(D) by the relative rounding of the entry, 1/(2·Dq): derive only when every
         // off-diagonal entry is at least 2^32 quanta (error ≤ 1.2e-10 per entry, ≤ 1e-12 for entries within 2^-10 of the
         // largest); a matrix with (near-)zero distances keeps logD of the exact doubles
-        if (n > 1 && hmn < (1ll << 32)) derived = false;
+        if (n > 1 && hmn < (1ll << 32)) {
+            // stored logD after all: the 47-bit cap on eD served only the packed copy and rc_qlog — quantise D again with every
+            // fraction bit the 64-bit sums allow
+            derived = false;
+            const int e_full = quant_exponent(n, maxD, c->bits);
+            if (e_full != c->eD) {
+                c->eD = e_full;
+                k_quantize<long long><<<gb, 256, 0, s>>>(tmpD, (int)n, c->ld, c->eD, (long long *)c->Dq_src, c->diag_src);
+            }
+        }
     }
     if (!derived && !log_staged) {
         // (stored mode reached through the fallback above: stage logD now)
@@ -4196,7 +4251,7 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
         }
         HIPCHK2(hipMemcpy(c->ltab, tab, sizeof(tab), hipMemcpyHostToDevice));
     }
-    if (derived && !(getenv("RC_NO_LQ_COPY") && atoi(getenv("RC_NO_LQ_COPY")))) {
+    if (derived && !(rc_env_diag("RC_NO_LQ_COPY") && atoi(rc_env_diag("RC_NO_LQ_COPY")))) {
         // random-access copy of the derived values for the resolver (see k_derived_fill); the row reduction ignores it
         HIPCHK2(hipMalloc(&c->Lq, (size_t)n * ld * esz));
         HIPCHK2(hipMalloc(&c->Lq_src, (size_t)n * ld * esz));
@@ -4219,7 +4274,7 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     HIPCHK2(hipMemcpyAsync(c->Dq, c->Dq_src, (size_t)n * ld * esz, hipMemcpyDeviceToDevice, s));
     if (c->Lq) HIPCHK2(hipMemcpyAsync(c->Lq, c->Lq_src, (size_t)n * ld * esz, hipMemcpyDeviceToDevice, s));
     HIPCHK2(hipMemcpyAsync(c->diagq, c->diag_src, (size_t)n * sizeof(long long), hipMemcpyDeviceToDevice, s));
-    if (c->derived && c->bits == 64 && !(getenv("RC_NO_PACK48") && atoi(getenv("RC_NO_PACK48")))) {
+    if (c->derived && c->bits == 64 && !(rc_env_diag("RC_NO_PACK48") && atoi(rc_env_diag("RC_NO_PACK48")))) {
         HIPCHK2(hipMalloc(&c->Dq48, (size_t)n * ld * 6));
         k_pack48<<<4096, 256, 0, s>>>((const long long *)c->Dq, (size_t)n * ld / 2, (unsigned *)c->Dq48);
     }
@@ -4254,18 +4309,25 @@ static int32_t alloc_ctx(int64_t n, int32_t storage_bits, int32_t device_id, int
     c->kcap = (int)kcap;
     c->kcap_auto = kcap_auto;
     c->kcap_max = (int)std::min<int64_t>(n, RC_MAX_KCAP);
-    c->kcap_fixed = getenv("RC_KCAP_FIXED") && atoi(getenv("RC_KCAP_FIXED"));
-    c->dbg = getenv("RC_DEBUG_FLAGS") ? atoi(getenv("RC_DEBUG_FLAGS")) : 0;
-    c->prefetch = !(getenv("RC_NO_PREFETCH") && atoi(getenv("RC_NO_PREFETCH")));
-    c->relayout = !(getenv("RC_NO_RELAYOUT") && atoi(getenv("RC_NO_RELAYOUT")));
-    c->res_one_stream = getenv("RC_RES_ONE_STREAM") ? atoi(getenv("RC_RES_ONE_STREAM")) != 0 : (n <= RC_RES_ONE_STREAM_MAX_N);
-    if (getenv("RC_SYM_VARIANT")) c->sym_variant = atoi(getenv("RC_SYM_VARIANT"));
-    if (getenv("RC_SYMW_PER_CU")) c->symw_per_cu = std::max(1, atoi(getenv("RC_SYMW_PER_CU")));
-    if (getenv("RC_SYML_PAD")) c->syml_pad = (size_t)std::max(0, atoi(getenv("RC_SYML_PAD")));
-    if (getenv("RC_SW_COARSE")) c->sw_coarse = std::min(128, std::max(8, atoi(getenv("RC_SW_COARSE")) & ~3));
-    if (getenv("RC_BULK_KERNEL")) c->bulk_kernel = !strcmp(getenv("RC_BULK_KERNEL"), "sym") ? 1 : (!strcmp(getenv("RC_BULK_KERNEL"), "perm") ? 0 : -1);
-    if (getenv("RC_RES_THREADS")) { const int rt_ = atoi(getenv("RC_RES_THREADS")); c->res_threads = (rt_ == 64 || rt_ == 128 || rt_ == 256) ? rt_ : 512; }
-    if (getenv("RC_SYM_ITEM_TILES")) c->sym_item_tiles = std::max(1, atoi(getenv("RC_SYM_ITEM_TILES")));
+    c->kcap_fixed = rc_env("RC_KCAP_FIXED") && atoi(rc_env("RC_KCAP_FIXED"));
+    c->dbg = rc_env_diag("RC_DEBUG_FLAGS") ? atoi(rc_env_diag("RC_DEBUG_FLAGS")) : 0;
+    if (rc_env("RC_NO_PRUNE") && atoi(rc_env("RC_NO_PRUNE"))) c->opt_prune = 0;
+    else if (rc_env("RC_PRUNE_ALWAYS") && atoi(rc_env("RC_PRUNE_ALWAYS"))) c->opt_prune = 1;
+    if (rc_env("RC_CHAIN_WORKERS")) c->opt_chain_workers = std::max(0, atoi(rc_env("RC_CHAIN_WORKERS")));
+    if (rc_env("RC_CHAIN_DEPTH")) c->opt_chain_depth = std::max(0, atoi(rc_env("RC_CHAIN_DEPTH")));
+    if (rc_env("RC_CHAIN_PIPELINE")) c->opt_chain_pipeline = atoi(rc_env("RC_CHAIN_PIPELINE")) != 0;
+    c->bulk_rows_forced = rc_env_diag("RC_BULK_ROWS") != nullptr;
+    c->sm_profile = rc_env_diag("RC_SM_PROFILE") != nullptr;
+    c->prefetch = !(rc_env_diag("RC_NO_PREFETCH") && atoi(rc_env_diag("RC_NO_PREFETCH")));
+    c->relayout = !(rc_env("RC_NO_RELAYOUT") && atoi(rc_env("RC_NO_RELAYOUT")));
+    c->res_one_stream = rc_env("RC_RES_ONE_STREAM") ? atoi(rc_env("RC_RES_ONE_STREAM")) != 0 : (n <= RC_RES_ONE_STREAM_MAX_N);
+    if (rc_env("RC_SYM_VARIANT")) c->sym_variant = atoi(rc_env("RC_SYM_VARIANT"));
+    if (rc_env_diag("RC_SYMW_PER_CU")) c->symw_per_cu = std::max(1, atoi(rc_env_diag("RC_SYMW_PER_CU")));
+    if (rc_env_diag("RC_SYML_PAD")) c->syml_pad = (size_t)std::max(0, atoi(rc_env_diag("RC_SYML_PAD")));
+    if (rc_env_diag("RC_SW_COARSE")) c->sw_coarse = std::min(128, std::max(8, atoi(rc_env_diag("RC_SW_COARSE")) & ~3));
+    if (rc_env("RC_BULK_KERNEL")) c->bulk_kernel = !strcmp(rc_env("RC_BULK_KERNEL"), "sym") ? 1 : (!strcmp(rc_env("RC_BULK_KERNEL"), "perm") ? 0 : -1);
+    if (rc_env_diag("RC_RES_THREADS")) { const int rt_ = atoi(rc_env_diag("RC_RES_THREADS")); c->res_threads = (rt_ == 64 || rt_ == 128 || rt_ == 256) ? rt_ : 512; }
+    if (rc_env_diag("RC_SYM_ITEM_TILES")) c->sym_item_tiles = std::max(1, atoi(rc_env_diag("RC_SYM_ITEM_TILES")));
     *out = c;
     return RC_OK;
 }
@@ -4290,7 +4352,7 @@ static int32_t build_syml2_lists(rc_ctx *c, int per_cu = 0)
 {
     const int n = c->n, ncb = (n + RC_SW_COLS - 1) / RC_SW_COLS, cap_blocks = (per_cu > 0 ? per_cu : c->symw_per_cu) * c->num_cus, nwaves = 4 * cap_blocks;
     struct Unit { int4 u; int cost; bool fast; };
-    const int slow_factor = getenv("RC_S2_SLOW_COST") ? std::max(1, atoi(getenv("RC_S2_SLOW_COST"))) : 3;
+    const int slow_factor = rc_env_diag("RC_S2_SLOW_COST") ? std::max(1, atoi(rc_env_diag("RC_S2_SLOW_COST"))) : 3;
     auto make_units = [&](int g, std::vector<Unit> &out) {
         out.clear();
         for (int J = ncb - 1; J >= 0; --J) {
@@ -4354,7 +4416,7 @@ static int32_t build_syml2_lists(rc_ctx *c, int per_cu = 0)
     // the flushes of a launch spread over its duration instead of coming at the same moments in every wave.  Measured: no gain
     // (74.9 against 73.5 us) — the ~18 us the atomics cost a launch (55 us without them) are not a drain at its end: 18 MB of 64-bit
     // atomics at the ~1 TB/s the memory side executes them is a per-CU occupancy of the vector memory path, spread or not.
-    if (getenv("RC_S2_STAGGER") && atoi(getenv("RC_S2_STAGGER"))) {
+    if (rc_env_diag("RC_S2_STAGGER") && atoi(rc_env_diag("RC_S2_STAGGER"))) {
         std::vector<int4> fast2;
         std::vector<int> wfast2((size_t)nwaves + 1, 0);
         fast2.reserve(2 * fast.size());
@@ -4386,7 +4448,7 @@ static int32_t build_syml2_lists(rc_ctx *c, int per_cu = 0)
     HIPCHK(c, hipMemcpy(c->wslow, wslow.data(), wslow.size() * sizeof(int), hipMemcpyHostToDevice));
     c->nfast = (int)fast.size(); c->nslow = (int)slow.size(); c->syml2_g = best_g;
     c->syml2_blocks = cap_blocks;      // every resident wave has its (possibly empty) share
-    if (getenv("RC_SM_PROFILE"))
+    if (rc_env_diag("RC_SM_PROFILE"))
         fprintf(stderr, "[rc_create] k_bulk_syml2: %d fast units of %d rows, %d slow units of %d rows over %d waves, makespan %lld tile costs\n",
                 c->nfast, best_g, c->nslow, RC_S2_SLOW_ROWS, nwaves, best);
     return RC_OK;
@@ -4396,7 +4458,7 @@ static int32_t build_syml2_lists(rc_ctx *c, int per_cu = 0)
 // which are put back afterwards.
 static int32_t build_syml2_alt(rc_ctx *c)
 {
-    if (c->symw_per_cu <= 2 || (getenv("RC_S2_NO_ALT") && atoi(getenv("RC_S2_NO_ALT")))) return RC_OK;
+    if (c->symw_per_cu <= 2 || (rc_env_diag("RC_S2_NO_ALT") && atoi(rc_env_diag("RC_S2_NO_ALT")))) return RC_OK;
     int4 *uf = c->ufast, *us = c->uslow;
     int *wf = c->wfast, *ws = c->wslow;
     const int nf = c->nfast, ns = c->nslow, nb = c->syml2_blocks, g = c->syml2_g;
@@ -4427,16 +4489,16 @@ static int32_t finish_create(rc_ctx *c)
         const size_t beside = syml ? (size_t)c->symw_per_cu * 40960 : (size_t)2 * 69632;   // (k_bulk_sym32: 67,864 B per block, k_bulk_sym: 67,288 B; measured: beside two of them 24.6 KB of tables become resident, 26.5 KB do not — 4 KiB allocation granules)
         const size_t avail = 160 * 1024 > beside + 1024 ? 160 * 1024 - beside - 1024 : 0;
         c->maxb = RC_MAXB;
-        if (getenv("RC_RES_MAXB")) c->maxb = std::max(16, std::min(RC_MAXB, atoi(getenv("RC_RES_MAXB"))));
+        if (rc_env("RC_RES_MAXB")) c->maxb = std::max(16, std::min(RC_MAXB, atoi(rc_env("RC_RES_MAXB"))));
         else if (c->n > 4096 && tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, RC_MAXB) > avail)
             for (int mb : {384, 256, 192, 128, 96, 64})
                 if (tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, mb) <= avail) { c->maxb = mb; break; }
         // a slot capacity whose tables cannot sit beside the reduction at any batch capacity (kcap >= 1024) must at least fit the CU:
         // kcap = 4096 needs 160 KiB at 512 entries per batch for n >= 8192, 149 KiB at 128
-        if (!getenv("RC_RES_MAXB") && tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, c->maxb) > 160 * 1024)
+        if (!rc_env("RC_RES_MAXB") && tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, c->maxb) > 160 * 1024)
             for (int mb : {384, 256, 192, 128, 96, 64})
                 if (tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, mb) <= 160 * 1024) { c->maxb = mb; break; }
-        if (getenv("RC_SM_PROFILE"))
+        if (rc_env_diag("RC_SM_PROFILE"))
             fprintf(stderr, "[rc_create] resolver batch capacity %d: tables %zu B (512: %zu, 256: %zu, 128: %zu, 64: %zu), %zu B free beside the row reduction\n", c->maxb,
                     tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, c->maxb), tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, 512), tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, 256),
                     tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, 128), tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, 64), avail);
@@ -4449,8 +4511,8 @@ static int32_t finish_create(rc_ctx *c)
         const int col_chunks = c->ld / (c->bits == 64 ? 512 : 1024);
         const int splits_target = std::max(1, 512 / col_chunks);
         c->rows_per_split = std::max(16, std::min(512, (c->n + splits_target - 1) / splits_target));
-        if (getenv("RC_BULK_ROWS")) c->rows_per_split = std::max(1, atoi(getenv("RC_BULK_ROWS")));
-        const int per_cu = getenv("RC_BULK_PER_CU") ? atoi(getenv("RC_BULK_PER_CU")) : 2;
+        if (rc_env_diag("RC_BULK_ROWS")) c->rows_per_split = std::max(1, atoi(rc_env_diag("RC_BULK_ROWS")));
+        const int per_cu = rc_env_diag("RC_BULK_PER_CU") ? atoi(rc_env_diag("RC_BULK_PER_CU")) : 2;
         // ... and the LDS the resolver's tables need must stay free beside them (160 KiB per CU): with the tables at 25-35 KiB
         // a fixed 150 KiB for the reduction left the resolver waiting for reduction blocks to retire
         const size_t lds_res = std::max(tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, c->maxb), 2 * sizeof(int) * (size_t)c->kcap);
@@ -4578,6 +4640,25 @@ extern "C" int32_t rc_get_matrix_rows(rc_ctx *c, int32_t which, const int64_t *r
     return RC_OK;
 }
 
+// Fixed-point row totals Σ_j D[i,j] and Σ_j logD[i,j] (value = q·2^-e) of the matrices as the caller gave them — k_rowtotals.
+extern "C" int32_t rc_debug_rowtotals(rc_ctx *c, int64_t *totD_q, int64_t *totL_q)
+{
+    if (!c || !totD_q || !totL_q) return fail(c, RC_ERR_ARG, "rc_debug_rowtotals: NULL argument");
+    HIPCHK(c, hipSetDevice(c->dev));
+    long long *d = nullptr;
+    HIPCHK(c, hipMalloc(&d, 2 * (size_t)c->n * sizeof(long long)));
+    const bool derive = c->derived && !c->Lq_src;
+    if (c->bits == 64) k_rowtotals<long long><<<c->n, 256, 0, c->sA>>>((const long long *)c->Dq_src, (const long long *)c->Lq_src, c->n, c->ld, derive ? 1 : 0, c->eD, std::ldexp(1.0, c->eL), c->ltab, d, d + c->n);
+    else k_rowtotals<int><<<c->n, 256, 0, c->sA>>>((const int *)c->Dq_src, (const int *)c->Lq_src, c->n, c->ld, 0, c->eD, 0.0, c->ltab, d, d + c->n);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(totD_q, d, (size_t)c->n * sizeof(long long), hipMemcpyDeviceToHost, c->sA);
+    if (e == hipSuccess) e = hipMemcpyAsync(totL_q, d + c->n, (size_t)c->n * sizeof(long long), hipMemcpyDeviceToHost, c->sA);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->sA);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, RC_ERR_HIP, "rc_debug_rowtotals: %s", hipGetErrorString(e));
+    return RC_OK;
+}
+
 extern "C" int32_t rc_set_params(rc_ctx *c, const rc_params *P)
 {
     if (!c || !P) return fail(c, RC_ERR_ARG, "rc_set_params: NULL argument");
@@ -4679,21 +4760,35 @@ static int capacity_for(const rc_ctx *c, long long need)
 static int32_t resize_capacity(rc_ctx *c, int new_kcap)
 {
     if (new_kcap == c->kcap) return RC_OK;
+    const int old_kcap = c->kcap;
+    c->have_state = false;                  // the old buffers go first: whatever happens below, the labels are gone from the device
     c->kcap = new_kcap;
     int32_t rc = alloc_slot_buffers(c);
-    if (rc != RC_OK) return rc;
-    rc = finish_create(c);
-    if (rc != RC_OK) return rc;
-    c->have_state = false;
+    if (rc == RC_OK) rc = finish_create(c);
+    if (rc != RC_OK) {
+        // out of device memory (kcap = 4096 at n = 8192 is 2.4 GB) or of LDS: back to the old capacity, so that the context stays
+        // usable after an rc_set_state that fits; if even that fails the context is dead and says so
+        char msg[512];
+        snprintf(msg, sizeof(msg), "%s", c->err);
+        c->kcap = old_kcap;
+        int32_t rc2 = alloc_slot_buffers(c);
+        if (rc2 == RC_OK) rc2 = finish_create(c);
+        if (rc2 != RC_OK) c->broken = true;
+        snprintf(c->err, sizeof(c->err), "growing the slot capacity %d -> %d failed: %s%s", old_kcap, new_kcap, msg,
+                 c->broken ? " (the context is unusable: destroy it)" : " (call rc_set_state again)");
+        snprintf(g_err, sizeof(g_err), "%s", c->err);
+        return rc;
+    }
     c->n_grows++;
     c->B_version = -2; c->ll_version = -1;
-    if (getenv("RC_SM_PROFILE")) fprintf(stderr, "[redclust] slot capacity -> %d (batch capacity %d)\n", c->kcap, c->maxb);
+    if (c->sm_profile) fprintf(stderr, "[redclust] slot capacity -> %d (batch capacity %d)\n", c->kcap, c->maxb);
     return RC_OK;
 }
 
 extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
 {
     if (!c || !clusts) return fail(c, RC_ERR_ARG, "rc_set_state: NULL argument");
+    if (c->broken) return fail(c, RC_ERR_STATE, "rc_set_state: the context lost its device buffers in a failed capacity growth; destroy it");
     HIPCHK(c, hipSetDevice(c->dev));
     HIPCHK(c, hipStreamSynchronize(c->sA));
     HIPCHK(c, hipStreamSynchronize(c->sB));
@@ -4745,7 +4840,7 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
         // blocks of 8000 rows each, 2.4 M element-wise atomics per launch, 260-340 us for k_bulk_syml2 instead of 70).  As ROWS they
         // cost a coalesced flush of direction 1 per row, in the first unit of every column block.  RC_LAYOUT_SMALL=0: by label only.
         {
-            static const int small_max = getenv("RC_LAYOUT_SMALL") ? atoi(getenv("RC_LAYOUT_SMALL")) : 7;
+            static const int small_max = rc_env_diag("RC_LAYOUT_SMALL") ? atoi(rc_env_diag("RC_LAYOUT_SMALL")) : 7;
             std::stable_sort(ipi.begin(), ipi.end(), [&](int a, int b) {
                 const bool la = size_by_label[(size_t)clusts[a]] > small_max, lb = size_by_label[(size_t)clusts[b]] > small_max;
                 return la != lb ? lb : clusts[a] < clusts[b];
@@ -4759,7 +4854,7 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
         // a column block or two.  Exactness does not depend on any of this.
         // (Kept as an experiment, RC_EVEN_RUNS=1: the ragged tail it creates costs more than it saves once the boundary lanes are
         // handled inside the kernel — k_bulk_syml2's donor lanes.)
-        if (uses_syml(c) && getenv("RC_EVEN_RUNS") && atoi(getenv("RC_EVEN_RUNS"))) {
+        if (uses_syml(c) && rc_env_diag("RC_EVEN_RUNS") && atoi(rc_env_diag("RC_EVEN_RUNS"))) {
             std::vector<int> body, tail;
             body.reserve((size_t)n);
             for (int w = 0; w < n;) {
@@ -4873,7 +4968,7 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
     // two compete for the CUs: the full-read kernel then takes half as many, longer splits (one block per CU at n = 8192 instead of
     // two), which leaves the resolver the issue slots it needs and still finishes inside its run (moving regime of bench.py:
     // 2,530 -> 3,230 sweeps/s; 1,024-row splits 2,890, 2,048-row splits 2,100: then the reduction is the longer of the two)
-    const int rows_split = (c->hsum->n_changes > 32 && !getenv("RC_BULK_ROWS")) ? std::max(c->rows_per_split, std::min(512, 2 * c->rows_per_split)) : c->rows_per_split;
+    const int rows_split = (c->hsum->n_changes > 32 && !c->bulk_rows_forced) ? std::max(c->rows_per_split, std::min(512, 2 * c->rows_per_split)) : c->rows_per_split;
     const int splits = (c->n + rows_split - 1) / rows_split;
     dim3 gb((unsigned)(c->ld / (c->bits == 64 ? 512 : 1024)), (unsigned)splits);
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
@@ -5067,6 +5162,12 @@ static int32_t sweep_enqueue(rc_ctx *c, double r, double p, uint64_t seed, uint6
         rc = rc_set_state(c, labels.data());
         if (rc != RC_OK) return rc;
     }
+    if (!c->recovering && c->inflight.size() >= 65536) {   // (a caller that never synchronises: bound the replay log — every entry before a
+        // completed sweep is dead.  BEFORE this sweep's view and record are made: the synchronisation may grow the capacity, which
+        // re-allocates the slot buffers and replays the log)
+        int32_t rcq = sync_and_check(c);
+        if (rcq != RC_OK) return rcq;
+    }
     View V = make_view(c);
     const long long t = c->t_next;
     if (t >= 0x7ffffff0ll) return fail(c, RC_ERR_STATE, "rc_gibbs_sweep: internal sweep counter exhausted; call rc_set_state");
@@ -5081,14 +5182,8 @@ static int32_t sweep_enqueue(rc_ctx *c, double r, double p, uint64_t seed, uint6
     sa.after0 = after0; sa.changes0 = changes0; sa.rounds0 = rounds0;
     // Pruning pays where most candidates are far from the point's own cluster — the stationary regime (N = 8192, K = 50: 15.7 k -> 16.4 k
     // sweeps/s) — and costs a few per cent where a chain moves among many small clusters (every stream evaluates the own cluster first)
-    const bool prune_off = getenv("RC_NO_PRUNE") && atoi(getenv("RC_NO_PRUNE"));                 // (read per sweep: tests switch them)
-    const bool prune_always = getenv("RC_PRUNE_ALWAYS") && atoi(getenv("RC_PRUNE_ALWAYS"));
-    sa.prune = (!prune_off && (prune_always || c->hsum->n_changes <= 2)) ? 1 : 0;   // (sigma = 0.18, 9 changes per sweep among 117 clusters: 9.8 k -> 9.2 k with it on)
+    sa.prune = (c->opt_prune != 0 && (c->opt_prune > 0 || c->hsum->n_changes <= 2)) ? 1 : 0;   // (rc_set_option "prune"; sigma = 0.18, 9 changes per sweep among 117 clusters: 9.8 k -> 9.2 k with it on)
     c->inflight.push_back(rc_ctx::SweepRec{r, p, seed, sweep_index, t});
-    if (c->inflight.size() > 65536) {   // (a caller that never synchronises: bound the replay log — every entry before a completed sweep is dead)
-        int32_t rcq = sync_and_check(c);
-        if (rcq != RC_OK) return rcq;
-    }
 #ifdef RC_TRACE_RESOLVE
     const size_t lds = std::max(tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, c->maxb), 2 * sizeof(int) * (size_t)c->kcap) + 4096;
 #else
@@ -5513,6 +5608,13 @@ extern "C" int32_t rc_record_sample(rc_ctx *c, int64_t *canonical_out)
     HIPCHK(c, hipSetDevice(c->dev));
     int32_t rc = ensure_counts(c);
     if (rc != RC_OK) return rc;
+    // Sweeps still in flight may have run out of slots: the capacity is grown and the sweeps resumed / replayed by sync_and_check,
+    // and a snapshot enqueued before that would hold the half-swept state (and its slot ids would be mapped through the layout of
+    // the re-installed state).  So the reader waits first.  (rc_run_chain synchronises before every snapshot of its own.)
+    if (!c->inflight.empty()) {
+        rc = sync_and_check(c);
+        if (rc != RC_OK) return rc;
+    }
     rc = order_A_after_sweeps(c);
     if (rc != RC_OK) return rc;
     k_snapshot<<<(c->ldc + 255) / 256, 256, 0, c->sA>>>(c->slot_of, c->pi, c->n, c->ldc, c->snap + (size_t)c->snap_cnt * c->ldc);
@@ -5604,7 +5706,9 @@ extern "C" int32_t rc_debug_rowsums(rc_ctx *c, int64_t label, int64_t *sumD_q, i
     if (!c->have_state) return fail(c, RC_ERR_STATE, "rc_debug_rowsums: no state set");
     HIPCHK(c, hipSetDevice(c->dev));
     int gen = 0;
-    int32_t rc = ensure_S(c, &gen);
+    int32_t rc = sync_and_check(c);        // (a sweep in flight may grow the capacity: buffers and generations change under it)
+    if (rc != RC_OK) return rc;
+    rc = ensure_S(c, &gen);
     if (rc != RC_OK) return rc;
     std::vector<int> so, ssize, slabel;
     rc = pull_state(c, so, ssize, slabel);
@@ -5674,6 +5778,25 @@ static double rc_uniform_mh(uint64_t seed, uint64_t iter, uint64_t mh, uint64_t 
     return ((double)bits + 0.5) * 0x1p-52;
 }
 
+// out = log.(D - Diagonal(D) + I) (types.jl:155) with libm's log of the caller's doubles — what the split–merge scans read (they are
+// pinned in the reference's literal arithmetic on log(D), golden_mh.npz).  Rows dealt to the host's cores: a serial loop is 0.5 s at
+// n = 8192 and 10 s at n = 32768.
+static void host_log_matrix(const double *D, int64_t n, double *out)
+{
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), (int64_t)64, n / 64 + 1}));
+    auto rows = [&](int t) {
+        for (int64_t i = t; i < n; i += nt)
+            for (int64_t j = 0; j < n; ++j) out[(size_t)(i * n + j)] = (i == j) ? 0.0 : std::log(D[(size_t)(i * n + j)]);
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) {
+        try { th.emplace_back(rows, t); }
+        catch (const std::system_error &) { for (int u = t; u < nt; ++u) rows(u); break; }   // (no more threads: the rest here)
+    }
+    rows(0);
+    for (auto &t : th) t.join();
+}
+
 extern "C" int32_t rc_attach_host_matrices(rc_ctx *c, const double *D, const double *logD_or_null)
 {
     if (!c || !D) return fail(c, RC_ERR_ARG, "rc_attach_host_matrices: NULL argument");
@@ -5684,9 +5807,9 @@ extern "C" int32_t rc_attach_host_matrices(rc_ctx *c, const double *D, const dou
         c->ownL.shrink_to_fit();
     } else {
         const size_t n = (size_t)c->n;
-        c->ownL.resize(n * n);
-        for (size_t i = 0; i < n; ++i)
-            for (size_t j = 0; j < n; ++j) c->ownL[i * n + j] = (i == j) ? 0.0 : std::log(D[i * n + j]);  // types.jl:155
+        try { c->ownL.resize(n * n); }
+        catch (const std::bad_alloc &) { c->hostD = nullptr; c->hostL = nullptr; return fail(c, RC_ERR_OOM, "rc_attach_host_matrices: no host memory for the %zu x %zu logD (pass logD)", n, n); }
+        host_log_matrix(D, (int64_t)n, c->ownL.data());
         c->hostL = c->ownL.data();
     }
     return RC_OK;
@@ -6232,7 +6355,31 @@ extern "C" int32_t rc_set_mode(rc_ctx *c, int32_t mode)
 }
 
 
-// Which row-reduction kernel the last enqueued sweep used (0: k_bulk, full read; 1: k_bulk_sym, upper triangle only)
+// Run-time options of one context (include/redclust_hip.h).  Their defaults are read from the environment ONCE, when the context is
+// created; nothing reads the environment per sweep or per chain, so contexts driven from different host threads (rc_run_chains,
+// one chain per GPU) can be configured independently.
+extern "C" int32_t rc_set_option(rc_ctx *c, const char *name, int64_t value)
+{
+    if (!c || !name) return fail(c, RC_ERR_ARG, "rc_set_option: NULL argument");
+    if (!strcmp(name, "prune")) {
+        if (value < -1 || value > 1) return fail(c, RC_ERR_ARG, "rc_set_option: prune must be -1 (automatic), 0 (never) or 1 (always)");
+        c->opt_prune = (int)value;
+    } else if (!strcmp(name, "chain_workers")) {
+        if (value < 0 || value > 1024) return fail(c, RC_ERR_ARG, "rc_set_option: chain_workers must be in 0..1024 (0 = automatic)");
+        c->opt_chain_workers = (int)value;
+    } else if (!strcmp(name, "chain_depth")) {
+        if (value < 0 || value > 64) return fail(c, RC_ERR_ARG, "rc_set_option: chain_depth must be in 0..64 (0 = automatic)");
+        c->opt_chain_depth = (int)value;
+    } else if (!strcmp(name, "chain_pipeline")) {
+        if (value != 0 && value != 1) return fail(c, RC_ERR_ARG, "rc_set_option: chain_pipeline must be 0 or 1");
+        c->opt_chain_pipeline = (int)value;
+    } else {
+        return fail(c, RC_ERR_ARG, "rc_set_option: unknown option '%s' (prune, chain_workers, chain_depth, chain_pipeline)", name);
+    }
+    return RC_OK;
+}
+
+// Which row-reduction kernel the last enqueued sweep used (0: k_bulk, full read; 1: one of the symmetric kernels, upper triangle only)
 // and the bytes of matrix data it has to read per launch — what bench.py prices the roofline against.
 extern "C" int32_t rc_bulk_kernel_info(rc_ctx *c, int32_t *which, double *algorithmic_bytes)
 {

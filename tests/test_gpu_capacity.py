@@ -62,6 +62,35 @@ def test_sweep_that_runs_out_of_slots_is_resumed(kcap, blocking):
     ctx.close()
 
 
+def test_record_sample_behind_an_asynchronous_sweep_that_overflows():
+    """rc_record_sample reads the label state: behind an rc_gibbs_sweep_async that runs out of slots it must wait for the
+    recovery (capacity doubled, sweep resumed) before it snapshots — the recorded labels and the co-clustering counts are those of
+    the completed sweep, not of the half-swept state mapped through the re-installed layout."""
+    D, truth = paper(1)
+    P = dict(T.likelihood_hyperparams(D, truth), repulsion=False)
+    init = np.ones(100, np.int64)
+    orc = O.Oracle(D, P)
+    orc.set_state(init)
+    ctx = rc.Context(D, logD=orc.logD, kcap=4)
+    ctx.set_params(**P)
+    ctx.set_state(init)
+    ctx.cocluster_reset()
+    expect = np.zeros((100, 100), np.uint32)
+    for t in range(3):
+        r, p = rp_schedule(t)
+        ctx.gibbs_sweep(r, p, 77, t, blocking=False)
+        canon = ctx.record_sample(True)                 # no synchronisation in between
+        orc.sweep_stable(r, p, 77, t)
+        ref = np.zeros(100, np.int64)
+        O.lib().orc_sortlabels(100, orc.clusts, ref)
+        assert np.array_equal(canon, ref), (t, int(np.sum(canon != ref)))
+        expect += (orc.clusts[:, None] == orc.clusts[None, :]).astype(np.uint32)
+    assert ctx.capacity_info()["n_grows"] >= 1 and orc.K > 4
+    assert np.array_equal(ctx.cocluster_counts(), expect)
+    same_state(ctx, orc, "end")
+    ctx.close()
+
+
 def test_set_state_with_more_clusters_than_slots_and_the_fixed_capacity_switch():
     D, truth = paper(1)
     P = T.likelihood_hyperparams(D, truth)

@@ -636,7 +636,7 @@ def test_pruned_candidates_change_no_draw(cache):
     D, truth = data["distancematrix"], data["clusts"]
     P = rc.likelihood_hyperparams(D, truth)
     init = np.random.default_rng(2).integers(1, 40, 700).astype(np.int64)
-    keys = ("RC_NO_PRUNE", "RC_PRUNE_ALWAYS", "RC_SCORE_CACHE")
+    keys = ("RC_SCORE_CACHE",)
     saved = {k: os.environ.get(k) for k in keys}
     try:
         os.environ["RC_SCORE_CACHE"] = cache
@@ -650,12 +650,12 @@ def test_pruned_candidates_change_no_draw(cache):
         other = rc.Context(D)
         other.set_params(**P)
         other.set_state(init)
+        ctx.set_option("prune", 1)        # in every sweep (rc_set_option: a per-context option, nothing reads the environment per sweep)
+        other.set_option("prune", 0)      # never
         moved = 0
         for t in range(12):
             r, p = rp_schedule(t)
-            os.environ.pop("RC_NO_PRUNE", None); os.environ["RC_PRUNE_ALWAYS"] = "1"
             ctx.gibbs_sweep(r, p, 31, t)
-            os.environ.pop("RC_PRUNE_ALWAYS", None); os.environ["RC_NO_PRUNE"] = "1"
             other.gibbs_sweep(r, p, 31, t)
             orc.sweep_stable(r, p, 31, t)
             a, b = ctx.get_state(), other.get_state()
