@@ -559,15 +559,19 @@ def main():
             # three proposals per iteration (splitmerge = "intended") — rollbacks, and what a rolled-back iteration costs (it is redone
             # by the synchronous path and the speculation restarts behind it) against the synchronous loop on the same chain
             hot = {}
-            for start, init_h in (("one_cluster", np.ones(100, np.int64)), ("random_labels", init1)):
+            # "every_proposal_accepted": the repulsion-free model from ONE cluster with the reference's split-merge AS WRITTEN — every
+            # proposal is a split, it is accepted, and quirk Q1 drops it again together with the iteration's sweep, so the
+            # chain stays in one cluster and EVERY iteration rolls the pipeline back: the cost of the rollback path at a 100 % rate
+            for start, init_h, Ph, smode in (("one_cluster", np.ones(100, np.int64), P1, "intended"), ("random_labels", init1, P1, "intended"),
+                                             ("every_proposal_accepted", np.ones(100, np.int64), dict(P1, repulsion=False), "as_written")):
                 legs_h = {}
                 for name, pipe in (("speculative", 1), ("synchronous", 0)):
                     cr = rc.Context(D1, device=dev0)
-                    cr.set_params(**P1); cr.set_state(init_h); cr.cocluster_reset(); cr.attach_host_matrices(D1)
+                    cr.set_params(**Ph); cr.set_state(init_h); cr.cocluster_reset(); cr.attach_host_matrices(D1)
                     cr.set_option("chain_pipeline", pipe)
                     its = 500
                     t1 = time.perf_counter()
-                    chh = cr.run_chain(its, 0, 10, 5, 3, 5, r, p, 1.0, splitmerge="intended")
+                    chh = cr.run_chain(its, 0, 10, 5, 3, 5, r, p, 1.0, splitmerge=smode)
                     t_h = time.perf_counter() - t1
                     cs = cr.chain_stats()
                     legs_h[name] = {"iterations_per_s": its / t_h, "seconds": t_h, "proposals": 3 * its, "splitmerge_acceptances": int(chh["splitmerge_acceptances"].sum()),
@@ -578,8 +582,9 @@ def main():
                 hot[start] = dict(legs_h, acceptance_rate=a_["splitmerge_acceptances"] / (3 * 500),
                                   same_chain=a_["splitmerge_acceptances"] == b_["splitmerge_acceptances"] and a_["K_final"] == b_["K_final"],
                                   # time the pipelined loop spends beyond what the synchronous loop needs for the SAME iterations, per rollback (negative: still ahead)
+                                  splitmerge=smode, repulsion=bool(Ph["repulsion"]),
                                   extra_ms_per_rollback_vs_synchronous=(a_["seconds"] - b_["seconds"]) / rb * 1e3)
-            defaults["with_many_accepted_proposals"] = dict(hot, iterations=500, numMH=3, data="paper dataset 1 (n = 100), splitmerge='intended'")
+            defaults["with_many_accepted_proposals"] = dict(hot, iterations=500, numMH=3, data="paper dataset 1 (n = 100)")
             defaults["with_accepted_proposals"] = dict(legs, iterations=3000, data="paper dataset 1 (n = 100), random initial labels, splitmerge='intended'",
                                                        same_chain=legs["speculative"]["splitmerge_acceptances"] == legs["synchronous"]["splitmerge_acceptances"]
                                                        and legs["speculative"]["K_final"] == legs["synchronous"]["K_final"])

@@ -101,7 +101,18 @@ typedef long long ll2 __attribute__((ext_vector_type(2)));
 typedef unsigned long long u64;
 
 #define RC_KEY_NONE 0xFFFFFFFFFFFFFFFFull
-#define RC_RES_THREADS 512  // k_resolve block: 32 points x 16 candidate streams; 2 waves/SIMD so it co-resides with k_bulk
+#ifndef RC_RES_THREADS
+#define RC_RES_THREADS 512  // k_resolve block beside a row reduction: 32 points x 16 candidate streams; 2 waves/SIMD so it co-resides with k_bulk
+#endif
+#ifndef RC_RES_THREADS_INC
+#define RC_RES_THREADS_INC 1024  // block size in the incremental mode — no row reduction beside the resolver, the CU is its own: four waves per SIMD
+                                 // hide the latency of the score arithmetic (f64 logs, dependent chains) twice as well as two: moving regime of
+                                 // bench.py 4.55 k -> 4.89 k sweeps/s, first pass 41.7 -> 39.4, validation 33.5 -> 29.5, commit 33.1 -> 28.4 us per sweep
+#endif
+#define RC_RES_THREADS_MAX (RC_RES_THREADS_INC > RC_RES_THREADS ? RC_RES_THREADS_INC : RC_RES_THREADS)
+#ifndef RC_RES_WIDE_MIN_K
+#define RC_RES_WIDE_MIN_K 96     // clusters from which the incremental mode takes the wide block
+#endif
 #ifndef RC_PTS
 #define RC_PTS 32           // points per chunk of the resolver (a power of two <= 32): a block's threads are RC_PTS points x (threads / RC_PTS)
                             // candidate streams; chunks are dealt to the blocks cyclically.  Finer chunks would spread the points still
@@ -1484,7 +1495,30 @@ __global__ __launch_bounds__(256, RC_SYML_MINWAVES) void k_bulk_syml32(View V, i
 // The remaining units (diagonal blocks, the ragged last column block) go through the round-2 unit code (syml_units with a
 // list), in the same launch, after the fast ones.
 // ---------------------------------------------------------------------------------------------------
-#define RC_S2_PITCH 66   // long longs per p-buffer row: 64 lanes + 2 (528 B: the transposed b128 reads of a lane group fall on 16 different bank quads)
+// LDS geometry of the fast path.  A 16-byte LDS access is served 16 lanes per cycle, each lane on one of the 16 bank quads.
+//  * p-buffer pitch: 68 long longs (544 B = 34 quads): in a transposed read lane (tr, tq) fetches 16 B at quad 2·tr + 4·tq + j/2
+//    (mod 16) — the lanes tq and tq + 4 of a row would meet on one quad, so the upper half of an octet row takes its four 16-byte
+//    pieces in the order 1, 0, 3, 2 (RC_S2_SWZ; the pieces are only summed): the 16 lanes of two rows then cover the 16 quads
+//    (round 3: pitch 66, no swizzle — SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 35 %).
+//  * log table: RC_S2_TABREP copies of every 16-byte entry side by side (entry j, copy lane mod TABREP at quad TABREP·j + copy): the
+//    table look-up is a gather by the entry's mantissa bits, different in every lane — with one copy 16 lanes throw their reads
+//    at 16 quads at random.
+#ifndef RC_S2_PITCH
+#define RC_S2_PITCH 68
+#endif
+#ifndef RC_S2_SWZ
+#define RC_S2_SWZ 1
+#endif
+#ifndef RC_S2_TABREP
+#define RC_S2_TABREP 1
+#endif
+// (beyond 40 KiB of LDS per block four blocks no longer fit a CU and the compiler stops holding the kernel to 128 registers — three of
+// these waves and one resolver wave per SIMD must fit its 512 — so the cap is stated)
+#if RC_S2_TABREP > 1
+#define RC_S2_VGPR_CAP __attribute__((amdgpu_num_vgpr(127)))
+#else
+#define RC_S2_VGPR_CAP
+#endif
 
 // sums of two / four 64-bit values over each group of 8 consecutive lanes (all lanes of the group receive the totals)
 __device__ __forceinline__ void row8_sum2_dpp(long long &a, long long &b)
@@ -1750,7 +1784,10 @@ __device__ __forceinline__ void syml2_fast(const View &V, long long *pb /* [2][8
 #pragma unroll
                             for (int u = 0; u < RC_S2_LOGS; ++u) pp[u] = rc_qlog_prep(((g_ + u) & 1) ? x[(g_ + u) >> 1].y : x[(g_ + u) >> 1].x, qeD);
 #pragma unroll
-                            for (int u = 0; u < RC_S2_LOGS; ++u) tv[u] = tab[pp[u].j];
+                            for (int u = 0; u < RC_S2_LOGS; ++u) {
+                                if (RC_S2_EXP & 16) tv[u] = tab[RC_S2_TABREP * ((lane & 15) + 16 * ((ar + u + g_) & 7))];   // timing experiment: a conflict-free gather
+                                else tv[u] = tab[RC_S2_TABREP * pp[u].j + (RC_S2_TABREP > 1 ? (lane & (RC_S2_TABREP - 1)) : 0)];
+                            }
 #pragma unroll
                             for (int u = 0; u < RC_S2_LOGS; ++u) {
                                 const long long v = rc_qlog_raw(pp[u], tv[u], qsL);
@@ -1809,9 +1846,10 @@ __device__ __forceinline__ void syml2_fast(const View &V, long long *pb /* [2][8
                 RC_PF(const long long pr0 = __builtin_amdgcn_s_memtime();)
                 __builtin_amdgcn_wave_barrier();
                 long long vD[8], vL[8];
+                const int jsw = (RC_S2_SWZ && (tq & 4)) ? 2 : 0;       // (see RC_S2_PITCH: the upper half of an octet row reads its pieces in the order 1, 0, 3, 2)
 #pragma unroll
                 for (int j = 0; j < 8; j += 2) {
-                    const ll2 qd = *(const ll2 *)&pD[tr * RC_S2_PITCH + 8 * tq + j], ql = *(const ll2 *)&pL[tr * RC_S2_PITCH + 8 * tq + j];
+                    const ll2 qd = *(const ll2 *)&pD[tr * RC_S2_PITCH + 8 * tq + (j ^ jsw)], ql = *(const ll2 *)&pL[tr * RC_S2_PITCH + 8 * tq + (j ^ jsw)];
                     vD[j] = qd.x; vD[j + 1] = qd.y; vL[j] = ql.x; vL[j + 1] = ql.y;
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -1822,7 +1860,8 @@ __device__ __forceinline__ void syml2_fast(const View &V, long long *pb /* [2][8
                     row8_sum2_dpp(sD, sL);
                     if (mine) { rDA += sD; rLA += sL; }
                 } else {
-                    const unsigned mB = (unsigned)(bB >> (8 * tq)) & 0xFFu;
+                    unsigned mB = (unsigned)(bB >> (8 * tq)) & 0xFFu;
+                    if (jsw) mB = ((mB & 0x33u) << 2) | ((mB >> 2) & 0x33u);   // value j of this lane came from source lane 8 tq + (j ^ 2)
                     long long sDA = 0, sLA = 0, sDB = 0, sLB = 0;
                     if (mB == 0) {
                         sDA = ((vD[0] + vD[1]) + (vD[2] + vD[3])) + ((vD[4] + vD[5]) + (vD[6] + vD[7]));
@@ -1893,17 +1932,19 @@ __device__ __forceinline__ void syml2_fast(const View &V, long long *pb /* [2][8
 // instead of 730) — which is why the ragged units have their own launch (k_bulk_syml_list) instead of sharing this kernel's
 // register allocation.
 template <bool DERIVED, bool PACK>
-__global__ __launch_bounds__(256, RC_SYML_MINWAVES) void k_bulk_syml2(View V, int wgen, int sgen, int cgen)
+__global__ __launch_bounds__(256, RC_SYML_MINWAVES) RC_S2_VGPR_CAP void k_bulk_syml2(View V, int wgen, int sgen, int cgen)
 {
-    __shared__ __attribute__((aligned(16))) long long lds[256 + 4 * (2 * 8 * RC_S2_PITCH + 128)];
+    constexpr int TABLL = 256 * RC_S2_TABREP;        // long longs of the log table (128 entries x 16 B x copies)
+    __shared__ __attribute__((aligned(16))) long long lds[TABLL + 4 * (2 * 8 * RC_S2_PITCH + 128)];
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int w = (int)blockIdx.x * 4 + wv;
     double2 *tab = (double2 *)lds;
-    if (DERIVED && threadIdx.x < 128) tab[threadIdx.x] = V.ltab[threadIdx.x];
+    if (DERIVED)
+        for (int q = threadIdx.x; q < 128 * RC_S2_TABREP; q += 256) tab[q] = V.ltab[q / RC_S2_TABREP];
     __syncthreads();
     long long *pf = nullptr;
     RC_PF(if (w < 8192 - 256) pf = (long long *)((char *)V.work[cgen] + 64) + (size_t)w * 16;)
-    syml2_fast<DERIVED, PACK>(V, lds + 256 + (size_t)wv * (2 * 8 * RC_S2_PITCH), lds + 256 + 4 * (2 * 8 * RC_S2_PITCH) + (size_t)wv * 128, tab, wgen, sgen, V.wfast[w], V.wfast[w + 1], pf);
+    syml2_fast<DERIVED, PACK>(V, lds + TABLL + (size_t)wv * (2 * 8 * RC_S2_PITCH), lds + TABLL + 4 * (2 * 8 * RC_S2_PITCH) + (size_t)wv * 128, tab, wgen, sgen, V.wfast[w], V.wfast[w + 1], pf);
     (void)cgen;
 }
 
@@ -2888,6 +2929,7 @@ __device__ __forceinline__ void batch_sim(const View &V, Tab &T, int total, int 
 #ifdef RC_PROF_SIM
     const long long pf0_ = __builtin_amdgcn_s_memrealtime();
     long long pf_pro_ = 0, pf_loop_ = 0, pf_epi_ = 0, pf_init_ = 0, pf_ser_ = 0, pf_b_ = 0, pf_d_ = 0, pf_ch_ = 0;
+    long long pc_n_[3] = {0, 0, 0}, pc_t_[3] = {0, 0, 0}, pc_pre_ = 0, pc_it_ = 0;   // per path (0 rename, 1 certain death, 2 general): entries, shader cycles; the iteration's preamble
 #endif
     const bool regs = V.kcap < 2048;
     unsigned U = 0xffffffffu;
@@ -2908,19 +2950,23 @@ __device__ __forceinline__ void batch_sim(const View &V, Tab &T, int total, int 
         const long long pc0_ = __builtin_amdgcn_s_memrealtime(); ++pf_ch_;
 #endif
         int va = 0, vt = -1, vla = 0, vcda = 0, vcdt = 0;
-        bool vfast = false, vsafe = false, vstay = false;
+        bool vfast = false, vsafe = false, vstay = false, vdeath = false;
         if (q0 + lane < nb0) {
             va = T.ba[q0 + lane]; vt = T.bb[q0 + lane]; vla = T.label[va];
             // target == source: the placeholder of a carried-over guess whose target cluster is gone (the assembly wrote it so)
             vstay = (vt == va);
             vcda = T.candie[va]; vcdt = vt >= 0 ? (int)T.candie[vt] : 0;
-            // a singleton nobody in the batch joins, drawing "new cluster": alone at its turn whatever happened before
-            vfast = vt < 0 && T.size[va] == 1 && !T.joined[va];
+            const bool lone_ = T.size[va] == 1 && !T.joined[va];   // a singleton nobody in the batch joins: alone at its turn whatever happened before
+            // ... drawing "new cluster"
+            vfast = vt < 0 && lone_;
+            // ... joining a cluster that cannot become empty inside the batch: a death whatever the order — what depends on the order is
+            // only what it does to the running state (one cluster less, its label free), see the short path below
+            vdeath = vt >= 0 && !vstay && lone_ && !vcdt;
             // a move between two clusters neither of which can become empty inside the batch: a plain move whatever the
             // order, nothing to simulate (the sizes of such clusters are not tracked here at all)
             vsafe = vt >= 0 && !vstay && !vcda && !vcdt;
         }
-        const u64 safemask = __ballot(vsafe), staymask = __ballot(vstay), fastmask = __ballot(vfast);
+        const u64 safemask = __ballot(vsafe), staymask = __ballot(vstay), fastmask = __ballot(vfast), deathmask = __ballot(vdeath);
         // results of entry q0 + lane (stored after the chunk).  The plain moves are not visited at all: their target is the
         // tentative one, and cluster count / smallest empty label are those left by the last visited entry before them
         int ob = vt, olab = 0, oflag = vstay ? (RC_BF_NOOP | RC_BF_STAY) : 0, oK = K;
@@ -2932,6 +2978,9 @@ __device__ __forceinline__ void batch_sim(const View &V, Tab &T, int total, int 
         const long long psim0_ = __builtin_amdgcn_s_memrealtime(); pf_pro_ += psim0_ - pc0_;
 #endif
         while (todo) {
+#ifdef RC_PROF_SIM
+            const long long pit0_ = __builtin_amdgcn_s_memtime(); ++pc_it_;
+#endif
             // the lone singletons that keep their label under the current smallest empty label change nothing: all of them up to
             // the next entry that needs the serial path are settled at once (a hundred of them per round in the moving regime)
             const u64 ser = todo & ~__ballot(vfast && se >= vla);
@@ -2948,6 +2997,9 @@ __device__ __forceinline__ void batch_sim(const View &V, Tab &T, int total, int 
             todo &= ~(1ull << e);
             ++nvisited;
             const int q = q0 + e;
+#ifdef RC_PROF_SIM
+            const long long pit1_ = __builtin_amdgcn_s_memtime(); pc_pre_ += pit1_ - pit0_;
+#endif
             if (regs && ((fastmask >> e) & 1ull)) {
                 // A lone singleton that draws "new cluster" and is still here: the smallest empty label is smaller than its own
                 // (the others were settled above), so it takes that label and frees its own — slot, sizes and cluster count stay.
@@ -2974,7 +3026,28 @@ __device__ __forceinline__ void batch_sim(const View &V, Tab &T, int total, int 
                 if (first_eff < 0) first_eff = q;
                 ++neff;
 #ifdef RC_PROF_SIM
-                ++pf_ser_;
+                ++pf_ser_; ++pc_n_[0]; pc_t_[0] += __builtin_amdgcn_s_memtime() - pit1_;
+#endif
+                continue;
+            }
+            if (regs && ((deathmask >> e) & 1ull)) {
+                // A lone singleton that joins a cluster which cannot die in this batch (most of the structural entries of the moving
+                // regime: twenty per batch): its cluster dies for certain — target, flag and sizes do not depend on the entries before
+                // it; the running state loses a cluster and gains a free label.  ~15 instructions and no LDS round trip instead of ~70
+                // through the general case below (0.55 us per entry on the one wave that applies them).
+                se = __builtin_amdgcn_readfirstlane(se); K = __builtin_amdgcn_readfirstlane(K);
+                neff = __builtin_amdgcn_readfirstlane(neff); first_eff = __builtin_amdgcn_readfirstlane(first_eff);
+                const int la_ = __builtin_amdgcn_readlane(vla, e), a_ = __builtin_amdgcn_readlane(va, e);
+                if (lane == ((la_ - 1) >> 5)) U &= ~(1u << ((la_ - 1) & 31));   // (a label beyond 2048 has no lane: never the smallest empty one)
+                if (la_ < se) se = la_;
+                K -= 1;
+                if (lane == 0) T.size[a_] = 0;                                   // (the caller restores the simulated sizes from the entries)
+                if (lane == e) { ob = vt; olab = 0; oflag = RC_BF_DEATH; }
+                if (lane >= e) oK = K;
+                if (first_eff < 0) first_eff = q;
+                ++neff;
+#ifdef RC_PROF_SIM
+                ++pf_ser_; ++pf_d_; ++pc_n_[1]; pc_t_[1] += __builtin_amdgcn_s_memtime() - pit1_;
 #endif
                 continue;
             }
@@ -3082,7 +3155,7 @@ __device__ __forceinline__ void batch_sim(const View &V, Tab &T, int total, int 
             if (lane == e) { ob = b; olab = lab; oflag = flag; }
             if (lane >= e) oK = K;
 #ifdef RC_PROF_SIM
-            ++pf_ser_; pf_b_ += (flag & RC_BF_BIRTH) ? 1 : 0; pf_d_ += (flag & RC_BF_DEATH) ? 1 : 0;
+            ++pf_ser_; pf_b_ += (flag & RC_BF_BIRTH) ? 1 : 0; pf_d_ += (flag & RC_BF_DEATH) ? 1 : 0; ++pc_n_[2]; pc_t_[2] += __builtin_amdgcn_s_memtime() - pit1_;
 #endif
         }
 #ifdef RC_PROF_SIM
@@ -3109,6 +3182,8 @@ __device__ __forceinline__ void batch_sim(const View &V, Tab &T, int total, int 
         long long *dbg_ = (long long *)((char *)V.work[0] + 64);
         dbg_[0] += 1; dbg_[1] += pf_init_; dbg_[2] += pf_pro_; dbg_[3] += pf_loop_; dbg_[4] += pf_epi_; dbg_[5] += pf_ser_; dbg_[6] += pf_b_; dbg_[7] += pf_d_; dbg_[8] += pf_ch_;
         dbg_[9] += nb0; dbg_[10] += __builtin_amdgcn_s_memrealtime() - pf0_;
+        for (int c_ = 0; c_ < 3; ++c_) { dbg_[11 + 2 * c_] += pc_n_[c_]; dbg_[12 + 2 * c_] += pc_t_[c_]; }
+        dbg_[17] += pc_it_; dbg_[18] += pc_pre_;
     }
 #endif
     if (lane == 0) { T.misc[3] = nb; T.misc[4] = hi; T.misc[5] = fail; T.misc[8] = nbirth; T.misc[9] = neff; T.misc[10] = first_eff; T.misc[13] = nvisited; }
@@ -3605,7 +3680,7 @@ __device__ __forceinline__ void resolve_body(const View &V, const SweepArgs &sa,
 #ifndef RC_RES_MINWAVES
 #define RC_RES_MINWAVES 4
 #endif
-__global__ __launch_bounds__(RC_RES_THREADS, RC_RES_MINWAVES) void k_resolve(View V, SweepArgs sa, int G)
+__global__ __launch_bounds__(RC_RES_THREADS_MAX, RC_RES_MINWAVES) void k_resolve(View V, SweepArgs sa, int G)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     resolve_body(V, sa, G, smem);
@@ -4525,7 +4600,11 @@ static int32_t finish_create(rc_ctx *c)
         }
     }
     // kernels whose dynamic LDS can exceed the 64 KiB default (large kcap)
-    const size_t lds_r = std::max(tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, c->maxb), 2 * sizeof(int) * (size_t)c->kcap);
+    size_t lds_r = std::max(tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, c->maxb), 2 * sizeof(int) * (size_t)c->kcap);
+    {   // (the wider block of the incremental mode needs a little more reduction scratch: used only while it fits the CU)
+        const size_t wide = tab_bytes(c->kcap, c->n, RC_RES_THREADS_INC / 64, c->maxb);
+        if (wide <= 160 * 1024) lds_r = std::max(lds_r, wide);
+    }
     const size_t lds_d = std::max(tab_bytes(c->kcap, c->n, 1), 2 * sizeof(int) * (size_t)c->kcap);
     const size_t lds_b = (size_t)c->kcap * 4 * sizeof(u64);
     hipError_t e1 = hipFuncSetAttribute((const void *)k_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
@@ -5184,17 +5263,20 @@ static int32_t sweep_enqueue(rc_ctx *c, double r, double p, uint64_t seed, uint6
     // sweeps/s) — and costs a few per cent where a chain moves among many small clusters (every stream evaluates the own cluster first)
     sa.prune = (c->opt_prune != 0 && (c->opt_prune > 0 || c->hsum->n_changes <= 2)) ? 1 : 0;   // (rc_set_option "prune"; sigma = 0.18, 9 changes per sweep among 117 clusters: 9.8 k -> 9.2 k with it on)
     c->inflight.push_back(rc_ctx::SweepRec{r, p, seed, sweep_index, t});
-#ifdef RC_TRACE_RESOLVE
-    const size_t lds = std::max(tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, c->maxb), 2 * sizeof(int) * (size_t)c->kcap) + 4096;
-#else
-    const size_t lds = std::max(tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, c->maxb), 2 * sizeof(int) * (size_t)c->kcap);
-#endif
     // Resolver block size.  With 256 threads (one wave per SIMD, 112 VGPRs) a k_resolve block fits on a CU beside two
     // k_bulk_sym blocks, so the resolver of sweep t really overlaps the row reduction of sweep t+1 (config 5:
     // 1.36 -> 0.99 ms per sweep).  With many label changes per sweep the rounds dominate and 512 threads are faster.
     int res_threads = c->res_threads;
     if (res_threads == 0)
-        res_threads = (!c->incremental && c->prefetch && c->last_bulk_kernel == 1 && c->hsum->n_changes <= 32) ? 256 : 512;
+        // (wide blocks pay with many candidates per point — 32 streams of K = 200 candidates; with a few dozen clusters the extra waves only wait)
+        res_threads = c->incremental ? ((c->hsum->K > RC_RES_WIDE_MIN_K && tab_bytes(c->kcap, c->n, RC_RES_THREADS_INC / 64, c->maxb) <= 160 * 1024) ? RC_RES_THREADS_INC : RC_RES_THREADS)
+                                     : ((c->prefetch && c->last_bulk_kernel == 1 && c->hsum->n_changes <= 32) ? 256 : RC_RES_THREADS);
+    // (the tables' layout depends on the waves per block — the reduction scratch of eval_chunk — and k_resolve carves it by its blockDim)
+#ifdef RC_TRACE_RESOLVE
+    const size_t lds = std::max(tab_bytes(c->kcap, c->n, res_threads / 64, c->maxb), 2 * sizeof(int) * (size_t)c->kcap) + 4096;
+#else
+    const size_t lds = std::max(tab_bytes(c->kcap, c->n, res_threads / 64, c->maxb), 2 * sizeof(int) * (size_t)c->kcap);
+#endif
     if (c->incremental) {
         // exact incremental mode: the row-sum table of the current labels already exists (one k_bulk after
         // rc_set_state) and every label change corrects it in place — no matrix traffic at all in this sweep
