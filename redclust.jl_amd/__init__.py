@@ -5,7 +5,7 @@ The directory name is not a valid Python identifier; import it through the repo-
 
     import redclust_amd as rc
 """
-from ._lib import Context, Comm, measure_read_ceiling, RedClustHIPError, RedClustDomainError, build, lib, SIGNATURES  # noqa: F401
+from ._lib import Context, Comm, measure_read_ceiling, RedClustHIPError, RedClustDomainError, build, build_diag, lib, SIGNATURES  # noqa: F401
 from .types import MCMCData, MCMCOptionsList, MCMCResult, MCMCState, PriorHyperparamsList  # noqa: F401
 from .sampler import runsampler, sample_r, sample_p, iac_ess_acf  # noqa: F401
 from .datagen import generatemixture, likelihood_hyperparams, likelihood_hyperparams_device  # noqa: F401

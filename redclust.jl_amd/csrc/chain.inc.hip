@@ -791,7 +791,8 @@ extern "C" int32_t rc_run_chain(rc_ctx *c, const rc_chain_options *o, rc_chain_o
     // are recorded, and the host part of a recorded sample is a job of its worker pool instead of the main thread's (thin = 1, the
     // reference's default, at N = 8192: 8.4 k -> 11 k it/s stationary, 1.4 k -> 3 k while 40 labels move per sweep).  The loop below
     // is the synchronous form (RC_CHAIN_PIPELINE=0): same chain, bit for bit.
-    if (o->numiters > 0 && c->opt_chain_pipeline)
+    // (a wide context — thousands of clusters — runs the synchronous form: every snapshot of the pipelined loop holds K x K block sums)
+    if (o->numiters > 0 && c->opt_chain_pipeline && !c->wide)
         return chain::run_chain_speculative(c, o, out);
     const long long grows0 = c->n_grows;
     struct GrowNote { rc_ctx *c; long long g0; ~GrowNote() { c->chain_grows = c->n_grows - g0; } } grow_note{c, grows0};

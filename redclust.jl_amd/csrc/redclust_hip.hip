@@ -122,10 +122,17 @@ typedef unsigned long long u64;
 #endif
 #define RC_PTS_LOG2 (RC_PTS == 32 ? 5 : RC_PTS == 16 ? 4 : RC_PTS == 8 ? 3 : RC_PTS == 4 ? 2 : -1)
 static_assert(RC_PTS_LOG2 > 0, "RC_PTS must be 4, 8, 16 or 32");
-#define RC_MAX_KCAP 4096
+#define RC_MAX_KCAP 4096          // slot capacity up to which the resolver's per-slot tables live in LDS (the fast path)
+#define RC_WIDE_MAX_KCAP 32767    // ... and the most a context holds at all: beyond RC_MAX_KCAP the tables live in global memory and the sweep is
+                                  // the plain sequential kernel k_sweep_wide (slow; slot ids are 16-bit in the label snapshots and batch records)
 #define RC_RES_ONE_STREAM_MAX_N 1024   // up to this size the in-order resolver chain wins (n = 1000: 26 k -> 32 k sweeps/s; n >= 2000: even or worse)
 #define RC_USED_LDS_MAX_N 16384   // up to this n the label-occupancy bitset of the resolver lives in LDS (n/8 bytes)
-#define RC_BIRTH_MAX 48           // new clusters per resolver batch
+#ifndef RC_BIRTH_MAX
+#define RC_BIRTH_MAX 24           // new clusters per resolver batch (a cut, not a limit of the chain: the rest of the batch is announced again).  Only the
+                                  // first sweeps from a poor labelling meet it: 24 / 48 / 72 / 96 / 144 births per batch all take 75 rounds for the first sweep
+                                  // from uniformly random labels — what ends a round there is the first violation, not the cut — and the simulation of the
+                                  // births behind it is wasted: 14.3 / 15.8 / 16.5 / 16.3 / 16.9 ms (round 4; moving regime of bench.py unchanged, 6 births per batch)
+#endif
 #define RC_MAXB 512          // tentative changers validated per resolve round
 #define RC_SPIN_LIMIT (1u << 23)
 #if defined(RC_PROF_SYML) || defined(RC_TRACE_RESOLVE)   // profiling / diagnostic builds: records behind the work counter
@@ -162,12 +169,14 @@ constexpr int RC_REC_SLOTS = 2;  // sample slots of the asynchronous recorder (r
 struct HostSummary {
     int K, n_changes, n_rounds, err, slot_hi, seq, runs, fail_t;
     int resume_after, fail_changes, fail_rounds, pad1;   // (see DevScalars)
-    int size_label[2 * RC_MAX_KCAP];  // [2k] = size of slot k, [2k+1] = its 1-based label (0 = free)
+    int size_label[2];      // really [2 * kcap_max] (hsum_bytes): [2k] = size of slot k, [2k+1] = its 1-based label (0 = free)
 };
+static size_t hsum_bytes(long long kcap_max) { return sizeof(HostSummary) + 2 * (size_t)kcap_max * sizeof(int); }
 
 // Everything a kernel needs, passed by value.
 struct View {
     int n, ld, kcap;
+    unsigned *wide_scratch;    // wide contexts (kcap > RC_MAX_KCAP): [(n+31)/32] label bitset, then 2·(kcap+1) ints of k_derive_wide / k_sweep_wide; null otherwise
     unsigned *used_scratch;    // [G][(n+31)/32] label bitsets of the resolver blocks when n > RC_USED_LDS_MAX_N
     double *wc;                // [kcap][ldw] score cache of the resolver (eval_chunk), valid inside one launch; null = off
     int ldw;                   // n rounded up to whole chunks
@@ -3686,23 +3695,263 @@ __global__ __launch_bounds__(RC_RES_THREADS_MAX, RC_RES_MINWAVES) void k_resolve
     resolve_body(V, sa, G, smem);
 }
 
+// ===================================================================================================
+// Wide contexts: more than RC_MAX_KCAP clusters.  The reference's state has room for n clusters (clustsizes of length n,
+// src/types.jl:131-137; a new cluster is offered whenever maxK allows, src/mcmc.jl:198-199).  The resolver keeps its per-slot
+// tables in LDS, which ends at 4096 slots; beyond, the context is WIDE: the slot tables stay in global memory, the row-sum table
+// has one generation that is maintained in place (as in the incremental mode), and the sweep is the loop of the reference itself
+// — one point after the other, src/mcmc.jl:192-252 — on ONE workgroup: its 1024 threads share the candidates of the point, the
+// arg-max goes through shuffles and LDS, a move corrects the two S rows it touches (exact integers).  Slow — tens to hundreds of
+// milliseconds per sweep — and far outside what the sampler is for (a chain among thousands of clusters is resolving births and
+// deaths all the time), but the state space of the reference is covered up to RC_WIDE_MAX_KCAP clusters instead of ending at an
+// error.  Same draws as every other path: the same score arithmetic (tab_base, log1p form), the same label-keyed uniforms, the
+// same tie rule.
+// ===================================================================================================
+__device__ __forceinline__ int wide_block_min(int v, int *lds /* [17] */)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int m = lds[0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = min(m, lds[w]);
+        lds[16] = m;
+    }
+    __syncthreads();
+    return lds[16];
+}
+
+// smallest label > lab (1-based) whose bit is clear in the global bitset; n + 1 if none.  All threads.
+__device__ __forceinline__ int wide_next_empty(const unsigned *used, int n, int lab, int *lds)
+{
+    const int nw = (n + 31) / 32;
+    int best = n + 1;
+    for (int w = (lab >> 5) + (int)threadIdx.x; w < nw; w += blockDim.x) {
+        unsigned inv = ~used[w];
+        if (w == (lab >> 5)) inv &= ~((1u << (lab & 31)) - 1u);
+        if (inv) { const int r = w * 32 + __ffs((int)inv); if (r <= n) best = min(best, r); break; }   // (a thread's words ascend: its first hit is its smallest)
+    }
+    return wide_block_min(best, lds);
+}
+
+// After rc_set_state / apply_labels in a wide context: label bitset and smallest empty label, the label snapshot and run count,
+// the host summary, and (rebuild_perm) the rows grouped by slot for the row reduction that fills the table.  One block.
+__global__ __launch_bounds__(1024) void k_derive_wide(View V, int rebuild_perm)
+{
+    __shared__ int red[17];
+    __shared__ int scan[1024];
+    unsigned *used = V.wide_scratch;
+    int *off = (int *)(V.wide_scratch + (V.n + 31) / 32), *cur = off + V.kcap + 1;
+    const int nw = (V.n + 31) / 32, hi = V.sc->slot_hi;
+    for (int w = threadIdx.x; w < nw; w += blockDim.x) used[w] = 0u;
+    __threadfence_block(); __syncthreads();
+    for (int k = threadIdx.x; k < hi; k += blockDim.x) {
+        const int lab = V.slot_label[k];
+        if (lab > 0) atomicOr(&used[(lab - 1) >> 5], 1u << ((lab - 1) & 31));
+    }
+    __threadfence_block(); __syncthreads();
+    const int se = wide_next_empty(used, V.n, 0, red);
+    if (threadIdx.x == 0) V.sc->smallest_empty = se;
+    __syncthreads();
+    snapshot_labels(V, 0, &red[0]);
+    for (int i = threadIdx.x; i < V.n; i += blockDim.x) V.snap[1][i] = V.snap[0][i];
+    __syncthreads();
+    write_summary(V, 0, 0);
+    __syncthreads();
+    if (!rebuild_perm) return;
+    // rows grouped by slot (k_bulk): counts, exclusive offsets (every thread scans a run of slots, the runs' totals through LDS), scatter
+    for (int k = threadIdx.x; k <= V.kcap; k += blockDim.x) cur[k] = 0;
+    __threadfence_block(); __syncthreads();
+    for (int i = threadIdx.x; i < V.n; i += blockDim.x) atomicAdd(&cur[V.slot_of[i]], 1);
+    __threadfence_block(); __syncthreads();
+    const int per = (V.kcap + (int)blockDim.x - 1) / (int)blockDim.x, k0 = (int)threadIdx.x * per, k1 = min(k0 + per, V.kcap);
+    int sum = 0;
+    for (int k = k0; k < k1; ++k) sum += cur[k];
+    scan[threadIdx.x] = sum;
+    __threadfence_block(); __syncthreads();
+    if (threadIdx.x == 0) { int o = 0; for (int q = 0; q < (int)blockDim.x; ++q) { const int x = scan[q]; scan[q] = o; o += x; } }
+    __threadfence_block(); __syncthreads();
+    int o = scan[threadIdx.x];
+    for (int k = k0; k < k1; ++k) { off[k] = o; o += cur[k]; }
+    __threadfence_block(); __syncthreads();
+    for (int k = threadIdx.x; k <= V.kcap; k += blockDim.x) cur[k] = 0;
+    __threadfence_block(); __syncthreads();
+    int *perm = V.perm[0], *pslot = V.pslot[0];
+    for (int i = threadIdx.x; i < V.n; i += blockDim.x) {
+        const int sl = V.slot_of[i];
+        const int p_ = off[sl] + atomicAdd(&cur[sl], 1);
+        perm[p_] = i; pslot[p_] = sl;
+    }
+    __threadfence_block(); __syncthreads();
+    for (int p_ = threadIdx.x; p_ < V.n; p_ += blockDim.x) { V.perm[1][p_] = perm[p_]; V.pslot[1][p_] = pslot[p_]; }
+}
+
+// One Gibbs sweep of a wide context (see above): src/mcmc.jl:192-252 point by point.  gen: the S generation that holds the row sums
+// of the current labels (corrected in place).  One block of 1024 threads; the state lives in global memory and is shared between
+// the threads of the block through it: every hand-over is a workgroup fence + barrier (RC_WIDE_SYNC — __syncthreads alone does
+// not wait for global stores on this target).
+#define RC_WIDE_SYNC() do { __threadfence_block(); __syncthreads(); } while (0)
+__global__ __launch_bounds__(1024) void k_sweep_wide(View V, SweepArgs sa, int gen)
+{
+    __shared__ int red[17];
+    __shared__ double rv[16];
+    __shared__ int rk[16], rs[16];
+    __shared__ int sh[2];
+    if (__hip_atomic_load(&V.sc->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // (a sweep before this one ran out of slots: the host grows the tables and replays)
+    unsigned *used = V.wide_scratch;
+    long long *SD = V.SD[gen], *SL = V.SL[gen];
+    const size_t ld = (size_t)V.ld;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
+    int K = V.sc->K, se = V.sc->smallest_empty, hi = V.sc->slot_hi, changes = sa.changes0, fcur = 0;
+    bool failed = false;
+    for (int i = sa.after0 + 1; i < V.n && !failed; ++i) {
+        // (everything read here was written before the last RC_WIDE_SYNC of the previous point)
+        const int u = V.pi[i], own = V.slot_of[u];
+        const int so = V.slot_size[own], la_own = V.slot_label[own], single = (so == 1);
+        const int Ki = K - single;
+        const long long dg = V.diagq[u];
+        double bestv = -INFINITY;
+        int bestkey = 0x7fffffff, bestslot = -2;
+        for (int k = threadIdx.x; k < hi; k += blockDim.x) {
+            const int lab = V.slot_label[k];
+            if (lab == 0) continue;
+            const int isown = (k == own);
+            const int s_ = V.slot_size[k] - isown;
+            if (s_ == 0) continue;                                               // its own singleton cluster (mcmc.jl:193-196)
+            long long sd = SD[(size_t)k * ld + u], sl = SL[(size_t)k * ld + u];
+            sd -= (isown ? dg : 0);                                              // i itself excluded (clusts[i] = -1)
+            const double SDr = (double)sd * V.scD, SLr = (double)sl * V.scL;
+            const double base = tab_base(V, sa, s_);
+            double lik = V.cL * SLr - (V.alpha + V.delta1 * (double)s_) * log1p(SDr / V.beta);
+            if (V.repulsion) lik += (V.zeta + V.delta2 * (double)s_) * log1p(SDr / V.gamma);
+            double v = base + lik;
+            const double un = rc_uniform(sa, (unsigned)i, (unsigned)lab);
+            v = v + (-log(-log(un)));
+            if (bestslot == -2 || v > bestv || (v == bestv && lab < bestkey)) { bestv = v; bestkey = lab; bestslot = k; }
+        }
+        const bool new_ok = (V.maxK == 0 || (long long)Ki < V.maxK) && Ki < V.n;
+        if (threadIdx.x == 0 && new_ok) {                                        // mcmc.jl:198-203, 228-230: last in the candidate order
+            const double un = rc_uniform(sa, (unsigned)i, 0u);
+            const double v = (log((double)(Ki + 1)) + sa.r * sa.log1mp) + (-log(-log(un)));
+            if (v > bestv || bestslot == -2) { bestv = v; bestkey = RC_NEWKEY; bestslot = -1; }
+        }
+#pragma unroll
+        for (int off_ = 32; off_ > 0; off_ >>= 1) {
+            const double ov = __shfl_xor(bestv, off_);
+            const int ok_ = __shfl_xor(bestkey, off_), os = __shfl_xor(bestslot, off_);
+            best_merge(bestv, bestkey, bestslot, ov, ok_, os);
+        }
+        __syncthreads();                                                         // (the previous point's readers of rv / sh are done)
+        if (lane == 0) { rv[wave] = bestv; rk[wave] = bestkey; rs[wave] = bestslot; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double bv = rv[0]; int bk = rk[0], bs = rs[0];
+            for (int w = 1; w < NW; ++w) best_merge(bv, bk, bs, rv[w], rk[w], rs[w]);
+            sh[0] = bs;
+        }
+        __syncthreads();
+        const int target = sh[0];      // a slot, -1 = new cluster, -2 = no candidate at all (alone and maxK forbids a new cluster): stays
+        if (target == own || target == -2) continue;
+        int b = target;
+        if (target == -1 && single) {
+            // a singleton that draws "new cluster": the smallest empty label once i is removed is min(its own, the smallest empty one)
+            if (se < la_own) {                                                   // it takes the smaller label and frees its own (mcmc.jl:199)
+                if (threadIdx.x == 0) {
+                    V.slot_label[own] = se;
+                    used[(se - 1) >> 5] |= 1u << ((se - 1) & 31);
+                    used[(la_own - 1) >> 5] &= ~(1u << ((la_own - 1) & 31));
+                }
+                RC_WIDE_SYNC();
+                se = wide_next_empty(used, V.n, se, red);                        // (the freed label la_own > se is among the candidates)
+                ++changes;
+            }
+            continue;
+        }
+        if (target == -1) {
+            // birth: the lowest free slot, label = the smallest empty label
+            for (;;) {
+                int mine = 0x7fffffff;
+                const int k = fcur + (int)threadIdx.x;
+                if (k < V.kcap && V.slot_label[k] == 0) mine = k;
+                const int f = wide_block_min(mine, red);
+                if (f != 0x7fffffff) { b = f; break; }
+                fcur += (int)blockDim.x;
+                if (fcur >= V.kcap) { b = -1; break; }
+            }
+            if (b < 0) {
+                // every slot is taken: the points before i are final, the state is consistent — the host grows the tables and
+                // resumes this sweep behind point i - 1 (recover_capacity)
+                if (threadIdx.x == 0) {
+                    V.sc->fail_t = sa.t; V.sc->resume_after = i - 1; V.sc->fail_changes = changes; V.sc->fail_rounds = sa.rounds0 + 1;
+                    V.hsum->fail_t = sa.t; V.hsum->resume_after = i - 1; V.hsum->fail_changes = changes; V.hsum->fail_rounds = sa.rounds0 + 1;
+                    atomicOr(&V.sc->err, RC_DERR_CAPACITY);
+                }
+                failed = true;
+                continue;
+            }
+            if (threadIdx.x == 0) {
+                V.slot_label[b] = se; V.slot_size[b] = 0;
+                used[(se - 1) >> 5] |= 1u << ((se - 1) & 31);
+            }
+            RC_WIDE_SYNC();
+            se = wide_next_empty(used, V.n, se, red);
+            K += 1;
+            hi = max(hi, b + 1);
+        }
+        // move u: own -> b.  S[own][j] -= X[u][j], S[b][j] += X[u][j] for every j (exact integers; the row of a cluster that dies
+        // ends as exact zeros, a new cluster's row starts from zeros)
+        for (int j = threadIdx.x; j < V.n; j += blockDim.x) {
+            const size_t e = (size_t)u * ld + j;
+            const long long xd = (V.bits == 64) ? ((const long long *)V.Dq)[e] : (long long)((const int *)V.Dq)[e];
+            const long long xl = rc_load_L(V, u, j, xd);
+            SD[(size_t)own * ld + j] -= xd; SD[(size_t)b * ld + j] += xd;
+            SL[(size_t)own * ld + j] -= xl; SL[(size_t)b * ld + j] += xl;
+        }
+        if (threadIdx.x == 0) {
+            V.slot_size[own] = so - 1; V.slot_size[b] += 1;
+            V.slot_of[u] = b;
+            if (single) {                                                        // the cluster dies: its label is free
+                V.slot_label[own] = 0;
+                used[(la_own - 1) >> 5] &= ~(1u << ((la_own - 1) & 31));
+            }
+        }
+        if (single) { K -= 1; if (la_own < se) se = la_own; if (own < fcur) fcur = own - (own % (int)blockDim.x); }
+        ++changes;
+        RC_WIDE_SYNC();
+    }
+    RC_WIDE_SYNC();
+    if (threadIdx.x == 0 && !failed) {
+        V.sc->K = K; V.sc->smallest_empty = se; V.sc->slot_hi = hi;
+        V.sc->n_changes = changes; V.sc->n_rounds = sa.rounds0 + 1;
+        if (changes) V.sc->last_change_sweep = sa.t;
+    }
+    RC_WIDE_SYNC();
+    if (failed) return;
+    snapshot_labels(V, sa.t & 1, &red[0]);
+    write_summary(V, changes, sa.rounds0 + 1);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // loglik block sums (src/mcmc.jl:26-53): B[k][t] = Σ_{i in slot k} S[t][i], accumulated as (hi, lo) halves
 // so that n² terms cannot overflow 64 bits.  One block per slot t; LDS bins per slot k.
 // out[(t*hi + k)*4 + {0,1,2,3}] = D_hi, D_lo, L_hi, L_lo   (hi = slot high-water mark; slots >= hi are free)
 // ---------------------------------------------------------------------------------------------------
 #define RC_LO_BITS 24
+#define RC_BS_TILE 4096   // slots k per block (LDS bins: 32 B each); blockIdx.y = tile of k — more than one only in wide contexts
 __global__ __launch_bounds__(256) void k_blocksums(View V, int gen, int hi, long long *out)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    u64 *bins = (u64 *)smem;  // [hi][4]
-    const int t = blockIdx.x;
+    u64 *bins = (u64 *)smem;  // [min(hi, RC_BS_TILE)][4]
+    const int t = blockIdx.x, k0 = (int)blockIdx.y * RC_BS_TILE, kn = min(hi - k0, RC_BS_TILE);
     if (V.slot_size[t] == 0) return;
-    for (int q = threadIdx.x; q < hi * 4; q += blockDim.x) bins[q] = 0;
+    for (int q = threadIdx.x; q < kn * 4; q += blockDim.x) bins[q] = 0;
     __syncthreads();
     const long long mask = ((long long)1 << RC_LO_BITS) - 1;
     for (int i = threadIdx.x; i < V.n; i += blockDim.x) {
-        const int k = V.slot_of[i];
+        const int k = V.slot_of[i] - k0;
+        if (k < 0 || k >= kn) continue;
         const long long d = V.SD[gen][(size_t)t * V.ld + i], l = V.SL[gen][(size_t)t * V.ld + i];
         atomicAdd(&bins[k * 4 + 0], (u64)(d >> RC_LO_BITS));
         atomicAdd(&bins[k * 4 + 1], (u64)(d & mask));
@@ -3710,7 +3959,7 @@ __global__ __launch_bounds__(256) void k_blocksums(View V, int gen, int hi, long
         atomicAdd(&bins[k * 4 + 3], (u64)(l & mask));
     }
     __syncthreads();
-    for (int q = threadIdx.x; q < hi * 4; q += blockDim.x) out[(size_t)t * hi * 4 + q] = (long long)bins[q];
+    for (int q = threadIdx.x; q < kn * 4; q += blockDim.x) out[((size_t)t * hi + k0) * 4 + q] = (long long)bins[q];
 }
 
 // Block sums of ONE would-be cluster against a bucketing of all points, straight from the matrices:
@@ -3899,6 +4148,9 @@ struct rc_ctx {
     // slot capacity (number of clusters the tables hold).  It grows on demand — rc_set_state with more clusters, a sweep or a
     // split–merge proposal that needs one more slot — up to kcap_max = min(n, RC_MAX_KCAP); the reference's clustsizes has
     // length n (types.jl:131-137, mcmc.jl:198-199).  kcap = 0 at rc_create: sized from the first state (kcap_auto).
+    bool wide = false;            // kcap > RC_MAX_KCAP: slot tables in global memory, one S generation, k_sweep_wide (see there)
+    unsigned *wide_scratch = nullptr;
+    size_t blocks_cap = 0;        // slots c->blocks is sized for (k_blocksums output, blocks_cap² x 32 B; wide contexts size it on demand)
     bool kcap_auto = false;
     bool kcap_fixed = false;      // RC_KCAP_FIXED=1: never grow (the old behaviour: RC_ERR_CAPACITY), for tests of the error path
     // run-time options: defaults from the environment when the context is created, changed afterwards with rc_set_option — nothing
@@ -3969,7 +4221,7 @@ static int32_t fail(rc_ctx *c, int32_t code, const char *fmt, ...)
 static View make_view(const rc_ctx *c)
 {
     View V{};
-    V.n = c->n; V.ld = c->ld; V.kcap = c->kcap; V.maxb = c->maxb; V.used_scratch = c->used_scratch;
+    V.n = c->n; V.ld = c->ld; V.kcap = c->kcap; V.maxb = c->maxb; V.used_scratch = c->used_scratch; V.wide_scratch = c->wide_scratch;
     V.wc = c->wc; V.wc_always = c->wc_always; V.ldw = (c->n + RC_PTS - 1) / RC_PTS * RC_PTS;
     V.Dq = c->Dq; V.Lq = c->Lq; V.Dq48 = c->Dq48; V.bits = c->bits; V.diagq = c->diagq; V.pi = c->pi;
     V.derived = c->derived ? 1 : 0; V.qsD = std::ldexp(1.0, -c->eD); V.qsL = std::ldexp(1.0, c->eL); V.ltab = c->ltab; V.qeD = c->eD;
@@ -4014,7 +4266,7 @@ static void free_all(rc_ctx *c)
     void *ptrs[] = {c->Dq48, c->ltab, c->Dq, c->Lq, c->Dq_src, c->Lq_src, c->diag_src, c->pi, c->ipi, c->diagq, c->SD[0], c->SD[1], c->SD[2], c->SL[0], c->SL[1], c->SL[2], c->slot_of,
                     c->slot_size, c->slot_label, c->slot_pos, c->slot_act, c->perm[0], c->perm[1], c->pslot[0],
                     c->pslot[1], c->lsnap[0], c->lsnap[1], c->work[0], c->work[1], c->cword[0], c->cword[1], c->rec, c->A, c->keys[0], c->keys[1], c->arrive[0], c->arrive[1], c->sc, c->blocks,
-                    c->counts, c->cc_out, c->snap, c->d_moves, c->used_scratch, c->wc, c->ufast, c->uslow, c->wfast, c->wslow, c->s2alt.ufast, c->s2alt.uslow, c->s2alt.wfast, c->s2alt.wslow};
+                    c->counts, c->cc_out, c->snap, c->d_moves, c->used_scratch, c->wide_scratch, c->wc, c->ufast, c->uslow, c->wfast, c->wslow, c->s2alt.ufast, c->s2alt.uslow, c->s2alt.wfast, c->s2alt.wslow};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->hsum) (void)hipHostFree(c->hsum);
@@ -4115,7 +4367,12 @@ static int32_t alloc_slot_buffers(rc_ctx *c)
     for (void **pp : ptrs)
         if (*pp) { (void)hipFree(*pp); *pp = nullptr; }
     const size_t ld = (size_t)c->ld, k = (size_t)c->kcap;
-    for (int g = 0; g < 3; ++g) {
+    c->wide = c->kcap > RC_MAX_KCAP;
+    if (c->wide_scratch) { (void)hipFree(c->wide_scratch); c->wide_scratch = nullptr; }
+    c->blocks_cap = 0;
+    // a wide context keeps ONE generation of the row-sum table, corrected in place (as the incremental mode does), no score cache,
+    // and sizes the block-sum buffer of the log-likelihood by the clusters in use when it is asked for (kcap² x 32 B is 34 GB at 32767)
+    for (int g = 0; g < (c->wide ? 1 : 3); ++g) {
         HIPCHK(c, hipMalloc(&c->SD[g], k * ld * sizeof(long long)));
         HIPCHK(c, hipMalloc(&c->SL[g], k * ld * sizeof(long long)));
     }
@@ -4123,9 +4380,14 @@ static int32_t alloc_slot_buffers(rc_ctx *c)
     HIPCHK(c, hipMalloc(&c->slot_label, k * sizeof(int)));
     HIPCHK(c, hipMalloc(&c->slot_pos, k * sizeof(short)));
     HIPCHK(c, hipMalloc(&c->slot_act, k * sizeof(short)));
-    if (!rc_env("RC_SCORE_CACHE") || atoi(rc_env("RC_SCORE_CACHE")) != 0)
-        HIPCHK(c, hipMalloc((void **)&c->wc, k * (size_t)((c->n + RC_PTS - 1) / RC_PTS * RC_PTS) * sizeof(double)));
-    HIPCHK(c, hipMalloc(&c->blocks, k * k * 4 * sizeof(long long)));
+    if (c->wide) {
+        HIPCHK(c, hipMalloc((void **)&c->wide_scratch, ((size_t)(c->n + 31) / 32 + 2 * (k + 1)) * sizeof(unsigned)));
+    } else {
+        if (!rc_env("RC_SCORE_CACHE") || atoi(rc_env("RC_SCORE_CACHE")) != 0)
+            HIPCHK(c, hipMalloc((void **)&c->wc, k * (size_t)((c->n + RC_PTS - 1) / RC_PTS * RC_PTS) * sizeof(double)));
+        HIPCHK(c, hipMalloc(&c->blocks, k * k * 4 * sizeof(long long)));
+        c->blocks_cap = k;
+    }
     HIPCHK(c, hipMemsetAsync(c->slot_size, 0, k * sizeof(int), c->sA));
     HIPCHK(c, hipMemsetAsync(c->slot_label, 0, k * sizeof(int), c->sA));
     HIPCHK(c, hipStreamSynchronize(c->sA));
@@ -4214,8 +4476,8 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     if (c->n > RC_USED_LDS_MAX_N) HIPCHK2(hipMalloc((void **)&c->used_scratch, (size_t)std::max(c->num_cus, 256) * (size_t)((c->n + 31) / 32) * sizeof(unsigned)));
     HIPCHK2(hipMalloc(&c->A, (size_t)(n + 1) * sizeof(double)));
     HIPCHK2(hipMalloc(&c->sc, sizeof(DevScalars)));
-    HIPCHK2(hipHostMalloc((void **)&c->hsum, sizeof(HostSummary), hipHostMallocMapped));
-    std::memset(c->hsum, 0, sizeof(HostSummary));
+    HIPCHK2(hipHostMalloc((void **)&c->hsum, hsum_bytes(c->kcap_max), hipHostMallocMapped));
+    std::memset(c->hsum, 0, hsum_bytes(c->kcap_max));
     HIPCHK2(hipHostGetDevicePointer((void **)&c->hsum_dev, c->hsum, 0));
     HIPCHK2(hipMemsetAsync(c->Dq, 0, (size_t)n * ld * esz, s));
     HIPCHK2(hipMemsetAsync(c->Dq_src, 0, (size_t)n * ld * esz, s));
@@ -4369,7 +4631,7 @@ static int32_t alloc_ctx(int64_t n, int32_t storage_bits, int32_t device_id, int
     // count by rc_set_state (twice its K, at least 128).
     const bool kcap_auto = (kcap == 0);
     if (kcap_auto) kcap = std::min<int64_t>(n, 128);
-    if (kcap < 1 || kcap > RC_MAX_KCAP) return fail(nullptr, RC_ERR_ARG, "rc_create: kcap must be in 0..%d (0 = automatic)", RC_MAX_KCAP);
+    if (kcap < 1 || kcap > RC_WIDE_MAX_KCAP) return fail(nullptr, RC_ERR_ARG, "rc_create: kcap must be in 0..%d (0 = automatic)", RC_WIDE_MAX_KCAP);
     if (kcap > n) kcap = n;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -4383,7 +4645,7 @@ static int32_t alloc_ctx(int64_t n, int32_t storage_bits, int32_t device_id, int
     c->bits = storage_bits;
     c->kcap = (int)kcap;
     c->kcap_auto = kcap_auto;
-    c->kcap_max = (int)std::min<int64_t>(n, RC_MAX_KCAP);
+    c->kcap_max = (int)std::min<int64_t>(n, RC_WIDE_MAX_KCAP);   // (beyond RC_MAX_KCAP the context is wide: k_sweep_wide)
     c->kcap_fixed = rc_env("RC_KCAP_FIXED") && atoi(rc_env("RC_KCAP_FIXED"));
     c->dbg = rc_env_diag("RC_DEBUG_FLAGS") ? atoi(rc_env_diag("RC_DEBUG_FLAGS")) : 0;
     if (rc_env("RC_NO_PRUNE") && atoi(rc_env("RC_NO_PRUNE"))) c->opt_prune = 0;
@@ -4554,6 +4816,16 @@ static int32_t finish_create(rc_ctx *c)
         if (rcl != RC_OK) return rcl;
     }
     if (!c->registered) { res_register(c); c->registered = true; }
+    if (c->wide) {
+        // no resolver, no LDS tables: only the geometry of the full-read row reduction (it fills the table once per rc_set_state)
+        const int nchunks_w = (c->n + RC_PTS - 1) / RC_PTS;
+        c->G = std::max(1, std::min(nchunks_w, c->num_cus));
+        const int col_chunks = c->ld / (c->bits == 64 ? 512 : 1024);
+        c->rows_per_split = std::max(16, std::min(512, (c->n + std::max(1, 512 / col_chunks) - 1) / std::max(1, 512 / col_chunks)));
+        c->bulk_lds = 0;
+        (void)hipFuncSetAttribute((const void *)k_blocksums, hipFuncAttributeMaxDynamicSharedMemorySize, RC_BS_TILE * 4 * (int)sizeof(u64));
+        return RC_OK;
+    }
     {
         // Resolver batch capacity.  The resolver of sweep t has to be resident beside the row-reduction blocks of sweep t+1
         // (its grid barrier needs every block at once; behind persistent reduction blocks it would wait for the whole
@@ -4606,7 +4878,7 @@ static int32_t finish_create(rc_ctx *c)
         if (wide <= 160 * 1024) lds_r = std::max(lds_r, wide);
     }
     const size_t lds_d = std::max(tab_bytes(c->kcap, c->n, 1), 2 * sizeof(int) * (size_t)c->kcap);
-    const size_t lds_b = (size_t)c->kcap * 4 * sizeof(u64);
+    const size_t lds_b = (size_t)std::min(c->kcap, RC_BS_TILE) * 4 * sizeof(u64);
     hipError_t e1 = hipFuncSetAttribute((const void *)k_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
     hipError_t e2 = hipFuncSetAttribute((const void *)k_blocksums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
     hipError_t e3 = hipFuncSetAttribute((const void *)k_derive, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d);
@@ -4831,6 +5103,7 @@ static int capacity_for(const rc_ctx *c, long long need)
 {
     long long k = 128;
     while (k < 2 * need) k *= 2;
+    if (need <= RC_MAX_KCAP) k = std::min<long long>(k, RC_MAX_KCAP);   // (as long as the clusters fit the fast path's tables the context stays on it)
     return (int)std::min<long long>(std::max<long long>(k, need), c->kcap_max);
 }
 
@@ -4864,6 +5137,19 @@ static int32_t resize_capacity(rc_ctx *c, int new_kcap)
     return RC_OK;
 }
 
+// derived tables after the slot tables changed (rc_set_state, apply_labels, rc_set_mode): in LDS on the fast path, in global memory for a wide context
+static int32_t launch_derive(rc_ctx *c, const View &V, int rebuild_perm)
+{
+    if (c->wide) {
+        k_derive_wide<<<1, 1024, 0, c->sA>>>(V, rebuild_perm);
+    } else {
+        const size_t lds = std::max(tab_bytes(c->kcap, c->n, 1), 2 * sizeof(int) * (size_t)c->kcap);
+        k_derive<<<1, 1024, lds, c->sA>>>(V, rebuild_perm);
+    }
+    HIPCHK(c, hipGetLastError());
+    return RC_OK;
+}
+
 extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
 {
     if (!c || !clusts) return fail(c, RC_ERR_ARG, "rc_set_state: NULL argument");
@@ -4884,7 +5170,7 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
             if (!seen[(size_t)clusts[i]]) { seen[(size_t)clusts[i]] = 1; ++K0; }
         }
         if (K0 > c->kcap_max)
-            return fail(c, RC_ERR_CAPACITY, "rc_set_state: %lld clusters, the library holds at most min(n, %d) = %d (the slot tables of the sweep kernel live in LDS)", K0, RC_MAX_KCAP, c->kcap_max);
+            return fail(c, RC_ERR_CAPACITY, "rc_set_state: %lld clusters, the library holds at most min(n, %d) = %d (slot ids are 16-bit)", K0, RC_WIDE_MAX_KCAP, c->kcap_max);
         if (!c->kcap_fixed && (K0 > c->kcap || (c->kcap_auto && !c->have_state && c->n_grows == 0 && capacity_for(c, K0) > c->kcap))) {
             int32_t rcg = resize_capacity(c, std::max(c->kcap, capacity_for(c, K0)));
             if (rcg != RC_OK) return rcg;
@@ -4979,6 +5265,7 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
     HIPCHK(c, hipMemcpy(c->sc, &s, sizeof(s), hipMemcpyHostToDevice));
     // every S generation may be stale: clear them all (keeps the "rows of free slots are zero" invariant)
     for (int g = 0; g < 3; ++g) {
+        if (!c->SD[g]) continue;   // (a wide context has one generation)
         HIPCHK(c, hipMemsetAsync(c->SD[g], 0, (size_t)c->kcap * c->ld * sizeof(long long), c->sA));
         HIPCHK(c, hipMemsetAsync(c->SL[g], 0, (size_t)c->kcap * c->ld * sizeof(long long), c->sA));
     }
@@ -4989,10 +5276,12 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
         HIPCHK(c, hipMemsetAsync(c->work[g], 0, 64, c->sA));
     }
     View V = make_view(c);
-    const size_t lds = std::max(tab_bytes(c->kcap, c->n, 1), 2 * sizeof(int) * (size_t)c->kcap);
-    k_derive<<<1, 1024, lds, c->sA>>>(V, 1);
-    HIPCHK(c, hipGetLastError());
+    {
+        int32_t rcd = launch_derive(c, V, 1);
+        if (rcd != RC_OK) return rcd;
+    }
     HIPCHK(c, hipStreamSynchronize(c->sA));
+    if (c->wide) { c->incremental = true; c->inc_gen = 0; }   // one generation, corrected in place by k_sweep_wide (never back to RC_MODE_FULL)
     c->last = s;
     c->t_next = 0;
     c->bulk_enq = -1;
@@ -5201,7 +5490,8 @@ static int32_t launch_resolve(rc_ctx *c, const View &V, const SweepArgs &sa, int
         if (rd.ev) HIPCHK(c, hipStreamWaitEvent(sx, rd.ev, 0));
         else HIPCHK(c, hipEventCreateWithFlags(&rd.ev, hipEventDisableTiming));
     }
-    k_resolve<<<c->G, res_threads, lds, sx>>>(V, sa, c->G);
+    if (c->wide) k_sweep_wide<<<1, 1024, 0, sx>>>(V, sa, c->inc_gen);
+    else k_resolve<<<c->G, res_threads, lds, sx>>>(V, sa, c->G);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(c, RC_ERR_HIP, "k_resolve launch failed: %s", hipGetErrorString(e));
     if (chain) HIPCHK(c, hipEventRecord(rd.ev, sx));
@@ -5275,7 +5565,7 @@ static int32_t sweep_enqueue(rc_ctx *c, double r, double p, uint64_t seed, uint6
 #ifdef RC_TRACE_RESOLVE
     const size_t lds = std::max(tab_bytes(c->kcap, c->n, res_threads / 64, c->maxb), 2 * sizeof(int) * (size_t)c->kcap) + 4096;
 #else
-    const size_t lds = std::max(tab_bytes(c->kcap, c->n, res_threads / 64, c->maxb), 2 * sizeof(int) * (size_t)c->kcap);
+    const size_t lds = c->wide ? 0 : std::max(tab_bytes(c->kcap, c->n, res_threads / 64, c->maxb), 2 * sizeof(int) * (size_t)c->kcap);
 #endif
     if (c->incremental) {
         // exact incremental mode: the row-sum table of the current labels already exists (one k_bulk after
@@ -5350,8 +5640,8 @@ static int32_t recover_capacity(rc_ctx *c)
     if (c->kcap_fixed || c->kcap >= c->kcap_max || log.empty() || log.front().t != fail_t) {
         c->have_state = c->have_state && !log.empty();
         return fail(c, RC_ERR_CAPACITY, c->kcap >= c->kcap_max && !c->kcap_fixed
-                        ? "number of clusters exceeded %d = min(n, %d), the most the library holds (the slot tables of the sweep kernel live in LDS)"
-                        : "number of clusters exceeded the slot capacity kcap=%d (fixed: RC_KCAP_FIXED)", c->kcap, RC_MAX_KCAP);
+                        ? "number of clusters exceeded %d = min(n, %d), the most the library holds (slot ids are 16-bit)"
+                        : "number of clusters exceeded the slot capacity kcap=%d (fixed: RC_KCAP_FIXED)", c->kcap, RC_WIDE_MAX_KCAP);
     }
     // the labels as they stand (straight from the device: the summary's tables are those of the failed launch as well, but the
     // sweep's error bit would turn pull_labels -> sync_and_check back into this function)
@@ -5452,10 +5742,13 @@ static double loglik_host_c(const rc_ctx *c, rc_ctx::LLCache &cache, int hi, con
     const long double lga = lgammal(al), lgz = lgammal(ze), lgd1 = lgammal(d1), lgd2 = lgammal(d2);
     const long double lb = logl(be), lg = logl(ga);
     const long double scD = ldexpl(1.0L, -c->eD), scL = ldexpl(1.0L, -c->eL);
-    if (hi > cache.ll_dim) {
-        cache.ll_dim = std::max(hi, std::min(c->kcap, 2 * hi));
+    // (the per-pair memo is 64 B per slot pair: kept up to the fast path's capacity; a wide context evaluates every term afresh)
+    const bool memo = hi <= RC_MAX_KCAP;
+    if (memo && hi > cache.ll_dim) {
+        cache.ll_dim = std::max(hi, std::min(std::min(c->kcap, RC_MAX_KCAP), 2 * hi));
         cache.ll_cache.assign((size_t)cache.ll_dim * cache.ll_dim, rc_ctx::LLTerm{});
     }
+    rc_ctx::LLTerm scratch_term;
     auto blk = [&](const long long *e, int which) -> long double {
         return ((long double)e[which ? 2 : 0] * (long double)(1ll << RC_LO_BITS) + (long double)e[which ? 3 : 1]) * (which ? scL : scD);
     };
@@ -5466,7 +5759,8 @@ static double loglik_host_c(const rc_ctx *c, rc_ctx::LLCache &cache, int hi, con
     long double L1 = 0, L2 = 0;
     for (int k : act) {
         const long long *e = &B[((size_t)k * hi + k) * 4];
-        rc_ctx::LLTerm &T = cache.ll_cache[(size_t)k * cache.ll_dim + k];
+        if (!memo) scratch_term = rc_ctx::LLTerm{};
+        rc_ctx::LLTerm &T = memo ? cache.ll_cache[(size_t)k * cache.ll_dim + k] : scratch_term;
         if (!(T.sk == ssize[k] && T.e[0] == e[0] && T.e[1] == e[1] && T.e[2] == e[2] && T.e[3] == e[3])) {
             const long double sz = ssize[k];
             const long double pairs = sz * (sz - 1) / 2;  // binomial(sz_k, 2)
@@ -5488,7 +5782,8 @@ static double loglik_host_c(const rc_ctx *c, rc_ctx::LLCache &cache, int hi, con
             for (size_t y = x + 1; y < act.size(); ++y) {
                 const int k = act[x], t = act[y];
                 const long long *e = &B[((size_t)t * hi + k) * 4];
-                rc_ctx::LLTerm &T = cache.ll_cache[(size_t)t * cache.ll_dim + k];
+                if (!memo) scratch_term = rc_ctx::LLTerm{};
+                rc_ctx::LLTerm &T = memo ? cache.ll_cache[(size_t)t * cache.ll_dim + k] : scratch_term;
                 if (!(T.sk == ssize[k] && T.st == ssize[t] && T.e[0] == e[0] && T.e[1] == e[1] && T.e[2] == e[2] && T.e[3] == e[3])) {
                     const long double pairs = (long double)ssize[k] * (long double)ssize[t];
                     const long double z = ze + d2 * pairs;
@@ -5523,7 +5818,15 @@ static int32_t loglik_enqueue(rc_ctx *c, int hi, long long *dst, hipStream_t cop
         (void)hipGetLastError();   // (hipErrorNotReady is not an error)
         c->ev_blocks_busy = nullptr;
     }
-    k_blocksums<<<hi, 256, (size_t)hi * 4 * sizeof(u64), c->sA>>>(V, gen, hi, c->blocks);
+    if ((size_t)hi > c->blocks_cap) {   // (wide contexts: the buffer follows the clusters in use)
+        HIPCHK(c, hipStreamSynchronize(c->sA));
+        if (c->blocks) (void)hipFree(c->blocks);
+        c->blocks = nullptr; c->blocks_cap = 0;
+        const size_t cap = std::min<size_t>((size_t)c->kcap, (size_t)hi + (size_t)hi / 4 + 64);
+        HIPCHK(c, hipMalloc(&c->blocks, cap * cap * 4 * sizeof(long long)));
+        c->blocks_cap = cap;
+    }
+    k_blocksums<<<dim3((unsigned)hi, (unsigned)((hi + RC_BS_TILE - 1) / RC_BS_TILE)), 256, (size_t)std::min(hi, RC_BS_TILE) * 4 * sizeof(u64), c->sA>>>(V, gen, hi, c->blocks);
     HIPCHK(c, hipGetLastError());
     if (copy_stream) {
         HIPCHK(c, hipEventRecord(c->ev_k, c->sA));
@@ -5538,7 +5841,8 @@ static int32_t loglik_enqueue(rc_ctx *c, int hi, long long *dst, hipStream_t cop
 static int32_t ensure_pinned(rc_ctx *c, int hi)
 {
     if (c->pinB[0] && hi <= c->pin_hi) return RC_OK;
-    const int cap = std::min(c->kcap, std::max(64, 2 * hi));
+    // (beyond the fast path's capacities the staging follows the clusters in use closely: 2·hi slots would be 4x the bytes, and they are GBs there)
+    const int cap = hi > RC_MAX_KCAP / 2 ? std::min(c->kcap, hi + hi / 8 + 64) : std::min(c->kcap, std::max(64, 2 * hi));
     HIPCHK(c, hipStreamSynchronize(c->sA));
     for (int q = 0; q < RC_REC_SLOTS; ++q) {
         if (c->pinB[q]) (void)hipHostFree(c->pinB[q]);
@@ -6012,9 +6316,10 @@ static int32_t apply_labels(rc_ctx *c, const std::vector<int64_t> &cur, const st
     HIPCHK(c, hipMemcpyAsync(c->slot_of, so.data(), so.size() * sizeof(int), hipMemcpyHostToDevice, c->sA));
     HIPCHK(c, hipMemcpyAsync(c->slot_size, ssize.data(), ssize.size() * sizeof(int), hipMemcpyHostToDevice, c->sA));
     HIPCHK(c, hipMemcpyAsync(c->slot_label, slabel.data(), slabel.size() * sizeof(int), hipMemcpyHostToDevice, c->sA));
-    const size_t lds = std::max(tab_bytes(c->kcap, c->n, 1), 2 * sizeof(int) * (size_t)c->kcap);
-    k_derive<<<1, 1024, lds, c->sA>>>(V, persist ? 1 : 0);
-    HIPCHK(c, hipGetLastError());
+    {
+        int32_t rcd = launch_derive(c, V, persist ? 1 : 0);
+        if (rcd != RC_OK) return rcd;
+    }
     HIPCHK(c, hipStreamSynchronize(c->sA));  // also keeps the stack buffers above alive until the copies are done
     c->last.K = K; c->last.slot_hi = hi;
     return RC_OK;
@@ -6397,6 +6702,7 @@ extern "C" int32_t rc_set_mode(rc_ctx *c, int32_t mode)
     HIPCHK(c, hipSetDevice(c->dev));
     const bool inc = (mode == RC_MODE_INCREMENTAL);
     if (inc == c->incremental) return RC_OK;
+    if (c->wide && !inc) return RC_OK;   // a wide context maintains its one table in place whatever the mode says (same results in both modes anyway)
     int32_t rc = sync_and_check(c, true);
     if (rc != RC_OK) return rc;
     if (inc) {
@@ -6425,9 +6731,8 @@ extern "C" int32_t rc_set_mode(rc_ctx *c, int32_t mode)
         const int minus1 = -1;
         HIPCHK(c, hipMemcpyAsync(&c->sc->last_change_sweep, &minus1, sizeof(int), hipMemcpyHostToDevice, c->sA));
         View V = make_view(c);
-        const size_t lds = std::max(tab_bytes(c->kcap, c->n, 1), 2 * sizeof(int) * (size_t)c->kcap);
-        k_derive<<<1, 1024, lds, c->sA>>>(V, 1);
-        HIPCHK(c, hipGetLastError());
+        rc = launch_derive(c, V, 1);
+        if (rc != RC_OK) return rc;
         HIPCHK(c, hipStreamSynchronize(c->sA));
         c->t_next = 0;
         c->bulk_enq = -1;
