@@ -34,7 +34,7 @@ extern "C" {
 #define RC_ERR_OOM (-3)      /* host or device allocation failed */
 #define RC_ERR_DOMAIN (-4)   /* D not symmetric / not finite / non-positive off-diagonal entry (log D = -Inf) */
 #define RC_ERR_STATE (-5)    /* call sequence error (params or state not set) */
-#define RC_ERR_CAPACITY (-6) /* number of clusters exceeded the slot capacity given to rc_create */
+#define RC_ERR_CAPACITY (-6) /* more clusters than the library holds (min(n, 32767)), or than a capacity fixed with RC_KCAP_FIXED */
 
 typedef struct rc_ctx rc_ctx;
 
@@ -68,10 +68,12 @@ typedef struct rc_sweep_stats {
  * kcap: INITIAL slot capacity (clusters the sweep kernel's tables hold).  It grows on demand — rc_set_state with more
  * clusters, a sweep or a split–merge proposal that needs one more slot: the tables are doubled, the sweep is resumed at the
  * point that needed the slot and the sweeps enqueued behind it are replayed; the chain is exactly the one a larger capacity
- * would have produced — up to min(n, 4096), the most the kernel's LDS-resident tables hold (the reference's clustsizes has
- * length n, src/types.jl:131-137, src/mcmc.jl:198-199: any n <= 4096 is unrestricted; beyond, more than 4096 simultaneous
- * clusters is RC_ERR_CAPACITY).  0 = automatic: sized from the first state (twice its cluster count, at least 128).  Small
- * capacities are faster (the tables sit beside more row-reduction blocks on a CU); rc_capacity_info reports the current one.
+ * would have produced.  Up to 4096 slots the kernel's tables live in LDS (the fast path).  Beyond — the reference's clustsizes
+ * has length n, src/types.jl:131-137, src/mcmc.jl:198-199 — the context becomes WIDE: tables in global memory, one row-sum
+ * table corrected in place, the sweep point by point on one workgroup (tens to hundreds of ms per sweep; the same draws), up
+ * to min(n, 32767) clusters (slot ids are 16-bit); more is RC_ERR_CAPACITY.  0 = automatic: sized from the first state (twice
+ * its cluster count, at least 128, on the fast path while the clusters fit it).  Small capacities are faster (the tables sit
+ * beside more row-reduction blocks on a CU); rc_capacity_info reports the current one.
  * device_id: HIP device ordinal. */
 int32_t rc_create(int64_t n, const double *D, const double *logD_or_null, int32_t storage_bits,
                   int32_t device_id, int64_t kcap, rc_ctx **out);
@@ -103,7 +105,7 @@ int32_t rc_get_state(rc_ctx *ctx, int64_t *clusts /* n */, int64_t *clustsizes /
  * would under the uniform stream (seed, sweep_index).  Blocking. */
 int32_t rc_gibbs_sweep(rc_ctx *ctx, double r, double p, uint64_t seed, uint64_t sweep_index);
 int32_t rc_last_sweep_stats(rc_ctx *ctx, rc_sweep_stats *out);
-/* Current slot capacity, its ceiling min(n, 4096), the number of growths so far and the resolver's batch capacity (each
+/* Current slot capacity, its ceiling min(n, 32767) (beyond 4096 slots the context is wide: see rc_create), the number of growths so far and the resolver's batch capacity (each
  * pointer may be NULL).  Diagnostics; no reference counterpart. */
 int32_t rc_capacity_info(rc_ctx *ctx, int64_t *kcap, int64_t *kcap_max, int64_t *n_grows, int64_t *batch_capacity);
 

@@ -402,7 +402,7 @@ class Context:
         return res
 
     def capacity_info(self) -> dict:
-        """Slot capacity now, its ceiling min(n, 4096), growths so far, the resolver's batch capacity."""
+        """Slot capacity now, its ceiling min(n, 32767) (wide beyond 4096 slots), growths so far, the resolver's batch capacity."""
         v = [C.c_int64(0) for _ in range(4)]
         self._chk(self.L.rc_capacity_info(self.h, *[C.byref(x) for x in v]))
         return dict(kcap=int(v[0].value), kcap_max=int(v[1].value), n_grows=int(v[2].value), batch_capacity=int(v[3].value))

@@ -2938,7 +2938,7 @@ __device__ __forceinline__ void batch_sim(const View &V, Tab &T, int total, int 
 #ifdef RC_PROF_SIM
     const long long pf0_ = __builtin_amdgcn_s_memrealtime();
     long long pf_pro_ = 0, pf_loop_ = 0, pf_epi_ = 0, pf_init_ = 0, pf_ser_ = 0, pf_b_ = 0, pf_d_ = 0, pf_ch_ = 0;
-    long long pc_n_[3] = {0, 0, 0}, pc_t_[3] = {0, 0, 0}, pc_pre_ = 0, pc_it_ = 0;   // per path (0 rename, 1 certain death, 2 general): entries, shader cycles; the iteration's preamble
+    long long pc_n_[3] = {0, 0, 0}, pc_t_[3] = {0, 0, 0}, pc_pre_ = 0, pc_it_ = 0, pc_g_[6] = {0, 0, 0, 0, 0, 0};   // per path (0 rename, 1 certain death, 2 general): entries, shader cycles; the iteration's preamble
 #endif
     const bool regs = V.kcap < 2048;
     unsigned U = 0xffffffffu;
@@ -2959,7 +2959,7 @@ __device__ __forceinline__ void batch_sim(const View &V, Tab &T, int total, int 
         const long long pc0_ = __builtin_amdgcn_s_memrealtime(); ++pf_ch_;
 #endif
         int va = 0, vt = -1, vla = 0, vcda = 0, vcdt = 0;
-        bool vfast = false, vsafe = false, vstay = false, vdeath = false;
+        bool vfast = false, vsafe = false, vstay = false, vdeath = false, vbirth = false;
         if (q0 + lane < nb0) {
             va = T.ba[q0 + lane]; vt = T.bb[q0 + lane]; vla = T.label[va];
             // target == source: the placeholder of a carried-over guess whose target cluster is gone (the assembly wrote it so)
@@ -2971,11 +2971,13 @@ __device__ __forceinline__ void batch_sim(const View &V, Tab &T, int total, int 
             // ... joining a cluster that cannot become empty inside the batch: a death whatever the order — what depends on the order is
             // only what it does to the running state (one cluster less, its label free), see the short path below
             vdeath = vt >= 0 && !vstay && lone_ && !vcdt;
+            // ... a point of a cluster that cannot become empty inside the batch, drawing "new cluster": a birth whatever the order
+            vbirth = vt < 0 && !lone_ && !vcda;
             // a move between two clusters neither of which can become empty inside the batch: a plain move whatever the
             // order, nothing to simulate (the sizes of such clusters are not tracked here at all)
             vsafe = vt >= 0 && !vstay && !vcda && !vcdt;
         }
-        const u64 safemask = __ballot(vsafe), staymask = __ballot(vstay), fastmask = __ballot(vfast), deathmask = __ballot(vdeath);
+        const u64 safemask = __ballot(vsafe), staymask = __ballot(vstay), fastmask = __ballot(vfast), deathmask = __ballot(vdeath), birthmask = __ballot(vbirth);
         // results of entry q0 + lane (stored after the chunk).  The plain moves are not visited at all: their target is the
         // tentative one, and cluster count / smallest empty label are those left by the last visited entry before them
         int ob = vt, olab = 0, oflag = vstay ? (RC_BF_NOOP | RC_BF_STAY) : 0, oK = K;
@@ -3057,6 +3059,42 @@ __device__ __forceinline__ void batch_sim(const View &V, Tab &T, int total, int 
                 ++neff;
 #ifdef RC_PROF_SIM
                 ++pf_ser_; ++pf_d_; ++pc_n_[1]; pc_t_[1] += __builtin_amdgcn_s_memtime() - pit1_;
+#endif
+                continue;
+            }
+            if (regs && ((birthmask >> e) & 1ull) && __builtin_amdgcn_readfirstlane(nbirth) < RC_BIRTH_MAX && __ballot(myfree != 0ull) != 0ull) {
+                // A certain birth (the source cluster cannot die in this batch) with a free slot at hand and the batch's births not
+                // used up — the other cases (no slot: capacity failure; too many births: cut) go through the general path below.
+                // Slot = lowest free slot of the committed table, label = smallest empty label (mcmc.jl:199).
+                se = __builtin_amdgcn_readfirstlane(se); K = __builtin_amdgcn_readfirstlane(K); nbirth = __builtin_amdgcn_readfirstlane(nbirth);
+                neff = __builtin_amdgcn_readfirstlane(neff); first_eff = __builtin_amdgcn_readfirstlane(first_eff);
+                const u64 anyfree = __ballot(myfree != 0ull);
+                const int fw = __ffsll((long long)anyfree) - 1;
+                const u64 word = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myfree >> 32), fw) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)myfree, fw);
+                const int bitpos = __ffsll((long long)word) - 1, f = fw * 64 + bitpos, lab_ = se;
+                if (lane == fw) myfree &= ~(1ull << bitpos);
+                if (lane == ((lab_ - 1) >> 5)) U |= 1u << ((lab_ - 1) & 31);
+                {   // smallest empty label above lab_
+                    const int w0 = lab_ >> 5;
+                    unsigned inv = (lane >= w0) ? ~U : 0u;
+                    if (lane == w0) inv &= ~((1u << (lab_ & 31)) - 1u);
+                    const u64 anyw = __ballot(inv != 0u);
+                    se = V.n + 1;
+                    if (anyw) {
+                        const int fl = __ffsll((long long)anyw) - 1;
+                        const int r = fl * 32 + __ffs(__builtin_amdgcn_readlane((int)inv, fl));   // 1-based label
+                        if (r <= V.n) se = r;
+                    }
+                }
+                K += 1;
+                if (lane == 0) { T.size[f] = 1; T.birth[nbirth] = (short)q; }
+                ++nbirth;
+                if (lane == e) { ob = f; olab = lab_; oflag = RC_BF_BIRTH; }
+                if (lane >= e) oK = K;
+                if (first_eff < 0) first_eff = q;
+                ++neff;
+#ifdef RC_PROF_SIM
+                ++pf_ser_; ++pf_b_; ++pc_n_[1]; pc_t_[1] += __builtin_amdgcn_s_memtime() - pit1_;
 #endif
                 continue;
             }
@@ -3165,6 +3203,7 @@ __device__ __forceinline__ void batch_sim(const View &V, Tab &T, int total, int 
             if (lane >= e) oK = K;
 #ifdef RC_PROF_SIM
             ++pf_ser_; pf_b_ += (flag & RC_BF_BIRTH) ? 1 : 0; pf_d_ += (flag & RC_BF_DEATH) ? 1 : 0; ++pc_n_[2]; pc_t_[2] += __builtin_amdgcn_s_memtime() - pit1_;
+            pc_g_[(flag & RC_BF_BIRTH) ? 0 : (flag & RC_BF_DEATH) ? 1 : (flag & RC_BF_RENAME) ? 2 : (flag & RC_BF_STAY) ? 3 : (flag & RC_BF_NOOP) ? 4 : 5] += 1;
 #endif
         }
 #ifdef RC_PROF_SIM
@@ -3193,6 +3232,7 @@ __device__ __forceinline__ void batch_sim(const View &V, Tab &T, int total, int 
         dbg_[9] += nb0; dbg_[10] += __builtin_amdgcn_s_memrealtime() - pf0_;
         for (int c_ = 0; c_ < 3; ++c_) { dbg_[11 + 2 * c_] += pc_n_[c_]; dbg_[12 + 2 * c_] += pc_t_[c_]; }
         dbg_[17] += pc_it_; dbg_[18] += pc_pre_;
+        for (int c_ = 0; c_ < 6; ++c_) dbg_[19 + c_] += pc_g_[c_];
     }
 #endif
     if (lane == 0) { T.misc[3] = nb; T.misc[4] = hi; T.misc[5] = fail; T.misc[8] = nbirth; T.misc[9] = neff; T.misc[10] = first_eff; T.misc[13] = nvisited; }

@@ -20,7 +20,7 @@ L.rc_debug_prof.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
 names = {6: "eval tentative", 7: "barrier 1", 8: "assemble batch", 14: "batch_sim", 9: "restore + lists", 10: "eval validate", 11: "barrier 2", 12: "commit"}
 base0 = None
 if os.environ.get("RC_PROF_SIM"):
-    L.rc_debug_prof(ctx.h, 0, out.ctypes.data_as(C.c_void_p)); base0 = out[:2].reshape(-1)[:19].astype(np.float64).copy()
+    L.rc_debug_prof(ctx.h, 0, out.ctypes.data_as(C.c_void_p)); base0 = out[:2].reshape(-1)[:25].astype(np.float64).copy()
 if os.environ.get("RC_PROF_COMMIT"): names = {2: "(commit: tables)", **names}   # -DRC_PROF_COMMIT build: column 2 = table rebuild inside the commit
 acc = {k: [] for k in names}; mx = {k: [] for k in names}; mn = {k: [] for k in names}; rounds = []; tot = []
 for t in range(60, 80):
@@ -37,8 +37,9 @@ print(f"   last sweep: prologue (tables) {pro:.1f} us, epilogue of blocks 0-3 {e
 for k, nm in names.items(): print(f"   {nm:16s} {np.mean(acc[k]):8.1f} us per sweep   {np.mean(acc[k]) / np.mean(rounds):7.1f} per round   (blocks: min {np.mean(mn[k]):7.1f} max {np.mean(mx[k]):7.1f} per sweep)")
 if os.environ.get("RC_PROF_SIM"):   # -DRC_PROF_SIM build: block 0's batch_sim accumulators (cumulative over all sweeps; 10 ns ticks) in row 0 of parity 0
     L.rc_debug_prof(ctx.h, 0, out.ctypes.data_as(C.c_void_p))
-    r = out[:2].reshape(-1)[:19].astype(np.float64) - base0; c = r[0]
+    r = out[:2].reshape(-1)[:25].astype(np.float64) - base0; c = r[0]
     print(f"   batch_sim calls {int(c)}: per call {r[10] / c / 100:.1f} us = state set-up {r[1] / c / 100:.1f} + chunk prefetch {r[2] / c / 100:.1f} + entry loop {r[3] / c / 100:.1f} + chunk write-back {r[4] / c / 100:.1f};"
           f" per call {r[9] / c:.0f} entries in {r[8] / c:.1f} chunks, {r[5] / c:.1f} applied one by one ({r[6] / c:.1f} births, {r[7] / c:.1f} deaths): {r[3] / max(r[5], 1) * 10:.0f} ns each")
     print(f"   serial entries per call by path: renames {r[11] / c:.1f} ({r[12] / max(r[11], 1):.0f} cycles each), certain deaths {r[13] / c:.1f} ({r[14] / max(r[13], 1):.0f} cycles each), "
           f"general {r[15] / c:.1f} ({r[16] / max(r[15], 1):.0f} cycles each); loop iterations {r[17] / c:.1f} per call, preamble {r[18] / max(r[17], 1):.0f} cycles each (s_memtime ticks)")
+    print(f"   general path per call: births {r[19] / c:.1f}, deaths {r[20] / c:.1f}, renames {r[21] / c:.1f}, placeholders {r[22] / c:.1f}, no-ops {r[23] / c:.1f}, plain moves {r[24] / c:.1f}")

@@ -4,9 +4,9 @@
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r04; mkdir -p $O; LOG=$O/verify.log; : > $LOG
 B=$PWD/build_r4
 echo "== pytest -m gpu (in-tree build)" | tee -a $LOG
-python -m pytest tests -m gpu -x -q 2>&1 | tail -4 | tee -a $LOG
+python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -3 | tee -a $LOG
 echo "== chaos build: moving-regime parity subset + multi-thread tests" | tee -a $LOG
-RC_LIB_PATH=$B/lib_chaos15.so timeout 1200 python -m pytest tests/test_gpu_derived_log.py tests/test_gpu_parity.py tests/test_gpu_threads.py tests/test_gpu_capacity.py -x -q -m gpu -k "derived_sweeps or derived_equals or many_small or synthetic_moving or long_trajectory or golden_sweeps or concurrent or resumed or record_sample" 2>&1 | tail -4 | tee -a $LOG
+RC_LIB_PATH=$B/lib_chaos15.so timeout 1200 python -m pytest tests/test_gpu_derived_log.py tests/test_gpu_parity.py tests/test_gpu_threads.py tests/test_gpu_capacity.py -x -q -m gpu -k "derived_sweeps or derived_equals or many_small or synthetic_moving or long_trajectory or golden_sweeps or concurrent or resumed or record_sample" 2>&1 | grep -E "passed|failed|error" | tail -3 | tee -a $LOG
 echo "== fuzz (tests/fuzz_parity.py): sweeps, large, chains pipelined vs synchronous, chains vs the oracle's loop" | tee -a $LOG
 for args in "500 41000" "40 42000 large" "400 43000 chains" "200 44000 oracle_chains"; do
   timeout 1500 python tests/fuzz_parity.py $args 2>&1 | tail -2 | tee -a $LOG
