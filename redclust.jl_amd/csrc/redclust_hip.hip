@@ -3235,7 +3235,231 @@ __device__ __forceinline__ void batch_sim(const View &V, Tab &T, int total, int 
         for (int c_ = 0; c_ < 6; ++c_) dbg_[19 + c_] += pc_g_[c_];
     }
 #endif
-    if (lane == 0) { T.misc[3] = nb; T.misc[4] = hi; T.misc[5] = fail; T.misc[8] = nbirth; T.misc[9] = neff; T.misc[10] = first_eff; T.misc[13] = nvisited; }
+    if (lane == 0) { T.misc[3] = nb; T.misc[4] = hi; T.misc[5] = fail; T.misc[8] = nbirth; T.misc[9] = neff; T.misc[10] = first_eff; T.misc[13] = nvisited; T.misc[18] = 0; }
+}
+
+// The same simulation, reorganised around what is really sequential (round 4; kcap < 2048, the label bitset in registers).
+// batch_sim above walks the entries that need the running state one after the other and does everything for each in turn —
+// sizes from LDS, kind of entry, free slot, label bitset, smallest empty label, cluster count, flags — 500 to 2000 cycles of
+// one wave per entry (profiles/r04: 28 such entries per batch in the moving regime, 20 of the 23 µs of a call, 55 µs per
+// sweep: the largest phase of the resolver).  Only two things are chains:
+//   (1) the running SIZES of the clusters that could become empty inside the batch, which decide what an entry IS — a move, a
+//       death, a birth, a singleton drawing "new cluster", a placeholder.  Most entries are decided by the chunk prefetch alone
+//       (lone singletons, clusters that cannot die); the others are walked in order with one LDS round trip each, and nothing else;
+//   (2) the free-LABEL set, a sequence of "label freed" (death), "take the smallest" (birth) and both (a singleton drawing "new
+//       cluster": it takes min(own label, smallest empty label), mcmc.jl:199).  One short scalar-driven loop over these events:
+//       lane w holds the free labels 32w+1 .. 32w+32 as a bit mask, the smallest empty label is a scalar; singletons that keep their
+//       label (own label below the smallest empty one) are skipped in bulk, as before.
+// Everything else is computed for the 64 entries of a chunk at once from the ballots of the kinds: cluster count after every
+// entry (prefix pop-counts), the births' slots (r-th free slot of the committed table), the list of births, the cut (a birth
+// without a free slot or beyond RC_BIRTH_MAX), effective-entry count.  T.size is put back before returning (misc[18] = 1: the
+// caller's restore is skipped).  Same results as batch_sim entry for entry (the randomised comparisons run both).
+__device__ __forceinline__ void batch_sim_fast(const View &V, Tab &T, int total, int cap)
+{
+    const int lane = threadIdx.x & 63;
+    const int nb0 = min(total, cap);
+    int K = T.misc[0], se = T.misc[1], nbirth = 0, neff = 0, first_eff = -1;
+    int nb = nb0, hi = (total > cap) ? T.misc[2] - 1 : V.n - 1, fail = 0, nvisited = 0;
+    bool stop = false;
+#ifdef RC_PROF_SIM
+    const long long pf0_ = __builtin_amdgcn_s_memrealtime();
+    long long pf_pro_ = 0, pf_loop_ = 0, pf_epi_ = 0, pf_init_ = 0, pf_b_ = 0, pf_d_ = 0, pf_ch_ = 0, pc_unc_ = 0, pc_unc_t_ = 0, pc_ev_ = 0, pc_ev_t_ = 0;
+#endif
+    // free labels (bit set = free): lane w holds labels 32w+1 .. 32w+32; free slots of the committed table: lane w holds slots 64w .. 64w+63
+    unsigned F = 0u;
+    if (lane < (V.n + 31) / 32) F = ~T.used[lane];
+    u64 myfree = 0;
+    int nfree = 0;
+    for (int w = 0; w * 64 < V.kcap; ++w) {
+        const int k = w * 64 + lane;
+        const u64 m = __ballot(k < V.kcap && T.label[k] == 0);
+        if (lane == w) myfree = m;
+        nfree += __popcll(m);
+    }
+    nfree = __builtin_amdgcn_readfirstlane(nfree);
+#ifdef RC_PROF_SIM
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pf_init_ = __builtin_amdgcn_s_memrealtime() - pf0_;
+#endif
+    const u64 le = (2ull << lane) - 1ull, lt = le >> 1;          // lanes <= / < this one
+    for (int q0 = 0; q0 < nb0 && !stop; q0 += 64) {
+#ifdef RC_PROF_SIM
+        const long long pc0_ = __builtin_amdgcn_s_memrealtime(); ++pf_ch_;
+#endif
+        const int cnt = min(64, nb0 - q0);
+        const bool in = lane < cnt;
+        int va = 0, vt = -1, vla = 0;
+        bool vstay = false, cda = false, cdt = false, lone = false;
+        if (in) {
+            va = T.ba[q0 + lane]; vt = T.bb[q0 + lane]; vla = T.label[va];
+            vstay = (vt == va);                                      // placeholder of a carried-over guess whose target is gone (assembly)
+            cda = T.candie[va] != 0; cdt = vt >= 0 && T.candie[vt] != 0;
+            lone = T.size[va] == 1 && !T.joined[va];                 // a singleton nobody in the batch joins: alone at its turn whatever happened before
+        }
+        // kinds the prefetch decides (see batch_sim): singleton drawing "new cluster"; certain death; certain birth; plain move
+        const bool c_snew = in && vt < 0 && lone, c_death = in && vt >= 0 && !vstay && lone && !cdt;
+        const bool c_birth = in && vt < 0 && !lone && !cda, c_safe = in && vt >= 0 && !vstay && !cda && !cdt;
+        u64 Mstay = __ballot(in && vstay), Msnew = __ballot(c_snew), Mdeath = __ballot(c_death), Mbirth = __ballot(c_birth), Mmove = __ballot(c_safe);
+        u64 uncm = __ballot(in && !vstay && !c_snew && !c_death && !c_birth && !c_safe);
+        const u64 cdam = __ballot(cda), cdtm = __ballot(cdt);
+        u64 decA = 0, incT = 0;                                      // entries that took a point out of a tracked source / put one into a tracked target
+#ifdef RC_PROF_SIM
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const long long psim0_ = __builtin_amdgcn_s_memrealtime(); pf_pro_ += psim0_ - pc0_;
+        const long long pu0_ = __builtin_amdgcn_s_memtime();
+#endif
+        // (1) the entries whose kind depends on the running sizes, in order: the two sizes are the one LDS round trip of an entry
+        while (uncm) {
+            const int e = __ffsll((long long)uncm) - 1;
+            const u64 bit = 1ull << e;
+            uncm &= ~bit;
+            ++nvisited;
+#ifdef RC_PROF_SIM
+            ++pc_unc_;
+#endif
+            const int a = __builtin_amdgcn_readlane(va, e), t = __builtin_amdgcn_readlane(vt, e);
+            const bool ca = (cdam & bit) != 0ull, ct = (cdtm & bit) != 0ull;
+            const int x_ = T.size[a], y_ = T.size[t >= 0 ? t : a];   // (both issued before either is waited for)
+            const int sza = __builtin_amdgcn_readfirstlane(x_), szt = __builtin_amdgcn_readfirstlane(y_);
+            if (t >= 0) {
+                if (ct && szt == 0) {
+                    Mstay |= bit;                                     // the target was emptied by an earlier entry: a placeholder ("stays")
+                } else {
+                    if (ca && sza == 1) Mdeath |= bit; else Mmove |= bit;
+                    if (ca) { if (lane == 0) T.size[a] = sza - 1; decA |= bit; }
+                    if (ct) { if (lane == 0) T.size[t] = szt + 1; incT |= bit; }
+                }
+            } else if (ca && sza == 1) {
+                Msnew |= bit;                                         // alone at its turn: keeps its label or takes a smaller one
+            } else {
+                Mbirth |= bit;
+                if (ca) { if (lane == 0) T.size[a] = sza - 1; decA |= bit; }
+            }
+        }
+#ifdef RC_PROF_SIM
+        pc_unc_t_ += __builtin_amdgcn_s_memtime() - pu0_;
+#endif
+        // the cut: a birth that finds no free slot (capacity: the host grows the tables if it is the batch's first entry) or is the
+        // batch's RC_BIRTH_MAX-th — the rest of the batch is announced again
+        int done = cnt;
+        const int nbc_all = __popcll(Mbirth), room = min(nfree, RC_BIRTH_MAX) - nbirth;
+        if (nbc_all > room) {
+            u64 m = Mbirth;
+            for (int r = 0; r < room; ++r) m &= m - 1ull;
+            const int e_cut = __ffsll((long long)m) - 1;
+            if (nbirth + room >= nfree) fail = (q0 + e_cut == 0);
+            nb = q0 + e_cut; hi = T.bx[nb] - 1; stop = true; done = e_cut;
+            const u64 tail = ~((1ull << e_cut) - 1ull);
+            // the sizes the entries at and behind the cut changed go back at once (those before it at the end, from their flag bits)
+            if (((decA & tail) >> lane) & 1ull) atomicAdd(&T.size[va], 1);
+            if (((incT & tail) >> lane) & 1ull) atomicSub(&T.size[vt], 1);
+            Mstay &= ~tail; Msnew &= ~tail; Mdeath &= ~tail; Mbirth &= ~tail; Mmove &= ~tail; decA &= ~tail; incT &= ~tail;
+        }
+        // (2) the label events, in order
+        int olab = 0;
+        {
+#ifdef RC_PROF_SIM
+            const long long pe0_ = __builtin_amdgcn_s_memtime();
+#endif
+            const u64 Mdb = Mdeath | Mbirth;
+            u64 todo = Mdb | Msnew;
+            se = __builtin_amdgcn_readfirstlane(se);
+            while (todo) {
+                // singletons whose own label lies below the smallest empty one keep it: nothing changes, nothing to do
+                const u64 ser = todo & (Mdb | __ballot(vla > se));
+                if (!ser) break;
+                const int e = __ffsll((long long)ser) - 1;
+                const u64 bit = 1ull << e;
+                todo &= ~((bit << 1) - 1ull);
+                ++nvisited;
+#ifdef RC_PROF_SIM
+                ++pc_ev_;
+#endif
+                const int la = __builtin_amdgcn_readlane(vla, e);
+                if (Mdeath & bit) {
+                    if (lane == ((la - 1) >> 5)) F |= 1u << ((la - 1) & 31);        // (a label beyond 2048 has no lane: never the smallest empty one)
+                    if (la < se) se = la;
+                } else {
+                    const int lab = se;                                              // birth / rename: the smallest empty label (mcmc.jl:199)
+                    if (lane == ((lab - 1) >> 5)) F &= ~(1u << ((lab - 1) & 31));
+                    const bool sn = (Msnew & bit) != 0ull;
+                    if (sn && lane == ((la - 1) >> 5)) F |= 1u << ((la - 1) & 31);   // the singleton's old label is free now
+                    const u64 anyw = __ballot(F != 0u);
+                    se = V.n + 1;
+                    if (anyw) {
+                        const int fl = __ffsll((long long)anyw) - 1;
+                        const int r = fl * 32 + __ffs(__builtin_amdgcn_readlane((int)F, fl));   // 1-based label
+                        if (r <= V.n) se = r;
+                    }
+                    if (sn && la < se) se = la;                                      // (labels beyond the 64 words are not seen by the scan)
+                    if (lane == e) olab = lab;
+                }
+            }
+#ifdef RC_PROF_SIM
+            pc_ev_t_ += __builtin_amdgcn_s_memtime() - pe0_;
+#endif
+        }
+#ifdef RC_PROF_SIM
+        const long long psim1_ = __builtin_amdgcn_s_memrealtime(); pf_loop_ += psim1_ - psim0_;
+        pf_b_ += __popcll(Mbirth); pf_d_ += __popcll(Mdeath);
+#endif
+        // everything else, for the whole chunk at once
+        const int nbc = __popcll(Mbirth);
+        int slots = 0;                                               // lane r: the r-th free slot of the committed table not yet handed out
+        for (int r = 0; r < nbc; ++r) {
+            const u64 anyfree = __ballot(myfree != 0ull);             // (non-zero: births <= room)
+            const int fw = __ffsll((long long)anyfree) - 1;
+            const u64 word = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myfree >> 32), fw) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)myfree, fw);
+            const int bitpos = __ffsll((long long)word) - 1;
+            if (lane == fw) myfree &= ~(1ull << bitpos);
+            if (lane == r) slots = fw * 64 + bitpos;
+        }
+        const bool isb = ((Mbirth >> lane) & 1ull) != 0ull, issn = ((Msnew >> lane) & 1ull) != 0ull, isst = ((Mstay >> lane) & 1ull) != 0ull;
+        const int brank = __popcll(Mbirth & lt);
+        const int bslot = __shfl(slots, brank & 63);
+        const int oK = K + __popcll(Mbirth & le) - __popcll(Mdeath & le);
+        int ob = vt, oflag = 0;
+        if (isst) { ob = va; oflag = RC_BF_NOOP | RC_BF_STAY; }
+        else if (issn) { ob = va; oflag = olab ? RC_BF_RENAME : RC_BF_NOOP; }
+        else if (isb) { ob = bslot; oflag = RC_BF_BIRTH; T.birth[nbirth + brank] = (short)(q0 + lane); }
+        else if ((Mdeath >> lane) & 1ull) oflag = RC_BF_DEATH;
+        {
+            const u64 effm = Mmove | Mdeath | Mbirth | __ballot(issn && olab != 0);
+            if (effm) {
+                if (first_eff < 0) first_eff = q0 + __ffsll((long long)effm) - 1;
+                neff += __popcll(effm);
+            }
+        }
+        if (lane < done) {
+            const int q = q0 + lane;
+            T.bb[q] = (short)ob; T.blab[q] = olab; T.bK[q] = (short)oK;
+            T.bflag[q] = (unsigned char)(oflag | (((decA >> lane) & 1ull) ? 0x20 : 0) | (((incT >> lane) & 1ull) ? 0x40 : 0));
+        }
+        K += nbc - __popcll(Mdeath);
+        nbirth += nbc;
+#ifdef RC_PROF_SIM
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pf_epi_ += __builtin_amdgcn_s_memrealtime() - psim1_;
+#endif
+    }
+    // the running sizes back to the committed ones (flag bits 0x20: left a tracked source, 0x40: joined a tracked target; bb of such
+    // an entry is still its guessed target: a move or a death)
+    __builtin_amdgcn_wave_barrier();
+    for (int q = lane; q < nb; q += 64) {
+        const int fl = T.bflag[q];
+        if (fl & 0x60) {
+            if (fl & 0x20) atomicAdd(&T.size[T.ba[q]], 1);
+            if (fl & 0x40) atomicSub(&T.size[T.bb[q]], 1);
+            T.bflag[q] = (unsigned char)(fl & 0x1f);
+        }
+    }
+#ifdef RC_PROF_SIM
+    if (blockIdx.x == 0 && lane == 0) {
+        long long *dbg_ = (long long *)((char *)V.work[0] + 64);
+        dbg_[0] += 1; dbg_[1] += pf_init_; dbg_[2] += pf_pro_; dbg_[3] += pf_loop_; dbg_[4] += pf_epi_; dbg_[5] += nvisited; dbg_[6] += pf_b_; dbg_[7] += pf_d_; dbg_[8] += pf_ch_;
+        dbg_[9] += nb0; dbg_[10] += __builtin_amdgcn_s_memrealtime() - pf0_;
+        dbg_[11] += pc_unc_; dbg_[12] += pc_unc_t_; dbg_[13] += pc_ev_; dbg_[14] += pc_ev_t_;
+    }
+#endif
+    if (lane == 0) { T.misc[3] = nb; T.misc[4] = hi; T.misc[5] = fail; T.misc[8] = nbirth; T.misc[9] = neff; T.misc[10] = first_eff; T.misc[13] = nvisited; T.misc[18] = 1; }
 }
 
 // Commit of the first `nc` batch changers: sizes, labels, cluster count, per-slot constants, slot_of, and the S
@@ -3518,7 +3742,11 @@ __device__ __forceinline__ void resolve_body(const View &V, const SweepArgs &sa,
         // clusters that could become empty inside the batch (more leavers than would leave one member): only their sizes matter
         for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) T.candie[k] = (T.size[k] - T.seg[k] < 1);
         __syncthreads();
+#ifdef RC_SIM_OLD   // (comparison builds: the one-entry-at-a-time simulation everywhere)
         if (threadIdx.x < 64) batch_sim(V, T, total, cap);
+#else
+        if (threadIdx.x < 64) { if (V.kcap < 2048) batch_sim_fast(V, T, total, cap); else batch_sim(V, T, total, cap); }
+#endif
         if (threadIdx.x == 0) *T.blk_key = RC_KEY_NONE;
         __syncthreads();
         RC_PHASE(14)
@@ -3527,11 +3755,12 @@ __device__ __forceinline__ void resolve_body(const View &V, const SweepArgs &sa,
         // the entries that touch each slot, grouped by slot: count, offsets, scatter, sort within a slot
         {
             const int nbk = T.misc[3];
+            const bool sizes_restored = T.misc[18] != 0;   // (batch_sim_fast puts the sizes back itself)
             for (int k = threadIdx.x; k <= V.kcap; k += blockDim.x) T.seg[k] = 0;
             __syncthreads();
             for (int q = threadIdx.x; q < nbk; q += blockDim.x) {
                 const int a_ = T.ba[q], b_ = T.bb[q], fl = T.bflag[q];
-                if (a_ != b_) {
+                if (a_ != b_ && !sizes_restored) {
                     if (T.candie[a_]) atomicAdd(&T.size[a_], 1);
                     if ((fl & RC_BF_BIRTH) || T.candie[b_]) atomicSub(&T.size[b_], 1);
                 }

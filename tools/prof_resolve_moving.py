@@ -40,6 +40,9 @@ if os.environ.get("RC_PROF_SIM"):   # -DRC_PROF_SIM build: block 0's batch_sim a
     r = out[:2].reshape(-1)[:25].astype(np.float64) - base0; c = r[0]
     print(f"   batch_sim calls {int(c)}: per call {r[10] / c / 100:.1f} us = state set-up {r[1] / c / 100:.1f} + chunk prefetch {r[2] / c / 100:.1f} + entry loop {r[3] / c / 100:.1f} + chunk write-back {r[4] / c / 100:.1f};"
           f" per call {r[9] / c:.0f} entries in {r[8] / c:.1f} chunks, {r[5] / c:.1f} applied one by one ({r[6] / c:.1f} births, {r[7] / c:.1f} deaths): {r[3] / max(r[5], 1) * 10:.0f} ns each")
+    if r[15] == 0 and r[13] > 0:   # batch_sim_fast (round 4): [11]/[12] entries decided from the running sizes, [13]/[14] label events (s_memtime ticks)
+        print(f"   batch_sim_fast: per call {r[11] / c:.1f} entries decided from the running sizes ({r[12] / max(r[11], 1):.0f} cycles each), {r[13] / c:.1f} label events ({r[14] / max(r[13], 1):.0f} cycles each)")
+        sys.exit(0)
     print(f"   serial entries per call by path: renames {r[11] / c:.1f} ({r[12] / max(r[11], 1):.0f} cycles each), certain deaths {r[13] / c:.1f} ({r[14] / max(r[13], 1):.0f} cycles each), "
           f"general {r[15] / c:.1f} ({r[16] / max(r[15], 1):.0f} cycles each); loop iterations {r[17] / c:.1f} per call, preamble {r[18] / max(r[17], 1):.0f} cycles each (s_memtime ticks)")
     print(f"   general path per call: births {r[19] / c:.1f}, deaths {r[20] / c:.1f}, renames {r[21] / c:.1f}, placeholders {r[22] / c:.1f}, no-ops {r[23] / c:.1f}, plain moves {r[24] / c:.1f}")
