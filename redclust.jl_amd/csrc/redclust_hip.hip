@@ -189,6 +189,7 @@ struct View {
     int derived;               // 1: logD is not stored; Lq(i,j) = rc_qlog(Dq(i,j)) for i != j, 0 on the diagonal
     double qsD, qsL;           // 2^-eD, 2^eL
     const double2 *ltab;       // [128] table of rc_qlog (see there)
+    const double2 *flt;        // [128] table of rc_flog: (1/c_i rounded, -log of that double) — the logarithms of the scores
     int qeD;                   // eD
     long long *SD[3], *SL[3];  // three generations of the [kcap][ld] row-sum table (software pipelining)
     int *slot_of;              // [n] slot of every point, INTERNAL point order
@@ -222,7 +223,7 @@ struct SweepArgs {
     int t;    // internal sweep index since rc_set_state: selects key / perm generations
     int own_gen, next_gen;  // S generation read (and corrected in place); generation being filled for the next sweep (-1: none)
     int zero_gen;           // S generation this launch clears for the row reduction two sweeps ahead (-1: none)
-    int dbg;  // timing ablations only (RC_DEBUG_FLAGS): 1 = skip candidate loop, 2 = skip grid barrier, 4 = skip gumbel
+    int dbg;  // timing ablations only (RC_DEBUG_FLAGS / rc_set_option "debug_flags", -DRC_DIAG builds): 1 = skip candidate loop, 2 = skip grid barrier, 4 = skip gumbel, 8 = no row-sum loads, 16 = no score-cache stores
     // a sweep resumed after the slot tables were grown (recover_capacity): the points <= after0 are final already, changes0 /
     // rounds0 are what the first part of the sweep had committed / run.  A fresh sweep: -1, 0, 0.
     int after0, changes0, rounds0;
@@ -237,8 +238,8 @@ __device__ __forceinline__ double rc_uniform(const SweepArgs &a, unsigned i, uns
     unsigned c0 = pos, c1 = i, c2 = a.sw_lo, c3 = a.sw_hi, k0 = a.k0, k1 = a.k1;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const u64 p0 = (u64)0xD2511F53u * (u64)c0, p1 = (u64)0xCD9E8D57u * (u64)c2;   // (one 32 x 32 -> 64 multiply each)
+        const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0, hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
         const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -397,6 +398,53 @@ __device__ __forceinline__ long long rc_qlog(long long dq, int eD, double sL, co
 {
     const QlogPrep P = rc_qlog_prep(dq, eD);
     return rc_qlog_finish(dq, P, tab[P.j], sL);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The logarithms of the candidate scores (round 4).  A candidate of k_resolve needs two log1p (cohesion and repulsion terms,
+// mcmc.jl:223-241) and the Gumbel noise -log(-log u) (utils.jl:4): with the device library's double-precision routines these are
+// 135 + 135 + 170 of its ~570 VALU instructions — the library works in double-double to stay below one ulp for EVERY argument,
+// special values included.  Here every argument is a positive normal number (u in (0,1), its negative log, 1 + a non-negative
+// ratio), so one table-driven routine serves all of them in ~25 instructions at the same ~1 ulp:
+//   x = 2^k z, z in [0.6875, 1.375) (the exponent is split at 0.6875 so that x near 1 has k = 0: no cancellation against k ln2);
+//   i = top 7 mantissa bits of z's offset: 128 intervals; c_i = its centre — but c_i = 1 in the two intervals that touch 1.0, where
+//   r = z - 1 is exact and the result keeps its RELATIVE accuracy (what -log u needs when u is close to 1: the large noise values);
+//   r = fma(z, invc_i, -1) with invc_i = 1/c_i rounded, logc_i = -log(invc_i) to 64 bits rounded once (built on the host in long
+//   double: log z = log1p(r) + logc_i holds for the STORED reciprocal, whatever its rounding); |r| <= 2^-7;
+//   log1p(r) = r + r^2 (-1/2 + r/3 - ... - r^6/8)   (next term r^9/9 <= 1.2e-20);
+//   result = (k ln2_hi + logc_i + r) [two-sum] + (k ln2_lo + r^2 p + extra).
+// log1p(x) = log(u) + c/u with u + c = 1 + x exactly (two-sum): c/u <= 2^-53, through `extra`.
+// (the method of the table-driven libm logarithms; tables and code are this library's own)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rc_flog(double x, const double2 *__restrict__ tab, double extra = 0.0)
+{
+    const int hi = __double2hiint(x);
+    const int tmp = hi - 0x3fe60000;
+    const int k = tmp >> 20;                                                // (arithmetic: x < 0.6875 has k < 0)
+    const double z = __hiloint2double(hi - (tmp & (int)0xfff00000u), __double2loint(x));
+    const double2 t = tab[(tmp >> 13) & 127];
+    const double r = fma(z, t.x, -1.0);
+    const double kd = (double)k;
+    const double h = fma(kd, 0x1.62e42fefa3800p-1, t.y);                    // k ln2_hi is exact (ln2_hi has 42 significant bits)
+    const double t1 = h + r;
+    const double lo = fma(kd, 0x1.ef35793c76730p-45, (h - t1) + r) + extra; // (|h| >= |r| or h = 0: the two-sum is exact)
+    double p = fma(r, -1.0 / 8, 1.0 / 7);
+    p = fma(r, p, -1.0 / 6);
+    p = fma(r, p, 1.0 / 5);
+    p = fma(r, p, -1.0 / 4);
+    p = fma(r, p, 1.0 / 3);
+    p = fma(r, p, -0.5);
+    return fma(r * r, p, lo) + t1;
+}
+__device__ __forceinline__ double rc_flog1p(double x, const double2 *__restrict__ tab)      // x >= 0
+{
+    const double u = 1.0 + x, v = u - 1.0;
+    const double c = (1.0 - (u - v)) + (x - v);
+    return rc_flog(u, tab, c * __builtin_amdgcn_rcp(u));
+}
+__device__ __forceinline__ double rc_gumbel(double un, const double2 *__restrict__ tab)     // -log(-log u), u in (0, 1)
+{
+    return -rc_flog(-rc_flog(un, tab), tab);
 }
 
 // logD entry (row, col) in internal order, stored or derived; xd = Dq(row, col) when the caller has it already
@@ -2620,7 +2668,9 @@ __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Ta
         auto consider = [&](const int k) {
             const int isown = (k == own);
             int sz = T.size[k], lab = T.label[k];
-            long long sd = SD[(size_t)k * ld + u], sl = SL[(size_t)k * ld + u];
+            long long sd, sl;
+            if (a.dbg & 8) { sd = 1ll << 40; sl = -(1ll << 40); }   // (timing ablation: no row-sum loads)
+            else { sd = SD[(size_t)k * ld + u]; sl = SL[(size_t)k * ld + u]; }
             bool touched;
             if (mode == 1 && k == hot) {
                 const int *hi_ = (const int *)hotacc;
@@ -2652,8 +2702,8 @@ __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Ta
                 }
             }
 #endif
-            double lik = V.cL * SLr - (V.alpha + V.delta1 * (double)s) * log1p(SDr / V.beta);
-            if (V.repulsion) lik += (V.zeta + V.delta2 * (double)s) * log1p(SDr / V.gamma);
+            double lik = V.cL * SLr - (V.alpha + V.delta1 * (double)s) * rc_flog1p(SDr / V.beta, V.flt);
+            if (V.repulsion) lik += (V.zeta + V.delta2 * (double)s) * rc_flog1p(SDr / V.gamma, V.flt);
             double v = base + lik;
 #ifndef RC_NO_PRUNE
             if (prune && !isown) {
@@ -2665,9 +2715,9 @@ __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Ta
 #endif
             if (!(a.dbg & 4)) {
                 const double un = rc_uniform(a, (unsigned)i, (unsigned)lab);
-                v = v + (-log(-log(un)));
+                v = v + rc_gumbel(un, V.flt);
             }
-            if (cmode != 0 && mode == 0 && !isown) wrow[(size_t)k * V.ldw] = v;   // tentative passes keep the cache current
+            if (cmode != 0 && mode == 0 && !isown && !(a.dbg & 16)) wrow[(size_t)k * V.ldw] = v;   // tentative passes keep the cache current (dbg 16: timing ablation)
             if (bestslot == -2 || v > bestv || (v == bestv && lab < bestpos)) { bestv = v; bestpos = lab; bestslot = k; }
         };
         // A point that is a cluster of its own has no own cluster to set the bar: every stream then starts with the new-cluster
@@ -2677,7 +2727,7 @@ __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Ta
         const bool new_first = prune && single && new_ok;
         if (new_first) {
             const double un = rc_uniform(a, (unsigned)i, 0u);
-            bestv = (log((double)(Ki + 1)) + a.r * a.log1mp) + (-log(-log(un)));
+            bestv = (log((double)(Ki + 1)) + a.r * a.log1mp) + rc_gumbel(un, V.flt);
             bestpos = RC_NEWKEY; bestslot = -1;
         }
         // With pruning every stream starts with the point's own cluster (itself removed): its score is the bar the stream's other
@@ -2750,12 +2800,12 @@ __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Ta
                 const long long xd = (V.bits == 64) ? ((const long long *)V.Dq)[e] : (long long)((const int *)V.Dq)[e];
                 const long long xl = rc_load_L(V, T.bu[q], u, xd);
                 const double SDr = (double)xd * V.scD, SLr = (double)xl * V.scL;
-                double lik = V.cL * SLr - (V.alpha + V.delta1) * log1p(SDr / V.beta);
-                if (V.repulsion) lik += (V.zeta + V.delta2) * log1p(SDr / V.gamma);
+                double lik = V.cL * SLr - (V.alpha + V.delta1) * rc_flog1p(SDr / V.beta, V.flt);
+                if (V.repulsion) lik += (V.zeta + V.delta2) * rc_flog1p(SDr / V.gamma, V.flt);
                 double v = tab_base(V, a, 1) + lik;
                 if (!(a.dbg & 4)) {
                     const double un = rc_uniform(a, (unsigned)i, (unsigned)lab);
-                    v = v + (-log(-log(un)));
+                    v = v + rc_gumbel(un, V.flt);
                 }
                 if (bestslot == -2 || v > bestv || (v == bestv && lab < bestpos)) { bestv = v; bestpos = lab; bestslot = T.bb[q]; }
             }
@@ -2763,7 +2813,7 @@ __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Ta
         // new-cluster candidate, last in the candidate order (mcmc.jl:198-203, 228-230); one stream handles it
         if (!new_first && st == (K % NS) && new_ok) {
             const double un = rc_uniform(a, (unsigned)i, 0u);
-            const double v = (log((double)(Ki + 1)) + a.r * a.log1mp) + (-log(-log(un)));
+            const double v = (log((double)(Ki + 1)) + a.r * a.log1mp) + rc_gumbel(un, V.flt);
             if (v > bestv || bestslot == -2) { bestv = v; bestpos = RC_NEWKEY; bestslot = -1; }
         }
     }
@@ -4093,17 +4143,17 @@ __global__ __launch_bounds__(1024) void k_sweep_wide(View V, SweepArgs sa, int g
             sd -= (isown ? dg : 0);                                              // i itself excluded (clusts[i] = -1)
             const double SDr = (double)sd * V.scD, SLr = (double)sl * V.scL;
             const double base = tab_base(V, sa, s_);
-            double lik = V.cL * SLr - (V.alpha + V.delta1 * (double)s_) * log1p(SDr / V.beta);
-            if (V.repulsion) lik += (V.zeta + V.delta2 * (double)s_) * log1p(SDr / V.gamma);
+            double lik = V.cL * SLr - (V.alpha + V.delta1 * (double)s_) * rc_flog1p(SDr / V.beta, V.flt);
+            if (V.repulsion) lik += (V.zeta + V.delta2 * (double)s_) * rc_flog1p(SDr / V.gamma, V.flt);
             double v = base + lik;
             const double un = rc_uniform(sa, (unsigned)i, (unsigned)lab);
-            v = v + (-log(-log(un)));
+            v = v + rc_gumbel(un, V.flt);
             if (bestslot == -2 || v > bestv || (v == bestv && lab < bestkey)) { bestv = v; bestkey = lab; bestslot = k; }
         }
         const bool new_ok = (V.maxK == 0 || (long long)Ki < V.maxK) && Ki < V.n;
         if (threadIdx.x == 0 && new_ok) {                                        // mcmc.jl:198-203, 228-230: last in the candidate order
             const double un = rc_uniform(sa, (unsigned)i, 0u);
-            const double v = (log((double)(Ki + 1)) + sa.r * sa.log1mp) + (-log(-log(un)));
+            const double v = (log((double)(Ki + 1)) + sa.r * sa.log1mp) + rc_gumbel(un, V.flt);
             if (v > bestv || bestslot == -2) { bestv = v; bestkey = RC_NEWKEY; bestslot = -1; }
         }
 #pragma unroll
@@ -4353,6 +4403,7 @@ struct rc_ctx {
     struct S2Alt { int4 *ufast = nullptr, *uslow = nullptr; int *wfast = nullptr, *wslow = nullptr; int nfast = 0, nslow = 0, blocks = 0; } s2alt;
     bool derived = false;               // logD derived from Dq on the fly (rc_qlog), not stored
     double2 *ltab = nullptr;            // device table of rc_qlog
+    double2 *flt = nullptr;             // device table of rc_flog
     int n_relayouts = 0;                // re-layouts done so far (rc_set_state + automatic ones)
     int bits = 64;
     long long *SD[3] = {nullptr, nullptr, nullptr}, *SL[3] = {nullptr, nullptr, nullptr};
@@ -4493,7 +4544,7 @@ static View make_view(const rc_ctx *c)
     V.n = c->n; V.ld = c->ld; V.kcap = c->kcap; V.maxb = c->maxb; V.used_scratch = c->used_scratch; V.wide_scratch = c->wide_scratch;
     V.wc = c->wc; V.wc_always = c->wc_always; V.ldw = (c->n + RC_PTS - 1) / RC_PTS * RC_PTS;
     V.Dq = c->Dq; V.Lq = c->Lq; V.Dq48 = c->Dq48; V.bits = c->bits; V.diagq = c->diagq; V.pi = c->pi;
-    V.derived = c->derived ? 1 : 0; V.qsD = std::ldexp(1.0, -c->eD); V.qsL = std::ldexp(1.0, c->eL); V.ltab = c->ltab; V.qeD = c->eD;
+    V.derived = c->derived ? 1 : 0; V.qsD = std::ldexp(1.0, -c->eD); V.qsL = std::ldexp(1.0, c->eL); V.ltab = c->ltab; V.flt = c->flt; V.qeD = c->eD;
     for (int g = 0; g < 3; ++g) { V.SD[g] = c->SD[g]; V.SL[g] = c->SL[g]; }
     for (int g = 0; g < 2; ++g) { V.perm[g] = c->perm[g]; V.pslot[g] = c->pslot[g]; V.keys[g] = c->keys[g]; V.arrive[g] = c->arrive[g]; V.snap[g] = c->lsnap[g]; V.work[g] = c->work[g]; V.cword[g] = c->cword[g]; }
     V.rec = c->rec;
@@ -4532,7 +4583,7 @@ static void free_all(rc_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->dev);
-    void *ptrs[] = {c->Dq48, c->ltab, c->Dq, c->Lq, c->Dq_src, c->Lq_src, c->diag_src, c->pi, c->ipi, c->diagq, c->SD[0], c->SD[1], c->SD[2], c->SL[0], c->SL[1], c->SL[2], c->slot_of,
+    void *ptrs[] = {c->Dq48, c->ltab, c->flt, c->Dq, c->Lq, c->Dq_src, c->Lq_src, c->diag_src, c->pi, c->ipi, c->diagq, c->SD[0], c->SD[1], c->SD[2], c->SL[0], c->SL[1], c->SL[2], c->slot_of,
                     c->slot_size, c->slot_label, c->slot_pos, c->slot_act, c->perm[0], c->perm[1], c->pslot[0],
                     c->pslot[1], c->lsnap[0], c->lsnap[1], c->work[0], c->work[1], c->cword[0], c->cword[1], c->rec, c->A, c->keys[0], c->keys[1], c->arrive[0], c->arrive[1], c->sc, c->blocks,
                     c->counts, c->cc_out, c->snap, c->d_moves, c->used_scratch, c->wide_scratch, c->wc, c->ufast, c->uslow, c->wfast, c->wslow, c->s2alt.ufast, c->s2alt.uslow, c->s2alt.wfast, c->s2alt.wslow};
@@ -4724,6 +4775,20 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
     HIPCHK2(hipMalloc(&c->pi, (size_t)n * sizeof(int)));
     HIPCHK2(hipMalloc(&c->ipi, (size_t)n * sizeof(int)));
     HIPCHK2(hipMalloc(&c->ltab, 128 * sizeof(double2)));
+    {   // table of rc_flog (see there): interval i of z's offset from 0.6875 in units of 2^-7 of the mantissa; long double on the host
+        double2 ft[128];
+        for (int i = 0; i < 128; ++i) {
+            const uint64_t b0 = ((uint64_t)(0x3fe60000u + ((uint32_t)i << 13))) << 32, b1 = ((uint64_t)(0x3fe60000u + ((uint32_t)(i + 1) << 13))) << 32;
+            double z0, z1;
+            memcpy(&z0, &b0, 8); memcpy(&z1, &b1, 8);
+            if (i == 79 || i == 80) { ft[i].x = 1.0; ft[i].y = 0.0; continue; }   // the intervals that touch 1.0: r = z - 1, exactly
+            const long double cc = 0.5L * ((long double)z0 + (long double)z1);
+            const double invc = (double)(1.0L / cc);
+            ft[i].x = invc; ft[i].y = (double)(-logl((long double)invc));
+        }
+        HIPCHK2(hipMalloc(&c->flt, sizeof(ft)));
+        HIPCHK2(hipMemcpy(c->flt, ft, sizeof(ft), hipMemcpyHostToDevice));
+    }
     for (int g = 0; g < 2; ++g) {
         HIPCHK2(hipMalloc(&c->perm[g], (size_t)n * sizeof(int)));
         HIPCHK2(hipMalloc(&c->pslot[g], (size_t)n * sizeof(int)));
@@ -7029,6 +7094,10 @@ extern "C" int32_t rc_set_option(rc_ctx *c, const char *name, int64_t value)
     } else if (!strcmp(name, "chain_pipeline")) {
         if (value != 0 && value != 1) return fail(c, RC_ERR_ARG, "rc_set_option: chain_pipeline must be 0 or 1");
         c->opt_chain_pipeline = (int)value;
+#ifdef RC_DIAG
+    } else if (!strcmp(name, "debug_flags")) {   // timing ablations (SweepArgs.dbg): results are wrong on purpose
+        c->dbg = (int)value;
+#endif
     } else {
         return fail(c, RC_ERR_ARG, "rc_set_option: unknown option '%s' (prune, chain_workers, chain_depth, chain_pipeline)", name);
     }
