@@ -168,6 +168,12 @@ int32_t rc_debug_rowsums(rc_ctx *ctx, int64_t label, int64_t *sumD_q /* n */, in
  * kernels: Σ_labels rc_debug_rowsums(label)[i] must equal it (the full matsum(x) of src/utils.jl:18-24 row by row). */
 int32_t rc_debug_rowtotals(rc_ctx *ctx, int64_t *totD_q /* n */, int64_t *totL_q /* n */);
 
+/* The logarithms the sweep kernel scores candidates with, evaluated on the device for m caller-supplied arguments: which = 0
+ * log(x) (x > 0, normal), 1 log1p(x) (x >= 0), 2 -log(-log(x)) (0 < x < 1: the Gumbel noise of src/utils.jl:4).  The reference
+ * calls Julia's log / log1p (src/mcmc.jl:223-241); the kernel uses one table-driven routine of its own (<= 1.5 ulp on these
+ * domains) — this entry lets the tests hold it against libm. */
+int32_t rc_debug_flog(rc_ctx *ctx, int32_t which, const double *x, int64_t m, double *out /* m */);
+
 /* Timing of the dominant kernel (row-bucket reduction) measured with HIP events on the stream it is launched
  * on: accumulated milliseconds and number of timed launches since the last reset.  enable: 0 = off, 1 = time
  * every launch, N > 1 = time every N-th launch, negative = just read the counters.  The two events of a timed

@@ -135,6 +135,7 @@ SIGNATURES = {
     "rc_state_restore": (C.c_int32, [C.c_void_p]),
     "rc_debug_rowsums": (C.c_int32, [C.c_void_p, C.c_int64, _ip, _ip, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rc_debug_rowtotals": (C.c_int32, [C.c_void_p, _ip, _ip]),
+    "rc_debug_flog": (C.c_int32, [C.c_void_p, C.c_int32, _dp, C.c_int64, _dp]),
     "rc_bulk_kernel_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "rc_set_bulk_kernel": (C.c_int32, [C.c_void_p, C.c_int32]),
     "rc_set_option": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64]),
@@ -355,6 +356,13 @@ class Context:
         tl = np.zeros(self.n, np.int64)
         self._chk(self.L.rc_debug_rowtotals(self.h, td, tl))
         return td, tl
+
+    def debug_flog(self, which, x):
+        """rc_debug_flog: the sweep kernel's own log (which = 0), log1p (1) or -log(-log(x)) (2) of every entry of x, on the device."""
+        x = np.ascontiguousarray(x, np.float64)
+        out = np.zeros_like(x)
+        self._chk(self.L.rc_debug_flog(self.h, int(which), x, x.size, out))
+        return out
 
     def bulk_kernel_info(self):
         w, b = C.c_int32(), C.c_double()

@@ -3567,13 +3567,16 @@ __device__ __forceinline__ int commit_batch(const View &V, const SweepArgs &sa, 
         // entry: 118 µs per round when a hundred changers joined one cluster.)
         for (int k = st; act && k < hi_slots; k += NS) {
             if ((k ? T.seg[k - 1] : 0) == T.seg[k]) continue;
+            // (the words to correct are requested before the group is walked: their round trip then runs beside the matrix entries'
+            // instead of behind it — the commit is a chain of dependent global round trips, not of instructions)
+            const size_t ik = (size_t)k * V.ld + i;
+            const long long oD = SDo[ik], oL = SLo[ik];
             long long dD = 0, dL = 0;
             int sz_ = 0, lab_ = 0;
             if (k == hot) { if (((const int *)hotacc)[5] == 0) continue; dD = hotacc[0]; dL = hotacc[1]; }
             else if (!batch_corr(V, T, k, i, nc, dD, dL, sz_, lab_)) continue;
-            const size_t ik = (size_t)k * V.ld + i;
-            if (dD) { SDo[ik] += dD; if (SDn) __hip_atomic_fetch_add((u64 *)(SDn + ik), (u64)dD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            if (dL) { SLo[ik] += dL; if (SLn) __hip_atomic_fetch_add((u64 *)(SLn + ik), (u64)dL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            if (dD) { SDo[ik] = oD + dD; if (SDn) __hip_atomic_fetch_add((u64 *)(SDn + ik), (u64)dD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            if (dL) { SLo[ik] = oL + dL; if (SLn) __hip_atomic_fetch_add((u64 *)(SLn + ik), (u64)dL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         }
         if (hot >= 0) __syncthreads();
     }
@@ -5326,6 +5329,31 @@ extern "C" int32_t rc_get_matrix_rows(rc_ctx *c, int32_t which, const int64_t *r
 }
 
 // Fixed-point row totals Σ_j D[i,j] and Σ_j logD[i,j] (value = q·2^-e) of the matrices as the caller gave them — k_rowtotals.
+// the score logarithms of the resolver on caller-supplied arguments (tests: against libm, tests/test_gpu_logs.py)
+__global__ void k_flog_eval(const double *__restrict__ x, long long m, int which, const double2 *__restrict__ tab, double *__restrict__ out)
+{
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < m) out[q] = which == 0 ? rc_flog(x[q], tab) : which == 1 ? rc_flog1p(x[q], tab) : rc_gumbel(x[q], tab);
+}
+extern "C" int32_t rc_debug_flog(rc_ctx *c, int32_t which, const double *x, int64_t m, double *out)
+{
+    if (!c || !x || !out || m < 0 || which < 0 || which > 2) return fail(c, RC_ERR_ARG, "rc_debug_flog: bad argument (which: 0 log, 1 log1p, 2 -log(-log))");
+    if (m == 0) return RC_OK;
+    HIPCHK(c, hipSetDevice(c->dev));
+    double *d = nullptr;
+    HIPCHK(c, hipMalloc(&d, 2 * (size_t)m * sizeof(double)));
+    hipError_t e = hipMemcpyAsync(d, x, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->sA);
+    if (e == hipSuccess) {
+        k_flog_eval<<<(unsigned)((m + 255) / 256), 256, 0, c->sA>>>(d, (long long)m, which, c->flt, d + m);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d + m, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, c->sA);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->sA);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, RC_ERR_HIP, "rc_debug_flog: %s", hipGetErrorString(e));
+    return RC_OK;
+}
+
 extern "C" int32_t rc_debug_rowtotals(rc_ctx *c, int64_t *totD_q, int64_t *totL_q)
 {
     if (!c || !totD_q || !totL_q) return fail(c, RC_ERR_ARG, "rc_debug_rowtotals: NULL argument");
