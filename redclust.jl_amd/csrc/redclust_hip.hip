@@ -362,22 +362,31 @@ __global__ __launch_bounds__(256) void k_pairwise(const double *__restrict__ pts
 //        Lq = bits(w) − bits(1.5·2^52)         (|Lq| < 2^51 by the choice of eL, so v and w stay in [2^52, 2^53): unit spacing)
 // 16 VALU instructions per entry — six of them double-precision FMAs / multiplies — and one 16-byte table read (round 2's form of
 // the same idea took 23: a degree-6 polynomial, the scaling and the rounding as separate steps); the libm log is ~100.
-// ltab[j] = (1/c_j, T_j): 128 entries, rebuilt per context once eL is known (create_impl).
+// ltab[j] = (2/c_j, T_j): 128 entries, rebuilt per context once eL is known (create_impl).
 // ---------------------------------------------------------------------------------------------------
 // Front end: the fixed-point entry is an integer below 2^52 (create_impl caps eD accordingly in the derived mode), so
 // OR-ing it into the mantissa of 2^52 and subtracting 2^52 converts it to a double exactly in two instructions; exponent,
 // table index and mantissa then come from the HIGH dword of that double with 32-bit operations (no count-leading-zeros,
 // no 64-bit shifts).  dq = 0 (padding, masked entries) gives a finite value the callers discard.
-struct QlogPrep { int j; double kd, m; };
+// (round 4: the mantissa is one v_frexp_mant_f64 — m/2 in [0.5, 1), the table holds 2/c_j: the same product, the same r, bit for
+// bit — instead of and + or + a register copy; the table offset is taken in bytes (shift + mask instead of shift + mask + shift))
+struct QlogPrep { int j; unsigned joff; double kd, m; };
 __device__ __forceinline__ QlogPrep rc_qlog_prep(long long dq, int eD)
 {
     const double x = __longlong_as_double(dq | 0x4330000000000000ll) - 0x1p52;
     const unsigned hi = (unsigned)__double2hiint(x);
+    int kbias;                                                              // 1023 + eD, opaque to the optimiser (which splits the sum into two vector subtractions per entry otherwise)
+    asm("s_add_i32 %0, %1, 0x3ff" : "=s"(kbias) : "s"(eD) : "scc");
     QlogPrep P;
-    P.kd = (double)((int)(hi >> 20) - (1023 + eD));                         // x·2^-eD = m·2^k, m in [1,2)
+    P.kd = (double)((int)(hi >> 20) - kbias);                               // x·2^-eD = m·2^k, m in [1,2)
     P.j = (int)((hi >> 13) & 127u);                                         // top 7 fraction bits
-    P.m = __hiloint2double((int)((hi & 0x000fffffu) | 0x3ff00000u), __double2loint(x));
+    P.joff = (hi >> 9) & 0x7f0u;                                            // 16 j: byte offset of entry j in a plain table
+    P.m = __builtin_amdgcn_frexp_mant(x);                                   // m / 2
     return P;
+}
+__device__ __forceinline__ double2 rc_qlog_entry(const double2 *__restrict__ tab, const QlogPrep &P)
+{
+    return *(const double2 *)((const char *)tab + P.joff);
 }
 // the value for dq > 0 — no select on dq: callers that may hold dq <= 0 mask the result
 __device__ __forceinline__ long long rc_qlog_raw(const QlogPrep &P, double2 t, double sL)
@@ -397,7 +406,7 @@ __device__ __forceinline__ long long rc_qlog_finish(long long dq, const QlogPrep
 __device__ __forceinline__ long long rc_qlog(long long dq, int eD, double sL, const double2 *__restrict__ tab)
 {
     const QlogPrep P = rc_qlog_prep(dq, eD);
-    return rc_qlog_finish(dq, P, tab[P.j], sL);
+    return rc_qlog_finish(dq, P, rc_qlog_entry(tab, P), sL);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -555,9 +564,9 @@ __global__ __launch_bounds__(256) void k_pack48(const long long *__restrict__ Dq
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < pairs; t += (size_t)gridDim.x * blockDim.x) {
         const ll2 v = *(const ll2 *)(Dq + 2 * t);
         const u64 a = (u64)v.x, b = (u64)v.y;
-        out[3 * t] = (unsigned)a;
-        out[3 * t + 1] = (unsigned)(a >> 32) | ((unsigned)b << 16);
-        out[3 * t + 2] = (unsigned)(b >> 16);
+        out[3 * t] = (unsigned)a;                                               // the low words as they are, the two 16-bit tops share the third
+        out[3 * t + 1] = (unsigned)b;
+        out[3 * t + 2] = (unsigned)(a >> 32) | ((unsigned)(b >> 32) << 16);
     }
 }
 
@@ -1612,8 +1621,8 @@ template <> struct S2Raw<true> {
     static __device__ __forceinline__ ll2 unpack(const rc_u3 &r)
     {
         ll2 x;
-        x.x = (long long)((u64)r.x | ((u64)(r.y & 0xffffu) << 32));
-        x.y = (long long)((u64)((r.y >> 16) | (r.z << 16)) | ((u64)(r.z >> 16) << 32));
+        x.x = (long long)((u64)r.x | ((u64)(r.z & 0xffffu) << 32));
+        x.y = (long long)((u64)r.y | ((u64)(r.z >> 16) << 32));
         return x;
     }
 };
@@ -1843,6 +1852,7 @@ __device__ __forceinline__ void syml2_fast(const View &V, long long *pb /* [2][8
 #pragma unroll
                             for (int u = 0; u < RC_S2_LOGS; ++u) {
                                 if (RC_S2_EXP & 16) tv[u] = tab[RC_S2_TABREP * ((lane & 15) + 16 * ((ar + u + g_) & 7))];   // timing experiment: a conflict-free gather
+                                else if (RC_S2_TABREP == 1) tv[u] = rc_qlog_entry(tab, pp[u]);
                                 else tv[u] = tab[RC_S2_TABREP * pp[u].j + (RC_S2_TABREP > 1 ? (lane & (RC_S2_TABREP - 1)) : 0)];
                             }
 #pragma unroll
@@ -2212,7 +2222,11 @@ struct Tab {
     short *act2;              // [kcap] the active slots again, those whose cached scores are valid first (tab_partition)
     unsigned char *dirty;     // [kcap] a committed change of this sweep touched the slot: its cached scores are void
     unsigned short *ccnt;     // [nchunks + 1] scratch: changers per chunk / exclusive offsets, saturating at 65535 (only offsets <= batch capacity matter)
+    int *cu;                  // [RC_CPB_LDS * RC_PTS] internal index of the points of this block's chunks (pi[i]: fixed for the launch) ...
+    short *cown;              // [RC_CPB_LDS * RC_PTS] ... and their slots (kept current by commit_batch); used when `cached` (at most RC_CPB_LDS chunks per block):
+    int cached;               // the first loads of every pass over a chunk — pi[i], then slot_of[pi[i]]: two dependent global round trips — come from LDS
 };
+#define RC_CPB_LDS 4
 #define RC_BF_DEATH 1   // the source cluster becomes empty
 #define RC_BF_BIRTH 2   // the target is a new cluster (slot bb, label blab)
 #define RC_BF_RENAME 4  // a singleton that takes a fresh, smaller label (slot unchanged, label blab)
@@ -2249,7 +2263,7 @@ __host__ __device__ inline size_t tab_layout(int kcap, int n, int nw, size_t *of
     off[22] = o; o = RC_A16(o + sizeof(short) * maxb);       // birth
     off[23] = o; o = RC_A16(o + sizeof(short) * 2 * maxb);   // pairs
     off[24] = o; o = RC_A16(o + (size_t)kcap);                  // candie
-    off[25] = o;                                                // (unused)
+    off[25] = o; o = RC_A16(o + (sizeof(int) + sizeof(short)) * RC_CPB_LDS * RC_PTS);   // cu, cown
     off[26] = o; o = RC_A16(o + (size_t)kcap);                  // joined
     off[27] = o; o = RC_A16(o + sizeof(short) * 2 * maxb);   // pairs_tmp
     off[28] = o;
@@ -2273,6 +2287,7 @@ __device__ __forceinline__ Tab tab_carve(char *smem, int kcap, int n, int nw, in
     T.pairs = (short *)(smem + off[23]); T.candie = (unsigned char *)(smem + off[24]);
     T.joined = (unsigned char *)(smem + off[26]); T.pairs_tmp = (short *)(smem + off[27]);
     T.act2 = (short *)(smem + off[10]); T.dirty = (unsigned char *)(smem + off[19]);
+    T.cu = (int *)(smem + off[25]); T.cown = (short *)(T.cu + RC_CPB_LDS * RC_PTS); T.cached = 0;
     return T;
 }
 
@@ -2347,6 +2362,48 @@ __device__ __forceinline__ void tab_structural(const View &V, Tab &T)
     }
     if (threadIdx.x == 0) T.misc[1] = T.misc[2];
     __syncthreads();
+}
+
+// After a commit with births / deaths / renames, fewer than 2048 slots (commit_batch): the freed labels are already cleared in
+// T.used; here the labels the first nc entries took, the smallest empty label, the list of active slots (ballot compaction in
+// slot order, as tab_structural) and the per-slot score constants — two block barriers where rebuilding everything took six.
+__device__ __forceinline__ void tab_after_commit(const View &V, const SweepArgs &a, Tab &T, int nc)
+{
+    const int nw = (V.n + 31) / 32, hi = T.misc[7];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, NW = blockDim.x >> 6;
+    for (int q = threadIdx.x; q < nc; q += blockDim.x) {
+        const int lab = T.blab[q];                                   // (0 unless the entry is a birth or a rename)
+        if (lab > 0) atomicOr(&T.used[(lab - 1) >> 5], 1u << ((lab - 1) & 31));
+    }
+    if (threadIdx.x == 0) T.misc[1] = V.n + 1;
+    for (int k = threadIdx.x; k < hi; k += blockDim.x) {            // score constants (tab_bases): sizes and labels are final
+        const int s = T.size[k];
+        if (T.label[k] > 0) {
+            T.base_o[k] = tab_base(V, a, s);
+            T.base_s[k] = (s >= 2) ? tab_base(V, a, s - 1) : 0.0;
+        }
+    }
+    int base = 0;
+    for (int k0 = 0; k0 < hi; k0 += blockDim.x) {
+        const int k = k0 + threadIdx.x;
+        const bool f = k < hi && T.label[k] > 0;
+        const u64 m = __ballot(f);
+        if (lane == 0) T.red_pos[wave] = __popcll(m);
+        __syncthreads();
+        if (k0 == 0)
+            for (int w = threadIdx.x; w < nw; w += blockDim.x) {   // smallest empty label (the bitset is final behind the barrier)
+                const unsigned inv = ~T.used[w];
+                if (inv) {
+                    const int lab = w * 32 + __ffs((int)inv);
+                    if (lab <= V.n) atomicMin(&T.misc[1], lab);
+                }
+            }
+        int before = 0, tot = 0;
+        for (int w = 0; w < NW; ++w) { const int x = T.red_pos[w]; tot += x; before += (w < wave) ? x : 0; }
+        if (f) T.act[base + before + __popcll(m & ((1ull << lane) - 1ull))] = (short)k;
+        base += tot;
+        __syncthreads();
+    }
 }
 
 __device__ __forceinline__ void tab_load(const View &V, Tab &T)
@@ -2616,14 +2673,25 @@ __device__ __forceinline__ double rc_pruned_bound(double tagged) { return (doubl
 // Always computed: the point's own cluster (its score excludes the point itself), the clusters born in the batch, the
 // new-cluster candidate.  The cached value is the very double the computation would produce again, so decisions are
 // unchanged; a computed candidate costs ~330 VALU instructions, a cached one a load (moving regime, K = 206: eight passes per sweep).
+// -DRC_PROF_EVAL (profiling builds): the longest thread of the block per part of a VALIDATION pass — cached clean slots / own cluster
+// and computed slots / births, new cluster and the arg-max — summed over the chunks into T.misc[19..21] (10 ns ticks)
+#ifdef RC_PROF_EVAL
+#define RC_PE_STAMP(k) if (mode == 1) { const long long n_ = __builtin_amdgcn_s_memrealtime(); pe_[(k) - 19] += (int)(n_ - pe_t); pe_t = n_; }
+#else
+#define RC_PE_STAMP(k)
+#endif
 __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Tab &T, const long long *SD, const long long *SL,
-                           int chunk, int lo, int hi, int mode, int nb, u64 *cword, unsigned *rec, unsigned stamp, int cmode,
+                           int chunk, int cidx /* chunk = blockIdx.x + cidx G */, int lo, int hi, int mode, int nb, u64 *cword, unsigned *rec, unsigned stamp, int cmode,
                            u64 *cword_next = nullptr, unsigned *rec_next = nullptr, unsigned stamp_next = 0u)
 {
     const int pt = threadIdx.x & (RC_PTS - 1), st = threadIdx.x >> RC_PTS_LOG2, NS = blockDim.x >> RC_PTS_LOG2;
     const int wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
     const int i = chunk * RC_PTS + pt;
     const bool valid = (i < V.n) && (i > lo) && (i <= hi);
+#ifdef RC_PROF_EVAL
+    int pe_[3] = {0, 0, 0};
+    long long pe_t = __builtin_amdgcn_s_memrealtime();
+#endif
     const int K = T.misc[0];
     double bestv = -INFINITY;
     int bestpos = 0x7fffffff, bestslot = -2;
@@ -2632,8 +2700,9 @@ __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Ta
     // at all — with it, as dead weight, the moving regime ran 3 % slower; sweeps that prune hardly ever validate)
     const bool prune = mode == 0 && a.prune != 0 && !(a.dbg & 5);
     if (valid) {
-        u = V.pi[i];  // matrices, S and slot_of are stored in the internal (cluster-contiguous) point order
-        own = V.slot_of[u];
+        // matrices, S and slot_of are stored in the internal (cluster-contiguous) point order
+        if (T.cached) { u = T.cu[cidx * RC_PTS + pt]; own = T.cown[cidx * RC_PTS + pt]; }
+        else { u = V.pi[i]; own = V.slot_of[u]; }
         // number of batch changers before i (bx ascending)
         if (mode == 1) {
             int lo_ = 0, hi_ = nb;
@@ -2665,12 +2734,9 @@ __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Ta
         const long long dg = V.diagq[u];
         double *const wrow = V.wc + i;   // column i of the score cache (used only when cmode != 0)
         const double inv_beta = 1.0 / V.beta, inv_gamma = 1.0 / V.gamma;
-        auto consider = [&](const int k) {
+        auto consider_v = [&](const int k, long long sd, long long sl) {   // (sd, sl: the slot's two row sums for this point, as stored)
             const int isown = (k == own);
             int sz = T.size[k], lab = T.label[k];
-            long long sd, sl;
-            if (a.dbg & 8) { sd = 1ll << 40; sl = -(1ll << 40); }   // (timing ablation: no row-sum loads)
-            else { sd = SD[(size_t)k * ld + u]; sl = SL[(size_t)k * ld + u]; }
             bool touched;
             if (mode == 1 && k == hot) {
                 const int *hi_ = (const int *)hotacc;
@@ -2717,9 +2783,12 @@ __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Ta
                 const double un = rc_uniform(a, (unsigned)i, (unsigned)lab);
                 v = v + rc_gumbel(un, V.flt);
             }
-            if (cmode != 0 && mode == 0 && !isown && !(a.dbg & 16)) wrow[(size_t)k * V.ldw] = v;   // tentative passes keep the cache current (dbg 16: timing ablation)
+            // tentative passes keep the cache current (dbg 16: timing ablation).  Entry (own slot, i) holds the point's OWN-cluster score
+            // (itself removed): a point that is still open has not moved in this sweep, so the entry never means anything else
+            if (cmode != 0 && mode == 0 && !(a.dbg & 16)) wrow[(size_t)k * V.ldw] = v;
             if (bestslot == -2 || v > bestv || (v == bestv && lab < bestpos)) { bestv = v; bestpos = lab; bestslot = k; }
         };
+        auto consider = [&](const int k) { consider_v(k, SD[(size_t)k * ld + u], SL[(size_t)k * ld + u]); };
         // A point that is a cluster of its own has no own cluster to set the bar: every stream then starts with the new-cluster
         // candidate instead (log, hash and noise: cheap, and a singleton's usual draw).  Lanes of a wave run in lock step — one
         // point without a bar makes its whole wave compute the noise of every candidate.
@@ -2734,10 +2803,20 @@ __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Ta
         // candidates must be able to reach (see "Pruned candidates"; the same candidate in several streams is harmless: equal score,
         // equal label).  Without, the own cluster is one candidate of one stream.
         if (cmode != 2) {
-            for (int pos = prune ? -1 : st; pos < ((a.dbg & 1) ? 0 : K); pos = (pos < 0) ? st : pos + NS) {
-                const int k = (pos < 0) ? own : (int)T.act[pos];
-                if (prune && pos >= 0 && k == own) continue;
-                consider(k);
+            // every candidate is computed: its two row sums are requested one candidate ahead (the loop is a chain of global round
+            // trips otherwise — with the table-driven logarithms a candidate is ~260 instructions, less than the latency of its loads)
+            const int Kl = (a.dbg & 1) ? 0 : K;
+            int pos = prune ? -1 : st;
+            int k = (pos < 0) ? own : (pos < Kl ? (int)T.act[pos] : 0);
+            long long sd = 0, sl = 0;
+            if (pos < Kl) { sd = SD[(size_t)k * ld + u]; sl = SL[(size_t)k * ld + u]; }
+            while (pos < Kl) {
+                const int posn = (pos < 0) ? st : pos + NS;
+                const int kn = posn < Kl ? (int)T.act[posn] : 0;
+                long long sdn = 0, sln = 0;
+                if (posn < Kl) { sdn = SD[(size_t)kn * ld + u]; sln = SL[(size_t)kn * ld + u]; }
+                if (!(prune && pos >= 0 && k == own)) consider_v(k, sd, sl);
+                pos = posn; k = kn; sd = sdn; sl = sln;
             }
         } else {
             const int Kc = T.misc[14];
@@ -2770,9 +2849,23 @@ __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Ta
                 }
             }
             // ... then the point's own cluster and the slots a change touched (computed)
+            RC_PE_STAMP(19)
             for (int pos = (prune || st == ((K + 1) % NS)) ? -1 : Kc + st; pos < K; pos = (pos < 0) ? Kc + st : pos + NS) {
                 const int k = (pos < 0) ? own : (int)T.act2[pos];
-                if (pos >= 0) {
+                if (pos < 0) {
+                    // the point's own cluster: its stored score stands while no committed change (dirty) and no batch entry before
+                    // the point touched the slot (a lone point has no own-cluster candidate and no stored score)
+                    if (single) continue;
+                    if (!T.dirty[k] && k != hot) {
+                        const int e0 = k ? T.seg[k - 1] : 0;
+                        if (mode == 0 || e0 == T.seg[k] || T.pairs[e0] >= j) {
+                            const double v = wrow[(size_t)k * V.ldw];
+                            const int lab = T.label[k];
+                            if (bestslot == -2 || v > bestv || (v == bestv && lab < bestpos)) { bestv = v; bestpos = lab; bestslot = k; }
+                            continue;
+                        }
+                    }
+                } else {
                     if (k == own) continue;
                     if (mode == 1 && !T.dirty[k]) {                // a slot of the batch: untouched for this point if no entry of its group precedes it
                         const int e0 = k ? T.seg[k - 1] : 0;
@@ -2791,6 +2884,7 @@ __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Ta
             }
         }
         // clusters created by the changers before i: singletons {x_q}, row sums = row x_q of the matrices
+        RC_PE_STAMP(20)
         if (mode == 1 && j > 0) {
             int lo_ = 0, hi_ = T.misc[8];
             while (lo_ < hi_) { const int mid = (lo_ + hi_) >> 1; if (T.birth[mid] < j) lo_ = mid + 1; else hi_ = mid; }
@@ -2817,6 +2911,10 @@ __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Ta
             if (v > bestv || bestslot == -2) { bestv = v; bestpos = RC_NEWKEY; bestslot = -1; }
         }
     }
+    RC_PE_STAMP(21)
+#ifdef RC_PROF_EVAL
+    if (mode == 1) { atomicMax(&T.misc[19], pe_[0]); atomicMax(&T.misc[20], pe_[1]); atomicMax(&T.misc[21], pe_[2]); }
+#endif
     if (hot >= 0) __syncthreads();   // (the records of the hot slot alias the reduction scratch)
     // reduce over the candidate streams: the 64 / RC_PTS streams of each wave by shuffles, then the waves through LDS
 #pragma unroll
@@ -3521,13 +3619,21 @@ __device__ __forceinline__ void batch_sim_fast(const View &V, Tab &T, int total,
 // Returns the number of label changes among the nc entries.
 __device__ __forceinline__ int commit_batch(const View &V, const SweepArgs &sa, Tab &T, int nc, int G, int own_gen, int next_gen)
 {
+#ifdef RC_PROF_COMMIT
+    const long long pcA_ = __builtin_amdgcn_s_memrealtime();
+#endif
     if (threadIdx.x == 0) { T.misc[11] = 0; T.misc[12] = 0; if (nc) T.misc[0] = T.bK[nc - 1]; }
     __syncthreads();
     // one thread per entry: a slot's label is written by at most one entry of a batch (a cluster dies, is born or is
     // relabelled at most once), sizes by LDS atomics
+    // With fewer than 2048 slots the label bitset T.used is the committed one at this point (built before the round's simulation,
+    // which only reads it): the commit then corrects it in place — the labels its entries free here, the labels they take after
+    // the barrier (a label freed by one entry can be taken by a later one) — instead of rebuilding it from all the labels.
+    const bool inc_used = V.kcap < 2048;
     for (int q = threadIdx.x; q < nc; q += blockDim.x) {
         const int a = T.ba[q], b = T.bb[q], flag = T.bflag[q];
         if (a != b) { atomicSub(&T.size[a], 1); atomicAdd(&T.size[b], 1); }
+        if (inc_used && (flag & (RC_BF_DEATH | RC_BF_RENAME))) { const int ol = T.label[a]; atomicAnd(&T.used[(ol - 1) >> 5], ~(1u << ((ol - 1) & 31))); }
         if (flag & RC_BF_DEATH) T.label[a] = 0;
         if (flag & RC_BF_BIRTH) { T.label[b] = T.blab[q]; atomicMax(&T.misc[7], b + 1); }
         if (flag & RC_BF_RENAME) T.label[a] = T.blab[q];
@@ -3538,10 +3644,14 @@ __device__ __forceinline__ int commit_batch(const View &V, const SweepArgs &sa, 
 #ifdef RC_PROF_COMMIT
     const long long pc0_ = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (T.misc[11]) tab_structural(V, T);
-    tab_bases(V, sa, T);
+    if (T.misc[11] && inc_used) tab_after_commit(V, sa, T, nc);
+    else {
+        if (T.misc[11]) tab_structural(V, T);
+        tab_bases(V, sa, T);
+    }
 #ifdef RC_PROF_COMMIT
-    if (threadIdx.x == 0) T.misc[13] = (int)(__builtin_amdgcn_s_memrealtime() - pc0_);
+    const long long pcB_ = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { T.misc[13] = (int)(pcB_ - pc0_); T.misc[19] = (int)(pc0_ - pcA_); }
 #endif
     const int nchunks = (V.n + RC_PTS - 1) / RC_PTS;
     const int pt = threadIdx.x & (RC_PTS - 1), st = threadIdx.x >> RC_PTS_LOG2, NS = blockDim.x >> RC_PTS_LOG2;
@@ -3550,10 +3660,10 @@ __device__ __forceinline__ int commit_batch(const View &V, const SweepArgs &sa, 
     const int hi_slots = T.misc[7];   // slots in use, births of this batch included
     const int hot = T.misc[16];        // the batch's largest group: its correction is shared by the streams of a point (hot_accumulate)
     long long *const hotacc = (long long *)T.red_v + 4 * pt;
-    for (int c = blockIdx.x; c < nchunks; c += G) {
+    for (int c = blockIdx.x, m = 0; c < nchunks; c += G, ++m) {
         const int io = c * RC_PTS + pt;
         const bool act = io < V.n;
-        const int i = act ? V.pi[io] : 0;
+        const int i = act ? (T.cached ? T.cu[m * RC_PTS + pt] : V.pi[io]) : 0;
         if (hot >= 0) {
             if (threadIdx.x < 4 * RC_PTS) ((long long *)T.red_v)[threadIdx.x] = 0;
             __syncthreads();
@@ -3580,8 +3690,18 @@ __device__ __forceinline__ int commit_batch(const View &V, const SweepArgs &sa, 
         }
         if (hot >= 0) __syncthreads();
     }
+#ifdef RC_PROF_COMMIT
+    __syncthreads();
+    if (threadIdx.x == 0) T.misc[20] = (int)(__builtin_amdgcn_s_memrealtime() - pcB_);
+#endif
     for (int q = threadIdx.x; q < nc; q += blockDim.x)
-        if (T.ba[q] != T.bb[q]) V.slot_of[T.bu[q]] = T.bb[q];  // same values from every block
+        if (T.ba[q] != T.bb[q]) {
+            V.slot_of[T.bu[q]] = T.bb[q];  // same values from every block
+            if (T.cached) {                 // ... and this block's copy of the slots of its own points
+                const int x = T.bx[q], cx = x >> RC_PTS_LOG2, d = cx - (int)blockIdx.x;
+                if (d >= 0 && d % G == 0) T.cown[(d / G) * RC_PTS + (x & (RC_PTS - 1))] = T.bb[q];
+            }
+        }
     __syncthreads();
     return T.misc[12];
 }
@@ -3646,7 +3766,21 @@ __device__ __forceinline__ void resolve_body(const View &V, const SweepArgs &sa,
     u64 *keys = V.keys[kg];
     u64 *const cword_gen = V.cword[kg];
     unsigned *arrive = V.arrive[kg];
+    {   // this block's chunks are c = blockIdx.x + m G: with few of them per block their points' internal indices and slots live in LDS
+        const int nchunks_ = (V.n + RC_PTS - 1) / RC_PTS, cpb = (nchunks_ + G - 1) / G;
+        T.cached = cpb <= RC_CPB_LDS;
+        if (T.cached)
+            for (int q = threadIdx.x; q < cpb * RC_PTS; q += blockDim.x) {
+                const int i_ = ((int)blockIdx.x + (q >> RC_PTS_LOG2) * G) * RC_PTS + (q & (RC_PTS - 1));
+                int u_ = 0, o_ = 0;
+                if (i_ < V.n) { u_ = V.pi[i_]; o_ = V.slot_of[u_]; }
+                T.cu[q] = u_; T.cown[q] = (short)o_;
+            }
+    }
     tab_load(V, T);
+#ifdef RC_PROF_EVAL
+    if (threadIdx.x == 0) { T.misc[19] = 0; T.misc[20] = 0; T.misc[21] = 0; }
+#endif
     for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) T.dirty[k] = 0;
     tab_bases(V, sa, T);
     // Score cache: filling it costs 8 B per (point, cluster) in the first pass — 1.5 % of a stationary sweep at n = 8192, which
@@ -3686,12 +3820,16 @@ __device__ __forceinline__ void resolve_body(const View &V, const SweepArgs &sa,
         unsigned *const rec = V.rec + (size_t)cur * (size_t)V.n, *const rec_next = V.rec + (size_t)(cur ^ 1) * (size_t)V.n;
         if (redraw) {
             RC_CHAOS_AT(0);
+#if defined(RC_PROF_COMMIT) || defined(RC_PROF_EVAL)
+            RC_PF(pt_ = __builtin_amdgcn_s_memrealtime();)
+#else
             RC_PF(pt_ = __builtin_amdgcn_s_memrealtime(); ps[13] += 1;)
+#endif
             gstamp += 1u;   // (words carried into this buffer are void: a chunk without changers writes none)
             // with the score cache a later pass computes only the slots a commit touched, and the cache is current again after it
             if (use_wc && !first_pass) tab_partition(V, T, false);
-            for (int c = blockIdx.x; c < nchunks; c += G)
-                if (c * RC_PTS + RC_PTS - 1 > after) eval_chunk(V, sa, T, SD, SL, c, after, V.n, 0, 0, cword, rec, gstamp, use_wc ? (first_pass ? 1 : 2) : 0);
+            for (int c = blockIdx.x, m = 0; c < nchunks; c += G, ++m)
+                if (c * RC_PTS + RC_PTS - 1 > after) eval_chunk(V, sa, T, SD, SL, c, m, after, V.n, 0, 0, cword, rec, gstamp, use_wc ? (first_pass ? 1 : 2) : 0);
             if (use_wc && !first_pass) { for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) T.dirty[k] = 0; }
             if (sa.dbg & 2) break;
             RC_PHASE(6)
@@ -3803,7 +3941,9 @@ __device__ __forceinline__ void resolve_body(const View &V, const SweepArgs &sa,
         if (threadIdx.x == 0) *T.blk_key = RC_KEY_NONE;
         __syncthreads();
         RC_PHASE(14)
+#if !defined(RC_PROF_COMMIT) && !defined(RC_PROF_EVAL)
         RC_PF(ps[15] += T.misc[13];)
+#endif
         // the simulated sizes back to the committed ones (only clusters that could die, and new ones, were simulated), and
         // the entries that touch each slot, grouped by slot: count, offsets, scatter, sort within a slot
         {
@@ -3899,11 +4039,16 @@ __device__ __forceinline__ void resolve_body(const View &V, const SweepArgs &sa,
         // points up to the first effective changer saw no change at all and are final as they are.
         const int vlo = (exact && neff > 0) ? T.bx[T.misc[10]] : after;
         if (use_wc) tab_partition(V, T, true);
-        for (int c = blockIdx.x; c < nchunks; c += G) {
+        for (int c = blockIdx.x, m = 0; c < nchunks; c += G, ++m) {
             if (c * RC_PTS + RC_PTS - 1 > vlo && c * RC_PTS <= hi)
-                eval_chunk(V, sa, T, SD, SL, c, vlo, hi, 1, nb, cword, rec, gstamp, use_wc ? 2 : 0, cword_next, rec_next, gstamp + 1u);
+                eval_chunk(V, sa, T, SD, SL, c, m, vlo, hi, 1, nb, cword, rec, gstamp, use_wc ? 2 : 0, cword_next, rec_next, gstamp + 1u);
         }
         __syncthreads();
+#ifdef RC_PROF_EVAL   // (this build: columns 2 / 13 / 15 = longest thread in the cached-slot part / computed part / rest of the validation passes)
+        RC_PF(ps[2] += T.misc[19]; ps[13] += T.misc[20]; ps[15] += T.misc[21];)
+        __syncthreads();
+        if (threadIdx.x == 0) { T.misc[19] = 0; T.misc[20] = 0; T.misc[21] = 0; }
+#endif
         RC_PHASE(10)
         const u64 mine = *T.blk_key;
         ok = grid_barrier(V, T, arrive, G, (unsigned)(++nbar), mine, keys + round);
@@ -3921,8 +4066,8 @@ __device__ __forceinline__ void resolve_body(const View &V, const SweepArgs &sa,
         }
         changes += commit_batch(V, sa, T, nc, G, own_gen, next_gen);
         RC_PHASE(12)
-#ifdef RC_PROF_COMMIT
-        RC_PF(ps[2] += T.misc[13];)
+#ifdef RC_PROF_COMMIT   // (this build: columns 2 / 13 / 15 = table rebuild / entry loop / row-sum corrections inside the commit)
+        RC_PF(ps[2] += T.misc[13]; ps[13] += T.misc[19]; ps[15] += T.misc[20];)
 #endif
         // Validation costs (points covered) x (changers before them); behind the first violation it only yields the next round's
         // guesses.  After a round that hit a violation the next batch takes one and a half times what was committed, at least
@@ -4920,7 +5065,7 @@ static int32_t create_impl(rc_ctx *c, int64_t n, const double *D, const double *
         double tab[256];
         for (int j = 0; j < 128; ++j) {
             const long double cj = 1.0L + ((long double)j + 0.5L) / 128.0L;
-            tab[2 * j] = (double)(1.0L / cj);
+            tab[2 * j] = 2.0 * (double)(1.0L / cj);                                  // (2/c_j: rc_qlog_prep hands over m/2)
             tab[2 * j + 1] = (double)(rintl(logl(cj) * ldexpl(1.0L, c->eL)) + 0x1.8p52L);
         }
         HIPCHK2(hipMemcpy(c->ltab, tab, sizeof(tab), hipMemcpyHostToDevice));

@@ -11,6 +11,7 @@ for v in "${@:-prof chaos15}"; do for name in $v; do
     profold) D="-DRC_DIAG -DRC_PROF_SYML -DRC_PROF_SIM -DRC_SIM_OLD";;
     chaos15) D="-DRC_DIAG -DRC_CHAOS=15";;
     profcommit) D="-DRC_DIAG -DRC_PROF_SYML -DRC_PROF_COMMIT";;
+    profeval) D="-DRC_DIAG -DRC_PROF_SYML -DRC_PROF_EVAL";;
     simold) D="-DRC_SIM_OLD";;
     *) echo "unknown variant $name"; exit 1;;
   esac

@@ -21,7 +21,8 @@ names = {6: "eval tentative", 7: "barrier 1", 8: "assemble batch", 14: "batch_si
 base0 = None
 if os.environ.get("RC_PROF_SIM"):
     L.rc_debug_prof(ctx.h, 0, out.ctypes.data_as(C.c_void_p)); base0 = out[:2].reshape(-1)[:25].astype(np.float64).copy()
-if os.environ.get("RC_PROF_COMMIT"): names = {2: "(commit: tables)", **names}   # -DRC_PROF_COMMIT build: column 2 = table rebuild inside the commit
+if os.environ.get("RC_PROF_COMMIT"): names = {13: "(commit: entries)", 2: "(commit: tables)", 15: "(commit: row sums)", **names}   # -DRC_PROF_COMMIT build: columns 13 / 2 / 15 = entry loop / table rebuild / row-sum corrections inside the commit
+if os.environ.get("RC_PROF_EVAL"): names = {2: "(valid.: cached)", 13: "(valid.: computed)", 15: "(valid.: births+new)", **names}   # -DRC_PROF_EVAL build: the longest thread per part of the validation passes
 acc = {k: [] for k in names}; mx = {k: [] for k in names}; mn = {k: [] for k in names}; rounds = []; tot = []
 for t in range(60, 80):
     ctx.gibbs_sweep(1.0, 0.5, 7, t, blocking=True)
