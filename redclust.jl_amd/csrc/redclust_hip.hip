@@ -223,7 +223,7 @@ struct SweepArgs {
     int t;    // internal sweep index since rc_set_state: selects key / perm generations
     int own_gen, next_gen;  // S generation read (and corrected in place); generation being filled for the next sweep (-1: none)
     int zero_gen;           // S generation this launch clears for the row reduction two sweeps ahead (-1: none)
-    int dbg;  // timing ablations only (RC_DEBUG_FLAGS / rc_set_option "debug_flags", -DRC_DIAG builds): 1 = skip candidate loop, 2 = skip grid barrier, 4 = skip gumbel, 8 = no row-sum loads, 16 = no score-cache stores
+    int dbg;  // timing ablations only (RC_DEBUG_FLAGS / rc_set_option "debug_flags", -DRC_DIAG builds): 1 = skip candidate loop, 2 = skip grid barrier, 4 = skip gumbel, 16 = no score-cache stores
     // a sweep resumed after the slot tables were grown (recover_capacity): the points <= after0 are final already, changes0 /
     // rounds0 are what the first part of the sweep had committed / run.  A fresh sweep: -1, 0, 0.
     int after0, changes0, rounds0;
@@ -2821,31 +2821,38 @@ __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Ta
         } else {
             const int Kc = T.misc[14];
             // the clean slots first (stored scores: their loads are in flight while nothing else is), ...
-            for (int pos = st; pos < Kc; pos += 4 * NS) {      // clean slots: the stored score — four loads in flight (one per turn was a memory round trip per candidate)
-                int kk[4];
-                double vv[4];
+            // RC_WC_BATCH loads in flight per turn — a turn is one global round trip, and with six a stream's share of ~200 clusters
+            // (32 streams per point) is one turn; the slot numbers are read again from LDS where they are used instead of being held
+#ifndef RC_WC_BATCH
+#define RC_WC_BATCH 6
+#endif
+            for (int pos = st; pos < Kc; pos += RC_WC_BATCH * NS) {
+                double vv[RC_WC_BATCH];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < RC_WC_BATCH; ++q) {
                     const int p_ = pos + q * NS;
-                    kk[q] = (p_ < Kc) ? (int)T.act2[p_] : own;
-                    vv[q] = (kk[q] != own) ? wrow[(size_t)kk[q] * V.ldw] : 0.0;
+                    const int kq = (p_ < Kc) ? (int)T.act2[p_] : own;
+                    vv[q] = (kq != own) ? wrow[(size_t)kq * V.ldw] : 0.0;
                 }
                 unsigned needm = 0u;   // (a bit mask, not an array indexed at run time: that would live in scratch memory)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (kk[q] == own) continue;
+                for (int q = 0; q < RC_WC_BATCH; ++q) {
+                    const int p_ = pos + q * NS;
+                    if (p_ >= Kc) continue;
+                    const int kq = (int)T.act2[p_];
+                    if (kq == own) continue;
                     const double v = vv[q];
                     if (v != v) {                                 // pruned when it was stored: still out of reach?
                         if (!(bestslot != -2 && rc_pruned_bound(v) < bestv)) needm |= 1u << q;
                         continue;
                     }
-                    const int lab = T.label[kk[q]];
-                    if (bestslot == -2 || v > bestv || (v == bestv && lab < bestpos)) { bestv = v; bestpos = lab; bestslot = kk[q]; }
+                    const int lab = T.label[kq];
+                    if (bestslot == -2 || v > bestv || (v == bestv && lab < bestpos)) { bestv = v; bestpos = lab; bestslot = kq; }
                 }
                 while (needm) {                                      // (rare: computed exactly, and stored if this pass keeps the cache)
                     const int q = __ffs((int)needm) - 1;
                     needm &= needm - 1u;
-                    consider(q == 0 ? kk[0] : q == 1 ? kk[1] : q == 2 ? kk[2] : kk[3]);
+                    consider((int)T.act2[pos + q * NS]);
                 }
             }
             // ... then the point's own cluster and the slots a change touched (computed)

@@ -1,6 +1,6 @@
 """Where does the first (tentative) pass of k_resolve spend its time?  Moving equilibrium (sigma 0.2, N = 8192), profiling build
-(-DRC_DIAG -DRC_PROF_SYML): one sweep from the same saved state per ablation (rc_set_option "debug_flags": 4 no Gumbel noise, 8 no
-row-sum loads, 16 no score-cache stores, 1 no candidate loop) — results of such sweeps are wrong on purpose, only the stamps count.
+(-DRC_DIAG -DRC_PROF_SYML): one sweep from the same saved state per ablation (rc_set_option "debug_flags": 4 no Gumbel noise, 16 no
+score-cache stores, 1 no candidate loop) — results of such sweeps are wrong on purpose, only the stamps count.
 RC_LIB_PATH=build_r4/lib_prof.so python3 tools/exp_tentative.py [incremental]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,7 +17,7 @@ ctx.synchronize()
 saved = ctx.get_state()[0].copy()
 L = rc.lib(); L.rc_debug_prof.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
 out = np.zeros((8192, 16), np.int64)
-for flags, name in ((0, "as is"), (4, "no Gumbel noise"), (8, "no row-sum loads"), (16, "no cache stores"), (28, "none of the three"), (1, "no candidate loop"), (0, "as is")):
+for flags, name in ((0, "as is"), (4, "no Gumbel noise"), (16, "no cache stores"), (20, "neither"), (0, "as is")):
     vals = []
     for rep in range(3):
         ctx.set_state(saved)
