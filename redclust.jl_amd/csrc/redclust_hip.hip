@@ -5368,7 +5368,8 @@ static int32_t finish_create(rc_ctx *c)
     }
     const size_t lds_d = std::max(tab_bytes(c->kcap, c->n, 1), 2 * sizeof(int) * (size_t)c->kcap);
     const size_t lds_b = (size_t)std::min(c->kcap, RC_BS_TILE) * 4 * sizeof(u64);
-    hipError_t e1 = hipFuncSetAttribute((const void *)k_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
+    // (the attribute belongs to the function, not to the context: a second context with smaller tables must not lower it under a first one's)
+    hipError_t e1 = hipFuncSetAttribute((const void *)k_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipError_t e2 = hipFuncSetAttribute((const void *)k_blocksums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
     hipError_t e3 = hipFuncSetAttribute((const void *)k_derive, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || lds_r > 160 * 1024 || lds_b > 160 * 1024)

@@ -40,8 +40,9 @@ def run(cases, first, nlo=40, nhi=1500, kmax=25):
         eD, eL = ctx.debug_rowsums(int(init[0]))[2:4]
         orc = O.Oracle(Dd, P, logD=L, eL=eL, eD=eD)
         orc.set_state(init)
-        mode = "incremental" if g.random() < 0.3 else "full"
+        mode = "incremental" if g.random() < 0.5 else "full"
         ctx.set_mode(mode)
+
         ok = True
         try:
             for t in range(5):

@@ -13,6 +13,8 @@ L = rc.lib()
 out = np.zeros((8192, 16), np.int64)
 L.rc_debug_prof.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
 names = {6: "eval tentative", 7: "barrier 1", 8: "assemble batch", 14: "batch_sim", 9: "restore + lists", 10: "eval validate", 11: "barrier 2", 12: "commit"}
+if os.environ.get("RC_PROF_COMMIT"): names = {13: "(commit: entries)", 2: "(commit: tables)", 15: "(commit: row sums)", **names}
+if os.environ.get("RC_PROF_EVAL"): names = {13: "(valid.: computed)", 15: "(valid.: births+new)", **names}
 ctx.gibbs_sweep(1.0, 0.5, 3, 0, blocking=True)
 st = ctx.sweep_stats()
 L.rc_debug_prof(ctx.h, 0, out.ctypes.data_as(C.c_void_p))
