@@ -202,6 +202,9 @@ int32_t rc_set_bulk_kernel(rc_ctx *ctx, int32_t which);
 /* Run-time options of one context.  Defaults come from the environment once, when the context is created (INTEGRATION.md
  * "Environment switches"); nothing reads the environment per sweep or per chain.
  *   "prune"          -1 automatic (default), 0 never, 1 always: candidates that cannot win skip their Gumbel noise (exact either way)
+ *   "lds_point_cache" 1 (default) / 0: the sweep kernel keeps the internal indices and clusters of each workgroup's points in LDS
+ *                    (possible while a workgroup owns at most 4 chunks of 32 points, i.e. n <= 128 x #CUs; larger problems and 0 read
+ *                    them from global memory in every pass; same results)
  *   "chain_workers"  worker threads of rc_run_chain (0 = automatic: the host's cores shared by the chains of this process)
  *   "chain_depth"    iterations rc_run_chain keeps in flight (0 = automatic: 24)
  *   "chain_pipeline" 1 (default): the pipelined loop; 0: its synchronous form (the same chain bit for bit)

@@ -376,7 +376,7 @@ class Context:
         self._chk(self.L.rc_set_bulk_kernel(self.h, {"auto": -1, "perm": 0, "sym": 1}[which]))
 
     def set_option(self, name, value):
-        """rc_set_option: "prune" (-1 automatic / 0 / 1), "chain_workers", "chain_depth" (0 = automatic), "chain_pipeline" (0 / 1)."""
+        """rc_set_option: "prune" (-1 automatic / 0 / 1), "lds_point_cache" (0 / 1), "chain_workers", "chain_depth" (0 = automatic), "chain_pipeline" (0 / 1)."""
         self._chk(self.L.rc_set_option(self.h, name.encode(), int(value)))
 
     def run_chain(self, numiters, burnin, thin, numGibbs, numMH, seed, r0, p0, proposalsd_r, splitmerge="as_written",

@@ -178,6 +178,7 @@ struct View {
     int n, ld, kcap;
     unsigned *wide_scratch;    // wide contexts (kcap > RC_MAX_KCAP): [(n+31)/32] label bitset, then 2·(kcap+1) ints of k_derive_wide / k_sweep_wide; null otherwise
     unsigned *used_scratch;    // [G][(n+31)/32] label bitsets of the resolver blocks when n > RC_USED_LDS_MAX_N
+    int cu_cache;              // 1: k_resolve keeps the indices and slots of each block's points in LDS when the block has at most RC_CPB_LDS chunks (rc_set_option "lds_point_cache")
     double *wc;                // [kcap][ldw] score cache of the resolver (eval_chunk), valid inside one launch; null = off
     int ldw;                   // n rounded up to whole chunks
     int wc_always;             // 1: fill the cache in every sweep; 0: only when the previous sweep changed labels
@@ -3775,7 +3776,7 @@ __device__ __forceinline__ void resolve_body(const View &V, const SweepArgs &sa,
     unsigned *arrive = V.arrive[kg];
     {   // this block's chunks are c = blockIdx.x + m G: with few of them per block their points' internal indices and slots live in LDS
         const int nchunks_ = (V.n + RC_PTS - 1) / RC_PTS, cpb = (nchunks_ + G - 1) / G;
-        T.cached = cpb <= RC_CPB_LDS;
+        T.cached = V.cu_cache != 0 && cpb <= RC_CPB_LDS;
         if (T.cached)
             for (int q = threadIdx.x; q < cpb * RC_PTS; q += blockDim.x) {
                 const int i_ = ((int)blockIdx.x + (q >> RC_PTS_LOG2) * G) * RC_PTS + (q & (RC_PTS - 1));
@@ -4630,6 +4631,7 @@ struct rc_ctx {
     bool kcap_fixed = false;      // RC_KCAP_FIXED=1: never grow (the old behaviour: RC_ERR_CAPACITY), for tests of the error path
     // run-time options: defaults from the environment when the context is created, changed afterwards with rc_set_option — nothing
     // reads the environment per sweep or per chain
+    int opt_cu_cache = 1;         // "lds_point_cache": 0 = k_resolve reads pi[] / slot_of[] from global memory in every pass (the path blocks with more than RC_CPB_LDS chunks take; tests)
     int opt_prune = -1;           // "prune": -1 automatic (on behind a sweep that changed at most 2 labels), 0 never, 1 always   (RC_NO_PRUNE / RC_PRUNE_ALWAYS)
     int opt_chain_workers = 0;    // "chain_workers": worker threads of rc_run_chain, 0 = automatic   (RC_CHAIN_WORKERS)
     int opt_chain_depth = 0;      // "chain_depth": iterations in flight, 0 = automatic   (RC_CHAIN_DEPTH)
@@ -4697,7 +4699,7 @@ static View make_view(const rc_ctx *c)
 {
     View V{};
     V.n = c->n; V.ld = c->ld; V.kcap = c->kcap; V.maxb = c->maxb; V.used_scratch = c->used_scratch; V.wide_scratch = c->wide_scratch;
-    V.wc = c->wc; V.wc_always = c->wc_always; V.ldw = (c->n + RC_PTS - 1) / RC_PTS * RC_PTS;
+    V.cu_cache = c->opt_cu_cache; V.wc = c->wc; V.wc_always = c->wc_always; V.ldw = (c->n + RC_PTS - 1) / RC_PTS * RC_PTS;
     V.Dq = c->Dq; V.Lq = c->Lq; V.Dq48 = c->Dq48; V.bits = c->bits; V.diagq = c->diagq; V.pi = c->pi;
     V.derived = c->derived ? 1 : 0; V.qsD = std::ldexp(1.0, -c->eD); V.qsL = std::ldexp(1.0, c->eL); V.ltab = c->ltab; V.flt = c->flt; V.qeD = c->eD;
     for (int g = 0; g < 3; ++g) { V.SD[g] = c->SD[g]; V.SL[g] = c->SL[g]; }
@@ -5152,7 +5154,7 @@ static int32_t alloc_ctx(int64_t n, int32_t storage_bits, int32_t device_id, int
     if (rc_env_diag("RC_SYML_PAD")) c->syml_pad = (size_t)std::max(0, atoi(rc_env_diag("RC_SYML_PAD")));
     if (rc_env_diag("RC_SW_COARSE")) c->sw_coarse = std::min(128, std::max(8, atoi(rc_env_diag("RC_SW_COARSE")) & ~3));
     if (rc_env("RC_BULK_KERNEL")) c->bulk_kernel = !strcmp(rc_env("RC_BULK_KERNEL"), "sym") ? 1 : (!strcmp(rc_env("RC_BULK_KERNEL"), "perm") ? 0 : -1);
-    if (rc_env_diag("RC_RES_THREADS")) { const int rt_ = atoi(rc_env_diag("RC_RES_THREADS")); c->res_threads = (rt_ == 64 || rt_ == 128 || rt_ == 256) ? rt_ : 512; }
+    if (rc_env_diag("RC_RES_THREADS")) { const int rt_ = atoi(rc_env_diag("RC_RES_THREADS")); c->res_threads = (rt_ == 64 || rt_ == 128 || rt_ == 256 || rt_ == 768 || rt_ == 1024) ? rt_ : 512; }
     if (rc_env_diag("RC_SYM_ITEM_TILES")) c->sym_item_tiles = std::max(1, atoi(rc_env_diag("RC_SYM_ITEM_TILES")));
     *out = c;
     return RC_OK;
@@ -5289,7 +5291,7 @@ static int32_t build_syml2_alt(rc_ctx *c)
     int *wf = c->wfast, *ws = c->wslow;
     const int nf = c->nfast, ns = c->nslow, nb = c->syml2_blocks, g = c->syml2_g;
     c->ufast = c->uslow = nullptr; c->wfast = c->wslow = nullptr;
-    const int32_t rc = build_syml2_lists(c, 2);
+    const int32_t rc = build_syml2_lists(c, rc_env_diag("RC_S2_ALT_PER_CU") ? std::max(1, atoi(rc_env_diag("RC_S2_ALT_PER_CU"))) : 2);
     c->s2alt.ufast = c->ufast; c->s2alt.uslow = c->uslow; c->s2alt.wfast = c->wfast; c->s2alt.wslow = c->wslow;
     c->s2alt.nfast = c->nfast; c->s2alt.nslow = c->nslow; c->s2alt.blocks = c->syml2_blocks;
     c->ufast = uf; c->uslow = us; c->wfast = wf; c->wslow = ws; c->nfast = nf; c->nslow = ns; c->syml2_blocks = nb; c->syml2_g = g;
@@ -7266,6 +7268,9 @@ extern "C" int32_t rc_set_option(rc_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "prune")) {
         if (value < -1 || value > 1) return fail(c, RC_ERR_ARG, "rc_set_option: prune must be -1 (automatic), 0 (never) or 1 (always)");
         c->opt_prune = (int)value;
+    } else if (!strcmp(name, "lds_point_cache")) {
+        if (value != 0 && value != 1) return fail(c, RC_ERR_ARG, "rc_set_option: lds_point_cache must be 0 or 1");
+        c->opt_cu_cache = (int)value;
     } else if (!strcmp(name, "chain_workers")) {
         if (value < 0 || value > 1024) return fail(c, RC_ERR_ARG, "rc_set_option: chain_workers must be in 0..1024 (0 = automatic)");
         c->opt_chain_workers = (int)value;
@@ -7280,7 +7285,7 @@ extern "C" int32_t rc_set_option(rc_ctx *c, const char *name, int64_t value)
         c->dbg = (int)value;
 #endif
     } else {
-        return fail(c, RC_ERR_ARG, "rc_set_option: unknown option '%s' (prune, chain_workers, chain_depth, chain_pipeline)", name);
+        return fail(c, RC_ERR_ARG, "rc_set_option: unknown option '%s' (prune, lds_point_cache, chain_workers, chain_depth, chain_pipeline)", name);
     }
     return RC_OK;
 }

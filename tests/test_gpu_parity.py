@@ -668,3 +668,32 @@ def test_pruned_candidates_change_no_draw(cache):
         for k, v in saved.items():
             if v is None: os.environ.pop(k, None)
             else: os.environ[k] = v
+
+
+@pytest.mark.parametrize("mode", ["full", "incremental"])
+def test_point_cache_in_lds_changes_no_draw(mode):
+    """k_resolve keeps the internal indices and slots of each workgroup's points in LDS while a workgroup owns at most four
+    chunks (n <= 128 x #CUs) and reads pi[] / slot_of[] from global memory in every pass beyond that.  The second path, which no
+    test size reaches, is forced with rc_set_option("lds_point_cache", 0): the same moving chain (births, deaths, renames) as
+    the default path and as the oracle, in both modes."""
+    data = rc.generatemixture(900, 8, seed=9, sigma=0.4)
+    D, truth = data["distancematrix"], data["clusts"]
+    P = rc.likelihood_hyperparams(D, truth)
+    init = np.random.default_rng(4).integers(1, 60, 900).astype(np.int64)
+    ctx, other = rc.Context(D), rc.Context(D)
+    for c in (ctx, other):
+        c.set_params(**P); c.set_state(init); c.set_mode(mode)
+    other.set_option("lds_point_cache", 0)
+    eD, eL = ctx.debug_rowsums(int(init[0]))[2:4]
+    orc = O.Oracle(ctx.get_matrix(0), P, logD=ctx.get_matrix(1), eL=eL, eD=eD)
+    orc.set_state(init)
+    moved = 0
+    for t in range(10):
+        r, p = rp_schedule(t)
+        ctx.gibbs_sweep(r, p, 77, t); other.gibbs_sweep(r, p, 77, t, blocking=bool(t & 1)); orc.sweep_stable(r, p, 77, t)
+        a, b = ctx.get_state(), other.get_state()
+        assert np.array_equal(a[0], orc.clusts) and np.array_equal(b[0], orc.clusts), (mode, t)
+        assert np.array_equal(a[1], orc.sizes) and a[2] == b[2] == orc.K
+        moved += orc.last_changes
+    assert moved > 100
+    ctx.close(); other.close()

@@ -10,6 +10,7 @@ for v in "${@:-prof chaos15}"; do for name in $v; do
     prof) D="-DRC_DIAG -DRC_PROF_SYML -DRC_PROF_SIM";;
     profold) D="-DRC_DIAG -DRC_PROF_SYML -DRC_PROF_SIM -DRC_SIM_OLD";;
     chaos15) D="-DRC_DIAG -DRC_CHAOS=15";;
+    diag) D="-DRC_DIAG";;
     profcommit) D="-DRC_DIAG -DRC_PROF_SYML -DRC_PROF_COMMIT";;
     profeval) D="-DRC_DIAG -DRC_PROF_SYML -DRC_PROF_EVAL";;
     simold) D="-DRC_SIM_OLD";;
