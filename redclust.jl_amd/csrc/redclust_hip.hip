@@ -2264,7 +2264,7 @@ __host__ __device__ inline size_t tab_layout(int kcap, int n, int nw, size_t *of
     off[22] = o; o = RC_A16(o + sizeof(short) * maxb);       // birth
     off[23] = o; o = RC_A16(o + sizeof(short) * 2 * maxb);   // pairs
     off[24] = o; o = RC_A16(o + (size_t)kcap);                  // candie
-    off[25] = o; o = RC_A16(o + (sizeof(int) + sizeof(short)) * RC_CPB_LDS * RC_PTS);   // cu, cown
+    off[25] = o; o = RC_A16(o + (kcap < 2048 ? (sizeof(int) + sizeof(short)) * RC_CPB_LDS * RC_PTS : 0));   // cu, cown (not beside the largest slot tables: kcap = 4096 with a forced batch capacity of 512 fills the CU's LDS to within 600 bytes)
     off[26] = o; o = RC_A16(o + (size_t)kcap);                  // joined
     off[27] = o; o = RC_A16(o + sizeof(short) * 2 * maxb);   // pairs_tmp
     off[28] = o;
@@ -3776,7 +3776,7 @@ __device__ __forceinline__ void resolve_body(const View &V, const SweepArgs &sa,
     unsigned *arrive = V.arrive[kg];
     {   // this block's chunks are c = blockIdx.x + m G: with few of them per block their points' internal indices and slots live in LDS
         const int nchunks_ = (V.n + RC_PTS - 1) / RC_PTS, cpb = (nchunks_ + G - 1) / G;
-        T.cached = V.cu_cache != 0 && cpb <= RC_CPB_LDS;
+        T.cached = V.cu_cache != 0 && cpb <= RC_CPB_LDS && V.kcap < 2048;
         if (T.cached)
             for (int q = threadIdx.x; q < cpb * RC_PTS; q += blockDim.x) {
                 const int i_ = ((int)blockIdx.x + (q >> RC_PTS_LOG2) * G) * RC_PTS + (q & (RC_PTS - 1));

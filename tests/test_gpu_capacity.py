@@ -173,3 +173,36 @@ def test_more_clusters_than_the_old_default_capacity():
     assert np.array_equal(ch["splitmerge_acceptances"], ref["sm_acc"])
     assert np.allclose(ch["logposterior"], ref["logposterior"], rtol=1e-9, atol=0)
     ctx.close()
+
+
+def test_largest_slot_tables_with_a_forced_batch_capacity():
+    """kcap = 4096 with the batch capacity forced to 512 (RC_RES_MAXB) fills a CU's 160 KiB of LDS to within a few hundred bytes
+    (the automatic choice is a smaller batch): rc_create must still accept it — anything added to the resolver's tables has to stay
+    out of this configuration (round 4: the LDS copy of the points' indices exists only below 2048 slots) — and a moving sweep
+    through it equals the oracle's."""
+    n, K = 4200, 12
+    data = rc.generatemixture(n, K, seed=3, sigma=0.3)
+    D, truth = data["distancematrix"], data["clusts"]
+    P = rc.likelihood_hyperparams(D, truth)
+    init = truth.copy()
+    idx = np.random.default_rng(1).choice(n, 200, replace=False)
+    init[idx] = np.random.default_rng(2).integers(1, K + 1, 200)
+    saved = os.environ.get("RC_RES_MAXB")
+    try:
+        os.environ["RC_RES_MAXB"] = "512"
+        ctx = rc.Context(D, kcap=4096)
+    finally:
+        if saved is None: os.environ.pop("RC_RES_MAXB", None)
+        else: os.environ["RC_RES_MAXB"] = saved
+    ctx.set_params(**P)
+    ctx.set_state(init)
+    assert ctx.capacity_info()["kcap"] == 4096 and ctx.capacity_info()["batch_capacity"] == 512
+    eD, eL = ctx.debug_rowsums(int(init[0]))[2:4]
+    orc = O.Oracle(ctx.get_matrix(0), P, logD=ctx.get_matrix(1), eL=eL, eD=eD)
+    orc.set_state(init)
+    for t in range(2):
+        r, p = rp_schedule(t)
+        ctx.gibbs_sweep(r, p, 5, t); orc.sweep_stable(r, p, 5, t)
+        lab, sizes, Kc = ctx.get_state()
+        assert np.array_equal(lab, orc.clusts) and np.array_equal(sizes, orc.sizes) and Kc == orc.K
+    ctx.close()
