@@ -3763,10 +3763,10 @@ __device__ __forceinline__ void resolve_body(const View &V, const SweepArgs &sa,
 #else
 #define RC_PHASE(k) RC_PF({ const long long now_ = __builtin_amdgcn_s_memrealtime(); ps[k] += now_ - pt_; pt_ = now_; })
 #endif
-    // A sweep that ran out of slots (or whose barrier timed out) left the error bit set: the sweeps enqueued behind it must not
-    // touch the state — the host grows the tables, resumes that sweep and replays these (recover_capacity).  The bit was set by a
-    // previous launch (resolvers are chained), so every block of this launch reads the same value.
-    if (__hip_atomic_load(&V.sc->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    // (the error word is requested together with the first wave of the prologue's loads and tested before anything is stored:
+    // a test of its own was a global round trip — ~3 us beside the streaming row reduction — in front of everything else)
+    const int err_word = __hip_atomic_load(&V.sc->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int sc_changes = V.sc->n_changes, sc_last = V.sc->last_change_sweep, sc_rounds = V.sc->n_rounds;   // (read before the first barrier: the epilogue rewrites them)
     Tab T = tab_carve(smem, V.kcap, V.n, blockDim.x >> 6, V.maxb);
     if (V.n > RC_USED_LDS_MAX_N) T.used = V.used_scratch + (size_t)blockIdx.x * (size_t)((V.n + 31) / 32);
     const int t = sa.t, own_gen = sa.own_gen, next_gen = sa.next_gen, kg = t & 1;
@@ -3774,29 +3774,57 @@ __device__ __forceinline__ void resolve_body(const View &V, const SweepArgs &sa,
     u64 *keys = V.keys[kg];
     u64 *const cword_gen = V.cword[kg];
     unsigned *arrive = V.arrive[kg];
-    {   // this block's chunks are c = blockIdx.x + m G: with few of them per block their points' internal indices and slots live in LDS
+    {
+        // Prologue: the slot tables (tab_load), their score constants (tab_bases) and — this block's chunks being c = blockIdx.x + m G,
+        // few per block — the internal indices and slots of its points, in ONE loop whose global loads go out in two waves: sizes,
+        // labels, act list and pi[i] first (with the error word and the previous sweep's counts), then what depends on them
+        // (A[size], A[size - 1], slot_of[pi[i]]).  As separate passes these were six dependent round trips: 9-10 us of a 33 us
+        // stationary resolver.
         const int nchunks_ = (V.n + RC_PTS - 1) / RC_PTS, cpb = (nchunks_ + G - 1) / G;
         T.cached = V.cu_cache != 0 && cpb <= RC_CPB_LDS && V.kcap < 2048;
-        if (T.cached)
-            for (int q = threadIdx.x; q < cpb * RC_PTS; q += blockDim.x) {
-                const int i_ = ((int)blockIdx.x + (q >> RC_PTS_LOG2) * G) * RC_PTS + (q & (RC_PTS - 1));
-                int u_ = 0, o_ = 0;
-                if (i_ < V.n) { u_ = V.pi[i_]; o_ = V.slot_of[u_]; }
-                T.cu[q] = u_; T.cown[q] = (short)o_;
+        const int ncu = T.cached ? cpb * RC_PTS : 0, kend = max(V.kcap, ncu);
+        int hK = 0, hse = 0, hhi = 0;
+        if (threadIdx.x == 0) { hK = V.sc->K; hse = V.sc->smallest_empty; hhi = V.sc->slot_hi; }
+        bool first = true;
+        for (int k = threadIdx.x; first || k < kend; k += blockDim.x) {
+            const bool isk = k < V.kcap;
+            int sz = 0, lb = 0, ac = 0, u_ = 0, o_ = 0, i_ = V.n;
+            if (isk) { sz = V.slot_size[k]; lb = V.slot_label[k]; ac = V.slot_act[k]; }
+            if (k < ncu) {
+                i_ = ((int)blockIdx.x + (k >> RC_PTS_LOG2) * G) * RC_PTS + (k & (RC_PTS - 1));
+                if (i_ < V.n) u_ = V.pi[i_];
             }
-    }
-    tab_load(V, T);
+            // A sweep that ran out of slots (or whose barrier timed out) left the error bit set: the sweeps enqueued behind it must not
+            // touch the state — the host grows the tables, resumes that sweep and replays these (recover_capacity).  The bit was set by
+            // a previous launch (resolvers are chained), so every block of this launch reads the same value.  Nothing was stored yet.
+            if (first && err_word != 0) return;
+            first = false;
+            double a1 = 0.0, a2 = 0.0;
+            if (isk && lb > 0) { a1 = V.A[sz]; if (sz >= 2) a2 = V.A[sz - 1]; }
+            if (i_ < V.n) o_ = V.slot_of[u_];
+            if (isk) {
+                T.size[k] = sz; T.label[k] = lb; T.act[k] = (short)ac; T.dirty[k] = 0;
+                if (lb > 0) {   // (tab_base: A[s] + (log p + log(s - 1 + r)))
+                    T.base_o[k] = a1 + (sa.logp + log((double)sz - 1.0 + sa.r));
+                    T.base_s[k] = (sz >= 2) ? a2 + (sa.logp + log((double)(sz - 1) - 1.0 + sa.r)) : 0.0;
+                }
+            }
+            if (k < ncu) { T.cu[k] = u_; T.cown[k] = (short)o_; }
+        }
+        if (threadIdx.x == 0) {
+            T.misc[0] = hK; T.misc[1] = hse; T.misc[7] = hhi;
+            *T.blk_key = RC_KEY_NONE;
 #ifdef RC_PROF_EVAL
-    if (threadIdx.x == 0) { T.misc[19] = 0; T.misc[20] = 0; T.misc[21] = 0; }
+            T.misc[19] = 0; T.misc[20] = 0; T.misc[21] = 0;
 #endif
-    for (int k = threadIdx.x; k < V.kcap; k += blockDim.x) T.dirty[k] = 0;
-    tab_bases(V, sa, T);
+        }
+        __syncthreads();
+    }
     // Score cache: filling it costs 8 B per (point, cluster) in the first pass — 1.5 % of a stationary sweep at n = 8192, which
-    // has no later pass to profit from it — so it is filled only when the previous sweep changed labels (read before the first
-    // grid barrier; block 0 rewrites the count in its epilogue).  Same results either way.
-    const bool use_wc = V.wc != nullptr && sa.dbg == 0 && (V.wc_always || V.sc->n_changes > 0);
-    const int last = V.sc->last_change_sweep;   // (read before the first barrier as well: the epilogue rewrites it)
-    const int prev_rounds = V.sc->n_rounds;     // rounds of the previous sweep = the key words it used (its generation is re-armed in the epilogue)
+    // has no later pass to profit from it — so it is filled only when the previous sweep changed labels.  Same results either way.
+    const bool use_wc = V.wc != nullptr && sa.dbg == 0 && (V.wc_always || sc_changes > 0);
+    const int last = sc_last;
+    const int prev_rounds = sc_rounds;     // rounds of the previous sweep = the key words it used (its generation is re-armed in the epilogue)
     RC_PF(ps[1] = __builtin_amdgcn_s_memrealtime();)
     const int nchunks = (V.n + RC_PTS - 1) / RC_PTS;
     int after = sa.after0, round = 0, changes = sa.changes0, nbar = 0;
