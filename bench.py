@@ -460,7 +460,7 @@ def main():
         for _ in range(60):                               # burn-in to the moving equilibrium
             cm.gibbs_sweep(r, p, 7, sw, blocking=False); sw += 1
         cm.synchronize()
-        msteps = max(20, min(args.steps, 200))
+        msteps = max(100, min(args.steps, 200))           # (an extra leg, not `value`: 100 sweeps at least — 20 sweeps of this chain are 3 ms and 600-1000 label changes, too few for a stable rate)
         ch = rounds = 0
         t1 = time.perf_counter()
         for _ in range(msteps):
