@@ -2225,6 +2225,7 @@ struct Tab {
     unsigned short *ccnt;     // [nchunks + 1] scratch: changers per chunk / exclusive offsets, saturating at 65535 (only offsets <= batch capacity matter)
     int *cu;                  // [RC_CPB_LDS * RC_PTS] internal index of the points of this block's chunks (pi[i]: fixed for the launch) ...
     short *cown;              // [RC_CPB_LDS * RC_PTS] ... and their slots (kept current by commit_batch); used when `cached` (at most RC_CPB_LDS chunks per block):
+    double2 *flt;             // [128] LDS copy of the table of rc_flog
     int cached;               // the first loads of every pass over a chunk — pi[i], then slot_of[pi[i]]: two dependent global round trips — come from LDS
 };
 #define RC_CPB_LDS 4
@@ -2264,10 +2265,10 @@ __host__ __device__ inline size_t tab_layout(int kcap, int n, int nw, size_t *of
     off[22] = o; o = RC_A16(o + sizeof(short) * maxb);       // birth
     off[23] = o; o = RC_A16(o + sizeof(short) * 2 * maxb);   // pairs
     off[24] = o; o = RC_A16(o + (size_t)kcap);                  // candie
-    off[25] = o; o = RC_A16(o + (kcap < 2048 ? (sizeof(int) + sizeof(short)) * RC_CPB_LDS * RC_PTS : 0));   // cu, cown (not beside the largest slot tables: kcap = 4096 with a forced batch capacity of 512 fills the CU's LDS to within 600 bytes)
+    off[25] = o; o = RC_A16(o + (kcap < 2048 ? (sizeof(int) + sizeof(short)) * RC_CPB_LDS * RC_PTS : 0));   // cu, cown (only below 2048 slots)
     off[26] = o; o = RC_A16(o + (size_t)kcap);                  // joined
     off[27] = o; o = RC_A16(o + sizeof(short) * 2 * maxb);   // pairs_tmp
-    off[28] = o;
+    off[28] = o; o = RC_A16(o + 128 * sizeof(double2));       // flt: the table of rc_flog (the score logarithms gather from it per lane)
     off[29] = o;
     return o;
 }
@@ -2289,6 +2290,7 @@ __device__ __forceinline__ Tab tab_carve(char *smem, int kcap, int n, int nw, in
     T.joined = (unsigned char *)(smem + off[26]); T.pairs_tmp = (short *)(smem + off[27]);
     T.act2 = (short *)(smem + off[10]); T.dirty = (unsigned char *)(smem + off[19]);
     T.cu = (int *)(smem + off[25]); T.cown = (short *)(T.cu + RC_CPB_LDS * RC_PTS); T.cached = 0;
+    T.flt = (double2 *)(smem + off[28]);
     return T;
 }
 
@@ -2769,8 +2771,8 @@ __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Ta
                 }
             }
 #endif
-            double lik = V.cL * SLr - (V.alpha + V.delta1 * (double)s) * rc_flog1p(SDr / V.beta, V.flt);
-            if (V.repulsion) lik += (V.zeta + V.delta2 * (double)s) * rc_flog1p(SDr / V.gamma, V.flt);
+            double lik = V.cL * SLr - (V.alpha + V.delta1 * (double)s) * rc_flog1p(SDr / V.beta, T.flt);
+            if (V.repulsion) lik += (V.zeta + V.delta2 * (double)s) * rc_flog1p(SDr / V.gamma, T.flt);
             double v = base + lik;
 #ifndef RC_NO_PRUNE
             if (prune && !isown) {
@@ -2782,7 +2784,7 @@ __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Ta
 #endif
             if (!(a.dbg & 4)) {
                 const double un = rc_uniform(a, (unsigned)i, (unsigned)lab);
-                v = v + rc_gumbel(un, V.flt);
+                v = v + rc_gumbel(un, T.flt);
             }
             // tentative passes keep the cache current (dbg 16: timing ablation).  Entry (own slot, i) holds the point's OWN-cluster score
             // (itself removed): a point that is still open has not moved in this sweep, so the entry never means anything else
@@ -2797,7 +2799,7 @@ __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Ta
         const bool new_first = prune && single && new_ok;
         if (new_first) {
             const double un = rc_uniform(a, (unsigned)i, 0u);
-            bestv = (log((double)(Ki + 1)) + a.r * a.log1mp) + rc_gumbel(un, V.flt);
+            bestv = (log((double)(Ki + 1)) + a.r * a.log1mp) + rc_gumbel(un, T.flt);
             bestpos = RC_NEWKEY; bestslot = -1;
         }
         // With pruning every stream starts with the point's own cluster (itself removed): its score is the bar the stream's other
@@ -2902,12 +2904,12 @@ __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Ta
                 const long long xd = (V.bits == 64) ? ((const long long *)V.Dq)[e] : (long long)((const int *)V.Dq)[e];
                 const long long xl = rc_load_L(V, T.bu[q], u, xd);
                 const double SDr = (double)xd * V.scD, SLr = (double)xl * V.scL;
-                double lik = V.cL * SLr - (V.alpha + V.delta1) * rc_flog1p(SDr / V.beta, V.flt);
-                if (V.repulsion) lik += (V.zeta + V.delta2) * rc_flog1p(SDr / V.gamma, V.flt);
+                double lik = V.cL * SLr - (V.alpha + V.delta1) * rc_flog1p(SDr / V.beta, T.flt);
+                if (V.repulsion) lik += (V.zeta + V.delta2) * rc_flog1p(SDr / V.gamma, T.flt);
                 double v = tab_base(V, a, 1) + lik;
                 if (!(a.dbg & 4)) {
                     const double un = rc_uniform(a, (unsigned)i, (unsigned)lab);
-                    v = v + rc_gumbel(un, V.flt);
+                    v = v + rc_gumbel(un, T.flt);
                 }
                 if (bestslot == -2 || v > bestv || (v == bestv && lab < bestpos)) { bestv = v; bestpos = lab; bestslot = T.bb[q]; }
             }
@@ -2915,7 +2917,7 @@ __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Ta
         // new-cluster candidate, last in the candidate order (mcmc.jl:198-203, 228-230); one stream handles it
         if (!new_first && st == (K % NS) && new_ok) {
             const double un = rc_uniform(a, (unsigned)i, 0u);
-            const double v = (log((double)(Ki + 1)) + a.r * a.log1mp) + rc_gumbel(un, V.flt);
+            const double v = (log((double)(Ki + 1)) + a.r * a.log1mp) + rc_gumbel(un, T.flt);
             if (v > bestv || bestslot == -2) { bestv = v; bestpos = RC_NEWKEY; bestslot = -1; }
         }
     }
@@ -3785,6 +3787,8 @@ __device__ __forceinline__ void resolve_body(const View &V, const SweepArgs &sa,
         const int ncu = T.cached ? cpb * RC_PTS : 0, kend = max(V.kcap, ncu);
         int hK = 0, hse = 0, hhi = 0;
         if (threadIdx.x == 0) { hK = V.sc->K; hse = V.sc->smallest_empty; hhi = V.sc->slot_hi; }
+        double2 fl_ = {0.0, 0.0};
+        if (threadIdx.x < 128) fl_ = V.flt[threadIdx.x];
         bool first = true;
         for (int k = threadIdx.x; first || k < kend; k += blockDim.x) {
             const bool isk = k < V.kcap;
@@ -3811,6 +3815,7 @@ __device__ __forceinline__ void resolve_body(const View &V, const SweepArgs &sa,
             }
             if (k < ncu) { T.cu[k] = u_; T.cown[k] = (short)o_; }
         }
+        if (threadIdx.x < 128) T.flt[threadIdx.x] = fl_;
         if (threadIdx.x == 0) {
             T.misc[0] = hK; T.misc[1] = hse; T.misc[7] = hhi;
             *T.blk_key = RC_KEY_NONE;
@@ -5361,9 +5366,10 @@ static int32_t finish_create(rc_ctx *c)
                 if (tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, mb) <= avail) { c->maxb = mb; break; }
         // a slot capacity whose tables cannot sit beside the reduction at any batch capacity (kcap >= 1024) must at least fit the CU:
         // kcap = 4096 needs 160 KiB at 512 entries per batch for n >= 8192, 149 KiB at 128
-        if (!rc_env("RC_RES_MAXB") && tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, c->maxb) > 160 * 1024)
-            for (int mb : {384, 256, 192, 128, 96, 64})
-                if (tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, mb) <= 160 * 1024) { c->maxb = mb; break; }
+        // (RC_RES_MAXB is an upper bound: a forced batch capacity that does not fit the CU with this slot capacity is lowered like the default)
+        if (tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, c->maxb) > 160 * 1024)
+            for (int mb : {384, 256, 192, 128, 96, 64, 32, 16})
+                if (mb < c->maxb && tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, mb) <= 160 * 1024) { c->maxb = mb; break; }
         if (rc_env_diag("RC_SM_PROFILE"))
             fprintf(stderr, "[rc_create] resolver batch capacity %d: tables %zu B (512: %zu, 256: %zu, 128: %zu, 64: %zu), %zu B free beside the row reduction\n", c->maxb,
                     tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, c->maxb), tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, 512), tab_bytes(c->kcap, c->n, RC_RES_THREADS / 64, 256),
