@@ -2203,6 +2203,8 @@ struct Tab {
     short *act;      // [kcap] the active slots (the candidates of mcmc.jl:195; in slot order — the order does not matter, see tab_structural)
     double *base_o;  // [kcap] A[s] + log p + log(s-1+r), s = size          (candidate cluster of another point)
     double *base_s;  // [kcap] same with s = size-1                          (the point's own cluster, itself removed)
+    double *base_p;  // [kcap + 1] same with s = size+1 (a cluster a batch entry joined: the usual size of a touched candidate under validation —
+                     //  without it every such candidate loads A[s] from global memory and takes a log); [kcap] = the constant of a cluster of one (births)
     unsigned *used;  // [(n+31)/32] label occupancy bitset, bit (label-1); built when a round has changers (LDS, or V.used_scratch for large n)
     double *red_v;   // [NW][32] reduction scratch (NW = waves per block)
     int *red_pos, *red_slot;
@@ -2269,7 +2271,7 @@ __host__ __device__ inline size_t tab_layout(int kcap, int n, int nw, size_t *of
     off[26] = o; o = RC_A16(o + (size_t)kcap);                  // joined
     off[27] = o; o = RC_A16(o + sizeof(short) * 2 * maxb);   // pairs_tmp
     off[28] = o; o = RC_A16(o + 128 * sizeof(double2));       // flt: the table of rc_flog (the score logarithms gather from it per lane)
-    off[29] = o;
+    off[29] = o; o = RC_A16(o + (kcap < 2048 ? sizeof(double) * (kcap + 1) : 0));   // base_p (only below 2048 slots: the largest tables fill the CU as they are)
     return o;
 }
 
@@ -2290,7 +2292,7 @@ __device__ __forceinline__ Tab tab_carve(char *smem, int kcap, int n, int nw, in
     T.joined = (unsigned char *)(smem + off[26]); T.pairs_tmp = (short *)(smem + off[27]);
     T.act2 = (short *)(smem + off[10]); T.dirty = (unsigned char *)(smem + off[19]);
     T.cu = (int *)(smem + off[25]); T.cown = (short *)(T.cu + RC_CPB_LDS * RC_PTS); T.cached = 0;
-    T.flt = (double2 *)(smem + off[28]);
+    T.flt = (double2 *)(smem + off[28]); T.base_p = (double *)(smem + off[29]);
     return T;
 }
 
@@ -2320,6 +2322,7 @@ __device__ __forceinline__ void tab_bases(const View &V, const SweepArgs &a, Tab
         if (T.label[k] > 0) {
             T.base_o[k] = tab_base(V, a, s);
             T.base_s[k] = (s >= 2) ? tab_base(V, a, s - 1) : 0.0;
+            if (V.kcap < 2048) T.base_p[k] = (s + 1 <= V.n) ? tab_base(V, a, s + 1) : 0.0;
         }
     }
     __syncthreads();
@@ -2384,6 +2387,7 @@ __device__ __forceinline__ void tab_after_commit(const View &V, const SweepArgs 
         if (T.label[k] > 0) {
             T.base_o[k] = tab_base(V, a, s);
             T.base_s[k] = (s >= 2) ? tab_base(V, a, s - 1) : 0.0;
+            if (V.kcap < 2048) T.base_p[k] = (s + 1 <= V.n) ? tab_base(V, a, s + 1) : 0.0;
         }
     }
     int base = 0;
@@ -2753,7 +2757,12 @@ __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Ta
             if (s == 0) return;  // empty once i is removed (its own singleton cluster, mcmc.jl:193-196) or emptied by the batch
             sd -= (isown ? dg : 0);                                              // i itself excluded (clusts[i] = -1)
             const double SDr = (double)sd * V.scD, SLr = (double)sl * V.scL;      // logD diagonal is 0 (types.jl:155)
-            const double base = touched ? tab_base(V, a, s) : (isown ? T.base_s[k] : T.base_o[k]);
+            double base;
+            if (!touched) base = isown ? T.base_s[k] : T.base_o[k];
+            else {   // (the same doubles tab_base would produce again: the common sizes of a touched cluster are tabulated per slot)
+                const int s0 = T.size[k];
+                base = (V.kcap < 2048 && s == s0 + 1) ? T.base_p[k] : (s == s0) ? T.base_o[k] : (s == s0 - 1 && s0 >= 2) ? T.base_s[k] : tab_base(V, a, s);
+            }
 #ifndef RC_NO_PRUNE
             if (prune && !isown && bestslot != -2) {
                 // cheap test first: log1p(x) >= x / (1 + x) and log1p(y) <= y bound the noise-free score from above with two
@@ -2906,7 +2915,7 @@ __device__ __forceinline__ void eval_chunk(const View &V, const SweepArgs &a, Ta
                 const double SDr = (double)xd * V.scD, SLr = (double)xl * V.scL;
                 double lik = V.cL * SLr - (V.alpha + V.delta1) * rc_flog1p(SDr / V.beta, T.flt);
                 if (V.repulsion) lik += (V.zeta + V.delta2) * rc_flog1p(SDr / V.gamma, T.flt);
-                double v = tab_base(V, a, 1) + lik;
+                double v = (V.kcap < 2048 ? T.base_p[V.kcap] : tab_base(V, a, 1)) + lik;
                 if (!(a.dbg & 4)) {
                     const double un = rc_uniform(a, (unsigned)i, (unsigned)lab);
                     v = v + rc_gumbel(un, T.flt);
@@ -3803,19 +3812,21 @@ __device__ __forceinline__ void resolve_body(const View &V, const SweepArgs &sa,
             // a previous launch (resolvers are chained), so every block of this launch reads the same value.  Nothing was stored yet.
             if (first && err_word != 0) return;
             first = false;
-            double a1 = 0.0, a2 = 0.0;
-            if (isk && lb > 0) { a1 = V.A[sz]; if (sz >= 2) a2 = V.A[sz - 1]; }
+            double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            if (isk && lb > 0) { a1 = V.A[sz]; if (sz >= 2) a2 = V.A[sz - 1]; if (V.kcap < 2048 && sz + 1 <= V.n) a3 = V.A[sz + 1]; }
             if (i_ < V.n) o_ = V.slot_of[u_];
             if (isk) {
                 T.size[k] = sz; T.label[k] = lb; T.act[k] = (short)ac; T.dirty[k] = 0;
                 if (lb > 0) {   // (tab_base: A[s] + (log p + log(s - 1 + r)))
                     T.base_o[k] = a1 + (sa.logp + log((double)sz - 1.0 + sa.r));
                     T.base_s[k] = (sz >= 2) ? a2 + (sa.logp + log((double)(sz - 1) - 1.0 + sa.r)) : 0.0;
+                    if (V.kcap < 2048) T.base_p[k] = (sz + 1 <= V.n) ? a3 + (sa.logp + log((double)(sz + 1) - 1.0 + sa.r)) : 0.0;
                 }
             }
             if (k < ncu) { T.cu[k] = u_; T.cown[k] = (short)o_; }
         }
         if (threadIdx.x < 128) T.flt[threadIdx.x] = fl_;
+        if (V.kcap < 2048 && threadIdx.x == 128 % blockDim.x) T.base_p[V.kcap] = tab_base(V, sa, 1);   // a cluster of one: the births of a batch as candidates
         if (threadIdx.x == 0) {
             T.misc[0] = hK; T.misc[1] = hse; T.misc[7] = hhi;
             *T.blk_key = RC_KEY_NONE;
