@@ -390,15 +390,30 @@ __device__ __forceinline__ double2 rc_qlog_entry(const double2 *__restrict__ tab
     return *(const double2 *)((const char *)tab + P.joff);
 }
 // the value for dq > 0 — no select on dq: callers that may hold dq <= 0 mask the result
-__device__ __forceinline__ long long rc_qlog_raw(const QlogPrep &P, double2 t, double sL)
+__device__ __forceinline__ long long rc_qlog_raw(const QlogPrep &P, double2 t, double sL, double third = 1.0 / 3, double mquarter = -1.0 / 4)
 {
     const double r = fma(P.m, t.x, -1.0);
-    double p = fma(r, -1.0 / 4, 1.0 / 3);
+    double p = fma(r, mquarter, third);   // (1/3 and -1/4: the streaming kernel hands them over in a vector / a scalar register pair, see rc_third_vgpr)
     p = fma(r, p, -1.0 / 2);
     const double q = fma(r * r, p, r);                                      // log1p(r)
     const double v = fma(P.kd, 0.69314718055994530942 * sL, t.y);           // (sL is a power of two: the product is ln2 scaled exactly)
     const double w = fma(q, sL, v);
     return __double_as_longlong(w) - __double_as_longlong(0x1.8p52);
+}
+// 1/3 in a vector register pair, opaque to the optimiser: fma(r, -1/4, 1/3) is then ONE v_fma_f64 (register, scalar constant, register).
+// With both constants scalar the instruction may hold only one of them, and the compiler copies 1/3 into the accumulator of a v_fmac
+// first: one more vector instruction per entry of the matrix.
+__device__ __forceinline__ double rc_mquarter_sgpr()
+{
+    int hi;
+    asm volatile("s_mov_b32 %0, 0xbfd00000" : "=s"(hi));            // -1/4, opaque: as a literal it exists only in the two-operand v_fmac form
+    return __hiloint2double(hi, 0);
+}
+__device__ __forceinline__ double rc_third_vgpr()
+{
+    unsigned lo, hi;
+    asm volatile("v_mov_b32 %0, 0x55555555\n\tv_mov_b32 %1, 0x3fd55555" : "=v"(lo), "=v"(hi));
+    return __hiloint2double((int)hi, (int)lo);
 }
 __device__ __forceinline__ long long rc_qlog_finish(long long dq, const QlogPrep &P, double2 t, double sL)
 {
@@ -1685,6 +1700,7 @@ __device__ __forceinline__ void syml2_fast(const View &V, long long *pb /* [2][8
     long long *SD = V.SD[wgen], *SL = V.SL[wgen];
     const int qeD = V.qeD;
     const double qsL = V.qsL;
+    const double qthird = rc_third_vgpr(), qmq = rc_mquarter_sgpr();
 #ifndef RC_S2_EXP
 #define RC_S2_EXP 0      // timing experiments only (tools/syml_variants.py): 1 no atomics, 2 no logs, 4 no direction 2, 8 no direction 1
 #endif
@@ -1858,7 +1874,7 @@ __device__ __forceinline__ void syml2_fast(const View &V, long long *pb /* [2][8
                             }
 #pragma unroll
                             for (int u = 0; u < RC_S2_LOGS; ++u) {
-                                const long long v = rc_qlog_raw(pp[u], tv[u], qsL);
+                                const long long v = rc_qlog_raw(pp[u], tv[u], qsL, qthird, qmq);
                                 if ((g_ + u) & 1) y[(g_ + u) >> 1].y = v; else y[(g_ + u) >> 1].x = v;
                             }
                         }
