@@ -580,9 +580,9 @@ __global__ __launch_bounds__(256) void k_pack48(const long long *__restrict__ Dq
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < pairs; t += (size_t)gridDim.x * blockDim.x) {
         const ll2 v = *(const ll2 *)(Dq + 2 * t);
         const u64 a = (u64)v.x, b = (u64)v.y;
-        out[3 * t] = (unsigned)a;                                               // the low words as they are, the two 16-bit tops share the third
-        out[3 * t + 1] = (unsigned)b;
-        out[3 * t + 2] = (unsigned)(a >> 32) | ((unsigned)(b >> 32) << 16);
+        out[3 * t] = (unsigned)a;                                               // the low words as they are, the two 16-bit tops share the middle word
+        out[3 * t + 1] = (unsigned)(a >> 32) | ((unsigned)(b >> 32) << 16);
+        out[3 * t + 2] = (unsigned)b;
     }
 }
 
@@ -1637,8 +1637,8 @@ template <> struct S2Raw<true> {
     static __device__ __forceinline__ ll2 unpack(const rc_u3 &r)
     {
         ll2 x;
-        x.x = (long long)((u64)r.x | ((u64)(r.z & 0xffffu) << 32));
-        x.y = (long long)((u64)r.y | ((u64)(r.z >> 16) << 32));
+        x.x = (long long)((u64)r.x | ((u64)(r.y & 0xffffu) << 32));
+        x.y = (long long)((u64)r.z | ((u64)(r.y >> 16) << 32));
         return x;
     }
 };
