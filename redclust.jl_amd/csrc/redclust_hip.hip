@@ -4463,7 +4463,17 @@ __global__ __launch_bounds__(1024) void k_sweep_wide(View V, SweepArgs sa, int g
         if (changes) V.sc->last_change_sweep = sa.t;
     }
     RC_WIDE_SYNC();
-    if (failed) return;
+    if (failed) {
+        // the host learns of the failure from the mapped summary (sync_and_check reads hsum->err, which only write_summary sets):
+        // without this a wide context that ran out of slots AGAIN — it was grown to twice its capacity, not to n — dropped the sweep
+        // and every sweep behind it silently (found by the large leg of the randomised checks, seed 69000: 2432 -> 4864 slots, then
+        // K = 4924)
+        if (threadIdx.x == 0) {
+            V.hsum->err = __hip_atomic_load(&V.sc->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            V.hsum->seq += 1;
+        }
+        return;
+    }
     snapshot_labels(V, sa.t & 1, &red[0]);
     write_summary(V, changes, sa.rounds0 + 1);
 }

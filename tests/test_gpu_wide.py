@@ -141,3 +141,34 @@ def test_chain_in_a_wide_context():
     assert ref["K"].min() > 4096
     assert np.allclose(ch["logposterior"], ref["logposterior"], rtol=1e-9, atol=0)
     ctx.close()
+
+
+def test_births_beyond_the_capacity_of_a_wide_context():
+    """A context that is wide already (kcap = 4200 > 4096 slots at n = 4300) and full but for 104 slots: the first points of the sweep
+    open new clusters, the WIDE kernel runs out of slots, the host grows the tables again (to n) and resumes the sweep behind the
+    point that needed the slot.  (Round 4: the wide kernel did not publish its capacity failure to the host summary — the sweep and
+    every sweep behind it were dropped silently; the randomised checks met it when a context grown 2432 -> 4864 needed 4924.)"""
+    n, K = 4300, 20
+    data = rc.generatemixture(n, K, seed=7, sigma=0.1)
+    sh = np.random.default_rng(3).permutation(n)
+    D = np.ascontiguousarray(data["distancematrix"][np.ix_(sh, sh)]); truth = data["clusts"][sh]
+    P = dict(rc.likelihood_hyperparams(D, truth), repulsion=False)
+    init = np.empty(n, np.int64); init[:205] = 1; init[205:] = np.arange(2, 4097)
+    L = np.log(np.where(np.eye(n, dtype=bool), 1.0, D))
+    ctx = rc.Context(D, logD=L, kcap=4200)
+    ctx.set_params(**P)
+    ctx.set_state(init)
+    assert ctx.capacity_info()["kcap"] == 4200 and ctx.get_state()[2] == 4096
+    eD, eL = ctx.debug_rowsums(1)[2:4]
+    orc = O.Oracle(D, P, logD=L, eL=eL, eD=eD)
+    orc.set_state(init)
+    for t in range(3):
+        ctx.gibbs_sweep(1.0, 0.5, 11, t, blocking=(t != 1))
+        orc.sweep_stable(1.0, 0.5, 11, t)
+        same_state(ctx, orc, t)
+        assert ctx.sweep_stats()["n_changes"] == orc.last_changes, t
+    info = ctx.capacity_info()
+    assert info["n_grows"] >= 1 and info["kcap"] == n, info
+    labs = np.unique(orc.clusts)
+    rowsums_match(ctx, orc, labs[[0, len(labs) // 2, -1]])
+    ctx.close()
