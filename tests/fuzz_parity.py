@@ -69,6 +69,52 @@ def run(cases, first, nlo=40, nhi=1500, kmax=25):
     return bad
 
 
+def run_wide(cases, first):
+    """Wide contexts (more than 4096 clusters; k_sweep_wide, k_derive_wide): n between 4150 and 5200, most points clusters of their own,
+    capacities that leave a wide context room to overflow again (explicit kcap between 4096 and n), both modes, both storage widths,
+    three sweeps against the oracle.  Slow (hundreds of milliseconds per sweep): a handful of cases."""
+    bad = 0
+    for seed in range(first, first + cases):
+        g = np.random.default_rng(seed)
+        n = int(g.integers(4150, 5200)); K = int(g.integers(3, 40)); dim = int(g.integers(max(2, K), K + 6))
+        sigma = float(g.uniform(0.1, 0.6))
+        data = rc.generatemixture(n, K, seed=seed, sigma=sigma, dim=dim)
+        sh = g.permutation(n)
+        D = np.ascontiguousarray(data["distancematrix"][np.ix_(sh, sh)]); truth = data["clusts"][sh]
+        P = dict(rc.likelihood_hyperparams(D, truth), repulsion=bool(g.random() < 0.5), maxK=0)
+        bits = int(g.choice([64, 32])); stored = bool(g.random() < 0.5) or bits == 32
+        kcap = int(g.choice([0, 4096, int(g.integers(4097, n)), n]))
+        orc0 = O.Oracle(D, P)
+        init = np.arange(1, n + 1, dtype=np.int64)
+        merged = g.choice(n, int(g.integers(0, n - 4100)), replace=False)       # some points share a few clusters: K stays above 4096
+        init[merged] = init[merged[: max(1, len(merged) // 50)]][g.integers(0, max(1, len(merged) // 50), len(merged))] if len(merged) else init[merged]
+        ok = True
+        try:
+            ctx = rc.Context(D, logD=orc0.logD if stored else None, kcap=kcap, storage_bits=bits)
+            ctx.set_params(**P)
+            L = ctx.get_matrix(1); Dd = ctx.get_matrix(0)
+            ctx.set_state(init)
+            eD, eL = ctx.debug_rowsums(int(init[0]))[2:4]
+            orc = O.Oracle(Dd, P, logD=L, eL=eL, eD=eD)
+            orc.set_state(init)
+            mode = "incremental" if g.random() < 0.5 else "full"
+            ctx.set_mode(mode)
+            for t in range(3):
+                r, p = float(g.uniform(0.3, 3.0)), float(g.uniform(0.05, 0.95))
+                ctx.gibbs_sweep(r, p, seed, t, blocking=bool(t & 1))
+                orc.sweep_stable(r, p, seed, t)
+                lab, sizes, Kc = ctx.get_state()
+                if not (np.array_equal(lab, orc.clusts) and np.array_equal(sizes, orc.sizes) and Kc == orc.K and ctx.sweep_stats()["n_changes"] == orc.last_changes):
+                    ok = False
+                    print(f"MISMATCH (wide) seed {seed} sweep {t}: n={n} K0={len(np.unique(init))} bits={bits} stored={stored} kcap={kcap} rep={P['repulsion']} mode={mode} differing {int(np.sum(lab != orc.clusts))} stats {ctx.sweep_stats()} oracle K {orc.K} changes {orc.last_changes} capacity {ctx.capacity_info()}")
+                    break
+            ctx.close()
+        except rc.RedClustHIPError as e:
+            ok = False; print(f"ERROR (wide) seed {seed}: {e}")
+        bad += not ok
+    return bad
+
+
 def run_chains(cases, first):
     """rc_run_chain with split-merge proposals: the speculative pipeline at a random depth / worker count against the synchronous
     loop (RC_CHAIN_PIPELINE=0) on random small problems — every output array and the final state must be identical."""
@@ -156,6 +202,8 @@ if __name__ == "__main__":
         bad = run_chains(cases, first)
     elif len(sys.argv) > 3 and sys.argv[3] == "oracle_chains":
         bad = run_chains_oracle(cases, first)
+    elif len(sys.argv) > 3 and sys.argv[3] == "wide":      # more than 4096 clusters
+        bad = run_wide(cases, first)
     elif len(sys.argv) > 3 and sys.argv[3] == "large":     # beyond the kernel-choice threshold (n > 2560): symmetric kernels, ragged column blocks, re-layouts
         bad = run(cases, first, 2600, 7000, 60)
     else:
