@@ -108,6 +108,14 @@ def run_wide(cases, first):
                     ok = False
                     print(f"MISMATCH (wide) seed {seed} sweep {t}: n={n} K0={len(np.unique(init))} bits={bits} stored={stored} kcap={kcap} rep={P['repulsion']} mode={mode} differing {int(np.sum(lab != orc.clusts))} stats {ctx.sweep_stats()} oracle K {orc.K} changes {orc.last_changes} capacity {ctx.capacity_info()}")
                     break
+            if ok:      # the observables of the state reached: log-likelihood (block sums tiled over thousands of slots), recorded sample
+                ll, ref = ctx.loglik(), orc.loglik_stable()
+                canon = ctx.record_sample(True)
+                ref_c = np.zeros(n, np.int64)
+                O.lib().orc_sortlabels(n, orc.clusts, ref_c)
+                if not (abs(ll - ref) <= 1e-9 * abs(ref) and np.array_equal(canon, ref_c)):
+                    ok = False
+                    print(f"MISMATCH (wide, observables) seed {seed}: n={n} bits={bits} stored={stored} kcap={kcap} mode={mode} loglik {ll} vs {ref} canonical labels equal {np.array_equal(canon, ref_c)} K {orc.K}")
             ctx.close()
         except rc.RedClustHIPError as e:
             ok = False; print(f"ERROR (wide) seed {seed}: {e}")
