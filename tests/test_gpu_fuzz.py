@@ -21,3 +21,11 @@ def test_randomised_chains_speculative_against_synchronous():
 def test_randomised_chains_against_the_oracle_loop():
     import fuzz_parity
     assert fuzz_parity.run_chains_oracle(12, 11000) == 0
+
+
+def test_randomised_wide_contexts_against_the_oracle():
+    """More than 4096 clusters (round 4: k_sweep_wide; capacities that leave a wide context room to overflow again — the case that
+    dropped sweeps silently until the large leg of these checks met it): three cases, three sweeps each, labels / sizes / K / change
+    counts exact, log-likelihood 1e-9, recorded sample exact.  By hand: 160 cases, 30 of them on the chaos build."""
+    import fuzz_parity
+    assert fuzz_parity.run_wide(3, 84000) == 0
