@@ -71,7 +71,10 @@ typedef struct rc_sweep_stats {
  * would have produced.  Up to 4096 slots the kernel's tables live in LDS (the fast path).  Beyond — the reference's clustsizes
  * has length n, src/types.jl:131-137, src/mcmc.jl:198-199 — the context becomes WIDE: tables in global memory, one row-sum
  * table corrected in place, the sweep point by point on one workgroup (tens to hundreds of ms per sweep; the same draws), up
- * to min(n, 32767) clusters (slot ids are 16-bit); more is RC_ERR_CAPACITY.  0 = automatic: sized from the first state (twice
+ * to min(n, 32767) clusters (slot ids are 16-bit); more is RC_ERR_CAPACITY.  A wide context NARROWS again once its state is down
+ * to 1024 clusters (a chain started from all singletons collapses within a sweep or two): rc_set_state, and rc_gibbs_sweep[_async]
+ * between two sweeps, re-install the labels with a capacity sized by the state — the same chain; not under a running rc_run_chain.
+ * 0 = automatic: sized from the first state (twice
  * its cluster count, at least 128, on the fast path while the clusters fit it).  Small capacities are faster (the tables sit
  * beside more row-reduction blocks on a CU); rc_capacity_info reports the current one.
  * device_id: HIP device ordinal. */

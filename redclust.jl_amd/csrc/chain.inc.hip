@@ -116,6 +116,7 @@ struct Pending {
     int64_t j = 0;
     double r = 0, p = 0;
     int hi = 0, K = 0;
+    int kcap = 0;             // slot capacity when the sample was taken: its slot ids are below this, whatever the capacity is when the host part runs (a wide context may have narrowed since)
     std::vector<int> ssize, slabel;
 };
 constexpr int REC_SLOT = RC_REC_SLOTS - 1;  // slot 0 belongs to rc_loglik (split–merge proposals call it)
@@ -127,6 +128,7 @@ static int32_t record_enqueue(rc_ctx *c, Pending &R, bool want_labels)
     if (rc != RC_OK) return rc;
     R.hi = std::max(1, std::min(c->kcap, c->hsum->slot_hi));
     R.K = c->hsum->K;
+    R.kcap = c->kcap;
     rc = ensure_pinned(c, R.hi);
     if (rc != RC_OK) return rc;
     R.ssize.resize((size_t)c->kcap); R.slabel.resize((size_t)c->kcap);
@@ -157,7 +159,7 @@ static int32_t record_finish(rc_ctx *c, Pending &R, rc_chain_outputs *out)
     if (out->clusts) {
         // sortlabels (utils.jl:69-74): relabel by order of first appearance; the snapshot is in the caller's point order
         int64_t *dst = out->clusts + (size_t)j * c->n;
-        std::vector<int> map((size_t)c->kcap, 0);
+        std::vector<int> map((size_t)std::max(R.kcap, c->kcap), 0);
         int next = 0;
         const unsigned short *lab = c->pinLab[REC_SLOT];
         for (int i = 0; i < c->n; ++i) {
@@ -782,6 +784,9 @@ extern "C" int32_t rc_run_chain(rc_ctx *c, const rc_chain_options *o, rc_chain_o
     if ((o->r_trace == nullptr) != (o->p_trace == nullptr)) return fail(c, RC_ERR_ARG, "rc_run_chain: give both r_trace and p_trace or neither");
     HIPCHK(c, hipSetDevice(c->dev));
     c->chain_rollbacks = c->chain_split_evals = c->chain_workers = c->chain_grows = 0;
+    // (a wide context does not narrow under a running chain loop: the loop's deferred record jobs and snapshots are tied to the slot
+    // tables they were taken from — sweep_enqueue; the sweep API narrows, and so does rc_set_state before a chain)
+    struct Active { rc_ctx *c; bool prev; Active(rc_ctx *c_) : c(c_), prev(c_->chain_active) { c->chain_active = true; } ~Active() { c->chain_active = prev; } } active_guard(c);
     struct Running {   // counted while the loop runs (unless rc_run_chains has counted all of its chains already)
         bool counted;
         Running() : counted(!t_counted_by_driver) { if (counted) ++g_chains_running; }

@@ -4677,6 +4677,8 @@ struct rc_ctx {
     long long bulk_enq = -1;  // highest sweep index whose k_bulk has been enqueued
     bool prefetch = true;     // enqueue k_bulk(t+1) together with k_resolve(t)
     bool incremental = false; // RC_MODE_INCREMENTAL: S is only maintained by exact corrections, never recomputed
+    bool chain_active = false;       // rc_run_chain is running on this context (no automatic narrowing of a wide context under it)
+    bool want_incremental = false;   // the mode the caller asked for (rc_set_mode): a wide context runs incrementally whatever was asked, and goes back to this when it narrows
     int inc_gen = 0;          // the S generation that incremental mode keeps current
     hipEvent_t ev_bulk[4] = {nullptr, nullptr, nullptr, nullptr}, ev_res[4] = {nullptr, nullptr, nullptr, nullptr};
     // timing of k_bulk
@@ -5762,6 +5764,12 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
         if (!c->kcap_fixed && (K0 > c->kcap || (c->kcap_auto && !c->have_state && c->n_grows == 0 && capacity_for(c, K0) > c->kcap))) {
             int32_t rcg = resize_capacity(c, std::max(c->kcap, capacity_for(c, K0)));
             if (rcg != RC_OK) return rcg;
+        } else if (!c->kcap_fixed && c->wide && K0 * 4 <= RC_MAX_KCAP) {
+            // A wide context (more than 4096 slots: the sweep point by point on one workgroup, hundreds of milliseconds) whose state
+            // has come down to a quarter of what the fast path holds goes back to it: the capacity follows the state downwards too
+            // (a chain started from all singletons collapses to a few dozen clusters within a sweep or two).
+            int32_t rcg = resize_capacity(c, capacity_for(c, K0));
+            if (rcg != RC_OK) return rcg;
         }
     }
     // clustsizes = counts(clusts, 1:n), K = sum(clustsizes .> 0)  (types.jl:135-136); slots in label order
@@ -5869,7 +5877,8 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
         if (rcd != RC_OK) return rcd;
     }
     HIPCHK(c, hipStreamSynchronize(c->sA));
-    if (c->wide) { c->incremental = true; c->inc_gen = 0; }   // one generation, corrected in place by k_sweep_wide (never back to RC_MODE_FULL)
+    if (c->wide) { c->incremental = true; c->inc_gen = 0; }   // one generation, corrected in place by k_sweep_wide (RC_MODE_FULL again once the context narrows)
+    else c->incremental = c->want_incremental;
     c->last = s;
     c->t_next = 0;
     c->bulk_enq = -1;
@@ -6110,6 +6119,18 @@ static int32_t sweep_enqueue(rc_ctx *c, double r, double p, uint64_t seed, uint6
     // reduction would be given up for that reason, and a fresh layout would bring it back, re-lay the points out:
     // drain the pipeline and set the same labels again.  Slot numbers change, the partition and its labels do not, and
     // all sums are exact integers, so the chain is bit-identical with or without this step.
+    // A wide context whose chain has come down to few clusters narrows again (rc_set_state of the same labels sizes the tables by the
+    // state): drain the pipeline, re-install.  The chain is bit-identical with or without this step, as with the re-layout below.
+    if (!c->recovering && !c->chain_active && c->wide && !c->kcap_fixed && c->t_next >= 2 && (long long)c->hsum->K * 4 <= RC_MAX_KCAP) {
+        std::vector<int64_t> labels, sizes;
+        int64_t K = 0;
+        rc = pull_labels(c, labels, sizes, K);
+        if (rc != RC_OK) return rc;
+        if (K * 4 <= RC_MAX_KCAP) {
+            rc = rc_set_state(c, labels.data());
+            if (rc != RC_OK) return rc;
+        }
+    }
     if (!c->recovering && !c->incremental && c->relayout && c->bulk_kernel < 0 && c->t_next >= 32 &&
         (long long)c->hsum->runs * 32 > (long long)c->n && (long long)c->hsum->K * 64 <= (long long)c->n) {
         std::vector<int64_t> labels, sizes;
@@ -7289,6 +7310,7 @@ extern "C" int32_t rc_set_mode(rc_ctx *c, int32_t mode)
     if (mode != RC_MODE_FULL && mode != RC_MODE_INCREMENTAL) return fail(c, RC_ERR_ARG, "rc_set_mode: unknown mode %d", mode);
     HIPCHK(c, hipSetDevice(c->dev));
     const bool inc = (mode == RC_MODE_INCREMENTAL);
+    c->want_incremental = inc;
     if (inc == c->incremental) return RC_OK;
     if (c->wide && !inc) return RC_OK;   // a wide context maintains its one table in place whatever the mode says (same results in both modes anyway)
     int32_t rc = sync_and_check(c, true);
