@@ -73,7 +73,7 @@ typedef struct rc_sweep_stats {
  * table corrected in place, the sweep point by point on one workgroup (tens to hundreds of ms per sweep; the same draws), up
  * to min(n, 32767) clusters (slot ids are 16-bit); more is RC_ERR_CAPACITY.  A wide context NARROWS again once its state is down
  * to 1024 clusters (a chain started from all singletons collapses within a sweep or two): rc_set_state, and rc_gibbs_sweep[_async]
- * between two sweeps, re-install the labels with a capacity sized by the state — the same chain; not under a running rc_run_chain.
+ * between two sweeps (also those of rc_run_chain), re-install the labels with a capacity sized by the state — the same chain.
  * 0 = automatic: sized from the first state (twice
  * its cluster count, at least 128, on the fast path while the clusters fit it).  Small capacities are faster (the tables sit
  * beside more row-reduction blocks on a CU); rc_capacity_info reports the current one.

@@ -169,7 +169,7 @@ static int32_t record_finish(rc_ctx *c, Pending &R, rc_chain_outputs *out)
         }
     }
     const double ll = loglik_host(c, R.hi, R.ssize.data(), c->pinB[REC_SLOT], R.slabel.data());                    // mcmc.jl:551
-    const double lp = logprior_host(c, R.ssize.data(), R.slabel.data(), R.r, R.p);
+    const double lp = logprior_host(c, R.ssize.data(), R.slabel.data(), R.r, R.p, (int)R.ssize.size());   // (the sample's own slot count: the context may have narrowed since)
     if (out->K) out->K[j] = R.K;
     if (out->r) out->r[j] = R.r;
     if (out->p) out->p[j] = R.p;
@@ -784,9 +784,8 @@ extern "C" int32_t rc_run_chain(rc_ctx *c, const rc_chain_options *o, rc_chain_o
     if ((o->r_trace == nullptr) != (o->p_trace == nullptr)) return fail(c, RC_ERR_ARG, "rc_run_chain: give both r_trace and p_trace or neither");
     HIPCHK(c, hipSetDevice(c->dev));
     c->chain_rollbacks = c->chain_split_evals = c->chain_workers = c->chain_grows = 0;
-    // (a wide context does not narrow under a running chain loop: the loop's deferred record jobs and snapshots are tied to the slot
-    // tables they were taken from — sweep_enqueue; the sweep API narrows, and so does rc_set_state before a chain)
-    struct Active { rc_ctx *c; bool prev; Active(rc_ctx *c_) : c(c_), prev(c_->chain_active) { c->chain_active = true; } ~Active() { c->chain_active = prev; } } active_guard(c);
+    // (a wide context may narrow under the synchronous loop below — sweep_enqueue: a sample's deferred host part keeps the slot count it
+    // was taken with, chain::Pending::kcap; the pipelined loop never sees a wide context)
     struct Running {   // counted while the loop runs (unless rc_run_chains has counted all of its chains already)
         bool counted;
         Running() : counted(!t_counted_by_driver) { if (counted) ++g_chains_running; }

@@ -4677,7 +4677,6 @@ struct rc_ctx {
     long long bulk_enq = -1;  // highest sweep index whose k_bulk has been enqueued
     bool prefetch = true;     // enqueue k_bulk(t+1) together with k_resolve(t)
     bool incremental = false; // RC_MODE_INCREMENTAL: S is only maintained by exact corrections, never recomputed
-    bool chain_active = false;       // rc_run_chain is running on this context (no automatic narrowing of a wide context under it)
     bool want_incremental = false;   // the mode the caller asked for (rc_set_mode): a wide context runs incrementally whatever was asked, and goes back to this when it narrows
     int inc_gen = 0;          // the S generation that incremental mode keeps current
     hipEvent_t ev_bulk[4] = {nullptr, nullptr, nullptr, nullptr}, ev_res[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -6121,7 +6120,7 @@ static int32_t sweep_enqueue(rc_ctx *c, double r, double p, uint64_t seed, uint6
     // all sums are exact integers, so the chain is bit-identical with or without this step.
     // A wide context whose chain has come down to few clusters narrows again (rc_set_state of the same labels sizes the tables by the
     // state): drain the pipeline, re-install.  The chain is bit-identical with or without this step, as with the re-layout below.
-    if (!c->recovering && !c->chain_active && c->wide && !c->kcap_fixed && c->t_next >= 2 && (long long)c->hsum->K * 4 <= RC_MAX_KCAP) {
+    if (!c->recovering && c->wide && !c->kcap_fixed && c->t_next >= 2 && (long long)c->hsum->K * 4 <= RC_MAX_KCAP) {
         std::vector<int64_t> labels, sizes;
         int64_t K = 0;
         rc = pull_labels(c, labels, sizes, K);

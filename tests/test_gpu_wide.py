@@ -211,3 +211,34 @@ def test_a_wide_context_narrows_when_the_chain_collapses(mode):
     ll, ref = ctx.loglik(), orc.loglik_stable()
     assert abs(ll - ref) <= 1e-9 * abs(ref), (ll, ref)
     ctx.close()
+
+
+@pytest.mark.parametrize("mode,numMH", [("full", 0), ("incremental", 0), ("full", 1)])
+def test_a_chain_narrows_a_wide_context(mode, numMH):
+    """rc_run_chain from all singletons (a wide context) with a p at which the chain collapses in the first sweeps: the context narrows
+    between two sweeps of the running loop, and every recorded sample — the one whose host part runs across the re-install too — equals
+    the oracle's (labels, K, logposterior).  (The first form of this counted the sample's clusters over the new, smaller capacity in the
+    log-prior: one wrong logposterior per chain, found by tools/fuzz_wide_chains.py.)"""
+    g = np.random.default_rng(95002)                       # (the case of tools/fuzz_wide_chains.py that showed it: n = 4245, K trace 829, 32, 30, ...)
+    n = int(g.integers(4150, 4700)); K = int(g.integers(5, 30))
+    data = rc.generatemixture(n, K, seed=95002, sigma=float(g.uniform(0.08, 0.3)))
+    D, truth = data["distancematrix"], data["clusts"]
+    P = dict(rc.likelihood_hyperparams(D, truth), repulsion=False)
+    L = np.log(np.where(np.eye(n, dtype=bool), 1.0, D))
+    init = np.arange(1, n + 1, dtype=np.int64)
+    ctx = rc.Context(D, logD=L)
+    ctx.set_params(**P); ctx.set_state(init); ctx.set_mode(mode); ctx.cocluster_reset()
+    assert ctx.capacity_info()["kcap"] > 4096
+    eD, eL = ctx.debug_rowsums(1)[2:4]
+    orc = O.Oracle(D, P, logD=L, eL=eL, eD=eD)
+    ctx.attach_host_matrices(D, L)
+    iters = 5
+    rtr = np.full(iters, 1.0); ptr = np.full(iters, 0.2)
+    ch = ctx.run_chain(iters, 0, 1, 2, numMH, 95002, 1.0, 0.2, 1.0, rp_trace=(rtr, ptr))
+    ref = O.run_chain(orc, init, 1.0, 0.2, iters, 0, 1, 2, numMH, 95002, stable=True, rp_trace=(rtr, ptr))
+    assert ref["K"][-1] * 4 <= 4096, ref["K"]
+    assert ctx.capacity_info()["kcap"] <= 4096             # narrowed under the loop
+    assert np.array_equal(ch["K"], ref["K"]) and np.array_equal(ch["clusts"], ref["clusts"])
+    assert np.array_equal(ch["splitmerge_acceptances"], ref["sm_acc"]) and np.array_equal(ch["splitmerge_splits"], ref["sm_split"])
+    assert np.allclose(ch["logposterior"], ref["logposterior"], rtol=1e-9, atol=0), (ch["logposterior"], ref["logposterior"])
+    ctx.close()
