@@ -247,7 +247,10 @@ def config5_leg(rc, dev0, kcap, steps):
            "sweeps_per_s": steps / dt, "ms_per_sweep": dt / steps * 1e3, "steps": steps, "windows_sweeps_per_s": [steps / x for x in tw],
            "label_changes_last_sweep": st["n_changes"], "K_final": st["K"], "capacity": ctx.capacity_info(), "setup_s": setup_s,
            "dtype": "i32 fixed-point storage of D and logD (2^-30 of the largest entry), i64 exact sums, f64 scores",
-           "roofline": dict(roof, bound="hbm", note="k_bulk_sym32 reads the upper triangles of D and logD (n(n+1)/2 x 4 B each = 4.29 GB per sweep): HBM-resident")}
+           "roofline": dict(roof, bound="hbm", note="k_bulk_sym32 reads the upper triangles of D and logD (n(n+1)/2 x 4 B each = 4.29 GB per sweep): HBM-resident.  "
+                                                       "Its launches alternate between two streams and each runs three blocks per CU beside the resolver: a launch's "
+                                                       "event-timed duration includes the time its blocks wait for those of the previous launch to retire, so `frac` "
+                                                       "(per launch) understates and `per_sweep_period.frac` is the sustained rate")}
     ctx.close()
     return out
 

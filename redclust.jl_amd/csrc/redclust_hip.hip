@@ -2044,20 +2044,36 @@ __global__ __launch_bounds__(256, RC_SYML_MINWAVES) void k_bulk_syml_list(View V
     syml_units<DERIVED, long long>(V, tl[wv], wgen, sgen, V.nslow, 0, 8, 8, (int)blockIdx.x * 4 + wv, (int)gridDim.x * 4, nullptr, V.uslow);
 }
 
-// k_bulk_sym32 — the same symmetric reduction for 32-bit storage: 32-row × 256-column int32 tiles (1 KiB row
-// segments), all 256 threads take a column in direction 1 and then a (row, matrix, 64-column quarter) in direction 2.
+// k_bulk_sym32 — the same symmetric reduction for 32-bit storage: TR-row × 256-column int32 tiles (1 KiB row
+// segments), all 256 threads take a column in direction 1 and then a (row, matrix, part of a 64-column quarter) in direction 2.
+// TR = 16 (default since round 4): 34 KiB blocks, three per CU — blocks in three different phases of (wait for the tile, write it to
+// LDS, barrier, reduce, barrier) instead of two, and at ≤ 128 registers a resolver wave fits beside three of its waves on a SIMD (four
+// blocks per CU read 5 % faster alone, but the resolver then waits for the reduction to retire: fewer sweeps per second).  A piece's
+// load for the next tile is issued right behind its LDS write, and every thread derives the rows' chunk uniformity itself (two barriers
+// per tile instead of three).  TR = 32, two 67 KiB blocks per CU, is the round-1 shape (diag builds: RC_SYM32_TR=32).
 #define RC_SYM32_TC 256
 #define RC_SYM32_TP (RC_SYM32_TC + 4)
-__global__ __launch_bounds__(256) void k_bulk_sym32(View V, int wgen, int zgen, int sgen, int cgen, int item_tiles, int nitems)
+#ifdef RC_DIAG   // timing ablations (wrong sums): debug flag 32 drops the direction-1 flushes, 64 the direction-2 flushes
+#define RC_SYM32_ABL1 && !(zgen & 32)
+#define RC_SYM32_ABL2 && !(zgen & 64)
+#else
+#define RC_SYM32_ABL1
+#define RC_SYM32_ABL2
+#endif
+template <int TR>
+__global__ __launch_bounds__(256, TR == 16 ? 4 : 2) void k_bulk_sym32(View V, int wgen, int zgen, int sgen, int cgen, int item_tiles, int nitems)
 {
     typedef int i4 __attribute__((ext_vector_type(4)));
-    __shared__ __attribute__((aligned(16))) int tt[2][RC_SYM_TR][RC_SYM32_TP];
+    constexpr int NQ = TR / 4;            // 16-byte pieces per thread, matrix and tile
+    constexpr int PARTS = 32 / TR;        // direction 2: lanes of a wave = TR rows × 2 matrices × PARTS parts of every 8-column chunk
+    __shared__ __attribute__((aligned(16))) int tt[2][TR][RC_SYM32_TP];
     __shared__ int item_sh, J_sh;
-    __shared__ int cslot[RC_SYM32_TC], rslot[RC_SYM_TR];
-    __shared__ int cchk[RC_SYM32_TC / 8], rchk[RC_SYM_TR / 8];
+    __shared__ int cslot[RC_SYM32_TC];
+    __shared__ __attribute__((aligned(16))) int rslot[TR];
+    __shared__ int cchk[RC_SYM32_TC / 8];
     const int tid = threadIdx.x;
     const size_t ld = (size_t)V.ld;
-    (void)zgen;  // generations are cleared and work counters re-armed by k_resolve (SweepArgs.zero_gen)
+    (void)zgen;  // generations are cleared and work counters re-armed by k_resolve (SweepArgs.zero_gen); diag builds: ablation flags
     const int *__restrict__ Dq = (const int *)V.Dq;
     const int *__restrict__ Lq = (const int *)V.Lq;
     const int *__restrict__ slot = V.snap[sgen];
@@ -2072,7 +2088,7 @@ __global__ __launch_bounds__(256) void k_bulk_sym32(View V, int wgen, int zgen, 
             int J = -1;
             if (item < nitems) {
                 for (J = ncb - 1;; --J) {
-                    const int ntile = (min(RC_SYM32_TC * J + RC_SYM32_TC, n) + RC_SYM_TR - 1) / RC_SYM_TR;
+                    const int ntile = (min(RC_SYM32_TC * J + RC_SYM32_TC, n) + TR - 1) / TR;
                     const int cnt = (ntile + item_tiles - 1) / item_tiles;
                     if (item < cnt) break;
                     item -= cnt;
@@ -2084,7 +2100,7 @@ __global__ __launch_bounds__(256) void k_bulk_sym32(View V, int wgen, int zgen, 
         const int J = J_sh, item = item_sh;
         if (J < 0) break;
         const int c0 = J * RC_SYM32_TC;
-        const int ntile = (min(c0 + RC_SYM32_TC, n) + RC_SYM_TR - 1) / RC_SYM_TR;
+        const int ntile = (min(c0 + RC_SYM32_TC, n) + TR - 1) / TR;
         const int t_begin = item * item_tiles, t_end = min(ntile, t_begin + item_tiles);
         cslot[tid] = (c0 + tid < n) ? slot[c0 + tid] : -1;
         __syncthreads();
@@ -2094,26 +2110,24 @@ __global__ __launch_bounds__(256) void k_bulk_sym32(View V, int wgen, int zgen, 
             for (int q = 1; q < 8; ++q) u = u && (cslot[tid * 8 + q] == s0);
             cchk[tid] = u ? s0 : -2;
         }
-        i4 d[8], l[8];
-        auto issue = [&](int t) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int piece = q * 256 + tid, lr = piece >> 6, lp = piece & 63;
-                const int r = min(t * RC_SYM_TR + lr, n - 1);
-                d[q] = __builtin_nontemporal_load((const i4 *)(Dq + (size_t)r * ld + c0 + lp * 4));
-                l[q] = __builtin_nontemporal_load((const i4 *)(Lq + (size_t)r * ld + c0 + lp * 4));
-            }
+        i4 d[NQ], l[NQ];
+        auto issue1 = [&](int t, int q) {
+            const int piece = q * 256 + tid, lr = piece >> 6, lp = piece & 63;
+            const int r = min(t * TR + lr, n - 1);
+            d[q] = __builtin_nontemporal_load((const i4 *)(Dq + (size_t)r * ld + c0 + lp * 4));
+            l[q] = __builtin_nontemporal_load((const i4 *)(Lq + (size_t)r * ld + c0 + lp * 4));
         };
-        issue(t_begin);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) issue1(t_begin, q);
         long long accD = 0, accL = 0;
         int cur = -1;
         const int b = c0 + tid;
         for (int t = t_begin; t < t_end; ++t) {
-            const int r0 = t * RC_SYM_TR;
+            const int r0 = t * TR;
             __syncthreads();
-            if (tid < RC_SYM_TR) rslot[tid] = (r0 + tid < n) ? slot[r0 + tid] : -1;
+            if (tid < TR) rslot[tid] = (r0 + tid < n) ? slot[r0 + tid] : -1;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 const int piece = q * 256 + tid, lr = piece >> 6, lp = piece & 63;
                 const int r = r0 + lr, bb = c0 + lp * 4;
                 const bool live = r < n;
@@ -2123,41 +2137,39 @@ __global__ __launch_bounds__(256) void k_bulk_sym32(View V, int wgen, int zgen, 
                     if (!(live && bb + e > r)) { x[e] = 0; y[e] = 0; }
                 *(i4 *)&tt[0][lr][lp * 4] = x;
                 *(i4 *)&tt[1][lr][lp * 4] = y;
-            }
-            if (t + 1 < t_end) issue(t + 1);
-            __syncthreads();
-            if (tid < RC_SYM_TR / 8) {
-                const int s0 = rslot[tid * 8];
-                bool u = true;
-                for (int q = 1; q < 8; ++q) u = u && (rslot[tid * 8 + q] == s0);
-                rchk[tid] = u ? s0 : -2;
+                if (t + 1 < t_end) issue1(t + 1, q);   // (the piece's registers are free: its load for the next tile goes out at once)
             }
             __syncthreads();
             // direction 1: column b gathers the rows of the tile
 #pragma unroll 1
-            for (int ch = 0; ch < RC_SYM_TR / 8; ++ch) {
-                long long xd[8], xl[8];
+            for (int ch = 0; ch < TR / 8; ++ch) {
+                int xd[8], xl[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) { xd[q] = tt[0][ch * 8 + q][tid]; xl[q] = tt[1][ch * 8 + q][tid]; }
-                const int cs_ = __builtin_amdgcn_readfirstlane(rchk[ch]);
+                int cs_;
+                {
+                    const i4 ra = *(const i4 *)&rslot[ch * 8], rb = *(const i4 *)&rslot[ch * 8 + 4];
+                    const bool u = ra[1] == ra[0] && ra[2] == ra[0] && ra[3] == ra[0] && rb[0] == ra[0] && rb[1] == ra[0] && rb[2] == ra[0] && rb[3] == ra[0];
+                    cs_ = __builtin_amdgcn_readfirstlane(u ? ra[0] : -2);
+                }
                 if (cs_ != -2) {
                     if (cs_ != cur) {
                         if (cur >= 0) {
-                            if (accD) __hip_atomic_fetch_add((u64 *)(SD + (size_t)cur * ld + b), (u64)accD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (accL) __hip_atomic_fetch_add((u64 *)(SL + (size_t)cur * ld + b), (u64)accL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (accD RC_SYM32_ABL1) __hip_atomic_fetch_add((u64 *)(SD + (size_t)cur * ld + b), (u64)accD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (accL RC_SYM32_ABL1) __hip_atomic_fetch_add((u64 *)(SL + (size_t)cur * ld + b), (u64)accL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                         accD = accL = 0; cur = cs_;
                     }
-                    accD += ((xd[0] + xd[1]) + (xd[2] + xd[3])) + ((xd[4] + xd[5]) + (xd[6] + xd[7]));
-                    accL += ((xl[0] + xl[1]) + (xl[2] + xl[3])) + ((xl[4] + xl[5]) + (xl[6] + xl[7]));
+                    accD += (((long long)xd[0] + xd[1]) + ((long long)xd[2] + xd[3])) + (((long long)xd[4] + xd[5]) + ((long long)xd[6] + xd[7]));
+                    accL += (((long long)xl[0] + xl[1]) + ((long long)xl[2] + xl[3])) + (((long long)xl[4] + xl[5]) + ((long long)xl[6] + xl[7]));
                 } else {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         const int sr = __builtin_amdgcn_readfirstlane(rslot[ch * 8 + q]);
                         if (sr != cur) {
                             if (cur >= 0) {
-                                if (accD) __hip_atomic_fetch_add((u64 *)(SD + (size_t)cur * ld + b), (u64)accD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                if (accL) __hip_atomic_fetch_add((u64 *)(SL + (size_t)cur * ld + b), (u64)accL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (accD RC_SYM32_ABL1) __hip_atomic_fetch_add((u64 *)(SD + (size_t)cur * ld + b), (u64)accD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (accL RC_SYM32_ABL1) __hip_atomic_fetch_add((u64 *)(SL + (size_t)cur * ld + b), (u64)accL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             }
                             accD = accL = 0; cur = sr;
                         }
@@ -2165,43 +2177,51 @@ __global__ __launch_bounds__(256) void k_bulk_sym32(View V, int wgen, int zgen, 
                     }
                 }
             }
-            // direction 2: wave w -> columns 64w..64w+63; lanes 0-31 rows of D, lanes 32-63 rows of logD
+            // direction 2: wave w -> columns 64w..64w+63; a lane = (row, matrix, part): with TR = 32 it reads whole 8-column chunks, with
+            // TR = 16 the two parts of a lane pair (lane, lane ^ 32) read four columns each and are added up when the sum is flushed
             {
-                const int quarter = tid >> 6, r = tid & 31, mat = (tid >> 5) & 1;
+                const int quarter = tid >> 6, lane = tid & 63, r = lane & (TR - 1), mat = (lane / TR) & 1, part = lane / (2 * TR);
                 long long *S = mat ? SL : SD;
                 const int arow = r0 + r;
                 long long acc = 0;
                 int cc = -1;
+                auto flush = [&]() {   // (cc is uniform over the wave, so is the control flow)
+                    if (PARTS == 2) acc += __shfl_xor(acc, 32);
+                    if (cc >= 0 && acc && arow < n && part == 0 RC_SYM32_ABL2) __hip_atomic_fetch_add((u64 *)(S + (size_t)cc * ld + arow), (u64)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                };
 #pragma unroll 2
                 for (int ch = 0; ch < 8; ++ch) {
                     const int cb = quarter * 64 + ch * 8;
-                    const i4 x0 = *(const i4 *)&tt[mat][r][cb], x1 = *(const i4 *)&tt[mat][r][cb + 4];
+                    i4 x0, x1;
+                    if (PARTS == 1) { x0 = *(const i4 *)&tt[mat][r][cb]; x1 = *(const i4 *)&tt[mat][r][cb + 4]; }
+                    else { x0 = *(const i4 *)&tt[mat][r][cb + part * 4]; x1 = i4{0, 0, 0, 0}; }
                     const int cs_ = __builtin_amdgcn_readfirstlane(cchk[cb >> 3]);
                     if (cs_ != -2) {
                         if (cs_ != cc) {
-                            if (cc >= 0 && acc && arow < n) __hip_atomic_fetch_add((u64 *)(S + (size_t)cc * ld + arow), (u64)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            flush();
                             acc = 0; cc = cs_;
                         }
-                        acc += (((long long)x0[0] + x0[1]) + ((long long)x0[2] + x0[3])) + (((long long)x1[0] + x1[1]) + ((long long)x1[2] + x1[3]));
+                        if (PARTS == 1) acc += (((long long)x0[0] + x0[1]) + ((long long)x0[2] + x0[3])) + (((long long)x1[0] + x1[1]) + ((long long)x1[2] + x1[3]));
+                        else acc += ((long long)x0[0] + x0[1]) + ((long long)x0[2] + x0[3]);
                     } else {
-                        const int xs[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
 #pragma unroll
                         for (int q = 0; q < 8; ++q) {
                             const int sc = __builtin_amdgcn_readfirstlane(cslot[cb + q]);
                             if (sc != cc) {
-                                if (cc >= 0 && acc && arow < n) __hip_atomic_fetch_add((u64 *)(S + (size_t)cc * ld + arow), (u64)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                flush();
                                 acc = 0; cc = sc;
                             }
-                            acc += xs[q];
+                            if (PARTS == 1) acc += (q < 4) ? x0[q & 3] : x1[q & 3];
+                            else acc += (part == (q >> 2)) ? x0[q & 3] : 0;
                         }
                     }
                 }
-                if (cc >= 0 && acc && arow < n) __hip_atomic_fetch_add((u64 *)(S + (size_t)cc * ld + arow), (u64)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                flush();
             }
         }
         if (cur >= 0) {
-            if (accD) __hip_atomic_fetch_add((u64 *)(SD + (size_t)cur * ld + b), (u64)accD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (accL) __hip_atomic_fetch_add((u64 *)(SL + (size_t)cur * ld + b), (u64)accL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (accD RC_SYM32_ABL1) __hip_atomic_fetch_add((u64 *)(SD + (size_t)cur * ld + b), (u64)accD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (accL RC_SYM32_ABL1) __hip_atomic_fetch_add((u64 *)(SL + (size_t)cur * ld + b), (u64)accL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (t_begin == 0 && b < n) {
             const long long x = V.diagq[b];
@@ -4642,6 +4662,8 @@ struct rc_ctx {
     int bulk_kernel = -1;      // RC_BULK_KERNEL: -1 auto, 0 k_bulk (full read, any layout), 1 k_bulk_sym (upper triangle)
     int last_bulk_kernel = 0;  // what the last enqueue chose
     int sym_item_tiles = 8;
+    int sym32_tr = 16;               // rows per tile of k_bulk_sym32 (16: 34 KiB blocks, 32: 67 KiB blocks)
+    int sym32_bpc = 3;               // its blocks per CU
     int res_threads = 0;       // k_resolve block size: 0 = adaptive, else forced by RC_RES_THREADS (256 or 512)
     double *A = nullptr;
     u64 *keys[2] = {nullptr, nullptr};
@@ -5226,6 +5248,9 @@ static int32_t alloc_ctx(int64_t n, int32_t storage_bits, int32_t device_id, int
     if (rc_env_diag("RC_SW_COARSE")) c->sw_coarse = std::min(128, std::max(8, atoi(rc_env_diag("RC_SW_COARSE")) & ~3));
     if (rc_env("RC_BULK_KERNEL")) c->bulk_kernel = !strcmp(rc_env("RC_BULK_KERNEL"), "sym") ? 1 : (!strcmp(rc_env("RC_BULK_KERNEL"), "perm") ? 0 : -1);
     if (rc_env_diag("RC_RES_THREADS")) { const int rt_ = atoi(rc_env_diag("RC_RES_THREADS")); c->res_threads = (rt_ == 64 || rt_ == 128 || rt_ == 256 || rt_ == 768 || rt_ == 1024) ? rt_ : 512; }
+    if (rc_env_diag("RC_SYM32_TR")) c->sym32_tr = atoi(rc_env_diag("RC_SYM32_TR")) == 32 ? 32 : 16;
+    c->sym32_bpc = c->sym32_tr == 16 ? 3 : 2;
+    if (rc_env_diag("RC_SYM32_BPC")) c->sym32_bpc = std::max(1, std::min(4, atoi(rc_env_diag("RC_SYM32_BPC"))));
     if (rc_env_diag("RC_SYM_ITEM_TILES")) c->sym_item_tiles = std::max(1, atoi(rc_env_diag("RC_SYM_ITEM_TILES")));
     *out = c;
     return RC_OK;
@@ -5395,7 +5420,7 @@ static int32_t finish_create(rc_ctx *c)
         // wave-autonomous kernel (64-bit, logD derived), two 65 KiB blocks of the block-tiled kernels otherwise; the
         // full-read kernel of small problems sizes itself around the resolver.  Largest capacity whose tables fit.
         const bool syml = uses_syml(c);
-        const size_t beside = syml ? (size_t)c->symw_per_cu * 40960 : (size_t)2 * 69632;   // (k_bulk_sym32: 67,864 B per block, k_bulk_sym: 67,288 B; measured: beside two of them 24.6 KB of tables become resident, 26.5 KB do not — 4 KiB allocation granules)
+        const size_t beside = syml ? (size_t)c->symw_per_cu * 40960 : (c->bits != 64 && c->sym32_tr == 16) ? (size_t)c->sym32_bpc * 36864 : (size_t)2 * 69632;   // (k_bulk_sym32: 67,864 B per block, k_bulk_sym: 67,288 B; measured: beside two of them 24.6 KB of tables become resident, 26.5 KB do not — 4 KiB allocation granules)
         const size_t avail = 160 * 1024 > beside + 1024 ? 160 * 1024 - beside - 1024 : 0;
         c->maxb = RC_MAXB;
         if (rc_env("RC_RES_MAXB")) c->maxb = std::max(16, std::min(RC_MAXB, atoi(rc_env("RC_RES_MAXB"))));
@@ -5998,19 +6023,25 @@ static int32_t enqueue_bulk(rc_ctx *c, const View &V, long long t)
         }
     } else if (use_sym) {
         const int TC = (c->bits == 64) ? RC_SYM_TC : RC_SYM32_TC;
+        const int TR = (c->bits == 64) ? RC_SYM_TR : c->sym32_tr;                   // rows per tile
+        const int item_tiles = c->sym_item_tiles * (RC_SYM_TR / TR);                 // (a work item is the same number of rows either way)
         const int ncb = (c->n + TC - 1) / TC;
         int nitems = 0;
         for (int J = 0; J < ncb; ++J) {
-            const int ntile = (std::min(TC * J + TC, c->n) + RC_SYM_TR - 1) / RC_SYM_TR;
-            nitems += (ntile + c->sym_item_tiles - 1) / c->sym_item_tiles;
+            const int ntile = (std::min(TC * J + TC, c->n) + TR - 1) / TR;
+            nitems += (ntile + item_tiles - 1) / item_tiles;
         }
-        const int nblocks = std::max(1, std::min(nitems, 2 * c->num_cus));
+        const int nblocks = std::max(1, std::min(nitems, (c->bits == 64 ? 2 : c->sym32_bpc) * c->num_cus));
         if (c->bits == 64 && c->derived)
             { auto kf_ = k_bulk_sym<true>; RC_BULK_LAUNCH(kf_, nblocks, 256, 0, V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), c->sym_item_tiles, nitems); }
         else if (c->bits == 64)
             { auto kf_ = k_bulk_sym<false>; RC_BULK_LAUNCH(kf_, nblocks, 256, 0, V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), c->sym_item_tiles, nitems); }
         else
-            { auto kf_ = k_bulk_sym32; RC_BULK_LAUNCH(kf_, nblocks, 256, 0, V, (int)(t % 3), (int)((t + 1) % 3), (int)(t & 1), (int)(t & 1), c->sym_item_tiles, nitems); }
+            {
+                // (the second generation argument is unused by this kernel: diag builds pass their timing-ablation flags through it)
+                if (c->sym32_tr == 16) { auto kf_ = k_bulk_sym32<16>; RC_BULK_LAUNCH(kf_, nblocks, 256, 0, V, (int)(t % 3), c->dbg, (int)(t & 1), (int)(t & 1), item_tiles, nitems); }
+                else { auto kf_ = k_bulk_sym32<32>; RC_BULK_LAUNCH(kf_, nblocks, 256, 0, V, (int)(t % 3), c->dbg, (int)(t & 1), (int)(t & 1), item_tiles, nitems); }
+            }
     } else {
         // bulk_lds: unused dynamic LDS that caps k_bulk at bulk_blocks_per_cu workgroups per CU, which (i) spreads the
         // grid evenly over the CUs and (ii) leaves registers/wave slots on every CU for the concurrent k_resolve
