@@ -57,7 +57,7 @@ print("headline: read %.1f MB written %.1f MB per launch (calibration %.4f / %.4
       (2 * f / 1e6, w / 1e6, fetch_factor, write_factor, counters["SQ_INSTS_VALU"] / 1e6, counters["SQ_LDS_BANK_CONFLICT"] / counters["SQ_LDS_IDX_ACTIVE"], clock_ghz or 0, avg_us or 0))
 
 # ---- config 5: k_bulk_sym32 at n = 32768 (HBM-resident)
-K5 = "k_bulk_sym32"
+K5 = "k_bulk_sym32<16>"
 f5 = g(f"c5:{K5}:FETCH_SIZE") * 1024
 w5 = g(f"c5:{K5}:WRITE_SIZE") * 1024
 avg5, calls5 = kernel_avg_us(S + "stats_c5/b_kernel_stats.csv", "k_bulk_sym32")
