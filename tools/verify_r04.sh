@@ -8,9 +8,9 @@ python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail 
 echo "== chaos build: moving-regime parity subset + multi-thread tests" | tee -a $LOG
 RC_LIB_PATH=$B/lib_chaos15.so timeout 1200 python -m pytest tests/test_gpu_derived_log.py tests/test_gpu_parity.py tests/test_gpu_threads.py tests/test_gpu_capacity.py -x -q -m gpu -k "derived_sweeps or derived_equals or many_small or synthetic_moving or long_trajectory or golden_sweeps or concurrent or resumed or record_sample" 2>&1 | grep -E "passed|failed|error" | tail -3 | tee -a $LOG
 echo "== fuzz (tests/fuzz_parity.py): sweeps, large, chains pipelined vs synchronous, chains vs the oracle's loop" | tee -a $LOG
-for args in "500 41000" "40 42000 large" "400 43000 chains" "200 44000 oracle_chains"; do
+for args in "500 71000" "40 72000 large" "400 73000 chains" "200 74000 oracle_chains" "12 75000 wide"; do
   timeout 1500 python tests/fuzz_parity.py $args 2>&1 | tail -2 | tee -a $LOG
 done
 echo "== fuzz on the chaos build" | tee -a $LOG
-RC_LIB_PATH=$B/lib_chaos15.so timeout 1200 python tests/fuzz_parity.py 250 45000 2>&1 | tail -2 | tee -a $LOG
-RC_LIB_PATH=$B/lib_chaos15.so timeout 1200 python tests/fuzz_parity.py 20 46000 large 2>&1 | tail -2 | tee -a $LOG
+RC_LIB_PATH=$B/lib_chaos15.so timeout 1200 python tests/fuzz_parity.py 250 76000 2>&1 | tail -2 | tee -a $LOG
+RC_LIB_PATH=$B/lib_chaos15.so timeout 1200 python tests/fuzz_parity.py 20 77000 large 2>&1 | tail -2 | tee -a $LOG
