@@ -11,7 +11,8 @@ if os.environ.get("SHUFFLE"):
     sh = np.random.default_rng(3).permutation(n)
     D = np.ascontiguousarray(D[np.ix_(sh, sh)]); truth = truth[sh]
 P = rc.likelihood_hyperparams(D, truth) if n <= 16384 else dict(delta1=20.0, delta2=30.0, alpha=1e6, beta=1e5, zeta=1e9, gamma=1e9, eta=1.0, sigma=1.0, u=1.0, v=1.0, repulsion=True, maxK=0)
-ctx = rc.Context(D, storage_bits=bits); ctx.set_params(**P); ctx.set_state(truth)
+L = np.log(np.where(np.eye(n, dtype=bool), 1.0, D)) if os.environ.get("STORED") else None   # STORED=1: the caller's logD (the Julia glue's exact_logD)
+ctx = rc.Context(D, logD=L, storage_bits=bits); ctx.set_params(**P); ctx.set_state(truth)
 for t in range(10): ctx.gibbs_sweep(1.0, 0.5, 1, t, blocking=False)
 ctx.synchronize()
 t0 = time.perf_counter()
