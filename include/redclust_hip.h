@@ -217,7 +217,8 @@ int32_t rc_set_option(rc_ctx *ctx, const char *name, int64_t value);
  * the caller's points by label), so that k_bulk_sym applies whatever order the caller's points come in; the sweep
  * still visits the points in the caller's order and every output is in the caller's order.  Label movement
  * fragments the layout; in automatic kernel mode the library re-lays the points out when the number of label runs
- * in internal order exceeds n/32 (at most once per 32 sweeps; the chain is bit-identical either way).  Returns the
+ * in internal order exceeds n/32 and a fresh layout would be below it again (at most once per 32 sweeps up to n/64 clusters, per
+ * 128 sweeps — doubling when a layout does not last — up to n/36; the chain is bit-identical either way).  Returns the
  * number of layouts built so far and the current run count.  RC_NO_RELAYOUT=1 keeps the caller's order throughout. */
 int32_t rc_layout_info(rc_ctx *ctx, int32_t *n_relayouts, int32_t *label_runs);
 

@@ -4662,6 +4662,7 @@ struct rc_ctx {
     int bulk_kernel = -1;      // RC_BULK_KERNEL: -1 auto, 0 k_bulk (full read, any layout), 1 k_bulk_sym (upper triangle)
     int last_bulk_kernel = 0;  // what the last enqueue chose
     int sym_item_tiles = 8;
+    long long relayout_gap = 128;    // sweeps between two automatic re-layouts while K is between n/64 and n/36 (sweep_enqueue)
     int sym32_tr = 16;               // rows per tile of k_bulk_sym32 (16: 34 KiB blocks, 32: 67 KiB blocks)
     int sym32_bpc = 3;               // its blocks per CU
     int res_threads = 0;       // k_resolve block size: 0 = adaptive, else forced by RC_RES_THREADS (256 or 512)
@@ -5919,7 +5920,8 @@ extern "C" int32_t rc_set_state(rc_ctx *c, const int64_t *clusts)
 // n = 4096: 58 vs 75 µs per sweep, n = 6000: 102 vs 70).
 static bool choose_sym(const rc_ctx *c)
 {
-    return c->bulk_kernel == 1 || (c->bulk_kernel < 0 && (long long)c->hsum->runs * 32 <= (long long)c->n &&
+    static const int runs_div = rc_env_diag("RC_SYM_RUNS_DIV") ? std::max(1, atoi(rc_env_diag("RC_SYM_RUNS_DIV"))) : 32;   // (diag builds: the threshold of the choice)
+    return c->bulk_kernel == 1 || (c->bulk_kernel < 0 && (long long)c->hsum->runs * runs_div <= (long long)c->n &&
                                    !(c->derived && c->n <= (sym_variant_of(c) == 3 ? 2560 : 4096)));
 }
 
@@ -6161,8 +6163,16 @@ static int32_t sweep_enqueue(rc_ctx *c, double r, double p, uint64_t seed, uint6
             if (rc != RC_OK) return rc;
         }
     }
-    if (!c->recovering && !c->incremental && c->relayout && c->bulk_kernel < 0 && c->t_next >= 32 &&
-        (long long)c->hsum->runs * 32 > (long long)c->n && (long long)c->hsum->K * 64 <= (long long)c->n) {
+    // (up to K = n/64 clusters a fresh layout is far below the n/32 runs the symmetric kernels accept: every 32 sweeps if need be.  Up to
+    // K = n/36 it still is — K plus a few runs — but a few dozen moves can undo it, and a re-layout costs what 40 sweeps do (n = 8192:
+    // 10 ms): there the interval starts at 128 sweeps and doubles whenever a layout did not last sixteen intervals.  Moving regime of
+    // bench.py, K = 212 at n = 8192: 379 runs and the full-read kernel, 4.0-4.2 k sweeps/s, against 220 runs and k_bulk_syml2, 4.4-4.6 k —
+    // which of the two a run ended in used to depend on when the last re-layout had happened while K was still below n/64)
+    const long long K_now = c->hsum->K;
+    const bool relay_near = c->t_next >= 32 && K_now * 64 <= (long long)c->n;
+    const bool relay_far = c->t_next >= c->relayout_gap && K_now * 36 <= (long long)c->n;
+    if (!c->recovering && !c->incremental && c->relayout && c->bulk_kernel < 0 && (long long)c->hsum->runs * 32 > (long long)c->n && (relay_near || relay_far)) {
+        if (!relay_near) c->relayout_gap = c->t_next < 16 * c->relayout_gap ? std::min<long long>(c->relayout_gap * 2, 1ll << 24) : 128;
         std::vector<int64_t> labels, sizes;
         int64_t K = 0;
         rc = pull_labels(c, labels, sizes, K);

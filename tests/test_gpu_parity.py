@@ -490,6 +490,36 @@ def test_automatic_relayout_is_invisible():
     ctx.close(); ref.close()
 
 
+def test_relayout_between_n64_and_n36_clusters():
+    """The moving regime with MANY clusters (n = 4096, K ≈ 75: between n/64 and n/36) fragments the layout beyond the n/32 label runs
+    the symmetric row reduction accepts (≈ 240 runs: the full-read kernel takes over).  A fresh layout has K plus a few runs again, so the
+    library re-lays the points out there too — after 128 sweeps at the earliest, with a doubling interval (round 4; before, a chain
+    that passed K = n/64 stayed on the full-read kernel for good) — and the chain is bit-identical to one that never re-lays out."""
+    n, K = 4096, 25
+    data = rc.generatemixture(n, K, seed=4, sigma=0.22)
+    D, truth = data["distancematrix"], data["clusts"]
+    P = rc.likelihood_hyperparams(D, truth)
+    ctx = rc.Context(D); ctx.set_params(**P); ctx.set_state(truth)
+    ref = rc.Context(D); ref.set_params(**P)
+    ref.set_bulk_kernel("perm")            # forced kernel: never re-lays out after rc_set_state
+    ref.set_state(truth)
+    seen_far = False
+    for t in range(280):
+        ctx.gibbs_sweep(1.0, 0.5, 9, t, blocking=False)
+        ref.gibbs_sweep(1.0, 0.5, 9, t, blocking=False)
+        if t % 40 == 39:
+            a, b = ctx.get_state(), ref.get_state()
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2], (t, ctx.layout_info(), ctx.sweep_stats(), ref.sweep_stats())
+            layouts, runs = ctx.layout_info()
+            if layouts == 0:
+                seen_far = seen_far or (a[2] * 64 > n and a[2] * 36 <= n and runs * 32 > n)
+    assert seen_far, ("the chain never was in the zone this test is about", ctx.layout_info(), ctx.sweep_stats())
+    layouts, runs = ctx.layout_info()
+    assert layouts >= 1 and runs * 32 <= n and ctx.bulk_kernel_name().startswith("k_bulk_syml2"), (layouts, runs, ctx.bulk_kernel_name())
+    assert ctx.loglik() == ref.loglik()
+    ctx.close(); ref.close()
+
+
 @pytest.mark.parametrize("variant", ["plain", "maxK", "norep", "bits32"])
 def test_long_trajectory_with_continual_movement(variant):
     """150 sweeps on overlapping clusters (σ large: labels keep moving every sweep — batches, violations, births and
