@@ -1,5 +1,5 @@
 #!/bin/bash
-# experiment: what the flushes of k_bulk_sym32 cost (timing ablations, diag build), item size
+# experiment: what the flushes of k_bulk_sym32 cost (timing ablations of the diag build: ABL=32 drops the direction-1 flushes, 64 the direction-2 ones; wrong sums), blocks per CU, item size
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r04p; mkdir -p $O
 export RC_LIB_PATH=$PWD/build_r4/lib_diag.so
 run() { echo "== $*"; env "$@" timeout 300 python tools/config5_rate.py 60 | python -c "
