@@ -9,6 +9,7 @@ d = rc.generatemixture(n, K, seed=1, points_only=True)
 ctx = rc.Context.from_points(d["points"], storage_bits=32)
 P = rc.likelihood_hyperparams_device(ctx, d["clusts"])
 ctx.set_params(**P); ctx.set_state(d["clusts"])
+if os.environ.get("MODE"): ctx.set_mode(os.environ["MODE"])   # MODE=incremental: what runsampler uses (no row reduction per sweep)
 if os.environ.get("ABL"): ctx.set_option("debug_flags", int(os.environ["ABL"]))   # (diag builds: timing ablations, wrong sums)
 sw = 0
 for _ in range(10):
